@@ -1,0 +1,278 @@
+/* oracle/ref_dump.c -- TEST INFRASTRUCTURE (golden-vector generator).
+ *
+ * Drives the REAL reference (compiled from /root/reference into oracle/_ref/libhdsdp_ref.so by
+ * oracle/Makefile) through its own public C API and dumps the inputs/outputs of the Schur hot path
+ * as .npy files.  oracle/gen_golden.py packs them into tests/golden/*.npz.  Nothing here is shipped
+ * or measured; this file only *calls* the reference (it includes the reference headers from where
+ * they lie), it contains none of its source.
+ *
+ * Call sequence follows the reference's own (dead) unit test tests/test_file_io.c:356-467
+ * (test_sdpa_io): HUserDataSetConeData -> HConeCreate/SetData/ProcData/PresolveData ->
+ * HConeSetStart(Rd) -> HConeGetLogBarrier(tau, y) -> HKKTCreate/Init -> HKKTBuildUp(type) ->
+ * HKKTExport -> HKKTFactorize -> HKKTSolve.
+ *
+ * usage: ref_dump <outdir> sdpa <file.dat-s> <Rd> <tau> <yscale>
+ *        ref_dump <outdir> syn  <n> <m>      <Rd> <tau> <yscale>     (SURVEY.md 8(d) generator)
+ *        ref_dump <outdir> mix  <n> <m>      <Rd> <tau> <yscale>     (all five coefficient types)
+ */
+#include "interface/hdsdp.h"
+#include "interface/hdsdp_utils.h"
+#include "interface/hdsdp_user_data.h"
+#include "interface/hdsdp_file_io.h"
+#include "interface/hdsdp_conic.h"
+#include "interface/hdsdp_schur.h"
+#include "linalg/hdsdp_sdpdata.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdint.h>
+
+static const char *g_out = NULL;
+
+static void npy_write(const char *name, const char *descr, int ndim, const long *dims, const void *data, size_t elsz) {
+    char path[1024], hdr[256], shape[128] = "";
+    snprintf(path, sizeof(path), "%s/%s.npy", g_out, name);
+    FILE *f = fopen(path, "wb");
+    if (!f) { perror(path); exit(2); }
+    size_t cnt = 1;
+    for (int i = 0; i < ndim; ++i) {
+        char t[32]; snprintf(t, sizeof(t), "%ld,", dims[i]); strcat(shape, t); cnt *= (size_t) dims[i];
+    }
+    int len = snprintf(hdr, sizeof(hdr), "{'descr': '%s', 'fortran_order': False, 'shape': (%s), }", descr, shape);
+    int total = 10 + len + 1;
+    int pad = (64 - total % 64) % 64;
+    unsigned short hlen = (unsigned short) (len + pad + 1);
+    fwrite("\x93NUMPY\x01\x00", 1, 8, f);
+    fwrite(&hlen, 2, 1, f);
+    fwrite(hdr, 1, len, f);
+    for (int i = 0; i < pad; ++i) fputc(' ', f);
+    fputc('\n', f);
+    fwrite(data, elsz, cnt, f);
+    fclose(f);
+}
+static void dump_d(const char *name, const double *x, long n) { npy_write(name, "<f8", 1, &n, x, 8); }
+static void dump_i(const char *name, const int *x, long n) { npy_write(name, "<i4", 1, &n, x, 4); }
+static void dump_d2(const char *name, const double *x, long r, long c) { long d[2] = {r, c}; npy_write(name, "<f8", 2, d, x, 8); }
+static void dump_s(const char *name, double v) { dump_d(name, &v, 1); }
+
+/* splitmix64 -> U(-1,1), SURVEY.md 8(d) */
+static uint64_t g_s = 0x9E3779B97F4A7C15ULL;
+static double urand(void) {
+    uint64_t z = (g_s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return 2.0 * ((double) (z >> 11) / 9007199254740992.0) - 1.0;
+}
+
+/* CSC of shape P x (m+1): column 0 = C, column c = A_c, rows = packed-lower col-major index */
+typedef struct { int n, m; int *beg, *idx; double *val; double *b; } csc_prob;
+
+static void gen_syn(csc_prob *p, int n, int m) {
+    long P = (long) n * (n + 1) / 2;
+    double *Apk = calloc((size_t) P * m, sizeof(double));
+    char *keep = calloc((size_t) P * m, 1);
+    for (int c = 0; c < m; ++c) {
+        long k = 0;
+        for (int j = 0; j < n; ++j) for (int i = j; i < n; ++i, ++k) {
+            double v = urand(); int kp = (urand() >= 0.2);
+            if (i == j || kp) { Apk[(size_t) c * P + k] = v; keep[(size_t) c * P + k] = 1; }
+        }
+    }
+    double *y0 = malloc(m * sizeof(double));
+    for (int i = 0; i < m; ++i) y0[i] = urand();
+    double *Cpk = calloc(P, sizeof(double));
+    { long k = 0; for (int j = 0; j < n; ++j) for (int i = j; i < n; ++i, ++k) Cpk[k] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < m; ++c) for (long k = 0; k < P; ++k) Cpk[k] += y0[c] * Apk[(size_t) c * P + k];
+    long tot = P; for (size_t q = 0; q < (size_t) P * m; ++q) tot += keep[q];
+    p->n = n; p->m = m;
+    p->beg = calloc(m + 2, sizeof(int)); p->idx = malloc(tot * sizeof(int)); p->val = malloc(tot * sizeof(double));
+    p->b = calloc(m, sizeof(double));
+    long pos = 0;
+    for (long k = 0; k < P; ++k) { p->idx[pos] = (int) k; p->val[pos++] = Cpk[k]; }
+    p->beg[1] = (int) pos;
+    for (int c = 0; c < m; ++c) {
+        for (long k = 0; k < P; ++k) if (keep[(size_t) c * P + k]) { p->idx[pos] = (int) k; p->val[pos++] = Apk[(size_t) c * P + k]; }
+        p->beg[c + 2] = (int) pos;
+        long k = 0; double tr = 0.0;
+        for (int j = 0; j < n; ++j) { tr += Apk[(size_t) c * P + k]; k += n - j; }
+        p->b[c] = tr;
+    }
+    free(Apk); free(keep); free(y0); free(Cpk);
+}
+
+/* multi-type mix: row c%6 -> 0 dense, 1 sparse, 2 sparse rank-1, 3 dense rank-1, 4 zero, 5 sparse (diag heavy) */
+static void gen_mix(csc_prob *p, int n, int m) {
+    long P = (long) n * (n + 1) / 2;
+    double *M = calloc((size_t) P * (m + 1), sizeof(double));
+    #define PK(i, j) ((long) (2 * n - (j) - 1) * (j) / 2 + (i))
+    double *a = malloc(n * sizeof(double));
+    for (int c = 1; c <= m; ++c) {
+        double *A = M + (size_t) c * P;
+        int kind = (c - 1) % 6;
+        if (kind == 0) {
+            for (long k = 0; k < P; ++k) A[k] = urand();
+        } else if (kind == 1) {
+            int nz = 2 + (c % 5);
+            for (int q = 0; q < nz; ++q) {
+                int i = (int) ((urand() + 1.0) * 0.5 * n) % n, j = (int) ((urand() + 1.0) * 0.5 * n) % n;
+                if (i < j) { int t = i; i = j; j = t; }
+                A[PK(i, j)] += urand();
+            }
+            A[PK((c * 7) % n, (c * 7) % n)] += 1.0 + 0.5 * urand();
+        } else if (kind == 2) {
+            memset(a, 0, n * sizeof(double));
+            int nz = 1 + (c % 4);
+            for (int q = 0; q < nz; ++q) a[(c * 3 + q * 5) % n] = 0.5 + 0.5 * (urand() + 1.0);
+            double sgn = (c % 4 == 2) ? -1.7 : 2.3;
+            for (int j = 0; j < n; ++j) for (int i = j; i < n; ++i) A[PK(i, j)] = sgn * a[i] * a[j];
+        } else if (kind == 3) {
+            for (int i = 0; i < n; ++i) a[i] = urand();
+            double sgn = (c % 4 == 3) ? -0.9 : 1.1;
+            for (int j = 0; j < n; ++j) for (int i = j; i < n; ++i) A[PK(i, j)] = sgn * a[i] * a[j];
+        } else if (kind == 4) {
+            /* zero row */
+        } else {
+            for (int i = 0; i < n; i += 3) A[PK(i, i)] = 1.0 + 0.25 * urand();
+            A[PK(n - 1, 0)] = 0.3;
+        }
+    }
+    /* C = I + sum y0_c A_c  (strictly dual feasible at y0) */
+    double *C = M;
+    for (int j = 0; j < n; ++j) C[PK(j, j)] = 1.0;
+    for (int c = 1; c <= m; ++c) { double y0 = 0.3 * urand(); for (long k = 0; k < P; ++k) C[k] += y0 * M[(size_t) c * P + k]; }
+    long tot = 0; for (size_t q = 0; q < (size_t) P * (m + 1); ++q) tot += (M[q] != 0.0);
+    p->n = n; p->m = m;
+    p->beg = calloc(m + 2, sizeof(int)); p->idx = malloc((tot + 1) * sizeof(int)); p->val = malloc((tot + 1) * sizeof(double));
+    p->b = calloc(m, sizeof(double));
+    long pos = 0;
+    for (int c = 0; c <= m; ++c) {
+        for (long k = 0; k < P; ++k) if (M[(size_t) c * P + k] != 0.0) { p->idx[pos] = (int) k; p->val[pos++] = M[(size_t) c * P + k]; }
+        p->beg[c + 1] = (int) pos;
+        if (c > 0) { double tr = 0.0; for (int j = 0; j < n; ++j) tr += M[(size_t) c * P + PK(j, j)]; p->b[c - 1] = tr; }
+    }
+    free(M); free(a);
+    #undef PK
+}
+
+int main(int argc, char **argv) {
+    if (argc < 7) { fprintf(stderr, "usage: see header\n"); return 2; }
+    g_out = argv[1];
+    const char *mode = argv[2];
+    hdsdp_retcode retcode = HDSDP_RETCODE_OK;
+    csc_prob pb; memset(&pb, 0, sizeof(pb));
+    double Rd, tau, yscale;
+
+    if (!strcmp(mode, "sdpa")) {
+        int nConstrs = 0, nBlks = 0, *BlkDims = NULL, nCols = 0, nLpCols = 0, nElem = 0;
+        int **cBeg = NULL, **cIdx = NULL, *LpBeg = NULL, *LpIdx = NULL;
+        double **cElem = NULL, *rowRHS = NULL, *LpElem = NULL;
+        HDSDP_CALL(HReadSDPA(argv[3], &nConstrs, &nBlks, &BlkDims, &rowRHS, &cBeg, &cIdx, &cElem,
+                             &nCols, &nLpCols, &LpBeg, &LpIdx, &LpElem, &nElem));
+        if (nBlks != 1 || nLpCols != 0) { fprintf(stderr, "harness handles single-block SDPs only\n"); return 2; }
+        pb.n = BlkDims[0]; pb.m = nConstrs; pb.beg = cBeg[0]; pb.idx = cIdx[0]; pb.val = cElem[0]; pb.b = rowRHS;
+        Rd = atof(argv[4]); tau = atof(argv[5]); yscale = atof(argv[6]);
+    } else {
+        int n = atoi(argv[3]), m = atoi(argv[4]);
+        if (argc < 8) { fprintf(stderr, "usage\n"); return 2; }
+        if (!strcmp(mode, "syn")) gen_syn(&pb, n, m); else gen_mix(&pb, n, m);
+        Rd = atof(argv[5]); tau = atof(argv[6]); yscale = atof(argv[7]);
+    }
+    int n = pb.n, m = pb.m;
+    long nnz = pb.beg[m + 1];
+    dump_i("csc_beg", pb.beg, m + 2); dump_i("csc_idx", pb.idx, nnz); dump_d("csc_val", pb.val, nnz);
+    dump_d("b", pb.b, m);
+    { int dims[2] = {n, m}; dump_i("dims", dims, 2); }
+    dump_s("Rd", Rd); dump_s("tau", tau);
+
+    user_data *ud = NULL; hdsdp_cone *cone = NULL; hdsdp_kkt *kkt = NULL;
+    double *y = calloc(m, sizeof(double)), *rhs = calloc(m, sizeof(double)), *sol = calloc(m, sizeof(double));
+    for (int i = 0; i < m; ++i) y[i] = yscale * sin(1.7 * (i + 1));
+    dump_d("y", y, m);
+    double logdet = 0.0;
+    HDSDP_CALL(HUserDataCreate(&ud));
+    HUserDataSetConeData(ud, HDSDP_CONETYPE_DENSE_SDP, m, n, pb.beg, pb.idx, pb.val);
+    HDSDP_CALL(HConeCreate(&cone, 0));
+    HDSDP_CALL(HConeSetData(cone, ud));
+    HDSDP_CALL(HConeProcData(cone));
+    HDSDP_CALL(HConePresolveData(cone));
+    HConeSetStart(cone, Rd);
+    int isInt = 0;
+    HDSDP_CALL(HConeCheckIsInterior(cone, tau, y, &isInt));
+    if (!isInt) { fprintf(stderr, "state is not interior; pick a more negative Rd\n"); return 3; }
+    HDSDP_CALL(HConeGetLogBarrier(cone, tau, y, BUFFER_DUALVAR, &logdet));
+    dump_s("logdet", logdet);
+
+    hdsdp_cone_sdp_dense *dc = (hdsdp_cone_sdp_dense *) cone->coneData;
+    /* classification, ordering, strategies (hdsdp_conic_sdp.c:602-676, hdsdp_sdpdata.c:2321-2458) */
+    {
+        int *types = malloc(m * sizeof(int)), *ranks = malloc(m * sizeof(int)), *nnzs = malloc(m * sizeof(int));
+        for (int i = 0; i < m; ++i) {
+            types[i] = (int) sdpDataMatGetType(dc->sdpRow[i]);
+            ranks[i] = sdpDataMatGetRank(dc->sdpRow[i]);
+            nnzs[i] = sdpDataMatGetNnz(dc->sdpRow[i]);
+        }
+        dump_i("coef_type", types, m); dump_i("coef_rank", ranks, m); dump_i("coef_nnz", nnzs, m);
+        dump_i("kkt_perm", dc->sdpConePerm, m); dump_i("kkt_strategy", dc->KKTStrategies, m);
+        int ot = (int) sdpDataMatGetType(dc->sdpObj); dump_i("obj_type", &ot, 1);
+        int ds = dc->isDualSparse; dump_i("dual_sparse", &ds, 1);
+    }
+    /* S as a dense lower-valid n x n column-major array */
+    {
+        double *S = calloc((size_t) n * n, sizeof(double));
+        if (dc->isDualSparse) {
+            for (int j = 0; j < n; ++j) for (int k = dc->dualMatBeg[j]; k < dc->dualMatBeg[j + 1]; ++k)
+                S[(size_t) j * n + dc->dualMatIdx[k]] = dc->dualMatElem[k];
+        } else {
+            for (int j = 0; j < n; ++j) for (int i = j; i < n; ++i) S[(size_t) j * n + i] = dc->dualMatElem[(size_t) j * n + i];
+        }
+        dump_d2("S", S, n, n);
+        free(S);
+    }
+    { double *dg = calloc(n, sizeof(double)); HFpLinsysGetDiag(dc->dualFactor, dg); dump_d("Ldiag", dg, n); free(dg); }
+
+    HDSDP_CALL(HKKTCreate(&kkt));
+    HDSDP_CALL(HKKTInit(kkt, m, 1, &cone));
+    if (kkt->isKKTSparse) { fprintf(stderr, "sparse Schur: harness dumps dense M only\n"); return 4; }
+
+    const int types[3] = { KKT_TYPE_INFEASIBLE, KKT_TYPE_HOMOGENEOUS, KKT_TYPE_CORRECTOR };
+    const char *tn[3] = { "inf", "hsd", "cor" };
+    char nm[64];
+    for (int t = 0; t < 3; ++t) {
+        HDSDP_CALL(HKKTBuildUp(kkt, types[t]));
+        if (t == 0) dump_d2("Sinv", kkt->invBuffer, n, n);
+        if (types[t] != KKT_TYPE_CORRECTOR) { snprintf(nm, 64, "M_%s", tn[t]); dump_d2(nm, kkt->kktMatElem, m, m); }
+        snprintf(nm, 64, "ASinv_%s", tn[t]); dump_d(nm, kkt->dASinvVec, m);
+        snprintf(nm, 64, "ASinvRdSinv_%s", tn[t]); dump_d(nm, kkt->dASinvRdSinvVec, m);
+        if (types[t] == KKT_TYPE_HOMOGENEOUS) {
+            dump_d("ASinvCSinv_hsd", kkt->dASinvCSinvVec, m);
+            double sc[4] = { kkt->dCSinv, kkt->dCSinvCSinv, kkt->dCSinvRdSinv, kkt->dTraceSinv };
+            dump_d("hsd_scalars", sc, 4);
+        }
+        if (types[t] == KKT_TYPE_INFEASIBLE) {
+            dump_s("TraceSinv_inf", kkt->dTraceSinv);
+            /* cross-strategy invariant (reference HUtilKKTCheck, hdsdp_utils.c:536-707): fixed M3 and M4 */
+        }
+    }
+    /* rebuild INFEASIBLE, then the three Phase-A solves (hdsdp_algo.c:1099-1101) */
+    HDSDP_CALL(HKKTBuildUp(kkt, KKT_TYPE_INFEASIBLE));
+    double *d2 = calloc(m, sizeof(double)), *d3 = calloc(m, sizeof(double));
+    HKKTExport(kkt, d2, d3, NULL, NULL, NULL, NULL, NULL);
+    /* the mix family has ZERO rows (singular M): add what the y-box cone would add to diag(M)
+       (hdsdp_conic_bound.c:201-229 writes through kkt->kktDiag[] exactly like this) */
+    double diag_add = !strcmp(mode, "mix") ? 1e-2 : 0.0;
+    for (int i = 0; i < m; ++i) *kkt->kktDiag[i] += diag_add;
+    dump_s("diag_add", diag_add);
+    HDSDP_CALL(HKKTFactorize(kkt));
+    HDSDP_CALL(HKKTSolve(kkt, pb.b, sol)); dump_d("sol_b", sol, m);
+    HDSDP_CALL(HKKTSolve(kkt, d2, NULL)); dump_d("sol_ASinv", d2, m);
+    HDSDP_CALL(HKKTSolve(kkt, d3, NULL)); dump_d("sol_ASinvRdSinv", d3, m);
+    /* fixed-strategy rebuilds: every strategy must give the same M (reference's own invariant) */
+    HDSDP_CALL(HKKTBuildUpFixed(kkt, KKT_TYPE_INFEASIBLE, KKT_M3)); dump_d2("M_inf_fixedM3", kkt->kktMatElem, m, m);
+    HDSDP_CALL(HKKTBuildUpFixed(kkt, KKT_TYPE_INFEASIBLE, KKT_M4)); dump_d2("M_inf_fixedM4", kkt->kktMatElem, m, m);
+    printf("ref_dump ok: n=%d m=%d nnz=%ld logdet=%.12e\n", n, m, nnz, logdet);
+exit_cleanup:
+    if (retcode != HDSDP_RETCODE_OK) fprintf(stderr, "ref_dump: reference returned %d\n", (int) retcode);
+    return (int) retcode;
+}
