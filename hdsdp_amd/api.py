@@ -1,0 +1,348 @@
+"""Host-side mirror of the reference operator interface for the Schur path, over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference (interface/hdsdp_schur.h:10-22,
+linalg/hdsdp_linsolver.h:16-28, interface/hdsdp_conic.h:27-61): `KKT.build_up(type)` is
+HKKTBuildUp, `KKT.factorize()` HKKTFactorize, `KKT.solve(rhs)` HKKTSolve, ... A non-OK
+`hdsdp_retcode` raises `HDSDPError` (the reference's `goto exit_cleanup`).
+
+There is NO CPU fallback: importing works without a GPU (symbol checks), any compute call needs
+the HIP extension and an MI355X.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+KKT_TYPE_INFEASIBLE, KKT_TYPE_CORRECTOR, KKT_TYPE_HOMOGENEOUS, KKT_TYPE_PRIMAL = 0, 1, 2, 3
+KKT_M1, KKT_M2, KKT_M3, KKT_M4, KKT_M5 = 0, 1, 2, 3, 4
+HDSDP_LINSYS_DENSE_DIRECT, HDSDP_LINSYS_DENSE_ITERATIVE = 0, 5
+RETCODE_OK, RETCODE_FAILED, RETCODE_MEMORY = 0, 1, 2
+BUFFER_DUALVAR = 0
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libhdsdp_mi355x.so")
+
+# every symbol include/hdsdp_mi355x.h declares
+EXPORTS = [
+    "HKKTCreate", "HKKTInit", "HKKTBuildUp", "HKKTBuildUpExtraCone", "HKKTBuildUpFixed", "HKKTExport",
+    "HKKTFactorize", "HKKTSolve", "HKKTRegularize", "HKKTRegisterPSDP", "HKKTClear", "HKKTDestroy",
+    "HFpLinsysCreate", "HFpLinsysSetParam", "HFpLinsysSymbolic", "HFpLinsysNumeric", "HFpLinsysSwitchToBackUp",
+    "HFpLinsysPsdCheck", "HFpLinsysFSolve", "HFpLinsysBSolve", "HFpLinsysSolve", "HFpLinsysGetDiag",
+    "HFpLinsysInvert", "HFpLinsysClear", "HFpLinsysDestroy",
+    "HMiConeCreateSDP", "HMiConeCreateSynthetic", "HMiConeDestroy", "HMiConeSetStart", "HMiConeUpdate",
+    "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
+    "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange",
+    "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
+    "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
+    "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming",
+]
+
+
+class HDSDPError(RuntimeError):
+    pass
+
+
+class hdsdp_kkt(C.Structure):  # interface/def_hdsdp_schur.h:32-68
+    _fields_ = [
+        ("nRow", C.c_int), ("nCones", C.c_int), ("maxConeDim", C.c_int), ("cones", C.c_void_p),
+        ("isKKTSparse", C.c_int), ("kktM", C.c_void_p),
+        ("invBuffer", C.POINTER(C.c_double)), ("kktBuffer", C.POINTER(C.c_double)),
+        ("kktBuffer2", C.POINTER(C.c_double)),
+        ("kktMatBeg", C.POINTER(C.c_int)), ("kktMatIdx", C.POINTER(C.c_int)),
+        ("kktMatElem", C.POINTER(C.c_double)), ("kktDiag", C.POINTER(C.POINTER(C.c_double))),
+        ("dASinvVec", C.POINTER(C.c_double)), ("dASinvCSinvVec", C.POINTER(C.c_double)),
+        ("dASinvRdSinvVec", C.POINTER(C.c_double)),
+        ("dCSinvCSinv", C.c_double), ("dCSinvRdSinv", C.c_double), ("dCSinv", C.c_double),
+        ("dTraceSinv", C.c_double), ("dPrimalX", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP extension; fails loudly if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HDSDPError(f"{LIB_PATH} is missing: run `python -m hdsdp_amd.build` (hipcc, gfx950). "
+                         "There is no CPU fallback for the Schur path.")
+    lib = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    kp = C.POINTER(hdsdp_kkt)
+    sig = {
+        "HKKTCreate": (C.c_int, [C.POINTER(kp)]),
+        "HKKTInit": (C.c_int, [kp, C.c_int, C.c_int, C.POINTER(vp)]),
+        "HKKTBuildUp": (C.c_int, [kp, C.c_int]),
+        "HKKTBuildUpExtraCone": (C.c_int, [kp, vp, C.c_int]),
+        "HKKTBuildUpFixed": (C.c_int, [kp, C.c_int, C.c_int]),
+        "HKKTExport": (None, [kp, dp, dp, dp, dp, dp, dp, dp]),
+        "HKKTFactorize": (C.c_int, [kp]),
+        "HKKTSolve": (C.c_int, [kp, dp, dp]),
+        "HKKTRegularize": (None, [kp, C.c_double]),
+        "HKKTRegisterPSDP": (None, [kp, vp]),
+        "HKKTClear": (None, [kp]),
+        "HKKTDestroy": (None, [C.POINTER(kp)]),
+        "HFpLinsysCreate": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int]),
+        "HFpLinsysSetParam": (None, [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]),
+        "HFpLinsysSymbolic": (C.c_int, [vp, ip, ip]),
+        "HFpLinsysNumeric": (C.c_int, [vp, ip, ip, dp]),
+        "HFpLinsysSwitchToBackUp": (C.c_int, [vp]),
+        "HFpLinsysPsdCheck": (C.c_int, [vp, ip, ip, dp, ip]),
+        "HFpLinsysFSolve": (None, [vp, C.c_int, dp, dp]),
+        "HFpLinsysBSolve": (None, [vp, C.c_int, dp, dp]),
+        "HFpLinsysSolve": (C.c_int, [vp, C.c_int, dp, dp]),
+        "HFpLinsysGetDiag": (C.c_int, [vp, dp]),
+        "HFpLinsysInvert": (None, [vp, dp, dp]),
+        "HFpLinsysClear": (None, [vp]),
+        "HFpLinsysDestroy": (None, [C.POINTER(vp)]),
+        "HMiConeCreateSDP": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, ip, ip, dp, C.c_int, C.c_int]),
+        "HMiConeCreateSynthetic": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "HMiConeDestroy": (None, [C.POINTER(vp)]),
+        "HMiConeSetStart": (None, [vp, C.c_double]),
+        "HMiConeUpdate": (None, [vp, C.c_double, dp]),
+        "HMiConeCheckIsInterior": (C.c_int, [vp, C.c_double, dp, ip]),
+        "HMiConeGetLogBarrier": (C.c_int, [vp, C.c_double, dp, C.c_int, dp]),
+        "HMiConeGetPresolve": (None, [vp, ip, ip, ip, ip, ip, ip]),
+        "HMiConeGetDualMatrix": (C.c_int, [vp, dp]),
+        "HMiConeGetTraces": (C.c_int, [vp, dp]),
+        "HMiConeGetPath": (C.c_int, [vp]),
+        "HMiKKTSetHostMirror": (None, [kp, C.c_int]),
+        "HMiConeSetExchange": (None, [vp, vp, vp, vp]),
+        "HMiConeGetExchangeBuffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]),
+        "HMiConeSetExchangeBuffers": (C.c_int, [vp, vp, vp]),
+        "HMiKKTDeviceMatrix": (vp, [kp, C.POINTER(C.c_int64)]),
+        "HMiDeviceInit": (C.c_int, [C.c_int]),
+        "HMiDeviceSynchronize": (C.c_int, []),
+        "HMiStream": (vp, []),
+        "HMiVersion": (C.c_char_p, []),
+        "HMiGetStageTimes": (None, [dp, C.c_int]),
+        "HMiGemmNT": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int64, C.c_int, vp, C.c_int64, C.c_int, C.c_int,
+                                C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]),
+        "HMiPotrf": (C.c_int, [vp, C.c_int, C.c_int64, ip]),
+        "HMiMfmaPeakProbe": (C.c_double, [C.c_int]),
+        "HMiSetKernelTiming": (None, [C.c_int]),
+        "HMiGetKernelTiming": (C.c_int, [dp, dp, C.POINTER(C.c_int64)]),
+    }
+    for name in EXPORTS:
+        fn = getattr(lib, name)  # AttributeError == missing export
+        fn.restype, fn.argtypes = sig[name]
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != RETCODE_OK:
+        raise HDSDPError(f"{what} returned hdsdp_retcode {rc}")
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class SDPCone:
+    """One SDP block living in HBM (the reference's hdsdp_cone with the dense-SDP slots of the Schur path)."""
+
+    def __init__(self, handle, n, m, rank=0, world=1):
+        self._h, self.n, self.m, self.rank, self.world = handle, n, m, rank, world
+
+    @classmethod
+    def from_csc(cls, n, m, beg, idx, val, iCone=0, rank=0, world=1):
+        """CSC of shape n(n+1)/2 x (m+1), column 0 = C (interface/def_hdsdp_user_data.h:16-32)."""
+        lib = load_library()
+        beg = np.ascontiguousarray(beg, dtype=np.int32)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        assert beg.shape[0] == m + 2
+        h = C.c_void_p()
+        _check(lib.HMiConeCreateSDP(C.byref(h), iCone, m, n, _iptr(beg), _iptr(idx), _dptr(val), rank, world),
+               "HMiConeCreateSDP")
+        return cls(h, n, m, rank, world)
+
+    @classmethod
+    def synthetic(cls, n, m, iCone=0, rank=0, world=1):
+        """SURVEY.md 8(d) strictly feasible dense family, generated in HBM."""
+        lib = load_library()
+        h = C.c_void_p()
+        _check(lib.HMiConeCreateSynthetic(C.byref(h), iCone, n, m, rank, world), "HMiConeCreateSynthetic")
+        return cls(h, n, m, rank, world)
+
+    def set_start(self, Rd):
+        load_library().HMiConeSetStart(self._h, float(Rd))
+
+    def check_is_interior(self, tau, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        ok = C.c_int(0)
+        _check(load_library().HMiConeCheckIsInterior(self._h, float(tau), _dptr(y), C.byref(ok)),
+               "HConeCheckIsInterior")
+        return bool(ok.value)
+
+    def log_barrier(self, tau, y=None):
+        out = C.c_double(0.0)
+        yp = None
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float64)
+            yp = _dptr(y)
+        _check(load_library().HMiConeGetLogBarrier(self._h, float(tau), yp, BUFFER_DUALVAR, C.byref(out)),
+               "HConeGetLogBarrier")
+        return out.value
+
+    def presolve(self):
+        m = self.m
+        out = {k: np.zeros(m, dtype=np.int32) for k in ("coef_type", "coef_rank", "coef_nnz", "kkt_perm", "kkt_strategy")}
+        ot = C.c_int(0)
+        load_library().HMiConeGetPresolve(self._h, _iptr(out["coef_type"]), _iptr(out["coef_rank"]),
+                                          _iptr(out["coef_nnz"]), _iptr(out["kkt_perm"]), _iptr(out["kkt_strategy"]),
+                                          C.byref(ot))
+        out["obj_type"] = ot.value
+        return out
+
+    def dual_matrix(self):
+        S = np.zeros((self.n, self.n), dtype=np.float64)  # column-major n x n seen as C-order transposed
+        _check(load_library().HMiConeGetDualMatrix(self._h, _dptr(S)), "HMiConeGetDualMatrix")
+        return S
+
+    def traces(self):
+        t = np.zeros(self.m, dtype=np.float64)
+        _check(load_library().HMiConeGetTraces(self._h, _dptr(t)), "HMiConeGetTraces")
+        return t
+
+    @property
+    def path(self):
+        return load_library().HMiConeGetPath(self._h)
+
+    def destroy(self):
+        if self._h:
+            load_library().HMiConeDestroy(C.byref(self._h))
+            self._h = None
+
+
+class KKT:
+    """hdsdp_kkt: the Schur operator (interface/hdsdp_schur.c)."""
+
+    def __init__(self, m, cones, host_mirror=True):
+        lib = load_library()
+        self.m = m
+        self.cones = list(cones)
+        self._k = C.POINTER(hdsdp_kkt)()
+        _check(lib.HKKTCreate(C.byref(self._k)), "HKKTCreate")
+        self._cone_arr = (C.c_void_p * len(self.cones))(*[c._h for c in self.cones])
+        _check(lib.HKKTInit(self._k, m, len(self.cones), self._cone_arr), "HKKTInit")
+        if not host_mirror:
+            lib.HMiKKTSetHostMirror(self._k, 0)
+
+    def build_up(self, typeKKT=KKT_TYPE_INFEASIBLE):
+        _check(load_library().HKKTBuildUp(self._k, typeKKT), "HKKTBuildUp")
+
+    def build_up_fixed(self, typeKKT, strategy):
+        _check(load_library().HKKTBuildUpFixed(self._k, typeKKT, strategy), "HKKTBuildUpFixed")
+
+    def factorize(self):
+        _check(load_library().HKKTFactorize(self._k), "HKKTFactorize")
+
+    def solve(self, rhs, inplace=False):
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        if inplace:
+            _check(load_library().HKKTSolve(self._k, _dptr(rhs), None), "HKKTSolve")
+            return rhs
+        sol = np.zeros_like(rhs)
+        _check(load_library().HKKTSolve(self._k, _dptr(rhs), _dptr(sol)), "HKKTSolve")
+        return sol
+
+    def regularize(self, reg):
+        load_library().HKKTRegularize(self._k, float(reg))
+
+    def export(self):
+        m = self.m
+        a, r, c = (np.zeros(m) for _ in range(3))
+        s = [C.c_double(0.0) for _ in range(4)]
+        load_library().HKKTExport(self._k, _dptr(a), _dptr(r), _dptr(c), C.byref(s[0]), C.byref(s[1]), C.byref(s[2]),
+                                  C.byref(s[3]))
+        return {"ASinv": a, "ASinvRdSinv": r, "ASinvCSinv": c, "CSinvCSinv": s[0].value, "CSinv": s[1].value,
+                "CSinvRdSinv": s[2].value, "TraceSinv": s[3].value}
+
+    @property
+    def M(self):
+        """kktMatElem as the reference leaves it: m x m column-major, lower triangle valid.
+        Returned in numpy C-order, i.e. M[j, i] is element (row i, col j): valid where i >= j."""
+        k = self._k.contents
+        return np.ctypeslib.as_array(k.kktMatElem, shape=(self.m, self.m))
+
+    def add_to_diag(self, v):
+        """what the y-box cone does through kktDiag[] (interface/hdsdp_conic_bound.c:201-229)"""
+        M = self.M
+        idx = np.arange(self.m)
+        M[idx, idx] += v
+
+    def stage_times_ms(self):
+        t = np.zeros(8)
+        load_library().HMiGetStageTimes(_dptr(t), 8)
+        return t
+
+    def destroy(self):
+        if self._k:
+            load_library().HKKTDestroy(C.byref(self._k))
+            self._k = None
+
+
+class LinSys:
+    """hdsdp_linsys_fp, dense direct backend (linalg/hdsdp_linsolver.c:1044-1286)."""
+
+    def __init__(self, n, ltype=HDSDP_LINSYS_DENSE_DIRECT):
+        self.n = n
+        self._h = C.c_void_p()
+        _check(load_library().HFpLinsysCreate(C.byref(self._h), n, ltype), "HFpLinsysCreate")
+
+    def numeric(self, A):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        _check(load_library().HFpLinsysNumeric(self._h, None, None, _dptr(A)), "HFpLinsysNumeric")
+
+    def psd_check(self, A):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        ok = C.c_int(0)
+        _check(load_library().HFpLinsysPsdCheck(self._h, None, None, _dptr(A), C.byref(ok)), "HFpLinsysPsdCheck")
+        return bool(ok.value)
+
+    def get_diag(self):
+        d = np.zeros(self.n)
+        _check(load_library().HFpLinsysGetDiag(self._h, _dptr(d)), "HFpLinsysGetDiag")
+        return d
+
+    def _rhs(self, rhs):
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        nrhs = 1 if rhs.ndim == 1 else rhs.shape[0]  # C-order (nrhs, n) == column-major n x nrhs
+        return rhs, nrhs
+
+    def solve(self, rhs):
+        rhs, nrhs = self._rhs(rhs)
+        sol = np.zeros_like(rhs)
+        _check(load_library().HFpLinsysSolve(self._h, nrhs, _dptr(rhs), _dptr(sol)), "HFpLinsysSolve")
+        return sol
+
+    def fsolve(self, rhs):
+        rhs, nrhs = self._rhs(rhs)
+        sol = np.zeros_like(rhs)
+        load_library().HFpLinsysFSolve(self._h, nrhs, _dptr(rhs), _dptr(sol))
+        return sol
+
+    def bsolve(self, rhs):
+        rhs, nrhs = self._rhs(rhs)
+        sol = np.zeros_like(rhs)
+        load_library().HFpLinsysBSolve(self._h, nrhs, _dptr(rhs), _dptr(sol))
+        return sol
+
+    def invert(self):
+        out = np.zeros((self.n, self.n))
+        aux = np.zeros(1)
+        load_library().HFpLinsysInvert(self._h, _dptr(out), _dptr(aux))
+        return out
+
+    def destroy(self):
+        if self._h:
+            load_library().HFpLinsysDestroy(C.byref(self._h))
+            self._h = None

@@ -1,0 +1,66 @@
+"""Build the HIP extension (gfx950) and the oracle's C restatement in-tree.
+
+    python -m hdsdp_amd.build            # libhdsdp_mi355x.so  (+ oracle/_build, + oracle/_ref if possible)
+
+hipcc cross-compiles without a GPU.  The built .so files are git-ignored but travel to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libhdsdp_mi355x.so")
+SOURCES = ["gemm_f64.hip", "chol.hip", "schur.hip", "engine.hip", "coeff.cpp"]
+HEADERS = ["hdm_common.h", "chol.h", "schur.h", "coeff.h", os.path.join(ROOT, "include", "hdsdp_mi355x.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=True):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(LIB, srcs + hdrs):
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if not force and not _stale(o, [s] + hdrs):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_oracle(verbose=True):
+    """CPU restatement (always) and, when /root/reference + MKL are present, the real reference."""
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-C", odir, "port"], stdout=None if verbose else subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/interface"):
+        subprocess.call(["make", "-C", odir, "ref"], stdout=None if verbose else subprocess.DEVNULL)
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)
+    build_oracle()

@@ -1,0 +1,26 @@
+// chol.h -- device-resident blocked Cholesky object (see chol.hip)
+#pragma once
+#include "hdm_common.h"
+
+struct HdmChol {
+    int n = 0, npad = 0, nblk = 0;
+    double *L = nullptr;     // npad x npad, column-major; lower triangle = Cholesky factor after factor()
+    double *Linv = nullptr;  // npad x npad, lower triangular inverse (explicit zeros above the diagonal)
+    double *Dinv = nullptr;  // nblk x (128 x 128) inverted diagonal blocks
+    double *Z = nullptr;     // npad x 128 scratch for invert_factor
+    double *vec = nullptr;   // 4 * npad scratch vectors
+    int *info_dev = nullptr;
+    bool factored = false, have_inv = false;
+
+    int init(int n);
+    void destroy();
+    int load_host(const double *A, long lda, hipStream_t s);
+    int load_device(const double *A, long lda, hipStream_t s);
+    int finish_load(hipStream_t s);
+    int factor(hipStream_t s, int *info_host);          // info = 0 ok, j+1 = first non-positive pivot
+    int invert_factor(hipStream_t s);                   // builds Linv (idempotent until the next load)
+    int get_diag(double *diag_host, hipStream_t s);
+    int solve_device(double *b_dev, double *x_dev, int nrhs, long ldv, int which, hipStream_t s);
+    int solve_host(const double *rhs, double *sol, int nrhs, int which, hipStream_t s);
+    int inverse_full(double *out_dev, long ldo, hipStream_t s);
+};

@@ -1,0 +1,330 @@
+// gemm_f64.hip -- fp64 MFMA (v_mfma_f64_16x16x4_f64) tiled GEMM family for gfx950 / MI355X.
+//
+// One kernel template serves every dense contraction on the Schur hot path:
+//   * congruence step 1   T_i  = Linv * A_i                     (K loop cut by the row tile: Linv lower)
+//   * congruence step 2   At_i = lower(T_i * Linv^T)            (K loop cut by the col tile, lower tiles,
+//                                                                16x16-blocked sqrt(2)-weighted output)
+//   * Gram / SYRK         M    = Ahat * Ahat^T  (K ~ n(n+1)/2)  (split-K slabs, lower tiles)
+//   * blocked Cholesky    panel TRSM via inverted diagonal block, trailing SYRK update, TRTRI products
+//
+// These replace the reference's level-1/2 BLAS loops: dspmv x n + ddot x n(n+1)/2 in
+// kkt3sinvAsinv (linalg/hdsdp_sdpdata.c:1184-1223), the packed dot kkt3AdotB (:1304-1328) and
+// dpotrf/dpotri/dtrsm (linalg/hdsdp_linsolver.c:1096,1250,1158).
+//
+// Geometry: 128x128 workgroup tile, 4 waves (2x2) of 64x64, 16 accumulators of 16x16 per wave
+// (128 VGPRs), BK=16 per LDS stage, 2 stages (72 KiB LDS => 2 workgroups/CU).
+// LDS images are padded so every ds_read_b64 fragment read is bank-conflict free:
+//   M-major tile  s[k][i], row stride 144 doubles (1152 B == 128 mod 256)
+//   K-major tile  s[i][k], row stride  18 doubles ( 144 B : 16 lanes hit 16 distinct bank pairs)
+// MFMA operand map (f64 16x16x4): lane l supplies X[x0 + (l&15)][k0 + (l>>4)] for both operands;
+// result lane l, reg r holds D[row=(l>>4)+4r][col=l&15].  We feed the C-row operand (A) as the
+// MFMA "B" input so that D's lane-contiguous index is C's row index => 128-byte contiguous stores.
+#include "hdm_common.h"
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#define LDM 144             // M-major LDS row stride (doubles)
+#define LDK 18              // K-major LDS row stride (doubles)
+#define STAGE_DOUBLES 2304  // 16*144 == 128*18
+
+struct HdmGemmDev {
+    HdmGemmArgs a;
+    const int2 *tiles;
+    int ntiles;
+};
+
+// this thread's 8 doubles of the (128 rows x 16 k) tile at row x0, k block kt
+template <bool KM>
+__device__ __forceinline__ void g2r(const double *__restrict__ X, long ld, long kblk, long seg_rows, long seg_extra,
+                                    int rows, int x0, int kt, int tid, double (&r)[8]) {
+    const double *src;
+    bool ok;
+    if (KM) {
+        int i = tid >> 1, k8 = (tid & 1) * 8;
+        int gi = x0 + i;
+        ok = gi < rows;
+        src = X + (long) kt * kblk + (long) gi * ld + k8;
+        if (seg_rows) src += (gi / seg_rows) * seg_extra;
+    } else {
+        int k = tid >> 4, i8 = (tid & 15) * 8;
+        int gi = x0 + i8;
+        ok = gi < rows;  // rows is a multiple of 8: the chunk is fully in or fully out
+        src = X + ((long) kt * HDM_BK + k) * ld + gi;
+    }
+    if (ok) {
+        const double2 *s2 = reinterpret_cast<const double2 *>(src);
+        double2 v0 = s2[0], v1 = s2[1], v2 = s2[2], v3 = s2[3];
+        r[0] = v0.x; r[1] = v0.y; r[2] = v1.x; r[3] = v1.y;
+        r[4] = v2.x; r[5] = v2.y; r[6] = v3.x; r[7] = v3.y;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = 0.0;
+    }
+}
+
+template <bool KM>
+__device__ __forceinline__ void r2s(double *__restrict__ s, int tid, const double (&r)[8]) {
+    double *dst;
+    if (KM) {
+        int i = tid >> 1, k8 = (tid & 1) * 8;
+        dst = s + i * LDK + k8;
+    } else {
+        int k = tid >> 4, i8 = (tid & 15) * 8;
+        dst = s + k * LDM + i8;
+    }
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    d2[0] = make_double2(r[0], r[1]);
+    d2[1] = make_double2(r[2], r[3]);
+    d2[2] = make_double2(r[4], r[5]);
+    d2[3] = make_double2(r[6], r[7]);
+}
+
+template <bool KM>
+__device__ __forceinline__ double frag(const double *__restrict__ s, int x, int k) {
+    return KM ? s[x * LDK + k] : s[k * LDM + x];
+}
+
+template <bool AKM, bool BKM, int ROLE>
+__global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
+    __shared__ __attribute__((aligned(16))) double smem[4 * STAGE_DOUBLES];
+    double *sA = smem;                      // [2][STAGE]
+    double *sB = smem + 2 * STAGE_DOUBLES;  // [2][STAGE]
+
+    const HdmGemmArgs &a = p.a;
+    // XCD-aware decode: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so the
+    // batch index (one constraint matrix / one K split) is the fast index: with batch % 8 == 0 the
+    // workgroups of one XCD keep to their own batch entries and share operand panels in that L2;
+    // tiles are walked heaviest-first (host-sorted list).
+    const int nb = a.batch;
+    const int wg = blockIdx.x;
+    const int z = wg % nb;
+    const int t = wg / nb;
+    if (t >= p.ntiles) return;
+    const int tm = p.tiles[t].x, tn = p.tiles[t].y;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int m0 = tm * HDM_TILE, n0 = tn * HDM_TILE;
+    long kbeg = 0, kend = a.K;
+    if (a.klimit == HDM_KLIM_BY_M) kend = min((long) a.K, (long) (tm + 1) * HDM_TILE);
+    if (a.klimit == HDM_KLIM_BY_N) kend = min((long) a.K, (long) (tn + 1) * HDM_TILE);
+    const double *A = a.A, *B = a.B;
+    if (a.epilogue == HDM_EPI_SLAB) {
+        kbeg = (long) z * a.k_chunk;
+        kend = min(kend, kbeg + a.k_chunk);
+    } else {
+        A += (long) z * a.strideA;
+        B += (long) z * a.strideB;
+    }
+
+    hdm_d4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
+
+    const int kt0 = (int) (kbeg / HDM_BK), kt1 = (int) (kend / HDM_BK);
+    double ra[8], rb[8];
+    if (kt0 < kt1) {
+        g2r<AKM>(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, m0, kt0, tid, ra);
+        g2r<BKM>(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, n0, kt0, tid, rb);
+        r2s<AKM>(sA, tid, ra);
+        r2s<BKM>(sB, tid, rb);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = (kt + 1 < kt1);
+        if (more) {
+            g2r<AKM>(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, m0, kt + 1, tid, ra);
+            g2r<BKM>(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, n0, kt + 1, tid, rb);
+        }
+        const double *cA = sA + cur * STAGE_DOUBLES;
+        const double *cB = sB + cur * STAGE_DOUBLES;
+#pragma unroll
+        for (int kk = 0; kk < HDM_BK; kk += 4) {
+            double fb[4], fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fb[i] = frag<AKM>(cA, wm * 64 + i * 16 + l15, kk + lq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[j] = frag<BKM>(cB, wn * 64 + j * 16 + l15, kk + lq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
+        }
+        if (more) {
+            r2s<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra);
+            r2s<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // lane l, reg r of acc[j][i] holds C[m0 + wm*64 + i*16 + l15][n0 + wn*64 + j*16 + lq + 4r]
+    if (a.epilogue == HDM_EPI_BLOCKED) {
+        double *dst = a.C;
+        const long row = a.blk_row0 + z;
+        const double rt2 = 1.4142135623730951;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int bi = (m0 + wm * 64 + i * 16) >> 4;
+                const int bj = (n0 + wn * 64 + j * 16) >> 4;
+                if (bi < bj || bi >= a.nblk) continue;  // (bj <= bi < nblk)
+                const double sc = (bi == bj) ? 1.0 : rt2;
+                const long sub = (long) bj * a.nblk - (long) bj * (bj - 1) / 2 + (bi - bj);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long pb = sub * 16 + lq + 4 * r;
+                    dst[(pb * a.blk_row_stride + row) * 16 + l15] = sc * acc[j][i][r];
+                }
+            }
+        }
+        return;
+    }
+    double *C = a.C;
+    if (a.epilogue == HDM_EPI_SLAB) C += (long) z * a.slab_stride;
+    else C += (long) z * a.strideC;
+    const bool diag_tile = a.lower_only && (tm == tn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gi = m0 + wm * 64 + i * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gj = n0 + wn * 64 + j * 16 + lq + 4 * r;
+                if (gi < a.M && gj < a.N && !(diag_tile && gi < gj)) {
+                    double *c = C + gi + (long) gj * a.ldc;
+                    double v = a.alpha * acc[j][i][r];
+                    if (a.beta != 0.0) v += a.beta * (*c);
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: tile lists (heaviest first) cached in device memory
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct TimedLaunch { hipEvent_t e0, e1; int role; double flops; };
+bool g_timing = false;
+std::vector<TimedLaunch> g_timed;
+struct TileList {
+    int2 *dev = nullptr;
+    int n = 0;
+};
+std::mutex g_tl_mutex;
+std::map<std::tuple<int, int, int, int, int>, TileList> g_tl_cache;
+
+int get_tiles(int MT, int NT, int klimit, int lower_only, TileList &out) {
+    int dev = 0;
+    HDM_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_tl_mutex);
+    auto key = std::make_tuple(dev, MT, NT, klimit, lower_only);
+    auto it = g_tl_cache.find(key);
+    if (it != g_tl_cache.end()) {
+        out = it->second;
+        return 0;
+    }
+    std::vector<std::pair<long, int2>> v;
+    for (int tm = 0; tm < MT; ++tm)
+        for (int tn = 0; tn < NT; ++tn) {
+            if (lower_only && tm < tn) continue;
+            long w = 1;
+            if (klimit == HDM_KLIM_BY_M) w = tm + 1;
+            if (klimit == HDM_KLIM_BY_N) w = tn + 1;
+            v.push_back({w, make_int2(tm, tn)});
+        }
+    std::stable_sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
+    std::vector<int2> h(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h[i] = v[i].second;
+    TileList tl;
+    tl.n = (int) h.size();
+    HDM_HIP_CHECK(hipMalloc((void **) &tl.dev, sizeof(int2) * std::max<size_t>(1, h.size())));
+    HDM_HIP_CHECK(hdm_memcpy_h2d_sync(tl.dev, h.data(), sizeof(int2) * h.size()));
+    g_tl_cache[key] = tl;
+    out = tl;
+    return 0;
+}
+}  // namespace
+
+int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
+    if (args.M <= 0 || args.N <= 0 || args.batch <= 0) return 0;
+    if ((args.M % 8) || (args.N % 8) || (args.K % HDM_BK)) {
+        fprintf(stderr, "[hdsdp_mi355x] gemm: M,N must be multiples of 8 and K of 16 (M=%d N=%d K=%d)\n",
+                args.M, args.N, args.K);
+        return 1;
+    }
+    if (args.epilogue == HDM_EPI_SLAB && (args.k_chunk <= 0 || args.k_chunk % HDM_BK)) {
+        fprintf(stderr, "[hdsdp_mi355x] gemm: bad k_chunk\n");
+        return 1;
+    }
+    const int MT = (args.M + HDM_TILE - 1) / HDM_TILE, NT = (args.N + HDM_TILE - 1) / HDM_TILE;
+    TileList tl;
+    if (get_tiles(MT, NT, args.klimit, args.lower_only, tl)) return 1;
+    HdmGemmDev d;
+    d.a = args;
+    if (d.a.a_kblk == 0) d.a.a_kblk = HDM_BK;
+    if (d.a.b_kblk == 0) d.a.b_kblk = HDM_BK;
+    d.tiles = tl.dev;
+    d.ntiles = tl.n;
+    const long nwg = (long) tl.n * args.batch;
+    dim3 grid((unsigned) nwg), block(256);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_timing) {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+        HDM_HIP_CHECK(hipEventRecord(e0, stream));
+    }
+    const int lay = (args.a_kmajor ? 2 : 0) | (args.b_kmajor ? 1 : 0);
+#define HDM_LAUNCH(AK, BK, R) hipLaunchKernelGGL((hdm_gemm_kernel<AK, BK, R>), grid, block, 0, stream, d)
+    switch (args.role) {
+        case HDM_ROLE_CONG1: HDM_LAUNCH(false, false, HDM_ROLE_CONG1); break;  // T = Linv * A
+        case HDM_ROLE_CONG2: HDM_LAUNCH(false, false, HDM_ROLE_CONG2); break;  // At = T * Linv^T
+        case HDM_ROLE_GRAM: HDM_LAUNCH(true, true, HDM_ROLE_GRAM); break;      // M = Ahat Ahat^T
+        default:
+            if (lay == 3) HDM_LAUNCH(true, true, HDM_ROLE_GENERIC);
+            else if (lay == 2) HDM_LAUNCH(true, false, HDM_ROLE_GENERIC);
+            else if (lay == 1) HDM_LAUNCH(false, true, HDM_ROLE_GENERIC);
+            else HDM_LAUNCH(false, false, HDM_ROLE_GENERIC);
+    }
+#undef HDM_LAUNCH
+    if (g_timing) {
+        HDM_HIP_CHECK(hipEventRecord(e1, stream));
+        std::lock_guard<std::mutex> lk(g_tl_mutex);
+        g_timed.push_back({e0, e1, args.role, args.flops});
+    }
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+void hdm_timing_enable(int on) { g_timing = (on != 0); }
+
+int hdm_timing_collect(double *ms, double *flops, long *launches) {
+    for (int r = 0; r < HDM_NROLES; ++r) { ms[r] = 0.0; flops[r] = 0.0; launches[r] = 0; }
+    std::lock_guard<std::mutex> lk(g_tl_mutex);
+    for (auto &t : g_timed) {
+        float e = 0.f;
+        HDM_HIP_CHECK(hipEventSynchronize(t.e1));
+        HDM_HIP_CHECK(hipEventElapsedTime(&e, t.e0, t.e1));
+        const int r = (t.role >= 0 && t.role < HDM_NROLES) ? t.role : 0;
+        ms[r] += e; flops[r] += t.flops; launches[r] += 1;
+        (void) hipEventDestroy(t.e0);
+        (void) hipEventDestroy(t.e1);
+    }
+    g_timed.clear();
+    return 0;
+}

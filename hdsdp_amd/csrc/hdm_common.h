@@ -1,0 +1,89 @@
+// hdm_common.h -- shared declarations for the MI355X (gfx950) HDSDP Schur engine.
+// Internal header (C++/HIP). The public C ABI lives in include/hdsdp_mi355x.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define HDM_TILE 128          // workgroup tile edge of the fp64 MFMA GEMM family
+#define HDM_BK 16             // k-depth of one LDS stage
+#define HDM_SUB 16            // MFMA sub-tile edge (v_mfma_f64_16x16x4_f64)
+
+typedef double hdm_d4 __attribute__((ext_vector_type(4)));
+
+#define HDM_HIP_CHECK(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            fprintf(stderr, "[hdsdp_mi355x] HIP error %s at %s:%d: %s\n", hipGetErrorName(_e),  \
+                    __FILE__, __LINE__, hipGetErrorString(_e));                                 \
+            return 1;                                                                           \
+        }                                                                                       \
+    } while (0)
+
+// hipMemset on the legacy stream may still be in flight when work is queued on the engine's non-blocking
+// stream: always drain it before anyone else touches the buffer.
+static inline hipError_t hdm_memset_sync(void *p, int v, size_t bytes) {
+    hipError_t e = hipMemset(p, v, bytes);
+    if (e != hipSuccess) return e;
+    return hipDeviceSynchronize();
+}
+
+static inline hipError_t hdm_memcpy_h2d_sync(void *dst, const void *src, size_t bytes) {
+    hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    return hipDeviceSynchronize();
+}
+
+static inline long hdm_roundup(long x, long q) { return (x + q - 1) / q * q; }
+
+// ---------------------------------------------------------------------------------------------
+// GEMM family (gemm_f64.hip).  Everything is column-major fp64.
+//   C[M x N] = alpha * A[M x K] * B[N x K]^T + beta * C
+// Operand storage is selected per operand:
+//   M-major ("N"): element (i,k) at X[i + k*ld]  (rows contiguous: a column-major M x K matrix)
+//   K-major ("T"): element (i,k) at X[i*ld + k]  (k contiguous: the transpose is column-major)
+// ---------------------------------------------------------------------------------------------
+enum HdmKLimit { HDM_KLIM_NONE = 0, HDM_KLIM_BY_M = 1, HDM_KLIM_BY_N = 2 };
+enum HdmEpilogue {
+    HDM_EPI_STORE = 0,    // C = alpha*acc + beta*C, column-major
+    HDM_EPI_BLOCKED = 1,  // congruence output: 16x16-blocked lower triangle, sqrt(2) off-diagonal blocks
+    HDM_EPI_SLAB = 2      // split-K partial sums into slab[blockIdx.z]
+};
+
+// kernel roles: a distinct kernel symbol per role so that rocprofv3 --stats separates the hot-path
+// launches (congruence step 1/2, Gram) from the small Cholesky/TRTRI helper GEMMs
+enum HdmRole { HDM_ROLE_GENERIC = 0, HDM_ROLE_CONG1 = 1, HDM_ROLE_CONG2 = 2, HDM_ROLE_GRAM = 3, HDM_NROLES = 4 };
+
+struct HdmGemmArgs {
+    const double *A, *B;
+    double *C;
+    long lda, ldb, ldc;
+    long strideA, strideB, strideC;  // batch strides (elements) along blockIdx.z (batch) -- 0 = shared
+    int M, N, K;
+    int a_kmajor, b_kmajor;
+    long a_kblk, b_kblk;  // K-major operands: elements between consecutive 16-deep k blocks (16 for a plain matrix)
+    // K-major operands may be cut into row segments (one per source rank after the multi-GPU transpose):
+    // element offset += (row / seg_rows) * seg_extra.  seg_rows == 0: one segment.
+    long seg_rows, seg_extra;
+    int klimit;       // HdmKLimit: triangular operand => shorter K loop for early tiles
+    int lower_only;   // only tiles with tile_m >= tile_n are computed (C symmetric / lower)
+    int epilogue;     // HdmEpilogue
+    int batch;        // number of batch entries (grid z for STORE/BLOCKED), or #K-splits for SLAB
+    double alpha, beta;
+    int role;         // HdmRole
+    double flops;     // algorithmic flops of this launch (valid data only), for the live roofline
+    // BLOCKED epilogue: destination chunk layout  dst[((blk*16 + c_local) * rowStride + row) * 16 + r_local]
+    long blk_row_stride;  // = m_pad (number of constraint rows per 16-wide p-block)
+    long blk_row0;        // constraint row of batch entry 0
+    int nblk;             // n/16: sub-blocks per matrix edge
+    // SLAB epilogue / split-K
+    long k_chunk;         // K range per split (multiple of HDM_BK)
+    long slab_stride;     // elements between slabs
+};
+
+int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream);
+// per-role live timing with HIP events on the launch stream (off by default)
+void hdm_timing_enable(int on);
+int hdm_timing_collect(double *ms, double *flops, long *launches);  // arrays of HDM_NROLES; resets

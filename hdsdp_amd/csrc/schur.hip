@@ -1,0 +1,326 @@
+// schur.hip -- data-movement and reduction kernels of the Schur build (all HBM-bound).
+//
+//   * hdm_unpack_sym_kernel     packed lower (reference DENSE layout, def_hdsdp_sdpdata.h:107-113,
+//                               PACK_IDX hdsdp_utils.h:49-53) -> full symmetric column-major, via an
+//                               LDS tile transpose so both triangles are written coalesced
+//   * hdm_synth_kernel          SURVEY.md 8(d) splitmix64 generator evaluated counter-based on device
+//   * hdm_blocked_eye_kernel    identity in the 16x16-blocked congruence layout (the "S row")
+//   * hdm_slab_reduce_kernel    split-K slab reduction of the Gram GEMM (deterministic order)
+//   * hdm_extract_kernel        scatter Gram rows/cols into M, ASinv, ASinvRdSinv, ASinvCSinv, scalars
+//   * hdm_sym_combine_kernel    S = tau*C - sum_i y_i A_i - Rd*I  (hdsdp_conic_sdp.c:343-402), lower part
+//   * hdm_r1_* kernels          rank-one (M2) path: M_ij = s_i s_j (a_i' S^-1 a_j)^2
+//                               (hdsdp_conic_sdp.c:687-778, hdsdp_sdpdata.c:1003-1118)
+#include "hdm_common.h"
+#include "schur.h"
+
+// ------------------------------------------------------------------------------------------
+// symmetric tile writer: a 32x32 lower tile source -> dst (full symmetric)
+// ------------------------------------------------------------------------------------------
+struct PackedSrc {
+    const double *p;  // packed lower, column-major
+    int n;
+    __device__ double operator()(int i, int j) const {  // i >= j, both < n
+        return p[(long) (2 * n - j - 1) * j / 2 + i];
+    }
+};
+
+__device__ __forceinline__ double hdm_splitmix_u(uint64_t t) {
+    // draw number t (0-based) of the SURVEY 8(d) stream: state s0 + (t+1)*gamma
+    const uint64_t g = 0x9E3779B97F4A7C15ULL;
+    uint64_t z = g + (t + 1) * g;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return 2.0 * ((double) (z >> 11) / 9007199254740992.0) - 1.0;
+}
+
+struct SynthSrc {
+    uint64_t base;  // 2 * c * P
+    int n;
+    __device__ double operator()(int i, int j) const {
+        uint64_t k = (uint64_t) ((long) (2 * n - j - 1) * j / 2 + i);
+        double v = hdm_splitmix_u(base + 2 * k);
+        double w = hdm_splitmix_u(base + 2 * k + 1);
+        return (i == j || w >= 0.2) ? v : 0.0;
+    }
+};
+
+template <class Src>
+__device__ __forceinline__ void write_sym_tile(const Src &src, double *__restrict__ dst, long ld, int n, int ti, int tj) {
+    // workgroup = 32 x 8 threads; tile (ti >= tj) of 32x32
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int jj = ty; jj < 32; jj += 8) {
+        int i = ti * 32 + tx, j = tj * 32 + jj;
+        double v = 0.0;
+        if (i < n && j < n) v = (i >= j) ? src(i, j) : src(j, i);
+        tile[jj][tx] = v;
+        if (i < ld && j < ld) dst[i + (long) j * ld] = v;
+    }
+    if (ti == tj) return;
+    __syncthreads();
+    for (int jj = ty; jj < 32; jj += 8) {
+        // transposed tile: element (row = tj*32 + tx, col = ti*32 + jj) = tile[tx][jj]
+        int i = tj * 32 + tx, j = ti * 32 + jj;
+        if (i < ld && j < ld) dst[i + (long) j * ld] = tile[tx][jj];
+    }
+}
+
+__global__ __launch_bounds__(256) void hdm_unpack_sym_kernel(const double *__restrict__ packed, long pstride,
+                                                              double *__restrict__ full, long fstride, int n, int ld,
+                                                              int nt) {
+    // grid.x = nt*(nt+1)/2 lower tiles, grid.y = matrix in batch
+    int t = blockIdx.x;
+    int tj = 0;
+    while (t >= nt - tj) { t -= nt - tj; ++tj; }
+    int ti = tj + t;
+    PackedSrc s{packed + (long) blockIdx.y * pstride, n};
+    write_sym_tile(s, full + (long) blockIdx.y * fstride, (long) ld, n, ti, tj);
+}
+
+__global__ __launch_bounds__(256) void hdm_synth_kernel(double *__restrict__ full, long fstride, int n, int ld, int nt,
+                                                         int c0) {
+    int t = blockIdx.x;
+    int tj = 0;
+    while (t >= nt - tj) { t -= nt - tj; ++tj; }
+    int ti = tj + t;
+    const uint64_t P = (uint64_t) n * (n + 1) / 2;
+    SynthSrc s{2 * (uint64_t) (c0 + blockIdx.y) * P, n};
+    write_sym_tile(s, full + (long) blockIdx.y * fstride, (long) ld, n, ti, tj);
+}
+
+// C = I + sum_c y0_c A_c accumulated sequentially in c (SURVEY 8(d) step iii), full symmetric output
+__global__ void hdm_synth_obj_kernel(double *__restrict__ C, int n, int ld, int m) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long) n * n) return;
+    int i = (int) (e % n), j = (int) (e / n);
+    if (i < j) return;
+    const uint64_t P = (uint64_t) n * (n + 1) / 2;
+    uint64_t k = (uint64_t) ((long) (2 * n - j - 1) * j / 2 + i);
+    double acc = (i == j) ? 1.0 : 0.0;
+    for (int c = 0; c < m; ++c) {
+        uint64_t base = 2 * (uint64_t) c * P;
+        double v = hdm_splitmix_u(base + 2 * k);
+        double w = hdm_splitmix_u(base + 2 * k + 1);
+        double a = (i == j || w >= 0.2) ? v : 0.0;
+        double y0 = hdm_splitmix_u(2 * (uint64_t) m * P + c);
+        acc += y0 * a;
+    }
+    C[i + (long) j * ld] = acc;
+    C[j + (long) i * ld] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void hdm_blocked_eye_kernel(double *__restrict__ dst, long row_stride, long row, int nblk, int n) {
+    // diagonal sub-blocks (bj == bi) of the "S row": At = L^-1 S L^-T = I (zero in the padding)
+    int b = blockIdx.x;  // sub-block index along the diagonal
+    int c = threadIdx.x >> 4, r = threadIdx.x & 15;
+    long sub = (long) b * nblk - (long) b * (b - 1) / 2;
+    long pb = sub * 16 + c;
+    int g = b * 16 + c;
+    dst[(pb * row_stride + row) * 16 + r] = (r == c && g < n) ? 1.0 : 0.0;
+}
+
+__global__ void hdm_slab_reduce_kernel(const double *__restrict__ slabs, long slab_stride, int nsplit,
+                                       double *__restrict__ out, long total) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += slabs[(long) k * slab_stride + e];
+    out[e] = s;
+}
+
+// G is the (R x R) augmented Gram matrix in segment order (lower valid, ld = ldg).  rows_seg maps a
+// segment-ordered row to its global constraint (-1 padding, <= -2 augmented).  The augmented rows sit in
+// segment 0 at pI ("I row": At = Linv Linv^T), pI+1 ("S row": At = I), pI+2 ("C row").
+__device__ __forceinline__ double hdm_gsym(const double *__restrict__ G, long ldg, long a, long p) {
+    return a >= p ? G[a + p * ldg] : G[p + a * ldg];
+}
+__global__ void hdm_extract_kernel(const double *__restrict__ G, long ldg, long R, long pI,
+                                   const int *__restrict__ rows_seg, double *__restrict__ M, long ldm,
+                                   double *__restrict__ asinv, double *__restrict__ asinvrd,
+                                   double *__restrict__ asinvc, double *__restrict__ scal, double Rd, int hsd) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < R * R) {
+        long a = e % R, b = e / R;
+        if (a >= b) {
+            int ga = rows_seg[a], gb = rows_seg[b];
+            if (ga >= 0 && gb >= 0) {
+                int r = ga > gb ? ga : gb, c = ga > gb ? gb : ga;
+                M[r + (long) c * ldm] += G[a + b * ldg];
+            }
+        }
+    }
+    if (e < R) {
+        int ga = rows_seg[e];
+        if (ga >= 0) {
+            asinvrd[ga] += Rd * hdm_gsym(G, ldg, e, pI);
+            asinv[ga] += hdm_gsym(G, ldg, e, pI + 1);
+            if (hsd) asinvc[ga] += hdm_gsym(G, ldg, e, pI + 2);
+        }
+    }
+    if (e == 0) {
+        // scal: [0] TraceSinv [1] CSinv [2] CSinvCSinv [3] CSinvRdSinv
+        if (Rd != 0.0) scal[0] += G[pI + 1 + pI * ldg];
+        if (hsd) {
+            scal[1] += G[pI + 2 + (pI + 1) * ldg];
+            scal[2] += G[pI + 2 + (pI + 2) * ldg];
+            scal[3] += Rd * G[pI + 2 + pI * ldg];
+        }
+    }
+}
+
+// S(lower incl. diag, full column-major n x n with ld) = tau*C - sum_i y_i A_i + eye*I
+__global__ void hdm_sym_combine_kernel(const double *__restrict__ A, long astride, int m,
+                                       const double *__restrict__ y, const double *__restrict__ C, double tau,
+                                       double eye, double *__restrict__ S, int n, long lda, long lds_) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long) n * n) return;
+    int i = (int) (e % n), j = (int) (e / n);
+    if (i < j) return;
+    long off = i + (long) j * lda;
+    double acc = tau * C[off];
+    for (int c = 0; c < m; ++c) acc -= y[c] * A[(long) c * astride + off];
+    if (i == j) acc += eye;
+    S[i + (long) j * lds_] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// rank-one (M2) path.  U = Linv * [a_1 .. a_m] (n x m), Gm = U^T U  =>  Gm_ij = a_i' S^-1 a_j
+//   M_ij = s_i s_j Gm_ij^2 ; ASinv_i = s_i Gm_ii ; ASinvRdSinv_i = Rd s_i |S^-1 a_i|^2 = Rd s_i |Linv^T u_i|^2
+// ------------------------------------------------------------------------------------------
+__global__ void hdm_r1_hadamard_kernel(const double *__restrict__ Gm, long ldg, const double *__restrict__ sgn,
+                                       const int *__restrict__ rows_global, int mloc, double *__restrict__ M, long ldm,
+                                       double *__restrict__ asinv) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long) mloc * mloc) return;
+    int i = (int) (e % mloc), j = (int) (e / mloc);
+    if (i < j) return;
+    double g = Gm[i + (long) j * ldg];
+    int gi = rows_global[i], gj = rows_global[j];
+    int r = gi > gj ? gi : gj, c = gi > gj ? gj : gi;
+    M[r + (long) c * ldm] += sgn[i] * sgn[j] * g * g;
+    if (i == j) asinv[gi] += sgn[i] * g;
+}
+
+__global__ void hdm_r1_colnorm_kernel(const double *__restrict__ V, long ldv, int n, const double *__restrict__ sgn,
+                                      const int *__restrict__ rows_global, int mloc, double Rd,
+                                      double *__restrict__ asinvrd) {
+    // one wave per column
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int c = blockIdx.x * 4 + wave;
+    if (c >= mloc) return;
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) { double v = V[i + (long) c * ldv]; s += v * v; }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) asinvrd[rows_global[c]] += Rd * sgn[c] * s;
+}
+
+// <A_i, X> for full symmetric A_i, X (both n x n, ld): one workgroup per constraint (corrector, M5 traces)
+__global__ __launch_bounds__(256) void hdm_sym_dot2_kernel(const double *__restrict__ A, long astride, int n, long lda,
+                                                            const double *__restrict__ X, const double *__restrict__ Y,
+                                                            long ldx, double *__restrict__ outx,
+                                                            double *__restrict__ outy, const int *__restrict__ rows_global,
+                                                            double sx, double sy) {
+    __shared__ double red[2][4];
+    const double *Ai = A + (long) blockIdx.x * astride;
+    double ax = 0.0, ay = 0.0;
+    for (long e = threadIdx.x; e < (long) n * n; e += 256) {
+        int i = (int) (e % n), j = (int) (e / n);
+        double a = Ai[i + (long) j * lda];
+        ax += a * X[i + (long) j * ldx];
+        if (Y) ay += a * Y[i + (long) j * ldx];
+    }
+    for (int off = 32; off > 0; off >>= 1) { ax += __shfl_down(ax, off, 64); ay += __shfl_down(ay, off, 64); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = ax; red[1][wave] = ay; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int gi = rows_global[blockIdx.x];
+        outx[gi] += sx * (red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        if (Y) outy[gi] += sy * (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------
+int hdm_unpack_sym(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s) {
+    int nt = (ld + 31) / 32;
+    dim3 grid(nt * (nt + 1) / 2, batch), block(32, 8);
+    hipLaunchKernelGGL(hdm_unpack_sym_kernel, grid, block, 0, s, packed, pstride, full, fstride, n, ld, nt);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_synth_fill(double *full, long fstride, int n, int ld, int c0, int batch, hipStream_t s) {
+    int nt = (ld + 31) / 32;
+    dim3 grid(nt * (nt + 1) / 2, batch), block(32, 8);
+    hipLaunchKernelGGL(hdm_synth_kernel, grid, block, 0, s, full, fstride, n, ld, nt, c0);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_synth_obj(double *C, int n, int ld, int m, hipStream_t s) {
+    long tot = (long) n * n;
+    hipLaunchKernelGGL(hdm_synth_obj_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, C, n, ld, m);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_blocked_eye(double *dst, long row_stride, long row, int nblk, int n, hipStream_t s) {
+    hipLaunchKernelGGL(hdm_blocked_eye_kernel, dim3(nblk), dim3(256), 0, s, dst, row_stride, row, nblk, n);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_slab_reduce(const double *slabs, long slab_stride, int nsplit, double *out, long total, hipStream_t s) {
+    hipLaunchKernelGGL(hdm_slab_reduce_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, slabs,
+                       slab_stride, nsplit, out, total);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_extract(const double *G, long ldg, long R, long pI, const int *rows_seg, double *M, long ldm, double *asinv,
+                double *asinvrd, double *asinvc, double *scal, double Rd, int hsd, hipStream_t s) {
+    long tot = R * R;
+    hipLaunchKernelGGL(hdm_extract_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, G, ldg, R, pI,
+                       rows_seg, M, ldm, asinv, asinvrd, asinvc, scal, Rd, hsd);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_sym_combine(const double *A, long astride, int m, const double *y, const double *C, double tau, double eye,
+                    double *S, int n, long lda, long lds_, hipStream_t s) {
+    long tot = (long) n * n;
+    hipLaunchKernelGGL(hdm_sym_combine_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, A, astride, m, y,
+                       C, tau, eye, S, n, lda, lds_);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_r1_hadamard(const double *Gm, long ldg, const double *sgn, const int *rows_global, int mloc, double *M,
+                    long ldm, double *asinv, hipStream_t s) {
+    long tot = (long) mloc * mloc;
+    hipLaunchKernelGGL(hdm_r1_hadamard_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, Gm, ldg, sgn,
+                       rows_global, mloc, M, ldm, asinv);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_r1_colnorm(const double *V, long ldv, int n, const double *sgn, const int *rows_global, int mloc, double Rd,
+                   double *asinvrd, hipStream_t s) {
+    hipLaunchKernelGGL(hdm_r1_colnorm_kernel, dim3((mloc + 3) / 4), dim3(256), 0, s, V, ldv, n, sgn, rows_global, mloc,
+                       Rd, asinvrd);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_sym_dot2(const double *A, long astride, int n, long lda, int count, const double *X, const double *Y, long ldx,
+                 double *outx, double *outy, const int *rows_global, double sx, double sy, hipStream_t s) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(hdm_sym_dot2_kernel, dim3(count), dim3(256), 0, s, A, astride, n, lda, X, Y, ldx, outx, outy,
+                       rows_global, sx, sy);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,257 @@
+/* hdsdp_mi355x.h -- C ABI of the MI355X-native Schur-complement / Cholesky engine for HDSDP.
+ *
+ * Drop-in boundary: this library exports the reference's own operator surface for the hot path,
+ *   HKKT*      (interface/hdsdp_schur.h:10-22)      -- Schur operator
+ *   HFpLinsys* (linalg/hdsdp_linsolver.h:16-28)     -- dense factor / solve operator
+ * with binary-compatible structs (hdsdp_kkt: interface/def_hdsdp_schur.h:32-68; hdsdp_linsys_fp:
+ * linalg/def_hdsdp_linsolver.h:40-63; hdsdp_cone: interface/def_hdsdp_conic.h:56-107), so that
+ * interface/hdsdp_algo.c keeps calling HKKTBuildUp / HKKTFactorize / HKKTSolve unchanged.
+ * Return codes and error behaviour follow interface/hdsdp.h:42-48 and hdsdp_utils.h:32-45
+ * ("not PSD" is a value, not an error: linalg/hdsdp_linsolver.c:1133-1140).
+ *
+ * The per-cone plug point is the reference's `coneBuildSchur` vtable slot
+ * (def_hdsdp_conic.h:80-81, wired at interface/hdsdp_conic.c:140-141): HKKTBuildUp calls
+ * cone->coneBuildSchur(cone->coneData, cone->iCone, kkt, typeKKT) exactly as
+ * HConeBuildSchurComplement does (interface/hdsdp_conic.c:308-328).  HMiCone* below creates a cone
+ * whose slot is the GPU builder (replacing sdpDenseConeGetKKT, hdsdp_conic_sdp.c:1726-1812).
+ *
+ * Plain C: pointers + sizes only.  All exported calls are synchronous on return for host-visible
+ * outputs.  One solver instance per process/GPU (as the reference: single-threaded caller).
+ */
+#ifndef HDSDP_MI355X_H
+#define HDSDP_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- interface/hdsdp.h:42-48 ---- */
+typedef enum { HDSDP_RETCODE_OK, HDSDP_RETCODE_FAILED, HDSDP_RETCODE_MEMORY } hdsdp_retcode;
+
+/* ---- interface/hdsdp_conic.h:16-19 ---- */
+#define KKT_TYPE_INFEASIBLE  (0)
+#define KKT_TYPE_CORRECTOR   (1)
+#define KKT_TYPE_HOMOGENEOUS (2)
+#define KKT_TYPE_PRIMAL      (3)
+
+/* ---- interface/def_hdsdp_schur.h:26-30 ---- */
+#define KKT_M1 (0)
+#define KKT_M2 (1)
+#define KKT_M3 (2)
+#define KKT_M4 (3)
+#define KKT_M5 (4)
+
+/* ---- linalg/def_hdsdp_linsolver.h:26-38 ---- */
+typedef enum {
+    HDSDP_LINSYS_DENSE_DIRECT,
+    HDSDP_LINSYS_SMALL_DIRECT,
+    HDSDP_LINSYS_SPARSE_DIRECT,
+    HDSDP_LINSYS_SPARSE_INDEFINITE,
+    HDSDP_LINSYS_SPARSE_ITERATIVE,
+    HDSDP_LINSYS_DENSE_ITERATIVE,
+    HDSDP_LINSYS_DENSE_INDEFINITE
+} linsys_type;
+
+/* ---- linalg/def_hdsdp_linsolver.h:40-63 (field order is ABI) ---- */
+typedef struct {
+    int nCol;
+    void *chol;
+    linsys_type LinType;
+    hdsdp_retcode (*cholCreate)(void **, int);
+    void (*cholSetParam)(void *, void *);
+    hdsdp_retcode (*cholSymbolic)(void *, int *, int *);
+    hdsdp_retcode (*cholNumeric)(void *, int *, int *, double *);
+    hdsdp_retcode (*cholPsdCheck)(void *, int *, int *, double *, int *);
+    void (*cholFSolve)(void *, int, double *, double *);
+    void (*cholBSolve)(void *, int, double *, double *);
+    hdsdp_retcode (*cholSolve)(void *, int, double *, double *);
+    hdsdp_retcode (*cholGetDiag)(void *, double *);
+    void (*cholInvert)(void *, double *, double *);
+    void (*cholDestroy)(void **);
+    int nSolves;
+    int nFactorizes;
+} hdsdp_linsys_fp;
+
+/* ---- interface/def_hdsdp_conic.h:21-31, :56-107 (field order is ABI) ---- */
+typedef enum {
+    HDSDP_CONETYPE_UNKNOWN,
+    HDSDP_CONETYPE_LP,
+    HDSDP_CONETYPE_BOUND,
+    HDSDP_CONETYPE_SCALAR_BOUND,
+    HDSDP_CONETYPE_DENSE_SDP,
+    HDSDP_CONETYPE_SPARSE_SDP,
+    HDSDP_CONETYPE_SOCP
+} cone_type;
+
+typedef struct {
+    int iCone;
+    cone_type cone;
+    void *usrData;
+    void *coneData;
+    hdsdp_retcode (*coneCreate)(void **);
+    hdsdp_retcode (*coneProcData)(void *, int, int, int *, int *, double *);
+    hdsdp_retcode (*conePresolveData)(void *);
+    void (*coneDestroyData)(void **);
+    void (*coneSetStart)(void *, double);
+    void (*coneUpdate)(void *, double, double *);
+    hdsdp_retcode (*coneRatioTest)(void *, double, double *, double, int, double *);
+    int64_t (*coneGetSymNnz)(void *);
+    int (*coneGetDim)(void *);
+    void (*coneAddSymNz)(void *, int, int *);
+    void (*coneGetKKTMap)(void *, int, int *);
+    hdsdp_retcode (*coneBuildSchur)(void *, int, void *, int);
+    hdsdp_retcode (*coneBuildSchurFixed)(void *, int, void *, int, int);
+    void (*coneBuildPrimalDirection)(void *, void *, double *, double *, int);
+    hdsdp_retcode (*coneInteriorCheck)(void *, double, double *, int *);
+    hdsdp_retcode (*coneInteriorCheckExpert)(void *, double, double, double *, double, int, int *);
+    hdsdp_retcode (*coneGetBarrier)(void *, double, double *, int, double *);
+    hdsdp_retcode (*coneAxpyBufferAndCheck)(void *, double, int, int *);
+    void (*coneReduceResi)(void *, double);
+    void (*coneSetPerturb)(void *, double);
+    void (*conePRecover)(void *, double, double *, double *, double *, double *);
+    void (*coneDRecover)(void *, double *, double *);
+    void (*coneATimesXpy)(void *, double *, double *);
+    double (*coneTraceCX)(void *, double *);
+    double (*coneXDotS)(void *, double *);
+    double (*coneGetCoeffNorm)(void *, int);
+    double (*coneGetObjNorm)(void *, int);
+    void (*coneScal)(void *, double);
+    void (*coneView)(void *);
+    void (*getstat)(void *, double *, int[20], double[20]);
+} hdsdp_cone;
+
+/* ---- interface/def_hdsdp_schur.h:32-68 (field order is ABI) ---- */
+typedef struct {
+    int nRow;
+    int nCones;
+    int maxConeDim;
+    hdsdp_cone **cones;
+    int isKKTSparse;
+    hdsdp_linsys_fp *kktM;
+    double *invBuffer;
+    double *kktBuffer;
+    double *kktBuffer2;
+    int *kktMatBeg;
+    int *kktMatIdx;
+    double *kktMatElem;
+    double **kktDiag;
+    double *dASinvVec;
+    double *dASinvCSinvVec;
+    double *dASinvRdSinvVec;
+    double dCSinvCSinv;
+    double dCSinvRdSinv;
+    double dCSinv;
+    double dTraceSinv;
+    double **dPrimalX;
+} hdsdp_kkt;
+
+/* =====================  Schur operator: interface/hdsdp_schur.h:10-22  ===================== */
+hdsdp_retcode HKKTCreate(hdsdp_kkt **pHKKT);                                              /* hdsdp_schur.c:167 */
+hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones);        /* :181 */
+hdsdp_retcode HKKTBuildUp(hdsdp_kkt *HKKT, int typeKKT);                                  /* :256 */
+hdsdp_retcode HKKTBuildUpExtraCone(hdsdp_kkt *HKKT, hdsdp_cone *cone, int typeKKT);       /* :270 */
+hdsdp_retcode HKKTBuildUpFixed(hdsdp_kkt *HKKT, int typeKKT, int kktStrategy);            /* :279 */
+void HKKTExport(hdsdp_kkt *HKKT, double *dKKTASinvVec, double *dKKTASinvRdSinvVec, double *dKKTASinvCSinvVec,
+                double *dCSinvCSinv, double *dCSinv, double *dCSinvRdCSinv, double *dTraceSinv); /* :293 */
+hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT);                                             /* :328 */
+hdsdp_retcode HKKTSolve(hdsdp_kkt *HKKT, double *dRhsVec, double *dLhsVec);               /* :338 */
+void HKKTRegularize(hdsdp_kkt *HKKT, double dKKTReg);                                     /* :348 */
+void HKKTRegisterPSDP(hdsdp_kkt *HKKT, double **dPrimalScalX);                            /* :375 */
+void HKKTClear(hdsdp_kkt *HKKT);                                                          /* :382 */
+void HKKTDestroy(hdsdp_kkt **pHKKT);                                                      /* :408 */
+
+/* ==================  linear-system operator: linalg/hdsdp_linsolver.h:16-28  ================ */
+hdsdp_retcode HFpLinsysCreate(hdsdp_linsys_fp **pHLin, int nCol, linsys_type Ltype);      /* hdsdp_linsolver.c:1859 */
+void HFpLinsysSetParam(hdsdp_linsys_fp *HLin, double relTol, double absTol, int nThreads, int maxIter,
+                       int nRestartFreq);                                                 /* :2000 */
+hdsdp_retcode HFpLinsysSymbolic(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx);   /* :2020 */
+hdsdp_retcode HFpLinsysNumeric(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx, double *colMatElem); /* :2026 */
+hdsdp_retcode HFpLinsysSwitchToBackUp(hdsdp_linsys_fp *HLin);                             /* :2047 */
+hdsdp_retcode HFpLinsysPsdCheck(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx, double *colMatElem,
+                                int *isPsd);                                              /* :2059 */
+void HFpLinsysFSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec);    /* :2065 */
+void HFpLinsysBSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec);    /* :2072 */
+hdsdp_retcode HFpLinsysSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec); /* :2079 */
+hdsdp_retcode HFpLinsysGetDiag(hdsdp_linsys_fp *HLin, double *diagElem);                  /* :2113 */
+void HFpLinsysInvert(hdsdp_linsys_fp *HLin, double *dFullMatrix, double *dAuxiMatrix);    /* :2119 */
+void HFpLinsysClear(hdsdp_linsys_fp *HLin);                                               /* :2126 */
+void HFpLinsysDestroy(hdsdp_linsys_fp **HLin);                                            /* :2138 */
+
+/* ==========  MI355X SDP cone: the reference's cone slots that feed the Schur path  ==========
+ * HMiConeCreateSDP    = HUserDataSetConeData + HConeCreate/SetData/ProcData/PresolveData for one
+ *                       HDSDP_CONETYPE_DENSE_SDP block (tests/test_file_io.c:402-416): the CSC input is
+ *                       the reference's user_data layout, shape n(n+1)/2 x (m+1), column 0 = C
+ *                       (interface/def_hdsdp_user_data.h:16-32).  Coefficient data is uploaded to HBM once.
+ * HMiConeCreateSynthetic builds the SURVEY.md 8(d) synthetic dense family directly in HBM (64-bit
+ *                       offsets; the reference's int32 CSC cannot hold n=m=2000 fully dense).
+ * rank/world shard the constraint rows (row i is owned by rank i % world); pass 0,1 for one GPU.
+ * The remaining functions dispatch through the cone vtable like interface/hdsdp_conic.c:203-330.
+ */
+hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *coneMatBeg,
+                               const int *coneMatIdx, const double *coneMatElem, int rank, int world);
+hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, int nRow, int rank, int world);
+void HMiConeDestroy(hdsdp_cone **pCone);
+void HMiConeSetStart(hdsdp_cone *cone, double dConeStartVal);                   /* HConeSetStart  hdsdp_conic.c:222 */
+void HMiConeUpdate(hdsdp_cone *cone, double barHsdTau, double *rowDual);        /* HConeUpdate    :228 */
+hdsdp_retcode HMiConeCheckIsInterior(hdsdp_cone *cone, double barHsdTau, double *rowDual, int *isInterior);
+hdsdp_retcode HMiConeGetLogBarrier(hdsdp_cone *cone, double barHsdTau, double *rowDual, int whichBuffer,
+                                   double *logdet);
+/* presolve results (classification hdsdp_sdpdata.c:2321-2458, ordering + plan hdsdp_conic_sdp.c:539-676);
+ * each output may be NULL; arrays have nRow entries */
+void HMiConeGetPresolve(hdsdp_cone *cone, int *coefType, int *coefRank, int *coefNnz, int *kktPerm,
+                        int *kktStrategy, int *objType);
+/* host copies of device state for parity checks: S (n x n, lower valid), b_i = tr(A_i) */
+hdsdp_retcode HMiConeGetDualMatrix(hdsdp_cone *cone, double *S);
+hdsdp_retcode HMiConeGetTraces(hdsdp_cone *cone, double *trA);
+/* which device path the cone's builder uses: 0 = dense congruence + Gram (MFMA), 1 = rank-one */
+int HMiConeGetPath(hdsdp_cone *cone);
+
+/* ===============================  device-resident fast path  ===============================
+ * The reference boundary hands host buffers (S in, M out).  For benchmarking with inputs resident in
+ * HBM, these keep M on the device between BuildUp / Factorize / Solve (no PCIe round trip of M).  */
+void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM);   /* default 1: kktMatElem is refreshed after BuildUp */
+/* multi-GPU (world > 1): constraint rows are sharded (row i on rank i % world).  Each rank congruence-
+ * transforms its own rows, a transpose (all-to-all) re-shards the transformed data from "by constraint"
+ * to "by packed-index range", each rank forms the Gram partial sum over its range, and an all-reduce
+ * (sum) assembles the augmented Gram matrix on every rank.  The two collectives are supplied by the host
+ * program (torch.distributed over RCCL in hdsdp_amd/dist.py); both are called with the engine stream
+ * idle and must return with the data in place.
+ *   alltoall(ctx): send chunk r of the send buffer to rank r, receive chunk r of the recv buffer from rank r
+ *   allreduce(ctx, buf, count): in-place sum of `count` doubles at device pointer `buf` over all ranks */
+typedef int (*hmi_alltoall_fn)(void *ctx);
+typedef int (*hmi_allreduce_fn)(void *ctx, void *buf, int64_t count);
+void HMiConeSetExchange(hdsdp_cone *cone, hmi_alltoall_fn a2a, hmi_allreduce_fn ar, void *ctx);
+/* exchange buffers (device pointers, `world` chunks of *chunkCount doubles each); the caller may instead
+ * supply its own (e.g. torch-allocated) buffers of that size before the first HKKTBuildUp */
+hdsdp_retcode HMiConeGetExchangeBuffers(hdsdp_cone *cone, void **sendBuf, void **recvBuf, int64_t *chunkCount);
+hdsdp_retcode HMiConeSetExchangeBuffers(hdsdp_cone *cone, void *sendBuf, void *recvBuf);
+void *HMiKKTDeviceMatrix(hdsdp_kkt *HKKT, int64_t *ld);   /* device pointer of M (m x m, lower valid) */
+
+/* ==================================  utilities  ================================== */
+int HMiDeviceInit(int device);         /* hipSetDevice + stream; returns 0 on success */
+int HMiDeviceSynchronize(void);
+void *HMiStream(void);                 /* hipStream_t all kernels are launched on */
+const char *HMiVersion(void);
+/* timing of the last HKKTBuildUp / HKKTFactorize / HKKTSolve stages measured with HIP events on the
+ * engine stream, milliseconds: [0] factor inverse, [1] congruence, [2] gram, [3] reduce+extract,
+ * [4] gram kernel launches, [5] congruence kernel launches */
+void HMiGetStageTimes(double *ms, int n);
+
+/* live per-kernel timing with HIP events on the engine stream (for bench.py's roofline block): roles are
+ * [0] helper GEMMs (Cholesky/TRTRI), [1] congruence step 1 (T = Linv A), [2] congruence step 2, [3] Gram.
+ * Each array has 4 entries: total ms, algorithmic flops and launch count since the last call. */
+void HMiSetKernelTiming(int on);
+int HMiGetKernelTiming(double *ms, double *flops, int64_t *launches);
+
+/* raw kernels (device pointers) exported for unit tests and micro-benchmarks */
+int HMiGemmNT(const double *A, int64_t lda, int aKMajor, const double *B, int64_t ldb, int bKMajor, double *C,
+              int64_t ldc, int M, int N, int K, double alpha, double beta, int kLimit, int lowerOnly);
+int HMiPotrf(double *A_dev, int n, int64_t lda, int *info);  /* in place, lower */
+double HMiMfmaPeakProbe(int iters);    /* measured fp64 MFMA TFLOP/s of a register-only loop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDSDP_MI355X_H */

@@ -14,6 +14,8 @@
  * usage: ref_dump <outdir> sdpa <file.dat-s> <Rd> <tau> <yscale>
  *        ref_dump <outdir> syn  <n> <m>      <Rd> <tau> <yscale>     (SURVEY.md 8(d) generator)
  *        ref_dump <outdir> mix  <n> <m>      <Rd> <tau> <yscale>     (all five coefficient types)
+ *        ref_dump -        bench <n> <m>     <Rd> <tau> <yscale>     (CPU baseline: prints one JSON line
+ *                                                                     with stage timings, dumps nothing)
  */
 #include "interface/hdsdp.h"
 #include "interface/hdsdp_utils.h"
@@ -176,11 +178,42 @@ int main(int argc, char **argv) {
     } else {
         int n = atoi(argv[3]), m = atoi(argv[4]);
         if (argc < 8) { fprintf(stderr, "usage\n"); return 2; }
-        if (!strcmp(mode, "syn")) gen_syn(&pb, n, m); else gen_mix(&pb, n, m);
+        if (!strcmp(mode, "syn") || !strcmp(mode, "bench")) gen_syn(&pb, n, m); else gen_mix(&pb, n, m);
         Rd = atof(argv[5]); tau = atof(argv[6]); yscale = atof(argv[7]);
     }
     int n = pb.n, m = pb.m;
     long nnz = pb.beg[m + 1];
+    if (!strcmp(mode, "bench")) {
+        /* the unit of work of BASELINE.json's metric, timed on the reference's CPU path */
+        user_data *ud = NULL; hdsdp_cone *cone = NULL; hdsdp_kkt *kkt = NULL;
+        double *y = calloc(m, sizeof(double)), *d2 = calloc(m, sizeof(double)), *d3 = calloc(m, sizeof(double));
+        double *sol = calloc(m, sizeof(double));
+        int isInt = 0;
+        HDSDP_CALL(HUserDataCreate(&ud));
+        HUserDataSetConeData(ud, HDSDP_CONETYPE_DENSE_SDP, m, n, pb.beg, pb.idx, pb.val);
+        HDSDP_CALL(HConeCreate(&cone, 0));
+        HDSDP_CALL(HConeSetData(cone, ud));
+        HDSDP_CALL(HConeProcData(cone));
+        HDSDP_CALL(HConePresolveData(cone));
+        HConeSetStart(cone, Rd);
+        HDSDP_CALL(HKKTCreate(&kkt));
+        HDSDP_CALL(HKKTInit(kkt, m, 1, &cone));
+        double t0 = HUtilGetTimeStamp();
+        HDSDP_CALL(HConeCheckIsInterior(cone, tau, y, &isInt));
+        double t1 = HUtilGetTimeStamp();
+        HDSDP_CALL(HKKTBuildUp(kkt, KKT_TYPE_INFEASIBLE));
+        double t2 = HUtilGetTimeStamp();
+        HKKTExport(kkt, d2, d3, NULL, NULL, NULL, NULL, NULL);
+        HDSDP_CALL(HKKTFactorize(kkt));
+        double t3 = HUtilGetTimeStamp();
+        HDSDP_CALL(HKKTSolve(kkt, pb.b, sol));
+        HDSDP_CALL(HKKTSolve(kkt, d2, NULL));
+        HDSDP_CALL(HKKTSolve(kkt, d3, NULL));
+        double t4 = HUtilGetTimeStamp();
+        printf("{\"n\": %d, \"m\": %d, \"interior\": %d, \"chol_s\": %.6f, \"buildup_s\": %.6f, \"factor_s\": %.6f, \"solve3_s\": %.6f}\n",
+               n, m, isInt, t1 - t0, t2 - t1, t3 - t2, t4 - t3);
+        return 0;
+    }
     dump_i("csc_beg", pb.beg, m + 2); dump_i("csc_idx", pb.idx, nnz); dump_d("csc_val", pb.val, nnz);
     dump_d("b", pb.b, m);
     { int dims[2] = {n, m}; dump_i("dims", dims, 2); }

@@ -1,0 +1,51 @@
+"""shared helpers for the parity tests"""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# the reference's own acceptance bar for Schur quantities (interface/hdsdp_utils.c:621-641):
+#   |a - b| / (|a| + 1e-4) < 1e-8
+KKT_TOL = 1e-8
+
+
+def kkt_err(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.max(np.abs(got - ref) / (np.abs(ref) + 1e-4))) if ref.size else 0.0
+
+
+# The reference's bar has an absolute floor of 1e-4, which is vacuous when S ~ 1e3 I makes every entry
+# of M ~ 1e-6; so every comparison ALSO has to pass a norm-wise relative bound.
+REL_TOL = 1e-10
+
+
+def rel_err(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    den = float(np.max(np.abs(ref))) if ref.size else 0.0
+    if den == 0.0:
+        return float(np.max(np.abs(got))) if got.size else 0.0
+    return float(np.max(np.abs(got - ref))) / den
+
+
+def check_close(got, ref, what=""):
+    e1, e2 = kkt_err(got, ref), rel_err(got, ref)
+    assert e1 < KKT_TOL, f"{what}: reference-bar error {e1:.3e}"
+    assert e2 < REL_TOL, f"{what}: norm-wise relative error {e2:.3e}"
+    return e2
+
+
+def lower_mask(m):
+    """golden / KKT.M arrays are column-major m x m seen in C order: element (row i, col j) sits at [j, i];
+    the reference fills row >= col only."""
+    return np.triu(np.ones((m, m), dtype=bool))
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def y_of(g):
+    return np.asarray(g["y"], dtype=np.float64)
