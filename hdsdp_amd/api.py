@@ -34,7 +34,7 @@ EXPORTS = [
     "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
-    "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming",
+    "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC",
 ]
 
 
@@ -122,6 +122,7 @@ def load_library():
                                 C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]),
         "HMiPotrf": (C.c_int, [vp, C.c_int, C.c_int64, ip]),
         "HMiMfmaPeakProbe": (C.c_double, [C.c_int]),
+        "HMiPresolveCSC": (C.c_int, [C.c_int, C.c_int, ip, ip, dp, ip, ip, ip, ip, ip, ip]),
         "HMiSetKernelTiming": (None, [C.c_int]),
         "HMiGetKernelTiming": (C.c_int, [dp, dp, C.POINTER(C.c_int64)]),
     }
@@ -143,6 +144,21 @@ def _dptr(a):
 
 def _iptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def presolve_csc(n, m, beg, idx, val):
+    """host-only presolve of one block (classification, ordering, strategy plan); needs no GPU"""
+    lib = load_library()
+    beg = np.ascontiguousarray(beg, dtype=np.int32)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    out = {k: np.zeros(m, dtype=np.int32) for k in ("coef_type", "coef_rank", "coef_nnz", "kkt_perm", "kkt_strategy")}
+    ot = C.c_int(0)
+    _check(lib.HMiPresolveCSC(m, n, _iptr(beg), _iptr(idx), _dptr(val), _iptr(out["coef_type"]),
+                              _iptr(out["coef_rank"]), _iptr(out["coef_nnz"]), _iptr(out["kkt_perm"]),
+                              _iptr(out["kkt_strategy"]), C.byref(ot)), "HMiPresolveCSC")
+    out["obj_type"] = ot.value
+    return out
 
 
 class SDPCone:

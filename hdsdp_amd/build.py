@@ -1,6 +1,6 @@
-"""Build the HIP extension (gfx950) and the oracle's C restatement in-tree.
+"""Build the HIP extension (gfx950) in-tree.
 
-    python -m hdsdp_amd.build            # libhdsdp_mi355x.so  (+ oracle/_build, + oracle/_ref if possible)
+    python -m hdsdp_amd.build            # hdsdp_amd/libhdsdp_mi355x.so
 
 hipcc cross-compiles without a GPU.  The built .so files are git-ignored but travel to the GPU box.
 """
@@ -53,14 +53,5 @@ def build_library(force=False, verbose=True):
     return LIB
 
 
-def build_oracle(verbose=True):
-    """CPU restatement (always) and, when /root/reference + MKL are present, the real reference."""
-    odir = os.path.join(ROOT, "oracle")
-    subprocess.check_call(["make", "-C", odir, "port"], stdout=None if verbose else subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/interface"):
-        subprocess.call(["make", "-C", odir, "ref"], stdout=None if verbose else subprocess.DEVNULL)
-
-
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv)
-    build_oracle()

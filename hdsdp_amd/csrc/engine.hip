@@ -281,13 +281,21 @@ int cone_alloc_gemm_work(MiCone *c) {
             HDM_HIP_CHECK(hdm_memset_sync(c->AhatAll, 0, ahat));
         }
     }
-    // Gram split-K: enough workgroups for 2 waves of 512 resident tiles
+    // Gram split-K: the grid is tiles x nsplit workgroups on 512 resident slots (256 CUs x 2).  Pick the
+    // split count whose last scheduling round is fullest (136 tiles x 15 = 2040 = 3.98 rounds at m = 2000;
+    // 8 splits would leave the third round 1/8 full), preferring >= 2 rounds and long K chunks.
     const long RT = (c->R + HDM_TILE - 1) / HDM_TILE;
     const long tiles = RT * (RT + 1) / 2;
-    long ns = std::max(1L, (1024 + tiles - 1) / tiles);
     const long kblocks = c->npb_loc;
-    ns = std::min(ns, std::max(1L, kblocks / 64));
-    ns = std::min(ns, 64L);
+    long ns = 1;
+    double best = -1.0;
+    const long slab_cap = std::max(1L, (long) ((4LL << 30) / (sizeof(double) * (double) c->R * c->R)));  // <= 4 GiB of slabs
+    for (long cand = 1; cand <= 64 && cand <= slab_cap && cand <= std::max(1L, kblocks / 64); ++cand) {
+        const double rounds = (double) (tiles * cand) / 512.0;
+        double eff = rounds / std::ceil(rounds);
+        if (rounds < 2.0) eff *= 0.5 + 0.25 * rounds;  // too few workgroups to hide the tail
+        if (eff > best + 1e-9) { best = eff; ns = cand; }
+    }
     c->nsplit = (int) ns;
     HDM_HIP_CHECK(hipMalloc((void **) &c->slabs, sizeof(double) * (size_t) c->R * c->R * c->nsplit));
     HDM_HIP_CHECK(hipMalloc((void **) &c->Gm, sizeof(double) * (size_t) c->R * c->R));
@@ -1151,6 +1159,22 @@ void HMiConeGetPresolve(hdsdp_cone *cone, int *coefType, int *coefRank, int *coe
         if (kktStrategy) kktStrategy[i] = c->blk.strategy[i];
     }
     if (objType) *objType = c->synthetic ? MI_COEFF_DENSE : c->blk.obj.type;
+}
+hdsdp_retcode HMiPresolveCSC(int nRow, int nCol, const int *coneMatBeg, const int *coneMatIdx,
+                             const double *coneMatElem, int *coefType, int *coefRank, int *coefNnz, int *kktPerm,
+                             int *kktStrategy, int *objType) {
+    if (nRow < 1 || nCol < 1 || !coneMatBeg) return HDSDP_RETCODE_FAILED;
+    MiBlockData blk;
+    if (mi_block_from_csc(blk, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem)) return HDSDP_RETCODE_FAILED;
+    for (int i = 0; i < nRow; ++i) {
+        if (coefType) coefType[i] = blk.rows[i].type;
+        if (coefRank) coefRank[i] = blk.rows[i].rank;
+        if (coefNnz) coefNnz[i] = blk.rows[i].nnz;
+        if (kktPerm) kktPerm[i] = blk.perm[i];
+        if (kktStrategy) kktStrategy[i] = blk.strategy[i];
+    }
+    if (objType) *objType = blk.obj.type;
+    return HDSDP_RETCODE_OK;
 }
 hdsdp_retcode HMiConeGetDualMatrix(hdsdp_cone *cone, double *S) {
     MiCone *c = (MiCone *) cone->coneData;

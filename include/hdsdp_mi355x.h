@@ -202,6 +202,10 @@ hdsdp_retcode HMiConeGetLogBarrier(hdsdp_cone *cone, double barHsdTau, double *r
  * each output may be NULL; arrays have nRow entries */
 void HMiConeGetPresolve(hdsdp_cone *cone, int *coefType, int *coefRank, int *coefNnz, int *kktPerm,
                         int *kktStrategy, int *objType);
+/* the same presolve without creating a cone (host only, touches no device): for CPU-side checks */
+hdsdp_retcode HMiPresolveCSC(int nRow, int nCol, const int *coneMatBeg, const int *coneMatIdx,
+                             const double *coneMatElem, int *coefType, int *coefRank, int *coefNnz, int *kktPerm,
+                             int *kktStrategy, int *objType);
 /* host copies of device state for parity checks: S (n x n, lower valid), b_i = tr(A_i) */
 hdsdp_retcode HMiConeGetDualMatrix(hdsdp_cone *cone, double *S);
 hdsdp_retcode HMiConeGetTraces(hdsdp_cone *cone, double *trA);

@@ -1,0 +1,97 @@
+"""CPU tests (no GPU): pin the oracle (oracle/hdsdp_oracle.c) against the golden vectors that were
+generated from the compiled reference.  This is what makes the oracle trustworthy as a checker."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from util import KKT_TOL, check_close, load_golden, lower_mask, y_of
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import oracle_py  # noqa: E402
+
+CSC_CASES = ["theta1_A", "theta1_B", "mcp100_A", "mcp100_B", "gpp100_A", "gpp100_B", "mix40_A", "mix40_B"]
+SYN_SMALL = ["syn64", "syn96x40_B"]
+
+
+def _block(name, g):
+    n, m = int(g["dims"][0]), int(g["dims"][1])
+    if "csc_beg" in g:
+        beg, idx, val = g["csc_beg"], g["csc_idx"], g["csc_val"]
+    else:
+        beg, idx, val, b = oracle_py.synth_csc(n, m)
+        assert int(beg[-1]) == int(g["csc_nnz"][0])
+        assert np.array_equal(b, g["b"])
+    return oracle_py.Block(n, m, beg, idx, val), n, m
+
+
+@pytest.mark.parametrize("name", CSC_CASES + SYN_SMALL)
+def test_oracle_matches_reference(name):
+    g = load_golden(name)
+    blk, n, m = _block(name, g)
+    Rd, tau, y = float(g["Rd"][0]), float(g["tau"][0]), y_of(g)
+    p = blk.presolve()
+    for k in ("coef_type", "coef_rank", "coef_nnz", "kkt_perm", "kkt_strategy"):
+        assert np.array_equal(p[k], g[k]), k
+    assert p["obj_type"] == int(g["obj_type"][0])
+    S = blk.assemble_S(tau, y, Rd)
+    msk = lower_mask(n)
+    check_close(S[msk], g["S"][msk], "S")
+    Lf, info = blk.factor(S)
+    assert info == 0
+    assert np.allclose(np.diag(Lf), g["Ldiag"], rtol=1e-12)
+    assert abs(blk.logdet(Lf) - float(g["logdet"][0])) <= 1e-12 * abs(float(g["logdet"][0]))
+    Sinv = blk.inverse(Lf)
+    check_close(Sinv, g["Sinv"], "Sinv")
+    mm = lower_mask(m)
+    k = blk.kkt_build(Sinv, Rd, 0)
+    check_close(k["M"][mm], g["M_inf"][mm], "M_inf")
+    check_close(k["ASinv"], g["ASinv_inf"], "ASinv")
+    check_close(k["ASinvRdSinv"], g["ASinvRdSinv_inf"], "ASinvRdSinv")
+    check_close([k["TraceSinv"]], g["TraceSinv_inf"], "TraceSinv")
+    h = blk.kkt_build(Sinv, Rd, 2)
+    check_close(h["M"][mm], g["M_hsd"][mm], "M_hsd")
+    check_close(h["ASinvCSinv"], g["ASinvCSinv_hsd"], "ASinvCSinv")
+    for got, ref in zip((h["CSinv"], h["CSinvCSinv"], h["CSinvRdSinv"], h["TraceSinv"]), g["hsd_scalars"]):
+        check_close([got], [ref], "hsd scalar")
+    c = blk.kkt_build(Sinv, Rd, 1)
+    check_close(c["ASinv"], g["ASinv_cor"], "cor ASinv")
+    check_close(c["ASinvRdSinv"], g["ASinvRdSinv_cor"], "cor ASinvRdSinv")
+    # fixed strategies: M3 and M4 always apply (HKKTBuildUpFixed, reference cross-strategy invariant)
+    for strat, key in ((2, "M_inf_fixedM3"), (3, "M_inf_fixedM4")):
+        f = blk.kkt_build(Sinv, Rd, 0, fixed=strat)
+        check_close(f["M"][mm], g[key][mm], key)
+    # the Schur solves (Jacobi PCG to the reference's tolerances)
+    Ms = k["M"].copy()
+    Ms[np.arange(m), np.arange(m)] += float(g["diag_add"][0])
+    for rhs, key in ((g["b"], "sol_b"), (g["ASinv_inf"], "sol_ASinv"), (g["ASinvRdSinv_inf"], "sol_ASinvRdSinv")):
+        x = oracle_py.pcg_solve(Ms, rhs)
+        assert np.linalg.norm(x - g[key]) <= 1e-8 * np.linalg.norm(g[key]), key
+    blk.close()
+
+
+def test_oracle_generator_checksums():
+    """SURVEY.md 8(c) known answers of the synthetic family at n=m=100 (full reference run)"""
+    g = load_golden("syn100")
+    beg, idx, val, b = oracle_py.synth_csc(100, 100)
+    assert int(beg[-1]) == 212782
+    blk = oracle_py.Block(100, 100, beg, idx, val)
+    S = blk.assemble_S(1.0, np.zeros(100), -1000.0)
+    Lf, info = blk.factor(S)
+    assert info == 0
+    assert abs(blk.logdet(Lf) - 6.909052338645e+02) < 1e-9
+    k = blk.kkt_build(blk.inverse(Lf), -1000.0, 0)
+    mm = lower_mask(100)
+    check_close(k["M"][mm], g["M_inf"][mm], "syn100 M")
+    assert abs(k["M"][mm].sum() - 1.367732857163390e-01) < 1e-12
+    blk.close()
+
+
+def test_potrf_reports_first_bad_pivot():
+    n = 12
+    A = np.eye(n) * 2.0
+    A[7, 7] = -1.0
+    Lf = A.copy()
+    info = oracle_py.lib().orc_potrf(n, Lf.ctypes.data_as(oracle_py.C.POINTER(oracle_py.C.c_double)))
+    assert info == 8
