@@ -281,19 +281,25 @@ int cone_alloc_gemm_work(MiCone *c) {
             HDM_HIP_CHECK(hdm_memset_sync(c->AhatAll, 0, ahat));
         }
     }
-    // Gram split-K: the grid is tiles x nsplit workgroups on 512 resident slots (256 CUs x 2).  Pick the
-    // split count whose last scheduling round is fullest (136 tiles x 15 = 2040 = 3.98 rounds at m = 2000;
-    // 8 splits would leave the third round 1/8 full), preferring >= 2 rounds and long K chunks.
+    // Gram split-K: the grid is tiles x nsplit workgroups on 512 resident slots (256 CUs x 2).  The split index
+    // is the fast workgroup index, and workgroups are dealt round-robin over the 8 XCDs: with nsplit a multiple
+    // of 8 every XCD keeps to its own K ranges, so the ~64 tiles it runs concurrently share their row/column
+    // panels in that XCD's L2 (profiles/r01_a: with nsplit = 15 the Gram kernel fetched 513 GB per launch,
+    // i.e. every tile load went to the fabric).  Among the multiples of 8 pick the one whose last scheduling
+    // round is fullest (136 tiles x 56 = 14.9 rounds at m = 2000).
     const long RT = (c->R + HDM_TILE - 1) / HDM_TILE;
     const long tiles = RT * (RT + 1) / 2;
     const long kblocks = c->npb_loc;
+    const long slab_cap = std::max(1L, (long) ((4LL << 30) / (sizeof(double) * (double) c->R * c->R)));  // <= 4 GiB of slabs
+    const long kcap = std::max(1L, kblocks / 64);
     long ns = 1;
     double best = -1.0;
-    const long slab_cap = std::max(1L, (long) ((4LL << 30) / (sizeof(double) * (double) c->R * c->R)));  // <= 4 GiB of slabs
-    for (long cand = 1; cand <= 64 && cand <= slab_cap && cand <= std::max(1L, kblocks / 64); ++cand) {
+    for (long cand = 1; cand <= 64 && cand <= slab_cap && cand <= kcap; ++cand) {
+        if (cand > 8 && cand % 8) continue;
         const double rounds = (double) (tiles * cand) / 512.0;
         double eff = rounds / std::ceil(rounds);
         if (rounds < 2.0) eff *= 0.5 + 0.25 * rounds;  // too few workgroups to hide the tail
+        if (cand < 8 && kcap >= 8 && slab_cap >= 8) eff *= 0.5;  // prefer XCD-aligned splits when possible
         if (eff > best + 1e-9) { best = eff; ns = cand; }
     }
     c->nsplit = (int) ns;

@@ -36,50 +36,62 @@ struct HdmGemmDev {
     int ntiles;
 };
 
-// this thread's 8 doubles of the (128 rows x 16 k) tile at row x0, k block kt
+// Tile staging: a (128 rows x 16 k) tile is 1024 chunks of 16 bytes; thread t moves chunks t, t+256, t+512,
+// t+768, so that the 64 lanes of a wave always touch 1 KiB of consecutive global memory per instruction
+// (full 128-byte lines) and every 8-lane ds_write_b128 group writes 128 consecutive LDS bytes = all 32
+// write banks once (the first version gave each thread 64 contiguous bytes: 4-way write conflicts,
+// SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE in profiles/r01_a_*).
+//   M-major tile [k][i]: chunk c -> k = c >> 6, i = (c & 63) * 2
+//   K-major tile [i][k]: chunk c -> i = c >> 3, k = (c & 7) * 2
 template <bool KM>
-__device__ __forceinline__ void g2r(const double *__restrict__ X, long ld, long kblk, long seg_rows, long seg_extra,
-                                    int rows, int x0, int kt, int tid, double (&r)[8]) {
-    const double *src;
-    bool ok;
-    if (KM) {
-        int i = tid >> 1, k8 = (tid & 1) * 8;
-        int gi = x0 + i;
-        ok = gi < rows;
-        src = X + (long) kt * kblk + (long) gi * ld + k8;
-        if (seg_rows) src += (gi / seg_rows) * seg_extra;
-    } else {
-        int k = tid >> 4, i8 = (tid & 15) * 8;
-        int gi = x0 + i8;
-        ok = gi < rows;  // rows is a multiple of 8: the chunk is fully in or fully out
-        src = X + ((long) kt * HDM_BK + k) * ld + gi;
-    }
-    if (ok) {
-        const double2 *s2 = reinterpret_cast<const double2 *>(src);
-        double2 v0 = s2[0], v1 = s2[1], v2 = s2[2], v3 = s2[3];
-        r[0] = v0.x; r[1] = v0.y; r[2] = v1.x; r[3] = v1.y;
-        r[4] = v2.x; r[5] = v2.y; r[6] = v3.x; r[7] = v3.y;
-    } else {
+struct Stager {
+    const double *p;  // this thread's chunk 0 of the current k block
+    long qstride;     // elements between the thread's 4 chunks
+    long kstep;       // elements between consecutive k blocks
+    unsigned okmask;  // bit q: chunk q lies inside the matrix
+
+    __device__ __forceinline__ void init(const double *X, long ld, long kblk, long seg_rows, long seg_extra, int rows,
+                                         int x0, int kt0, int tid) {
+        okmask = 0;
+        if (KM) {
+            const int i = tid >> 3, k2 = (tid & 7) * 2;
+            // a 128-row tile never straddles a row segment, so the segment offset is tile-uniform
+            const long segoff = seg_rows ? (x0 / seg_rows) * seg_extra : 0;
+            p = X + segoff + (long) kt0 * kblk + (long) (x0 + i) * ld + k2;
+            qstride = 32 * ld;
+            kstep = kblk;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = 0.0;
+            for (int q = 0; q < 4; ++q) okmask |= (x0 + i + 32 * q < rows) ? (1u << q) : 0u;
+        } else {
+            const int k = tid >> 6, i2 = (tid & 63) * 2;
+            p = X + ((long) kt0 * HDM_BK + k) * ld + x0 + i2;
+            qstride = 4 * ld;
+            kstep = (long) HDM_BK * ld;
+            okmask = (x0 + i2 < rows) ? 0xFu : 0u;  // rows is even: the 2-double chunk is fully in or out
+        }
     }
-}
+    __device__ __forceinline__ void load(double2 (&r)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            r[q] = (okmask >> q) & 1u ? *reinterpret_cast<const double2 *>(p + q * qstride) : make_double2(0.0, 0.0);
+        p += kstep;
+    }
+};
 
 template <bool KM>
-__device__ __forceinline__ void r2s(double *__restrict__ s, int tid, const double (&r)[8]) {
-    double *dst;
-    if (KM) {
-        int i = tid >> 1, k8 = (tid & 1) * 8;
-        dst = s + i * LDK + k8;
-    } else {
-        int k = tid >> 4, i8 = (tid & 15) * 8;
-        dst = s + k * LDM + i8;
+__device__ __forceinline__ void r2s(double *__restrict__ s, int tid, const double2 (&r)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double *dst;
+        if (KM) {
+            const int i = (tid >> 3) + 32 * q, k2 = (tid & 7) * 2;
+            dst = s + i * LDK + k2;
+        } else {
+            const int k = (tid >> 6) + 4 * q, i2 = (tid & 63) * 2;
+            dst = s + k * LDM + i2;
+        }
+        *reinterpret_cast<double2 *>(dst) = r[q];
     }
-    double2 *d2 = reinterpret_cast<double2 *>(dst);
-    d2[0] = make_double2(r[0], r[1]);
-    d2[1] = make_double2(r[2], r[3]);
-    d2[2] = make_double2(r[4], r[5]);
-    d2[3] = make_double2(r[6], r[7]);
 }
 
 template <bool KM>
@@ -130,24 +142,32 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         for (int i = 0; i < 4; ++i) acc[j][i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
 
     const int kt0 = (int) (kbeg / HDM_BK), kt1 = (int) (kend / HDM_BK);
-    double ra[8], rb[8];
+    double2 ra[4], rb[4];
+    Stager<AKM> stA;
+    Stager<BKM> stB;
+    stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, m0, kt0, tid);
+    stB.init(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, n0, kt0, tid);
     if (kt0 < kt1) {
-        g2r<AKM>(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, m0, kt0, tid, ra);
-        g2r<BKM>(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, n0, kt0, tid, rb);
+        stA.load(ra);
+        stB.load(rb);
         r2s<AKM>(sA, tid, ra);
         r2s<BKM>(sB, tid, rb);
     }
     __syncthreads();
 
+    // lower-only diagonal tiles: the (rows 0-63, cols 64-127) quadrant lies strictly above the diagonal; its
+    // wave issues no MFMAs and leaves the SIMD to the co-resident workgroup
+    const bool idle_wave = a.lower_only && (tm == tn) && (wm == 0) && (wn == 1);
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         const bool more = (kt + 1 < kt1);
         if (more) {
-            g2r<AKM>(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, m0, kt + 1, tid, ra);
-            g2r<BKM>(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, n0, kt + 1, tid, rb);
+            stA.load(ra);
+            stB.load(rb);
         }
         const double *cA = sA + cur * STAGE_DOUBLES;
         const double *cB = sB + cur * STAGE_DOUBLES;
+        if (!idle_wave) {
 #pragma unroll
         for (int kk = 0; kk < HDM_BK; kk += 4) {
             double fb[4], fa[4];
@@ -160,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
+        }
         }
         if (more) {
             r2s<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra);
