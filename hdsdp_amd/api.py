@@ -35,6 +35,7 @@ EXPORTS = [
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
     "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC",
+    "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
 ]
 
 
@@ -123,6 +124,11 @@ def load_library():
         "HMiPotrf": (C.c_int, [vp, C.c_int, C.c_int64, ip]),
         "HMiMfmaPeakProbe": (C.c_double, [C.c_int]),
         "HMiPresolveCSC": (C.c_int, [C.c_int, C.c_int, ip, ip, dp, ip, ip, ip, ip, ip, ip]),
+        "HMiReadSDPA": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+        "HMiSDPAGetDims": (None, [vp, ip, ip, ip]),
+        "HMiSDPAGetBlock": (C.c_int, [vp, C.c_int, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp)]),
+        "HMiSDPAGetRHS": (dp, [vp]),
+        "HMiSDPAFree": (None, [C.POINTER(vp)]),
         "HMiSetKernelTiming": (None, [C.c_int]),
         "HMiGetKernelTiming": (C.c_int, [dp, dp, C.POINTER(C.c_int64)]),
     }
@@ -159,6 +165,30 @@ def presolve_csc(n, m, beg, idx, val):
                               _iptr(out["kkt_strategy"]), C.byref(ot)), "HMiPresolveCSC")
     out["obj_type"] = ot.value
     return out
+
+
+def read_sdpa(fname):
+    """SDPA sparse file -> dict(m, b, blocks=[dict(n, beg, idx, val)], n_lp) in the reference's CSC layout"""
+    lib = load_library()
+    h = C.c_void_p()
+    _check(lib.HMiReadSDPA(os.fsencode(fname), C.byref(h)), f"HMiReadSDPA({fname})")
+    try:
+        m, nb, nlp = C.c_int(), C.c_int(), C.c_int()
+        lib.HMiSDPAGetDims(h, C.byref(m), C.byref(nb), C.byref(nlp))
+        b = np.ctypeslib.as_array(lib.HMiSDPAGetRHS(h), shape=(m.value,)).copy()
+        blocks = []
+        for i in range(nb.value):
+            dim = C.c_int()
+            pb, pi, pv = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_double)()
+            _check(lib.HMiSDPAGetBlock(h, i, C.byref(dim), C.byref(pb), C.byref(pi), C.byref(pv)), "HMiSDPAGetBlock")
+            beg = np.ctypeslib.as_array(pb, shape=(m.value + 2,)).copy()
+            nnz = int(beg[-1])
+            idx = np.ctypeslib.as_array(pi, shape=(max(nnz, 1),))[:nnz].copy()
+            val = np.ctypeslib.as_array(pv, shape=(max(nnz, 1),))[:nnz].copy()
+            blocks.append({"n": dim.value, "beg": beg, "idx": idx, "val": val})
+        return {"m": m.value, "b": b, "blocks": blocks, "n_lp": nlp.value}
+    finally:
+        lib.HMiSDPAFree(C.byref(h))
 
 
 class SDPCone:

@@ -16,65 +16,159 @@
 #define NB 128
 
 // ------------------------------------------------------------------------------------------
-// diagonal block: in-LDS Cholesky (lower) + in-place triangular inverse
+// diagonal block: Cholesky (lower) + triangular inverse of one 128 x 128 block by one workgroup.
+//
+// Blocked inside LDS with 32-wide panels so the latency-bound chain is short:
+//   * the 32 x 32 diagonal sub-block is factored AND inverted entirely in registers by one wave
+//     (lane l holds row l; pivots / multipliers are broadcast with v_readlane, no LDS, no barriers);
+//   * panel  P = B * inv(L_pp)^T  and the trailing update  A22 -= P P^T  are small LDS matmuls
+//     spread over all 256 threads;
+//   * the full 128 x 128 inverse is then assembled block column by block column, right to left:
+//     X[j+1:, j] = -X[j+1:, j+1:] * (L[j+1:, j] * X_jj).
+// L goes to global memory as soon as a piece is final; the inverse is left in LDS and written once.
 // ------------------------------------------------------------------------------------------
+#define PB 32
+__device__ __forceinline__ double hdm_readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void hdm_potrf_diag_kernel(double *__restrict__ A, long ld, double *__restrict__ Dinv,
                                                               int *__restrict__ info, int col0) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *a = sm;               // [NB][NB] column-major
-    double *v = sm + NB * NB;     // [NB] scratch column
-    int &bad = *reinterpret_cast<int *>(sm + NB * NB + NB);  // kept inside the one dynamic LDS block
+    double *a = sm;             // [NB][NB] column-major: L below the diagonal blocks, inverses on them
+    double *w = sm + NB * NB;   // [96][PB] scratch for the inverse assembly
     const int tid = threadIdx.x;
-    if (tid == 0) bad = 0;
     for (int e = tid; e < NB * NB; e += 256) {
         int i = e & (NB - 1), j = e >> 7;
         a[e] = (i >= j) ? A[i + (long) j * ld] : 0.0;
     }
     __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        double d = a[j + j * NB];
-        if (!(d > 0.0)) {  // also catches NaN
-            if (tid == 0 && !bad) {
-                bad = 1;
-                atomicCAS(info, 0, col0 + j + 1);
+
+    for (int p = 0; p < NB / PB; ++p) {
+        const int c0 = p * PB;
+        if (tid < 64) {
+            // ---- wave 0: register Cholesky + inverse of the 32 x 32 diagonal sub-block
+            const int l = tid & 31;
+            double r[PB];
+#pragma unroll
+            for (int k = 0; k < PB; ++k) r[k] = (tid < PB && k <= l) ? a[(c0 + l) + (c0 + k) * NB] : 0.0;
+            int bad = 0;
+            double *colj = w + PB * (PB + 1);  // [PB] broadcast buffer (double-buffered by parity of j)
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                double *cb = colj + (j & 1) * PB;
+                if (tid < PB) cb[l] = r[j];                 // unscaled column j: element (l, j)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                double d = cb[j];                           // pivot, wave-uniform broadcast read
+                if (!(d > 0.0)) {                           // also catches NaN
+                    if (!bad) bad = j + 1;
+                    d = 1.0;
+                }
+                const double piv = sqrt(d), rinv = 1.0 / piv;
+                r[j] = (l == j) ? piv : r[j] * rinv;
+#pragma unroll
+                for (int k = j + 1; k < PB; ++k) r[k] -= r[j] * (cb[k] * rinv);   // L[l][j] * L[k][j]
+                __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting later steps' loads
             }
-            d = 1.0;  // keep going with a harmless pivot; the factor is flagged invalid
+            if (bad && tid == 0) atomicCAS(info, 0, col0 + c0 + bad);
+            if (tid < PB) {
+#pragma unroll
+                for (int k = 0; k < PB; ++k)
+                    if (k <= l) A[(c0 + l) + (long) (c0 + k) * ld] = r[k];
+            }
+            // inverse: lane c owns column c of X = inv(L_pp); X[i][c] = (delta_ic - sum_{k<i} L[i][k] X[k][c]) / L[i][i]
+            // L[i][k] is wave-uniform: read it back from a small LDS copy (broadcast reads; keeping all of it in
+            // SGPRs via readlane overflows the scalar file)
+            double *lp = w;  // [PB][PB+1]
+            if (tid < PB) {
+#pragma unroll
+                for (int k = 0; k < PB; ++k) lp[l * (PB + 1) + k] = r[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double x[PB];
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                double s = (i == l) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) s -= lp[i * (PB + 1) + k] * x[k];
+                x[i] = s / lp[i * (PB + 1) + i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (tid < PB) {
+#pragma unroll
+                for (int i = 0; i < PB; ++i) a[(c0 + i) + (c0 + l) * NB] = x[i];  // exact zeros above the diagonal
+            }
         }
-        const double piv = sqrt(d);
-        const double rinv = 1.0 / piv;
-        __syncthreads();  // everyone has read a[j,j]
-        for (int i = j + tid; i < NB; i += 256) a[i + j * NB] = (i == j) ? piv : a[i + j * NB] * rinv;
         __syncthreads();
-        const int rows = NB - 1 - j;
-        for (int e = tid; e < rows * rows; e += 256) {
-            int i = j + 1 + e % rows, k = j + 1 + e / rows;
-            if (i >= k) a[i + k * NB] -= a[i + j * NB] * a[k + j * NB];
+        const int t0 = c0 + PB, nr = NB - t0;
+        if (nr <= 0) break;
+        {   // ---- panel: P[r][c] = sum_{k<=c} B[r][k] * X[c][k]   (B = rows t0.. of block column p)
+            const int c = tid & 31;
+            for (int rr = tid >> 5; rr < nr; rr += 8) {
+                const int rg = t0 + rr;
+                const double *brow = a + rg + c0 * NB, *xrow = a + (c0 + c) + c0 * NB;
+                double s = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < PB; ++k) s += brow[k * NB] * xrow[k * NB];
+                // the 32 lanes that share row rg sit in one wave and run in lockstep: every one of them has
+                // finished reading the row before the first of them stores into it
+                __builtin_amdgcn_wave_barrier();
+                a[rg + (c0 + c) * NB] = s;
+                A[rg + (long) (c0 + c) * ld] = s;
+            }
+        }
+        __syncthreads();
+        {   // ---- trailing update: A22[i][k] -= sum_q P[i][q] * P[k][q],  i >= k
+            const int tx = tid & 15, ty = tid >> 4;
+            for (int kk = ty; kk < nr; kk += 16) {
+                for (int ii = tx + (kk & ~15); ii < nr; ii += 16) {
+                    if (ii < kk) continue;
+                    const int ig = t0 + ii, kg = t0 + kk;
+                    double s = 0.0;
+#pragma unroll 8
+                    for (int q = 0; q < PB; ++q) s += a[ig + (c0 + q) * NB] * a[kg + (c0 + q) * NB];
+                    a[ig + kg * NB] -= s;
+                }
+            }
         }
         __syncthreads();
     }
-    // write L (lower triangle only; the strict upper part of the block is left untouched)
-    for (int e = tid; e < NB * NB; e += 256) {
-        int i = e & (NB - 1), j = e >> 7;
-        if (i >= j) A[i + (long) j * ld] = a[e];
-    }
-    __syncthreads();
-    // in-place lower triangular inverse (unblocked, column sweep from the right)
-    for (int j = NB - 1; j >= 0; --j) {
-        const double ajj = 1.0 / a[j + j * NB];
-        const int rows = NB - 1 - j;
-        for (int i = tid; i < rows; i += 256) v[i] = a[j + 1 + i + j * NB];
-        __syncthreads();
-        // y = Ainv[j+1:, j+1:] * v  (lower triangular trmv), then column j = -ajj * y
-        for (int i = tid; i < rows; i += 256) {
-            double s = 0.0;
-            const int gi = j + 1 + i;
-            for (int k = 0; k <= i; ++k) s += a[gi + (j + 1 + k) * NB] * v[k];
-            a[gi + j * NB] = -ajj * s;
+    // ---- inverse assembly (diagonal sub-blocks of `a` already hold their inverses)
+    for (int j = NB / PB - 2; j >= 0; --j) {
+        const int c0 = j * PB, r0 = c0 + PB, nr = NB - r0;
+        const int rl = tid & 31, cg = tid >> 5;
+        // W = L[r0:, c0:c0+32] * X_jj
+        for (int rb = 0; rb < nr; rb += 32) {
+            const int rg = r0 + rb + rl;
+            const double *lrow = a + rg + c0 * NB;
+            for (int c = cg; c < PB; c += 8) {
+                const double *xcol = a + c0 + (c0 + c) * NB;
+                double s = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < PB; ++k) s += lrow[k * NB] * xcol[k];
+                w[(rb + rl) + c * 96] = s;
+            }
         }
-        if (tid == 0) a[j + j * NB] = ajj;
+        __syncthreads();
+        // X[r0:, c0:c0+32] = -Xtrail * W   (Xtrail = a[r0:, r0:], lower triangular with exact zeros above)
+        for (int rb = 0; rb < nr; rb += 32) {
+            const int rg = r0 + rb + rl;
+            for (int c = cg; c < PB; c += 8) {
+                double s = 0.0;
+                const int kmax = (rb + 32 < nr) ? rb + 32 : nr;
+#pragma unroll 8
+                for (int k = 0; k < kmax; ++k) s += a[rg + (r0 + k) * NB] * w[k + c * 96];
+                a[rg + (c0 + c) * NB] = -s;
+            }
+        }
         __syncthreads();
     }
-    for (int e = tid; e < NB * NB; e += 256) Dinv[e] = a[e];  // upper part is exactly zero
+    for (int e = tid; e < NB * NB; e += 256) Dinv[e] = a[e];
 }
 
 // pad region of an (npad x npad) matrix whose valid part is n x n: identity on the diagonal
@@ -193,7 +287,7 @@ int HdmChol::init(int n_) {
     HDM_HIP_CHECK(hipMalloc((void **) &vec, sizeof(double) * (size_t) npad * 4));
     HDM_HIP_CHECK(hdm_memset_sync(L, 0, mat));
     HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (NB * NB + NB + 2) * (int) sizeof(double)));
+                                      (NB * NB + 96 * 32 + 64) * (int) sizeof(double)));
     return 0;
 }
 
@@ -236,7 +330,7 @@ int HdmChol::finish_load(hipStream_t s) {
 int HdmChol::factor(hipStream_t s, int *info_host) {
     HDM_HIP_CHECK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
     const long ld = npad;
-    const size_t shm = (NB * NB + NB + 2) * sizeof(double);
+    const size_t shm = (NB * NB + 96 * 32 + 64) * sizeof(double);
     for (int k = 0; k < nblk; ++k) {
         double *Akk = L + (long) k * NB * (ld + 1);
         hipLaunchKernelGGL(hdm_potrf_diag_kernel, dim3(1), dim3(256), shm, s, Akk, ld, Dinv + (long) k * NB * NB,

@@ -99,7 +99,7 @@ __device__ __forceinline__ double frag(const double *__restrict__ s, int x, int 
     return KM ? s[x * LDK + k] : s[k * LDM + x];
 }
 
-template <bool AKM, bool BKM, int ROLE>
+template <bool AKM, bool BKM, int ROLE, int VAR>
 __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     __shared__ __attribute__((aligned(16))) double smem[4 * STAGE_DOUBLES];
     double *sA = smem;                      // [2][STAGE]
@@ -117,6 +117,14 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     if (t >= p.ntiles) return;
     const int tm = p.tiles[t].x, tn = p.tiles[t].y;
 
+    if (VAR & 1) {
+        // static, complementary priorities for the two workgroups that share a CU: the wave slot id of
+        // HW_REG_HW_ID (bits 3:0) alternates between co-resident workgroups, so one of them owns the matrix
+        // pipe whenever it has MFMAs ready and the other fills its barrier / staging gaps
+        const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        if (hwid & 1) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -170,6 +178,10 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         if (!idle_wave) {
 #pragma unroll
         for (int kk = 0; kk < HDM_BK; kk += 4) {
+            if ((VAR & 2) && kk == 8 && more) {  // stage the next tile into the other buffer mid-stream
+                r2s<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra);
+                r2s<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb);
+            }
             double fb[4], fa[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fb[i] = frag<AKM>(cA, wm * 64 + i * 16 + l15, kk + lq);
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
                     acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
         }
         }
-        if (more) {
+        if (more && (!(VAR & 2) || idle_wave)) {
             r2s<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra);
             r2s<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb);
         }
@@ -311,17 +323,27 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
         HDM_HIP_CHECK(hipEventRecord(e0, stream));
     }
     const int lay = (args.a_kmajor ? 2 : 0) | (args.b_kmajor ? 1 : 0);
-#define HDM_LAUNCH(AK, BK, R) hipLaunchKernelGGL((hdm_gemm_kernel<AK, BK, R>), grid, block, 0, stream, d)
-    switch (args.role) {
-        case HDM_ROLE_CONG1: HDM_LAUNCH(false, false, HDM_ROLE_CONG1); break;  // T = Linv * A
-        case HDM_ROLE_CONG2: HDM_LAUNCH(false, false, HDM_ROLE_CONG2); break;  // At = T * Linv^T
-        case HDM_ROLE_GRAM: HDM_LAUNCH(true, true, HDM_ROLE_GRAM); break;      // M = Ahat Ahat^T
-        default:
-            if (lay == 3) HDM_LAUNCH(true, true, HDM_ROLE_GENERIC);
-            else if (lay == 2) HDM_LAUNCH(true, false, HDM_ROLE_GENERIC);
-            else if (lay == 1) HDM_LAUNCH(false, true, HDM_ROLE_GENERIC);
-            else HDM_LAUNCH(false, false, HDM_ROLE_GENERIC);
+#define HDM_LAUNCH(AK, BK, R, V) hipLaunchKernelGGL((hdm_gemm_kernel<AK, BK, R, V>), grid, block, 0, stream, d)
+#define HDM_LAUNCH_V(AK, BK, R)                                   \
+    switch (g_var) {                                              \
+        case 1: HDM_LAUNCH(AK, BK, R, 1); break;                  \
+        case 2: HDM_LAUNCH(AK, BK, R, 2); break;                  \
+        case 3: HDM_LAUNCH(AK, BK, R, 3); break;                  \
+        default: HDM_LAUNCH(AK, BK, R, 0);                        \
     }
+    static int g_var = -1;
+    if (g_var < 0) { const char *e = getenv("HDM_VAR"); g_var = e ? atoi(e) : 0; }
+    switch (args.role) {
+        case HDM_ROLE_CONG1: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG1); break;  // T = Linv * A
+        case HDM_ROLE_CONG2: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG2); break;  // At = T * Linv^T
+        case HDM_ROLE_GRAM: HDM_LAUNCH_V(true, true, HDM_ROLE_GRAM); break;      // M = Ahat Ahat^T
+        default:
+            if (lay == 3) HDM_LAUNCH(true, true, HDM_ROLE_GENERIC, 0);
+            else if (lay == 2) HDM_LAUNCH(true, false, HDM_ROLE_GENERIC, 0);
+            else if (lay == 1) HDM_LAUNCH(false, true, HDM_ROLE_GENERIC, 0);
+            else HDM_LAUNCH(false, false, HDM_ROLE_GENERIC, 0);
+    }
+#undef HDM_LAUNCH_V
 #undef HDM_LAUNCH
     if (g_timing) {
         HDM_HIP_CHECK(hipEventRecord(e1, stream));

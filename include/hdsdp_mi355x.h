@@ -233,6 +233,18 @@ hdsdp_retcode HMiConeGetExchangeBuffers(hdsdp_cone *cone, void **sendBuf, void *
 hdsdp_retcode HMiConeSetExchangeBuffers(hdsdp_cone *cone, void *sendBuf, void *recvBuf);
 void *HMiKKTDeviceMatrix(hdsdp_kkt *HKKT, int64_t *ld);   /* device pointer of M (m x m, lower valid) */
 
+/* ================================  ingest (host only)  ================================
+ * SDPA sparse format reader with the reference's semantics (interface/hdsdp_file_io.c:34-381): one CSC per
+ * SDP block, shape n(n+1)/2 x (m+1), column 0 = C = -F0; rhs = the c vector.  Pointers stay valid until
+ * HMiSDPAFree. */
+typedef struct HMiSDPA_s HMiSDPA;
+hdsdp_retcode HMiReadSDPA(const char *fname, HMiSDPA **out);
+void HMiSDPAGetDims(const HMiSDPA *p, int *nConstrs, int *nBlks, int *nLpCols);
+hdsdp_retcode HMiSDPAGetBlock(const HMiSDPA *p, int iBlk, int *dim, const int **beg, const int **idx,
+                              const double **val);
+const double *HMiSDPAGetRHS(const HMiSDPA *p);
+void HMiSDPAFree(HMiSDPA **pp);
+
 /* ==================================  utilities  ================================== */
 int HMiDeviceInit(int device);         /* hipSetDevice + stream; returns 0 on success */
 int HMiDeviceSynchronize(void);

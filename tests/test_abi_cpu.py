@@ -105,3 +105,37 @@ def test_product_never_touches_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 for needle in ("oracle", "libhdsdp_ref", "ref_dump"):
                     assert needle not in txt, (os.path.join(dp, f), needle)
+
+
+@pytest.mark.parametrize("inst", ["theta1", "mcp100", "gpp100"])
+def test_sdpa_reader_matches_reference_reader(inst):
+    """our .dat-s reader vs the CSC the reference's HReadSDPA produced (stored in the golden files)"""
+    from hdsdp_amd import api
+    from util import GOLDEN
+    d = api.read_sdpa(os.path.join(GOLDEN, inst + ".dat-s"))
+    g = load_golden(inst + "_A")
+    assert d["m"] == int(g["dims"][1]) and len(d["blocks"]) == 1 and d["blocks"][0]["n"] == int(g["dims"][0])
+    blk = d["blocks"][0]
+    assert np.array_equal(blk["beg"], g["csc_beg"])
+    assert np.array_equal(blk["idx"], g["csc_idx"])
+    assert np.array_equal(blk["val"], g["csc_val"])
+    assert np.array_equal(d["b"], g["b"])
+
+
+def test_sdpa_reader_multi_block_and_errors(tmp_path):
+    from hdsdp_amd import api
+    from util import GOLDEN
+    d = api.read_sdpa(os.path.join(GOLDEN, "truss1.dat-s"))   # 6 blocks of 2 + one of 1
+    assert d["m"] == 6 and [b["n"] for b in d["blocks"]] == [2, 2, 2, 2, 2, 2, 1]
+    assert d["blocks"][6]["beg"][1] == 1 and d["blocks"][6]["val"][0] == 1.0   # C = -F0: "0 7 1 1 -1.0"
+    bad = tmp_path / "bad.dat-s"
+    bad.write_text("2\n1\n3\n1.0 2.0\n1 1 1 9 1.0\n")
+    with pytest.raises(api.HDSDPError):
+        api.read_sdpa(str(bad))
+    with pytest.raises(api.HDSDPError):
+        api.read_sdpa(str(tmp_path / "missing.dat-s"))
+    ragged = tmp_path / "ragged.dat-s"
+    ragged.write_text('"comment\n* another\n 2 = m\n 1\n {3}\n {1.0, 2.0}\n0 1 1 1 2.0\n1 1 2 1 0.5\n1 1 3 3 1e-13\n2 1 3 3 -4\n')
+    r = api.read_sdpa(str(ragged))
+    blk = r["blocks"][0]
+    assert list(blk["beg"]) == [0, 1, 2, 3] and list(blk["idx"]) == [0, 1, 5] and list(blk["val"]) == [-2.0, 0.5, -4.0]
