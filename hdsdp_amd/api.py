@@ -34,7 +34,7 @@ EXPORTS = [
     "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
-    "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC",
+    "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
 ]
 
@@ -129,6 +129,8 @@ def load_library():
         "HMiSDPAGetBlock": (C.c_int, [vp, C.c_int, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp)]),
         "HMiSDPAGetRHS": (dp, [vp]),
         "HMiSDPAFree": (None, [C.POINTER(vp)]),
+        "HMiMfmaIssueProbe": (C.c_double, [C.c_int, C.c_int, C.c_int]),
+        "HMiSetDebugBuffer": (None, [vp, C.c_int]),
         "HMiSetKernelTiming": (None, [C.c_int]),
         "HMiGetKernelTiming": (C.c_int, [dp, dp, C.POINTER(C.c_int64)]),
     }

@@ -41,68 +41,88 @@ __global__ __launch_bounds__(256) void hdm_potrf_diag_kernel(double *__restrict_
     double *a = sm;             // [NB][NB] column-major: L below the diagonal blocks, inverses on them
     double *w = sm + NB * NB;   // [96][PB] scratch for the inverse assembly
     const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 256) {
-        int i = e & (NB - 1), j = e >> 7;
-        a[e] = (i >= j) ? A[i + (long) j * ld] : 0.0;
+    // block load: 16 independent global loads in flight per thread (a conditional load per iteration would
+    // serialise 64 global round trips)
+    for (int e0 = tid; e0 < NB * NB; e0 += 256 * 16) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = e0 + q * 256;
+            v[q] = A[(e & (NB - 1)) + (long) (e >> 7) * ld];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = e0 + q * 256;
+            a[e] = ((e & (NB - 1)) >= (e >> 7)) ? v[q] : 0.0;
+        }
     }
     __syncthreads();
 
     for (int p = 0; p < NB / PB; ++p) {
         const int c0 = p * PB;
         if (tid < 64) {
-            // ---- wave 0: register Cholesky + inverse of the 32 x 32 diagonal sub-block
+            // ---- wave 0: Cholesky + in-place inverse of the 32 x 32 diagonal sub-block, LDS resident.
+            // Lane l owns row l (factorisation) / column l (inverse); the wave runs in lockstep, so a
+            // wavefront fence between a store phase and the dependent load phase is all the ordering needed.
             const int l = tid & 31;
-            double r[PB];
-#pragma unroll
-            for (int k = 0; k < PB; ++k) r[k] = (tid < PB && k <= l) ? a[(c0 + l) + (c0 + k) * NB] : 0.0;
+            const bool on = tid < PB;
+            double *blk = a + c0 + c0 * NB;          // blk[i + k*NB] = element (i, k) of the sub-block
+#define HDM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
             int bad = 0;
-            double *colj = w + PB * (PB + 1);  // [PB] broadcast buffer (double-buffered by parity of j)
-#pragma unroll
             for (int j = 0; j < PB; ++j) {
-                double *cb = colj + (j & 1) * PB;
-                if (tid < PB) cb[l] = r[j];                 // unscaled column j: element (l, j)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                double d = cb[j];                           // pivot, wave-uniform broadcast read
-                if (!(d > 0.0)) {                           // also catches NaN
+                double d = blk[j + j * NB];          // pivot (uniform broadcast read)
+                if (!(d > 0.0)) {                    // also catches NaN
                     if (!bad) bad = j + 1;
                     d = 1.0;
                 }
                 const double piv = sqrt(d), rinv = 1.0 / piv;
-                r[j] = (l == j) ? piv : r[j] * rinv;
+                double v = 0.0;
+                if (on && l >= j) {
+                    v = (l == j) ? piv : blk[l + j * NB] * rinv;
+                    blk[l + j * NB] = v;             // column j of L
+                }
+                HDM_WAVE_SYNC();
+                if (on && l > j) {
+                    // row l, cols j+1..l; iterations are independent: issue the LDS reads in batches of 8
+                    int k = j + 1;
+                    for (; k + 7 <= l; k += 8) {
+                        double t[8], u[8];
 #pragma unroll
-                for (int k = j + 1; k < PB; ++k) r[k] -= r[j] * (cb[k] * rinv);   // L[l][j] * L[k][j]
-                __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting later steps' loads
+                        for (int q = 0; q < 8; ++q) { t[q] = blk[l + (k + q) * NB]; u[q] = blk[(k + q) + j * NB]; }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) blk[l + (k + q) * NB] = t[q] - v * u[q];
+                    }
+                    for (; k <= l; ++k) blk[l + k * NB] -= v * blk[k + j * NB];
+                }
+                HDM_WAVE_SYNC();
             }
             if (bad && tid == 0) atomicCAS(info, 0, col0 + c0 + bad);
-            if (tid < PB) {
-#pragma unroll
-                for (int k = 0; k < PB; ++k)
-                    if (k <= l) A[(c0 + l) + (long) (c0 + k) * ld] = r[k];
+            if (on) {
+                for (int k = 0; k <= l; ++k) A[(c0 + l) + (long) (c0 + k) * ld] = blk[l + k * NB];
             }
-            // inverse: lane c owns column c of X = inv(L_pp); X[i][c] = (delta_ic - sum_{k<i} L[i][k] X[k][c]) / L[i][i]
-            // L[i][k] is wave-uniform: read it back from a small LDS copy (broadcast reads; keeping all of it in
-            // SGPRs via readlane overflows the scalar file)
-            double *lp = w;  // [PB][PB+1]
-            if (tid < PB) {
-#pragma unroll
-                for (int k = 0; k < PB; ++k) lp[l * (PB + 1) + k] = r[k];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            double x[PB];
-#pragma unroll
+            // in-place inverse, row by row: X[i][c] = (delta_ic - sum_{k=c}^{i-1} L[i][k] X[k][c]) / L[i][i];
+            // row i of L is last read in step i, rows < i already hold X
             for (int i = 0; i < PB; ++i) {
-                double s = (i == l) ? 1.0 : 0.0;
+                double s = 0.0;
+                const double dinv = 1.0 / blk[i + i * NB];
+                if (on && l <= i) {
+                    s = (l == i) ? 1.0 : 0.0;
+                    int k = l;
+                    for (; k + 7 < i; k += 8) {
+                        double t[8], u[8];
 #pragma unroll
-                for (int k = 0; k < i; ++k) s -= lp[i * (PB + 1) + k] * x[k];
-                x[i] = s / lp[i * (PB + 1) + i];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (tid < PB) {
+                        for (int q = 0; q < 8; ++q) { t[q] = blk[i + (k + q) * NB]; u[q] = blk[(k + q) + l * NB]; }
 #pragma unroll
-                for (int i = 0; i < PB; ++i) a[(c0 + i) + (c0 + l) * NB] = x[i];  // exact zeros above the diagonal
+                        for (int q = 0; q < 8; ++q) s -= t[q] * u[q];
+                    }
+                    for (; k < i; ++k) s -= blk[i + k * NB] * blk[k + l * NB];
+                    s *= dinv;
+                }
+                HDM_WAVE_SYNC();
+                if (on && l <= i) blk[i + l * NB] = s;
+                HDM_WAVE_SYNC();
             }
+#undef HDM_WAVE_SYNC
         }
         __syncthreads();
         const int t0 = c0 + PB, nr = NB - t0;

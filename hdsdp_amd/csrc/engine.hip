@@ -156,7 +156,7 @@ void lin_destroy(void **pchol) {
 // =============================================================================================
 // MI355X SDP cone
 // =============================================================================================
-enum { PATH_GEMM = 0, PATH_R1 = 1 };
+enum { PATH_GEMM = 0, PATH_R1 = 1, PATH_SPARSE = 2 };
 
 struct MiKKTPriv;
 
@@ -179,6 +179,8 @@ struct MiCone {
     double *Avec = nullptr;    // n16 x mloc16 rank-one factors (R1 path)
     double *sgn = nullptr;     // mloc signs (R1 path)
     int mloc16 = 0;
+    int *sp_rp = nullptr, *sp_ti = nullptr, *sp_tj = nullptr;  // sparse path: triplets of the owned rows
+    double *sp_tv = nullptr;
     int *rows_seg = nullptr;   // world*Lr: segment-ordered Gram row -> global constraint (-1 pad, -2.. aug)
     int *rows_own = nullptr;   // mloc: owned row -> global constraint
     double *S = nullptr, *Scheck = nullptr;  // n x n (ld n16) dual matrix buffers
@@ -416,6 +418,7 @@ int gram_all(MiCone *c) {
 
 hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
 hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
+hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
 
 hdsdp_retcode cone_build_schur(void *cd, int iCone, void *kktv, int typeKKT) {
     (void) iCone;
@@ -433,6 +436,7 @@ hdsdp_retcode cone_build_schur(void *cd, int iCone, void *kktv, int typeKKT) {
         return HDSDP_RETCODE_FAILED;
     }
     if (c->path == PATH_R1) return build_r1_path(c, kkt, pv, typeKKT);
+    if (c->path == PATH_SPARSE) return build_sparse_path(c, kkt, pv, typeKKT);
     return build_gemm_path(c, kkt, pv, typeKKT);
 }
 hdsdp_retcode cone_build_schur_fixed(void *cd, int iCone, void *kktv, int typeKKT, int strategy) {
@@ -558,6 +562,32 @@ __global__ void mi_mat_dot_kernel(const double *__restrict__ X, long ldx, const 
     if (threadIdx.x == 0) *out += scale * (red[0] + red[1] + red[2] + red[3]);
 }
 
+__device__ __forceinline__ double mi_hash_unit(unsigned x) {  // pseudo-random in (-1, 1)
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return (double) (int) x / 2147483648.0;
+}
+// same loop on full-range pseudo-random operands (data-dependent power -> sustained clock)
+__global__ __launch_bounds__(256, 2) void mi_mfma_probe_rand_kernel(double *out, int iters) {
+    hdm_d4 acc[4][4];
+    const unsigned gid = blockIdx.x * 256 + threadIdx.x;
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
+            for (int r = 0; r < 4; ++r) acc[j][i][r] = mi_hash_unit(gid * 64 + j * 16 + i * 4 + r);
+    double fa[4], fb[4];
+    for (int i = 0; i < 4; ++i) { fa[i] = mi_hash_unit(gid * 8 + i + 1000003u); fb[i] = mi_hash_unit(gid * 8 + 4 + i + 7000001u); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
+    }
+    double s = 0.0;
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) s += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+    if (s == 12345.678) out[0] = s;
+}
+
 __global__ void mi_mfma_probe_kernel(double *out, int iters) {
     hdm_d4 acc[8];
     for (int i = 0; i < 8; ++i) acc[i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
@@ -569,6 +599,58 @@ __global__ void mi_mfma_probe_kernel(double *out, int iters) {
     double s = 0.0;
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678) out[0] = s;  // keep the loop alive
+}
+
+// GEMM-shaped MFMA issue probe: 16 accumulators fed by 4 + 4 operand registers exactly like the GEMM inner loop,
+// no memory traffic at all.  NW = waves per workgroup.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void mi_mfma_probe2_kernel(double *out, int iters) {
+    hdm_d4 acc[4][4];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) acc[j][i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
+    double fa[4], fb[4];
+    for (int i = 0; i < 4; ++i) { fa[i] = 1.0 + threadIdx.x * 1e-9 * (i + 1); fb[i] = 1.0 - threadIdx.x * 1e-9 * (i + 2); }
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
+        } else if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0], fb[0], acc[j][i], 0, 0, 0);
+        } else {  // 8 accumulators only (2 x 4), GEMM operand pattern
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
+        }
+    }
+    double s = 0.0;
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) s += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+    if (s == 12345.678) out[0] = s;
+}
+
+template <int NACC, int LB>
+__global__ __launch_bounds__(256, LB) void mi_mfma_probe3_kernel(double *out, int iters) {
+    hdm_d4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;
 }
 
 namespace {
@@ -642,6 +724,53 @@ hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKK
     return HDSDP_RETCODE_OK;
 }
 
+hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT) {
+    // every constraint is a short triplet list: gather from X = S^-1 (reference strategy M5, and the corrector /
+    // HSD components that the reference evaluates with the same gathers, hdsdp_conic_sdp.c:923-1056)
+    MiLin *l = (MiLin *) c->dualFactor->chol;
+    HdmChol &ch = l->ch;
+    const int m = kkt->nRow;
+    const long ldx = ch.npad;
+    RC(ch.inverse_full(c->Xinv, ldx, g.stream));
+    long ldm = 0;
+    double *Mdev = kkt_Mdev(kkt, &ldm);
+    RC(hdm_sparse_dot(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Xinv, ldx, c->mloc, c->rows_own, 1.0, pv->vecs, g.stream));
+    if (c->Rd != 0.0) {
+        HdmGemmArgs q = {};  // Y = X X^T = S^-2
+        q.A = c->Xinv; q.lda = ldx; q.B = c->Xinv; q.ldb = ldx; q.C = c->Yinv; q.ldc = ldx;
+        q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE;
+        RC(hdm_launch_gemm(q, g.stream));
+        RC(hdm_sparse_dot(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Yinv, ldx, c->mloc, c->rows_own, c->Rd,
+                          pv->vecs + m, g.stream));
+    }
+    if (typeKKT == KKT_TYPE_CORRECTOR) return HDSDP_RETCODE_OK;
+    if (c->Rd != 0.0)
+        hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Xinv, ldx, nullptr, 0L, c->n, 1, 1.0,
+                           pv->vecs + 3 * m);
+    RC(hdm_sparse_pairs(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Xinv, ldx, c->mloc, c->rows_own, Mdev, ldm, g.stream));
+    if (typeKKT == KKT_TYPE_HOMOGENEOUS) {
+        HdmGemmArgs w = {};  // W = X C,  Ct = W X = X C X
+        w.A = c->Xinv; w.lda = ldx; w.B = c->Cfull; w.ldb = c->n16; w.C = c->W; w.ldc = ldx;
+        w.M = c->n16; w.N = c->n16; w.K = c->n16; w.batch = 1; w.alpha = 1.0; w.epilogue = HDM_EPI_STORE;
+        RC(hdm_launch_gemm(w, g.stream));
+        HdmGemmArgs x = {};
+        x.A = c->W; x.lda = ldx; x.B = c->Xinv; x.ldb = ldx; x.C = c->Ct; x.ldc = ldx;
+        x.M = c->n16; x.N = c->n16; x.K = c->n16; x.batch = 1; x.alpha = 1.0; x.epilogue = HDM_EPI_STORE;
+        RC(hdm_launch_gemm(x, g.stream));
+        RC(hdm_sparse_dot(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Ct, ldx, c->mloc, c->rows_own, 1.0,
+                          pv->vecs + 2 * m, g.stream));
+        hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, (long) c->n16, c->Xinv, ldx, c->n,
+                           0, 1.0, pv->vecs + 3 * m + 1);
+        hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, (long) c->n16, c->Ct, ldx, c->n, 0,
+                           1.0, pv->vecs + 3 * m + 2);
+        if (c->Rd != 0.0)
+            hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, (long) c->n16, c->Yinv, ldx,
+                               c->n, 0, c->Rd, pv->vecs + 3 * m + 3);
+    }
+    HIP_RC(hipGetLastError());
+    return HDSDP_RETCODE_OK;
+}
+
 void cone_destroy_data(void **pcd) {
     if (!pcd || !*pcd) return;
     MiCone *c = (MiCone *) *pcd;
@@ -653,6 +782,10 @@ void cone_destroy_data(void **pcd) {
         if (c->AhatAll && c->AhatAll != c->AhatLoc) (void) hipFree(c->AhatAll);
         if (c->AhatLoc) (void) hipFree(c->AhatLoc);
     }
+    if (c->sp_rp) (void) hipFree(c->sp_rp);
+    if (c->sp_ti) (void) hipFree(c->sp_ti);
+    if (c->sp_tj) (void) hipFree(c->sp_tj);
+    if (c->sp_tv) (void) hipFree(c->sp_tv);
     if (c->rows_seg) (void) hipFree(c->rows_seg);
     if (c->rows_own) (void) hipFree(c->rows_own);
     if (c->trA) free(c->trA);
@@ -703,6 +836,7 @@ int HMiDeviceSynchronize(void) {
 }
 void *HMiStream(void) { return ensure_ctx() ? nullptr : (void *) g.stream; }
 void HMiSetKernelTiming(int on) { hdm_timing_enable(on); }
+void HMiSetDebugBuffer(void *dev, int role) { hdm_set_debug_buffer((unsigned long long *) dev, role); }
 int HMiGetKernelTiming(double *ms, double *flops, int64_t *launches) {
     long l[HDM_NROLES];
     if (hdm_timing_collect(ms, flops, l)) return 1;
@@ -1075,8 +1209,21 @@ hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol
         if (t == MI_COEFF_SPR1 || t == MI_COEFF_DSR1) r1++;
     }
     c->path = (nz > 0 && r1 == nz && world == 1) ? PATH_R1 : PATH_GEMM;
+    if (c->path == PATH_GEMM && world == 1 && nz > 0) {
+        // sparse gather path: only triplet-class rows, and the pair products are far cheaper than m congruences
+        bool all_sparse = true;
+        double tot = 0.0;
+        for (int i = 0; i < nRow; ++i) {
+            int t = c->blk.rows[i].type;
+            if (t == MI_COEFF_DENSE || t == MI_COEFF_DSR1) all_sparse = false;
+            tot += (double) c->blk.rows[i].idx.size();
+        }
+        if (all_sparse && tot * tot < 0.05 * (double) nRow * nCol * (double) nCol * nCol) c->path = PATH_SPARSE;
+    }
     const char *force = getenv("HDSDP_MI355X_FORCE_GEMM");
     if (force && atoi(force)) c->path = PATH_GEMM;
+    const char *forcesp = getenv("HDSDP_MI355X_FORCE_PATH");
+    if (forcesp && world == 1) c->path = atoi(forcesp);
     if (upload_dense_rows(c)) return HDSDP_RETCODE_MEMORY;   // dense copies also feed the S assembly
     if (c->path == PATH_R1) {
         c->mloc16 = (int) hdm_roundup(std::max(1, c->mloc), 16);
@@ -1097,6 +1244,34 @@ hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol
             return HDSDP_RETCODE_MEMORY;
         if (hdm_memcpy_h2d_sync(c->Avec, hA.data(), av) != hipSuccess ||
             hdm_memcpy_h2d_sync(c->sgn, hs.data(), sizeof(double) * c->mloc16) != hipSuccess)
+            return HDSDP_RETCODE_FAILED;
+    }
+    if (c->path == PATH_SPARSE) {
+        std::vector<int> rp(c->mloc + 1, 0), ti, tj;
+        std::vector<double> tv;
+        for (int q = 0; q < c->mloc; ++q) {
+            const MiCoeff &co = c->blk.rows[c->own[q]];
+            for (size_t e = 0; e < co.idx.size(); ++e) {
+                long pk = co.idx[e];
+                int col = 0; long start = 0;
+                while (pk >= start + (nCol - col)) { start += nCol - col; ++col; }
+                ti.push_back(col + (int) (pk - start)); tj.push_back(col); tv.push_back(co.val[e]);
+            }
+            rp[q + 1] = (int) ti.size();
+        }
+        const size_t nt = std::max<size_t>(1, ti.size());
+        const size_t nn2 = sizeof(double) * (size_t) hdm_roundup(nCol, 128) * hdm_roundup(nCol, 128);
+        if (hipMalloc((void **) &c->sp_rp, sizeof(int) * rp.size()) != hipSuccess ||
+            hipMalloc((void **) &c->sp_ti, sizeof(int) * nt) != hipSuccess ||
+            hipMalloc((void **) &c->sp_tj, sizeof(int) * nt) != hipSuccess ||
+            hipMalloc((void **) &c->sp_tv, sizeof(double) * nt) != hipSuccess ||
+            hipMalloc((void **) &c->Xinv, nn2) != hipSuccess || hipMalloc((void **) &c->Yinv, nn2) != hipSuccess ||
+            hipMalloc((void **) &c->W, nn2) != hipSuccess || hipMalloc((void **) &c->Ct, nn2) != hipSuccess)
+            return HDSDP_RETCODE_MEMORY;
+        if (hdm_memcpy_h2d_sync(c->sp_rp, rp.data(), sizeof(int) * rp.size()) != hipSuccess ||
+            (ti.size() && (hdm_memcpy_h2d_sync(c->sp_ti, ti.data(), sizeof(int) * ti.size()) != hipSuccess ||
+                           hdm_memcpy_h2d_sync(c->sp_tj, tj.data(), sizeof(int) * tj.size()) != hipSuccess ||
+                           hdm_memcpy_h2d_sync(c->sp_tv, tv.data(), sizeof(double) * tv.size()) != hipSuccess)))
             return HDSDP_RETCODE_FAILED;
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
@@ -1236,6 +1411,41 @@ double HMiMfmaPeakProbe(int iters) {
     (void) hipEventElapsedTime(&ms, g.ev[6], g.ev[7]);
     (void) hipFree(out);
     const double flops = (double) blocks * (threads / 64) * (double) iters * 8 * 2.0 * 16 * 16 * 4;
+    return flops / (ms * 1e-3) / 1e12;
+}
+
+// mode 0: GEMM operand pattern, mode 1: one operand pair; wgPerCu workgroups of 256 threads per CU
+double HMiMfmaIssueProbe(int mode, int wgPerCu, int iters) {
+    if (ensure_ctx()) return -1.0;
+    double *out = nullptr;
+    if (hipMalloc((void **) &out, 8) != hipSuccess) return -1.0;
+    const int blocks = 256 * wgPerCu, threads = 256;
+    for (int rep = 0; rep < 2; ++rep) {
+        if (rep == 1) (void) hipEventRecord(g.ev[6], g.stream);
+        if (mode == 300) {
+            hipLaunchKernelGGL(mi_mfma_probe_rand_kernel, dim3(blocks), dim3(threads), 0, g.stream, out, iters);
+        } else if (mode == 200) {
+            hipLaunchKernelGGL(mi_mfma_probe_kernel, dim3(blocks), dim3(threads), 0, g.stream, out, iters * 2);
+        } else if (mode >= 100) {
+            const int it3 = iters * 16 / (mode % 100);
+            switch (mode) {
+                case 104: hipLaunchKernelGGL((mi_mfma_probe3_kernel<4, 1>), dim3(blocks), dim3(threads), 0, g.stream, out, it3); break;
+                case 108: hipLaunchKernelGGL((mi_mfma_probe3_kernel<8, 1>), dim3(blocks), dim3(threads), 0, g.stream, out, it3); break;
+                case 112: hipLaunchKernelGGL((mi_mfma_probe3_kernel<12, 1>), dim3(blocks), dim3(threads), 0, g.stream, out, it3); break;
+                case 116: hipLaunchKernelGGL((mi_mfma_probe3_kernel<16, 1>), dim3(blocks), dim3(threads), 0, g.stream, out, it3); break;
+                case 124: hipLaunchKernelGGL((mi_mfma_probe3_kernel<24, 1>), dim3(blocks), dim3(threads), 0, g.stream, out, it3); break;
+                default: break;
+            }
+        } else if (mode == 0) hipLaunchKernelGGL(mi_mfma_probe2_kernel<0>, dim3(blocks), dim3(threads), 0, g.stream, out, iters);
+        else if (mode == 1) hipLaunchKernelGGL(mi_mfma_probe2_kernel<1>, dim3(blocks), dim3(threads), 0, g.stream, out, iters);
+        else hipLaunchKernelGGL(mi_mfma_probe2_kernel<2>, dim3(blocks), dim3(threads), 0, g.stream, out, iters);
+    }
+    (void) hipEventRecord(g.ev[7], g.stream);
+    (void) hipEventSynchronize(g.ev[7]);
+    float ms = 0;
+    (void) hipEventElapsedTime(&ms, g.ev[6], g.ev[7]);
+    (void) hipFree(out);
+    const double flops = (double) blocks * (threads / 64) * (double) iters * 16 * 2.0 * 16 * 16 * 4;
     return flops / (ms * 1e-3) / 1e12;
 }
 

@@ -34,6 +34,7 @@ struct HdmGemmDev {
     HdmGemmArgs a;
     const int2 *tiles;
     int ntiles;
+    unsigned long long *dbg;  // diagnostic builds only (VAR & 32): 8 words per workgroup
 };
 
 // Tile staging: a (128 rows x 16 k) tile is 1024 chunks of 16 bytes; thread t moves chunks t, t+256, t+512,
@@ -112,21 +113,26 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     // tiles are walked heaviest-first (host-sorted list).
     const int nb = a.batch;
     const int wg = blockIdx.x;
-    const int z = wg % nb;
-    const int t = wg / nb;
-    if (t >= p.ntiles) return;
+    int z, t;
+    if ((nb & 7) == 0) {
+        // workgroup ids are dealt round-robin over the 8 XCDs: XCD x walks batch entries x, x+8, ... one after the
+        // other and, inside an entry, the tile list in order -- so the ~64 workgroups an XCD runs at any time work
+        // on ONE operand set and on neighbouring tiles, and share their row/column panels in that XCD's L2
+        const int idx = wg >> 3;
+        z = (wg & 7) + 8 * (idx / p.ntiles);
+        t = idx % p.ntiles;
+    } else {
+        z = wg % nb;
+        t = wg / nb;
+    }
+    if (t >= p.ntiles || z >= nb) return;
     const int tm = p.tiles[t].x, tn = p.tiles[t].y;
 
-    if (VAR & 1) {
-        // static, complementary priorities for the two workgroups that share a CU: the wave slot id of
-        // HW_REG_HW_ID (bits 3:0) alternates between co-resident workgroups, so one of them owns the matrix
-        // pipe whenever it has MFMAs ready and the other fills its barrier / staging gaps
-        const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-        if (hwid & 1) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(0);
-    }
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
+    if ((VAR & 32) && p.dbg) t_start = __builtin_amdgcn_s_memtime();
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile/sub-tile index math runs on the SALU
     const int wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, lq = lane >> 4;
 
@@ -150,63 +156,105 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         for (int i = 0; i < 4; ++i) acc[j][i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
 
     const int kt0 = (int) (kbeg / HDM_BK), kt1 = (int) (kend / HDM_BK);
-    double2 ra[4], rb[4];
     Stager<AKM> stA;
     Stager<BKM> stB;
     stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, m0, kt0, tid);
     stB.init(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, n0, kt0, tid);
-    if (kt0 < kt1) {
-        stA.load(ra);
-        stB.load(rb);
-        r2s<AKM>(sA, tid, ra);
-        r2s<BKM>(sB, tid, rb);
-    }
-    __syncthreads();
-
     // lower-only diagonal tiles: the (rows 0-63, cols 64-127) quadrant lies strictly above the diagonal; its
     // wave issues no MFMAs and leaves the SIMD to the co-resident workgroup
     const bool idle_wave = a.lower_only && (tm == tn) && (wm == 0) && (wn == 1);
-    int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = (kt + 1 < kt1);
-        if (more) {
-            stA.load(ra);
-            stB.load(rb);
-        }
-        const double *cA = sA + cur * STAGE_DOUBLES;
-        const double *cB = sB + cur * STAGE_DOUBLES;
-        if (!idle_wave) {
+
+    double cfa[4] = {1.0 + lane, 2.0, 3.0 - lane, 4.0}, cfb[4] = {0.5, 0.25 * lane, 0.125, 1.0};  // timing-only (VAR & 16)
+    auto compute = [&](const double *cA, const double *cB) {
+        if (idle_wave) return;
 #pragma unroll
         for (int kk = 0; kk < HDM_BK; kk += 4) {
-            if ((VAR & 2) && kk == 8 && more) {  // stage the next tile into the other buffer mid-stream
-                r2s<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra);
-                r2s<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb);
-            }
             double fb[4], fa[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fb[i] = frag<AKM>(cA, wm * 64 + i * 16 + l15, kk + lq);
+            for (int i = 0; i < 4; ++i) fb[i] = (VAR & 16) ? cfb[i] : frag<AKM>(cA, wm * 64 + i * 16 + l15, kk + lq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fa[j] = frag<BKM>(cB, wn * 64 + j * 16 + l15, kk + lq);
+            for (int j = 0; j < 4; ++j) fa[j] = (VAR & 16) ? cfa[j] : frag<BKM>(cB, wn * 64 + j * 16 + l15, kk + lq);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
         }
+    };
+
+    if (VAR & 2) {
+        // Two k blocks in flight: global loads are issued two stages ahead into two register sets, so a load has
+        // two full MFMA stages (~8 us) to land before its ds_write.  With one stage of look-ahead both co-resident
+        // workgroups regularly parked on vmcnt together (SQ_WAIT_ANY 14.6 % of wave cycles, MFMA pipe 83.5 %).
+        double2 a0[4], b0[4], a1[4], b1[4];
+        const int nst = kt1 - kt0;
+        if (nst > 0) {
+            stA.load(a0); stB.load(b0);
+            r2s<AKM>(sA, tid, a0); r2s<BKM>(sB, tid, b0);
         }
-        if (more && (!(VAR & 2) || idle_wave)) {
-            r2s<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra);
-            r2s<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb);
+        if (nst > 1) { stA.load(a1); stB.load(b1); }
+        if (nst > 2) { stA.load(a0); stB.load(b0); }
+        __syncthreads();
+        if ((VAR & 32) && p.dbg) t_pro = __builtin_amdgcn_s_memtime();
+        for (int t = 0; t < nst; t += 2) {
+            compute(sA, sB);
+            if (t + 1 < nst) {
+                r2s<AKM>(sA + STAGE_DOUBLES, tid, a1); r2s<BKM>(sB + STAGE_DOUBLES, tid, b1);
+                if (t + 3 < nst) { stA.load(a1); stB.load(b1); }
+            }
+            __syncthreads();
+            if (t + 1 >= nst) break;
+            compute(sA + STAGE_DOUBLES, sB + STAGE_DOUBLES);
+            if (t + 2 < nst) {
+                r2s<AKM>(sA, tid, a0); r2s<BKM>(sB, tid, b0);
+                if (t + 4 < nst) { stA.load(a0); stB.load(b0); }
+            }
+            __syncthreads();
+        }
+    } else {
+        double2 ra[4], rb[4];
+        if (kt0 < kt1) {
+            stA.load(ra);
+            stB.load(rb);
+            r2s<AKM>(sA, tid, ra);
+            r2s<BKM>(sB, tid, rb);
         }
         __syncthreads();
-        cur ^= 1;
+        if ((VAR & 32) && p.dbg) t_pro = __builtin_amdgcn_s_memtime();
+        int cur = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const bool more = (kt + 1 < kt1);
+            if (more && !(VAR & 4)) {
+                stA.load(ra);
+                stB.load(rb);
+            }
+            compute(sA + cur * STAGE_DOUBLES, sB + cur * STAGE_DOUBLES);
+            if (more && !(VAR & 4)) {
+                r2s<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra);
+                r2s<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb);
+            }
+            if (!(VAR & 8)) __syncthreads();   // VAR & 4/8/16: timing-only ablations (wrong results)
+            cur ^= 1;
+        }
     }
 
+    if ((VAR & 32) && p.dbg) t_loop = __builtin_amdgcn_s_memtime();
+    auto stamp_end = [&]() {
+        if ((VAR & 32) && p.dbg && tid == 0) {
+            unsigned long long *d = p.dbg + (size_t) blockIdx.x * 8;
+            d[0] = t_start; d[1] = t_pro; d[2] = t_loop; d[3] = __builtin_amdgcn_s_memtime();
+            d[4] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);    // HW_REG_HW_ID[15:0]: wave, simd, pipe, cu, sh, se
+            d[5] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
+            d[6] = (unsigned long long) (kt1 - kt0);
+            d[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
     // ---------------------------------------------------------------- epilogue
     // lane l, reg r of acc[j][i] holds C[m0 + wm*64 + i*16 + l15][n0 + wn*64 + j*16 + lq + 4r]
     if (a.epilogue == HDM_EPI_BLOCKED) {
-        double *dst = a.C;
-        const long row = a.blk_row0 + z;
+        // one base pointer per lane, everything else is wave-uniform 64-bit strides
+        const long rs16 = a.blk_row_stride * 16;                       // elements between consecutive p-blocks
+        double *lane_base = a.C + (a.blk_row0 + z) * 16 + l15 + (long) lq * rs16;
         const double rt2 = 1.4142135623730951;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -214,22 +262,48 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
             for (int i = 0; i < 4; ++i) {
                 const int bi = (m0 + wm * 64 + i * 16) >> 4;
                 const int bj = (n0 + wn * 64 + j * 16) >> 4;
-                if (bi < bj || bi >= a.nblk) continue;  // (bj <= bi < nblk)
+                if (bi < bj || bi >= a.nblk) continue;  // (bj <= bi < nblk), wave-uniform
                 const double sc = (bi == bj) ? 1.0 : rt2;
                 const long sub = (long) bj * a.nblk - (long) bj * (bj - 1) / 2 + (bi - bj);
+                double *q = lane_base + sub * 16 * rs16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long pb = sub * 16 + lq + 4 * r;
-                    dst[(pb * a.blk_row_stride + row) * 16 + l15] = sc * acc[j][i][r];
-                }
+                for (int r = 0; r < 4; ++r) q[(long) (4 * r) * rs16] = sc * acc[j][i][r];
             }
         }
+        stamp_end();
         return;
     }
     double *C = a.C;
     if (a.epilogue == HDM_EPI_SLAB) C += (long) z * a.slab_stride;
     else C += (long) z * a.strideC;
     const bool diag_tile = a.lower_only && (tm == tn);
+    const bool inside = (m0 + HDM_TILE <= a.M) && (n0 + HDM_TILE <= a.N) && !diag_tile;   // wave-uniform
+    if (inside) {
+        // interior tile: no per-element predicates, one lane pointer, uniform column strides
+        double *lane_c = C + (m0 + wm * 64 + l15) + (long) (n0 + wn * 64 + lq) * a.ldc;
+        const long c4 = 4 * a.ldc;
+        if (a.beta == 0.0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double *q = lane_c + (long) (j * 4 + r) * c4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[i * 16] = a.alpha * acc[j][i][r];
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double *q = lane_c + (long) (j * 4 + r) * c4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[i * 16] = a.alpha * acc[j][i][r] + a.beta * q[i * 16];
+                }
+        }
+        stamp_end();
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -247,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
             }
         }
     }
+    stamp_end();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -256,6 +331,8 @@ namespace {
 struct TimedLaunch { hipEvent_t e0, e1; int role; double flops; };
 bool g_timing = false;
 std::vector<TimedLaunch> g_timed;
+unsigned long long *g_dbg = nullptr;
+int g_dbg_role = -1;
 struct TileList {
     int2 *dev = nullptr;
     int n = 0;
@@ -315,6 +392,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     if (d.a.b_kblk == 0) d.a.b_kblk = HDM_BK;
     d.tiles = tl.dev;
     d.ntiles = tl.n;
+    d.dbg = (g_dbg && args.role == g_dbg_role) ? g_dbg : nullptr;
     const long nwg = (long) tl.n * args.batch;
     dim3 grid((unsigned) nwg), block(256);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -326,13 +404,23 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
 #define HDM_LAUNCH(AK, BK, R, V) hipLaunchKernelGGL((hdm_gemm_kernel<AK, BK, R, V>), grid, block, 0, stream, d)
 #define HDM_LAUNCH_V(AK, BK, R)                                   \
     switch (g_var) {                                              \
-        case 1: HDM_LAUNCH(AK, BK, R, 1); break;                  \
         case 2: HDM_LAUNCH(AK, BK, R, 2); break;                  \
-        case 3: HDM_LAUNCH(AK, BK, R, 3); break;                  \
+        case 4: HDM_LAUNCH(AK, BK, R, 4); break;                  \
+        case 12: HDM_LAUNCH(AK, BK, R, 12); break;                \
+        case 28: HDM_LAUNCH(AK, BK, R, 28); break;                \
+        case 32: HDM_LAUNCH(AK, BK, R, 32); break;                \
+        case 60: HDM_LAUNCH(AK, BK, R, 60); break;                \
+        case 36: HDM_LAUNCH(AK, BK, R, 36); break;                \
+        case 44: HDM_LAUNCH(AK, BK, R, 44); break;                \
         default: HDM_LAUNCH(AK, BK, R, 0);                        \
     }
-    static int g_var = -1;
-    if (g_var < 0) { const char *e = getenv("HDM_VAR"); g_var = e ? atoi(e) : 0; }
+    // HDM_VAR selects a kernel variant for A/B runs and diagnostics (tools/var_sweep.sh, tools/wg_timeline.py):
+    //   2 = global loads two stages ahead (default for the congruence kernels: -2 %; +4 % on the Gram kernel,
+    //   which keeps the one-stage form), 32 = per-workgroup s_memtime stamps, 4/12/28/36/44/60 = timing-only
+    //   ablations (no staging / no barriers / no LDS reads: results are wrong by construction).
+    static int g_env_var = -2;
+    if (g_env_var == -2) { const char *e = getenv("HDM_VAR"); g_env_var = e ? atoi(e) : -1; }
+    const int g_var = g_env_var >= 0 ? g_env_var : (args.role == HDM_ROLE_GRAM ? 0 : 2);
     switch (args.role) {
         case HDM_ROLE_CONG1: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG1); break;  // T = Linv * A
         case HDM_ROLE_CONG2: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG2); break;  // At = T * Linv^T
@@ -371,3 +459,6 @@ int hdm_timing_collect(double *ms, double *flops, long *launches) {
     g_timed.clear();
     return 0;
 }
+
+// diagnostic: per-workgroup timestamps of the next launches with the given role (HDM_VAR=32 builds the stamps in)
+void hdm_set_debug_buffer(unsigned long long *dev, int role) { g_dbg = dev; g_dbg_role = role; }

@@ -86,4 +86,5 @@ struct HdmGemmArgs {
 int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream);
 // per-role live timing with HIP events on the launch stream (off by default)
 void hdm_timing_enable(int on);
+void hdm_set_debug_buffer(unsigned long long *dev, int role);
 int hdm_timing_collect(double *ms, double *flops, long *launches);  // arrays of HDM_NROLES; resets

@@ -17,3 +17,7 @@ int hdm_r1_colnorm(const double *V, long ldv, int n, const double *sgn, const in
                    double *asinvrd, hipStream_t s);
 int hdm_sym_dot2(const double *A, long astride, int n, long lda, int count, const double *X, const double *Y, long ldx,
                  double *outx, double *outy, const int *rows_global, double sx, double sy, hipStream_t s);
+int hdm_sparse_pairs(const int *rp, const int *ti, const int *tj, const double *tv, const double *X, long ldx, int mloc,
+                     const int *rows_global, double *M, long ldm, hipStream_t s);
+int hdm_sparse_dot(const int *rp, const int *ti, const int *tj, const double *tv, const double *Y, long ldy, int mloc,
+                   const int *rows_global, double scale, double *out, hipStream_t s);

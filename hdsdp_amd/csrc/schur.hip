@@ -243,6 +243,66 @@ __global__ __launch_bounds__(256) void hdm_sym_dot2_kernel(const double *__restr
 }
 
 // ------------------------------------------------------------------------------------------
+// sparse (M5) path: no intermediate matrix, entries of X = S^-1 are gathered per pair of nonzeros
+// (reference: KKT5Pair_Sparse_Sparse, linalg/hdsdp_sdpdata.c:1711-1760, and its rank-one variants).
+// Constraint i is a list of lower triplets (p >= q, a); one wavefront per pair (i >= j):
+//   M_ij = sum_{(p,q,a) in A_i} sum_{(r,s,b) in A_j} a b [ X_qr X_sp + (r!=s) X_qs X_rp + (p!=q) X_pr X_sq + (p!=q)(r!=s) X_ps X_rq ]
+// lanes stride over the nnz_i x nnz_j products, the partial sums are reduced with wave shuffles.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hdm_sparse_pair_kernel(const int *__restrict__ rp, const int *__restrict__ ti,
+                                                               const int *__restrict__ tj, const double *__restrict__ tv,
+                                                               const double *__restrict__ X, long ldx, int mloc,
+                                                               const int *__restrict__ rows_global,
+                                                               double *__restrict__ M, long ldm) {
+    const int lane = threadIdx.x & 63;
+    const long t = (long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long npairs = (long) mloc * (mloc + 1) / 2;
+    if (t >= npairs) return;
+    long i = (long) ((sqrt(8.0 * (double) t + 1.0) - 1.0) * 0.5);
+    while (i * (i + 1) / 2 > t) --i;
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    const long j = t - i * (i + 1) / 2;
+    const int bi = rp[i], ni = rp[i + 1] - bi, bj = rp[j], nj = rp[j + 1] - bj;
+    double acc = 0.0;
+    const long tot = (long) ni * nj;
+    for (long e = lane; e < tot; e += 64) {
+        const int ei = bi + (int) (e / nj), ej = bj + (int) (e % nj);
+        const int p = ti[ei], q = tj[ei], r = ti[ej], s = tj[ej];
+        double g = X[q + r * ldx] * X[s + p * ldx];
+        if (r != s) g += X[q + s * ldx] * X[r + p * ldx];
+        if (p != q) {
+            g += X[p + r * ldx] * X[s + q * ldx];
+            if (r != s) g += X[p + s * ldx] * X[r + q * ldx];
+        }
+        acc += tv[ei] * tv[ej] * g;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0 && tot > 0) {
+        const int gi = rows_global[i], gj = rows_global[j];
+        const int rr = gi > gj ? gi : gj, cc = gi > gj ? gj : gi;
+        M[rr + (long) cc * ldm] += acc;
+    }
+}
+
+// out[row] += scale * <A_row, Y> for triplet rows and a full symmetric Y: one wavefront per row
+__global__ __launch_bounds__(256) void hdm_sparse_dot_kernel(const int *__restrict__ rp, const int *__restrict__ ti,
+                                                              const int *__restrict__ tj, const double *__restrict__ tv,
+                                                              const double *__restrict__ Y, long ldy, int mloc,
+                                                              const int *__restrict__ rows_global, double scale,
+                                                              double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= mloc) return;
+    double acc = 0.0;
+    for (int e = rp[i] + lane; e < rp[i + 1]; e += 64) {
+        const int p = ti[e], q = tj[e];
+        acc += tv[e] * Y[p + q * ldy] * (p != q ? 2.0 : 1.0);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) out[rows_global[i]] += scale * acc;
+}
+
+// ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
 int hdm_unpack_sym(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s) {
@@ -321,6 +381,25 @@ int hdm_sym_dot2(const double *A, long astride, int n, long lda, int count, cons
     if (count <= 0) return 0;
     hipLaunchKernelGGL(hdm_sym_dot2_kernel, dim3(count), dim3(256), 0, s, A, astride, n, lda, X, Y, ldx, outx, outy,
                        rows_global, sx, sy);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_sparse_pairs(const int *rp, const int *ti, const int *tj, const double *tv, const double *X, long ldx, int mloc,
+                     const int *rows_global, double *M, long ldm, hipStream_t s) {
+    const long npairs = (long) mloc * (mloc + 1) / 2;
+    if (npairs <= 0) return 0;
+    hipLaunchKernelGGL(hdm_sparse_pair_kernel, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, s, rp, ti, tj, tv, X, ldx,
+                       mloc, rows_global, M, ldm);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_sparse_dot(const int *rp, const int *ti, const int *tj, const double *tv, const double *Y, long ldy, int mloc,
+                   const int *rows_global, double scale, double *out, hipStream_t s) {
+    if (mloc <= 0) return 0;
+    hipLaunchKernelGGL(hdm_sparse_dot_kernel, dim3((mloc + 3) / 4), dim3(256), 0, s, rp, ti, tj, tv, Y, ldy, mloc,
+                       rows_global, scale, out);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

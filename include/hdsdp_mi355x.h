@@ -260,12 +260,16 @@ void HMiGetStageTimes(double *ms, int n);
  * Each array has 4 entries: total ms, algorithmic flops and launch count since the last call. */
 void HMiSetKernelTiming(int on);
 int HMiGetKernelTiming(double *ms, double *flops, int64_t *launches);
+/* diagnostic builds (HDM_VAR=32): per-workgroup s_memtime stamps of launches with the given role, 8 words each */
+void HMiSetDebugBuffer(void *dev, int role);
 
 /* raw kernels (device pointers) exported for unit tests and micro-benchmarks */
 int HMiGemmNT(const double *A, int64_t lda, int aKMajor, const double *B, int64_t ldb, int bKMajor, double *C,
               int64_t ldc, int M, int N, int K, double alpha, double beta, int kLimit, int lowerOnly);
 int HMiPotrf(double *A_dev, int n, int64_t lda, int *info);  /* in place, lower */
 double HMiMfmaPeakProbe(int iters);    /* measured fp64 MFMA TFLOP/s of a register-only loop */
+/* GEMM-shaped issue probe: mode 0 = 16 accumulators x (4+4) operand registers, 1 = one operand pair */
+double HMiMfmaIssueProbe(int mode, int wgPerCu, int iters);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ from util import KKT_TOL, check_close, kkt_err, load_golden, lower_mask, y_of
 pytestmark = pytest.mark.gpu
 
 CSC_CASES = ["theta1_A", "theta1_B", "mcp100_A", "mcp100_B", "gpp100_A", "gpp100_B", "mix40_A", "mix40_B"]
-SYN_CASES = ["syn64", "syn96x40_B", "syn100", "syn200"]
+SYN_CASES = ["syn64", "syn96x40_B", "syn100", "syn200", "syn2000x32"]
 
 
 def _make_cone(name, g):
@@ -108,6 +108,49 @@ def test_forced_dense_path_matches(name, monkeypatch):
         cone.destroy()
 
 
+@pytest.mark.parametrize("name,path", [("theta1_A", 2), ("theta1_B", 2), ("theta1_B", 0), ("mcp100_B", 2), ("mcp100_B", 0),
+                                       ("gpp100_B", 2), ("mix40_B", 2), ("mix40_B", 0)])
+def test_every_device_path_gives_the_same_numbers(name, path, monkeypatch):
+    """the three device paths (0 dense congruence + Gram, 1 rank-one, 2 sparse gather) are interchangeable"""
+    from hdsdp_amd import api
+    monkeypatch.setenv("HDSDP_MI355X_FORCE_PATH", str(path))
+    g = load_golden(name)
+    cone, n, m = _make_cone(name, g)
+    try:
+        assert cone.path == path
+        cone.set_start(float(g["Rd"][0]))
+        assert cone.check_is_interior(float(g["tau"][0]), y_of(g))
+        kkt = api.KKT(m, [cone])
+        msk = lower_mask(m)
+        kkt.build_up(api.KKT_TYPE_HOMOGENEOUS)
+        ex = kkt.export()
+        check_close(kkt.M[msk], g["M_hsd"][msk], name)
+        check_close(ex["ASinv"], g["ASinv_hsd"], name)
+        check_close(ex["ASinvRdSinv"], g["ASinvRdSinv_hsd"], name)
+        check_close(ex["ASinvCSinv"], g["ASinvCSinv_hsd"], name)
+        for got, ref in zip((ex["CSinv"], ex["CSinvCSinv"], ex["CSinvRdSinv"], ex["TraceSinv"]), g["hsd_scalars"]):
+            check_close([got], [ref], name)
+        kkt.build_up(api.KKT_TYPE_CORRECTOR)
+        ex = kkt.export()
+        check_close(ex["ASinv"], g["ASinv_cor"], name)
+        check_close(ex["ASinvRdSinv"], g["ASinvRdSinv_cor"], name)
+        kkt.destroy()
+    finally:
+        cone.destroy()
+
+
+def test_default_path_selection():
+    """theta1 (sparse rows) -> gather path, mcp100/gpp100 (rank-one rows) -> rank-one path, dense rows -> MFMA path"""
+    from hdsdp_amd import api
+    for name, want in (("theta1_A", 2), ("mcp100_A", 1), ("gpp100_A", 1), ("mix40_A", 0), ("syn64", 0)):
+        g = load_golden(name)
+        cone, n, m = _make_cone(name, g)
+        try:
+            assert cone.path == want, name
+        finally:
+            cone.destroy()
+
+
 def test_presolve_plan_matches_reference():
     """classification, ordering and strategy plan (host logic) on the GPU box build of the library"""
     from hdsdp_amd import api
@@ -124,3 +167,87 @@ def test_presolve_plan_matches_reference():
             assert p["obj_type"] == int(g["obj_type"][0]), name
         finally:
             cone.destroy()
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json full size (configs[3]: n = m = 2000) through size-independent properties
+# ----------------------------------------------------------------------------------------------
+def _splitmix_u(t):
+    """draw number t (0-based, numpy uint64 array) of the SURVEY.md 8(d) stream -> U(-1, 1)"""
+    g = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        z = g + (t.astype(np.uint64) + np.uint64(1)) * g
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return 2.0 * ((z >> np.uint64(11)).astype(np.float64) / 9007199254740992.0) - 1.0
+
+
+def _synth_matrix(n, c):
+    """constraint matrix c (0-based) of the synthetic family as a dense symmetric numpy array"""
+    P = n * (n + 1) // 2
+    k = np.arange(P, dtype=np.uint64)
+    base = np.uint64(2 * c * P)
+    v = _splitmix_u(base + np.uint64(2) * k)
+    w = _splitmix_u(base + np.uint64(2) * k + np.uint64(1))
+    jj = np.repeat(np.arange(n), np.arange(n, 0, -1))
+    ii = np.concatenate([np.arange(j, n) for j in range(n)])
+    keep = (ii == jj) | (w >= 0.2)
+    A = np.zeros((n, n))
+    A[ii, jj] = np.where(keep, v, 0.0)
+    return A + np.tril(A, -1).T
+
+
+def test_full_size_known_answers():
+    """n = m = 2000 at y = y0 (the generator's strictly feasible point): S = I exactly, so
+    ASinv_i = tr(A_i) = b_i, M_ij = <A_i, A_j>, logdet S = 0; and at Rd = -3 (S = 4 I) everything scales by
+    powers of 4 (linearity).  Then the Schur system is solved and the residual checked on the host."""
+    from hdsdp_amd import api
+    n = m = 2000
+    P = n * (n + 1) // 2
+    y0 = _splitmix_u(np.uint64(2 * m * P) + np.arange(m, dtype=np.uint64))
+    cone = api.SDPCone.synthetic(n, m)
+    try:
+        b = cone.traces()
+        kkt = api.KKT(m, [cone])
+        cone.set_start(0.0)
+        assert cone.check_is_interior(1.0, y0)
+        assert abs(cone.log_barrier(1.0)) < 1e-7
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        ex1 = kkt.export()
+        M1 = kkt.M.copy()
+        assert np.max(np.abs(ex1["ASinv"] - b)) <= 1e-9 * np.max(np.abs(b))
+        assert np.all(ex1["ASinvRdSinv"] == 0.0)
+        rows = [0, 1, 777, 1999]
+        mats = {i: _synth_matrix(n, i) for i in rows}
+        for i in rows:
+            assert abs(np.trace(mats[i]) - b[i]) < 1e-9
+            for j in rows:
+                ref = float(np.sum(mats[i] * mats[j]))
+                got = M1[min(i, j), max(i, j)]      # C-order view: lower triangle sits at [col, row]
+                assert abs(got - ref) <= 1e-9 * abs(ref), (i, j, got, ref)
+        # S = 4 I
+        cone.set_start(-3.0)
+        assert cone.check_is_interior(1.0, y0)
+        assert abs(cone.log_barrier(1.0) - n * np.log(4.0)) < 1e-6
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        ex4 = kkt.export()
+        msk = lower_mask(m)
+        assert np.max(np.abs(kkt.M[msk] * 16.0 - M1[msk])) <= 1e-9 * np.max(np.abs(M1[msk]))
+        assert np.max(np.abs(ex4["ASinv"] * 4.0 - b)) <= 1e-9 * np.max(np.abs(b))
+        assert np.max(np.abs(ex4["ASinvRdSinv"] - (-3.0) * b / 16.0)) <= 1e-9 * np.max(np.abs(b))
+        assert abs(ex4["TraceSinv"] - n / 4.0) < 1e-8
+        # solve and check the residual with the host copy of M
+        kkt.factorize()
+        x = kkt.solve(b)
+        Mfull = np.triu(kkt.M) + np.triu(kkt.M, 1).T
+        r = Mfull @ x - b
+        assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(b)
+        # corrector leaves M alone and reproduces the vectors
+        kkt.build_up(api.KKT_TYPE_CORRECTOR)
+        exc = kkt.export()
+        assert np.max(np.abs(exc["ASinv"] - ex4["ASinv"])) <= 1e-10 * np.max(np.abs(ex4["ASinv"]))
+        assert np.max(np.abs(exc["ASinvRdSinv"] - ex4["ASinvRdSinv"])) <= 1e-10 * np.max(np.abs(ex4["ASinvRdSinv"]))
+        kkt.destroy()
+    finally:
+        cone.destroy()
