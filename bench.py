@@ -28,14 +28,20 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X vendor figure for dense fp64 matrix; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 
 
+# HBM bytes per launch of the hot kernels from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 for
+# the gfx950 wide-read correction + WRITE_SIZE, separate --pmc runs, n=m=2000): filled in by hand from the summaries,
+# bench.py cannot run the profiler on itself.  None = not measured for the current kernel generation.
+TRAFFIC_BYTES_PER_LAUNCH = {}
+
+
 def survey_flops(n, m):
     """SURVEY.md 8(d) operation count of one iteration (reference M3 count, kept for comparability)"""
     return 3.0 * m * n ** 3 + 0.5 * m * (m + 1) * n * (n + 1) + n ** 3 + m ** 3 / 3.0 + 6.0 * m * m
 
 
 def executed_flops(n, m):
-    """what our formulation needs on valid data: congruence 4/3 n^3 per row, Gram over the packed index"""
-    return m * (4.0 / 3.0) * n ** 3 + 0.5 * (m + 3) * (m + 4) * n * (n + 1) + n ** 3 + m ** 3 / 3.0 + 6.0 * m * m
+    """what our formulation needs on valid data: congruence n^3 per row (triangular factors), Gram over the packed index"""
+    return m * 1.0 * n ** 3 + 0.5 * (m + 3) * (m + 4) * n * (n + 1) + n ** 3 + m ** 3 / 3.0 + 6.0 * m * m
 
 
 def cpu_baseline(n, m, budget_cols=4):
@@ -159,24 +165,24 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps / elapsed
-    # dominant kernel: congruence step 1 (T = Linv * A_i), fp64 MFMA bound
-    dom = 1
+    # dominant kernel = the role with the largest share of the timed region (all three are fp64-MFMA bound)
+    names = {1: "hdm_gemm_kernel<false,true,1> (congruence step 1: U = Linv*A_L, triangular x triangular)",
+             2: "hdm_gemm_kernel<false,false,2> (congruence step 2: At = U*Linv^T + Linv*U^T, SYR2K form)",
+             3: "hdm_gemm_kernel<true,true,3> (Gram: M = Ahat*Ahat^T over the packed index)"}
+    short = {1: "congruence_step1", 2: "congruence_step2", 3: "gram"}
+    dom = max((1, 2, 3), key=lambda r: kms[r])
     dom_ms = kms[dom] / max(1, kln[dom])
     achieved = (kfl[dom] / max(1, kln[dom])) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     roofline = {
-        "bound": "mfma", "kernel": "hdm_gemm_kernel<false,false,1> (congruence step 1: T = Linv*A_i)",
+        "bound": "mfma", "kernel": names[dom],
         "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom),
         "avg_launch_ms": round(float(dom_ms), 4), "launches": int(kln[dom]),
         "flops_per_launch": float(kfl[dom] / max(1, kln[dom])),
-        "other_kernels": {
-            "congruence_step2": {"ms_per_step": round(float(kms[2]) / args.steps, 3),
-                                 "tflops": round(float(kfl[2] / max(kms[2], 1e-9) / 1e9), 2)},
-            "gram": {"ms_per_step": round(float(kms[3]) / args.steps, 3),
-                     "tflops": round(float(kfl[3] / max(kms[3], 1e-9) / 1e9), 2)},
-            "congruence_step1": {"ms_per_step": round(float(kms[1]) / args.steps, 3)},
-            "helper_gemms": {"ms_per_step": round(float(kms[0]) / args.steps, 3)},
-        },
+        "kernels": {short[r]: {"ms_per_step": round(float(kms[r]) / args.steps, 3),
+                               "tflops": round(float(kfl[r] / max(kms[r], 1e-9) / 1e9), 2),
+                               "launches_per_step": int(kln[r] // args.steps)} for r in (1, 2, 3)},
+        "helper_gemms_ms_per_step": round(float(kms[0]) / args.steps, 3),
     }
     out = {
         "metric": "IPM iterations/sec (Schur build+factor+solve), n=%d m=%d dense SDP" % (n, m),

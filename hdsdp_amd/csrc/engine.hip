@@ -174,8 +174,9 @@ struct MiCone {
     MiBlockData blk;           // presolve results (empty rows for synthetic)
     std::vector<int> own;      // global indices of the owned constraints
     // device data
-    double *Afull = nullptr;   // mloc x (n16 x n16) full symmetric constraint matrices (GEMM path)
-    double *Cfull = nullptr;   // n16 x n16 objective
+    double *Afull = nullptr;   // mloc x (n16 x n16) constraint matrices in A_L form: strict lower + half diagonal
+    double *Cfull = nullptr;   // n16 x n16 objective, full symmetric
+    double *CL = nullptr;      // objective in A_L form (GEMM path, HSD builds)
     double *Avec = nullptr;    // n16 x mloc16 rank-one factors (R1 path)
     double *sgn = nullptr;     // mloc signs (R1 path)
     int mloc16 = 0;
@@ -273,6 +274,7 @@ int cone_alloc_gemm_work(MiCone *c) {
     if (bc >= 8) bc = bc / 8 * 8;
     c->Bc = (int) std::min<long>(bc, std::max(1, c->mloc));
     HDM_HIP_CHECK(hipMalloc((void **) &c->T, nn * (size_t) c->Bc));
+    HDM_HIP_CHECK(hdm_memset_sync(c->T, 0, nn * (size_t) c->Bc));  // step 1 writes lower tiles only; the rest must read as 0
     const size_t ahat = sizeof(double) * (size_t) c->world * c->npb_loc * c->Lr * 16;
     if (!c->AhatLoc) {
         HDM_HIP_CHECK(hipMalloc((void **) &c->AhatLoc, ahat));
@@ -374,25 +376,31 @@ hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, dou
 
 // --- the GPU Schur builder ---------------------------------------------------------------------
 int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, int count, long row0) {
-    // rows row0 .. row0+count-1 of AhatLoc  <-  blocked( Linv * A * Linv^T )
+    // rows row0 .. row0+count-1 of AhatLoc  <-  blocked( Linv * A * Linv^T ),  A = A_L + A_L^T given in A_L form:
+    //   step 1  U  = Linv * A_L                 (lower x lower = lower triangular: k in [col tile, row tile], n^3/3)
+    //   step 2  At = U * Linv^T + Linv * U^T    (SYR2K form, lower tiles, k <= col tile, 2n^3/3)
+    // i.e. n^3 flops per constraint instead of the 4/3 n^3 of (Linv A) Linv^T, and half the intermediate traffic.
     const long nn = (long) c->n16 * c->n16;
+    const double n3 = (double) c->n * c->n * c->n;
     for (int b0 = 0; b0 < count; b0 += c->Bc) {
         const int nb = std::min(c->Bc, count - b0);
-        HdmGemmArgs k1 = {};  // T = Linv * A   (Linv lower => K cut by the row tile)
+        HdmGemmArgs k1 = {};
         k1.A = ch.Linv; k1.lda = ch.npad; k1.strideA = 0;
-        k1.B = Asrc + (long) b0 * astride; k1.ldb = c->n16; k1.strideB = astride;
+        k1.B = Asrc + (long) b0 * astride; k1.ldb = c->n16; k1.strideB = astride; k1.b_kmajor = 1;
         k1.C = c->T; k1.ldc = c->n16; k1.strideC = nn;
         k1.M = c->n16; k1.N = c->n16; k1.K = c->n16; k1.batch = nb; k1.alpha = 1.0;
-        k1.klimit = HDM_KLIM_BY_M; k1.epilogue = HDM_EPI_STORE; k1.role = HDM_ROLE_CONG1;
-        k1.flops = (double) nb * c->n * c->n * c->n;  // n^2 outputs x (n/2 average k) x 2
+        k1.klimit = HDM_KLIM_BAND; k1.lower_only = 1; k1.epilogue = HDM_EPI_STORE; k1.role = HDM_ROLE_CONG1;
+        k1.flops = (double) nb * n3 / 3.0;
         if (hdm_launch_gemm(k1, g.stream)) return 1;
-        HdmGemmArgs k2 = {};  // At = lower(T * Linv^T), blocked + sqrt(2) weights
+        HdmGemmArgs k2 = {};
         k2.A = c->T; k2.lda = c->n16; k2.strideA = nn;
         k2.B = ch.Linv; k2.ldb = ch.npad; k2.strideB = 0;
+        k2.A2 = ch.Linv; k2.lda2 = ch.npad; k2.strideA2 = 0;
+        k2.B2 = c->T; k2.ldb2 = c->n16; k2.strideB2 = nn;
         k2.C = c->AhatLoc; k2.M = c->n16; k2.N = c->n16; k2.K = c->n16; k2.batch = nb; k2.alpha = 1.0;
         k2.klimit = HDM_KLIM_BY_N; k2.lower_only = 1; k2.epilogue = HDM_EPI_BLOCKED;
         k2.blk_row_stride = c->Lr; k2.blk_row0 = row0 + b0; k2.nblk = c->nblk; k2.role = HDM_ROLE_CONG2;
-        k2.flops = (double) nb * c->n * c->n * c->n / 3.0;
+        k2.flops = (double) nb * n3 * 2.0 / 3.0;
         if (hdm_launch_gemm(k2, g.stream)) return 1;
     }
     return 0;
@@ -465,7 +473,7 @@ hdsdp_retcode corrector_components(MiCone *c, HdmChol &ch, MiKKTPriv *pv, int m)
         Y = c->Yinv;
     }
     RC(hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, pv->vecs,
-                    pv->vecs + m, c->rows_own, 1.0, c->Rd, g.stream));
+                    pv->vecs + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));   // A is stored in A_L form: <A, X> = 2 <A_L, X>
     if (c->world > 1) {
         HIP_RC(hipStreamSynchronize(g.stream));
         if (!c->allreduce || c->allreduce(c->xctx, pv->vecs, (int64_t) 2 * m)) return HDSDP_RETCODE_FAILED;
@@ -495,7 +503,13 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
         k2.klimit = HDM_KLIM_BY_N; k2.lower_only = 1; k2.epilogue = HDM_EPI_BLOCKED;
         k2.blk_row_stride = c->Lr; k2.blk_row0 = c->mloc; k2.nblk = c->nblk;
         RC(hdm_launch_gemm(k2, g.stream));
-        if (typeKKT == KKT_TYPE_HOMOGENEOUS) RC(congruence_rows(c, ch, c->Cfull, nn, 1, c->mloc + 2));
+        if (typeKKT == KKT_TYPE_HOMOGENEOUS) {
+            if (!c->CL) {
+                HIP_RC(hipMalloc((void **) &c->CL, sizeof(double) * (size_t) nn));
+                RC(hdm_lower_half(c->Cfull, c->CL, c->n, c->n16, g.stream));
+            }
+            RC(congruence_rows(c, ch, c->CL, nn, 1, c->mloc + 2));
+        }
     }
     HIP_RC(hipEventRecord(g.ev[2], g.stream));
     if (c->world > 1) {
@@ -774,7 +788,7 @@ hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int ty
 void cone_destroy_data(void **pcd) {
     if (!pcd || !*pcd) return;
     MiCone *c = (MiCone *) *pcd;
-    double *bufs[] = {c->Afull, c->Cfull, c->Avec, c->sgn, c->S, c->Scheck, c->ydev, c->T, c->slabs, c->Gm,
+    double *bufs[] = {c->Afull, c->Cfull, c->CL, c->Avec, c->sgn, c->S, c->Scheck, c->ydev, c->T, c->slabs, c->Gm,
                       c->U, c->V, c->Gr1, c->Ct, c->W, c->Xinv, c->Yinv};
     for (double *b : bufs)
         if (b) (void) hipFree(b);
@@ -1157,6 +1171,7 @@ static int upload_dense_rows(MiCone *c) {
     const long P = (long) c->n * (c->n + 1) / 2;
     const long nn = (long) c->n16 * c->n16;
     HDM_HIP_CHECK(hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) nn * std::max(1, c->mloc)));
+    HDM_HIP_CHECK(hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) nn * std::max(1, c->mloc)));
     const int chunk = (int) std::max(1L, std::min<long>(64, (256L << 20) / (P * 8)));
     double *stage_dev = nullptr, *stage_host = nullptr;
     HDM_HIP_CHECK(hipMalloc((void **) &stage_dev, sizeof(double) * (size_t) P * chunk));
@@ -1169,7 +1184,7 @@ static int upload_dense_rows(MiCone *c) {
             for (size_t e = 0; e < co.idx.size(); ++e) stage_host[(size_t) q * P + co.idx[e]] = co.val[e];
         }
         HDM_HIP_CHECK(hipMemcpyAsync(stage_dev, stage_host, sizeof(double) * (size_t) P * nc, hipMemcpyHostToDevice, g.stream));
-        if (hdm_unpack_sym(stage_dev, P, c->Afull + (long) r0 * nn, nn, c->n, c->n16, nc, g.stream)) return 1;
+        if (hdm_unpack_low(stage_dev, P, c->Afull + (long) r0 * nn, nn, c->n, c->n16, nc, g.stream)) return 1;
         HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
     }
     {   // objective
@@ -1291,8 +1306,9 @@ hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, in
                 (double) nn * c->mloc * 8 / (1 << 30));
         return HDSDP_RETCODE_MEMORY;
     }
+    if (hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) nn * std::max(1, c->mloc)) != hipSuccess) return HDSDP_RETCODE_FAILED;
     for (int q = 0; q < c->mloc; ++q)  // owned rows are strided in the global numbering
-        if (hdm_synth_fill(c->Afull + (long) q * nn, nn, c->n, c->n16, c->own[q], 1, g.stream)) return HDSDP_RETCODE_FAILED;
+        if (hdm_synth_fill_low(c->Afull + (long) q * nn, nn, c->n, c->n16, c->own[q], 1, g.stream)) return HDSDP_RETCODE_FAILED;
     if (hdm_synth_obj(c->Cfull, c->n, c->n16, c->m, g.stream)) return HDSDP_RETCODE_FAILED;
     // b_i = tr(A_i): diagonal draws only (host, m*n splitmix evaluations)
     c->trA = (double *) calloc(nRow, sizeof(double));

@@ -70,12 +70,32 @@ struct Stager {
             kstep = (long) HDM_BK * ld;
             okmask = (x0 + i2 < rows) ? 0xFu : 0u;  // rows is even: the 2-double chunk is fully in or out
         }
+        left = -1;  // single product: never switches
+        p2 = p; qstride2 = qstride; kstep2 = kstep;
+    }
+    const double *p2;  // second operand (dual-product mode): the stream continues there after `left` loads
+    long qstride2, kstep2;
+    int left;
+
+    __device__ __forceinline__ void chain(const double *X2, long ld2, int x0, int kt0, int tid, int nst) {
+        // same tile rows, same row count => the same okmask; only the base pointer and the strides change
+        if (KM) {
+            p2 = X2 + (long) kt0 * HDM_BK + (long) (x0 + (tid >> 3)) * ld2 + (tid & 7) * 2;
+            qstride2 = 32 * ld2;
+            kstep2 = HDM_BK;
+        } else {
+            p2 = X2 + ((long) kt0 * HDM_BK + (tid >> 6)) * ld2 + x0 + (tid & 63) * 2;
+            qstride2 = 4 * ld2;
+            kstep2 = (long) HDM_BK * ld2;
+        }
+        left = nst;
     }
     __device__ __forceinline__ void load(double2 (&r)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             r[q] = (okmask >> q) & 1u ? *reinterpret_cast<const double2 *>(p + q * qstride) : make_double2(0.0, 0.0);
         p += kstep;
+        if (--left == 0) { p = p2; qstride = qstride2; kstep = kstep2; }
     }
 };
 
@@ -140,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     long kbeg = 0, kend = a.K;
     if (a.klimit == HDM_KLIM_BY_M) kend = min((long) a.K, (long) (tm + 1) * HDM_TILE);
     if (a.klimit == HDM_KLIM_BY_N) kend = min((long) a.K, (long) (tn + 1) * HDM_TILE);
+    if (a.klimit == HDM_KLIM_BAND) { kbeg = (long) tn * HDM_TILE; kend = min((long) a.K, (long) (tm + 1) * HDM_TILE); }
     const double *A = a.A, *B = a.B;
     if (a.epilogue == HDM_EPI_SLAB) {
         kbeg = (long) z * a.k_chunk;
@@ -160,6 +181,11 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     Stager<BKM> stB;
     stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, m0, kt0, tid);
     stB.init(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, n0, kt0, tid);
+    const int npass = a.A2 ? 2 : 1;
+    if (a.A2) {
+        stA.chain(a.A2 + (long) z * a.strideA2, a.lda2, m0, kt0, tid, kt1 - kt0);
+        stB.chain(a.B2 + (long) z * a.strideB2, a.ldb2, n0, kt0, tid, kt1 - kt0);
+    }
     // lower-only diagonal tiles: the (rows 0-63, cols 64-127) quadrant lies strictly above the diagonal; its
     // wave issues no MFMAs and leaves the SIMD to the co-resident workgroup
     const bool idle_wave = a.lower_only && (tm == tn) && (wm == 0) && (wn == 1);
@@ -187,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         // two full MFMA stages (~8 us) to land before its ds_write.  With one stage of look-ahead both co-resident
         // workgroups regularly parked on vmcnt together (SQ_WAIT_ANY 14.6 % of wave cycles, MFMA pipe 83.5 %).
         double2 a0[4], b0[4], a1[4], b1[4];
-        const int nst = kt1 - kt0;
+        const int nst = (kt1 - kt0) * npass;
         if (nst > 0) {
             stA.load(a0); stB.load(b0);
             r2s<AKM>(sA, tid, a0); r2s<BKM>(sB, tid, b0);
@@ -213,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         }
     } else {
         double2 ra[4], rb[4];
+        const int kt1x = kt0 + (kt1 - kt0) * npass;
         if (kt0 < kt1) {
             stA.load(ra);
             stB.load(rb);
@@ -222,8 +249,8 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         __syncthreads();
         if ((VAR & 32) && p.dbg) t_pro = __builtin_amdgcn_s_memtime();
         int cur = 0;
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const bool more = (kt + 1 < kt1);
+        for (int kt = kt0; kt < kt1x; ++kt) {
+            const bool more = (kt + 1 < kt1x);
             if (more && !(VAR & 4)) {
                 stA.load(ra);
                 stB.load(rb);
@@ -357,6 +384,7 @@ int get_tiles(int MT, int NT, int klimit, int lower_only, TileList &out) {
             long w = 1;
             if (klimit == HDM_KLIM_BY_M) w = tm + 1;
             if (klimit == HDM_KLIM_BY_N) w = tn + 1;
+            if (klimit == HDM_KLIM_BAND) { if (tm < tn) continue; w = tm - tn + 1; }
             v.push_back({w, make_int2(tm, tn)});
         }
     std::stable_sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
@@ -422,8 +450,8 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     if (g_env_var == -2) { const char *e = getenv("HDM_VAR"); g_env_var = e ? atoi(e) : -1; }
     const int g_var = g_env_var >= 0 ? g_env_var : (args.role == HDM_ROLE_GRAM ? 0 : 2);
     switch (args.role) {
-        case HDM_ROLE_CONG1: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG1); break;  // T = Linv * A
-        case HDM_ROLE_CONG2: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG2); break;  // At = T * Linv^T
+        case HDM_ROLE_CONG1: HDM_LAUNCH_V(false, true, HDM_ROLE_CONG1); break;   // U = Linv * A_L (A_L k-contiguous)
+        case HDM_ROLE_CONG2: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG2); break;  // At = U Linv^T + Linv U^T
         case HDM_ROLE_GRAM: HDM_LAUNCH_V(true, true, HDM_ROLE_GRAM); break;      // M = Ahat Ahat^T
         default:
             if (lay == 3) HDM_LAUNCH(true, true, HDM_ROLE_GENERIC, 0);

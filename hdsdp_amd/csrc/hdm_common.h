@@ -45,7 +45,7 @@ static inline long hdm_roundup(long x, long q) { return (x + q - 1) / q * q; }
 //   M-major ("N"): element (i,k) at X[i + k*ld]  (rows contiguous: a column-major M x K matrix)
 //   K-major ("T"): element (i,k) at X[i*ld + k]  (k contiguous: the transpose is column-major)
 // ---------------------------------------------------------------------------------------------
-enum HdmKLimit { HDM_KLIM_NONE = 0, HDM_KLIM_BY_M = 1, HDM_KLIM_BY_N = 2 };
+enum HdmKLimit { HDM_KLIM_NONE = 0, HDM_KLIM_BY_M = 1, HDM_KLIM_BY_N = 2, HDM_KLIM_BAND = 3 };  // BAND: k in [tn*128, (tm+1)*128)
 enum HdmEpilogue {
     HDM_EPI_STORE = 0,    // C = alpha*acc + beta*C, column-major
     HDM_EPI_BLOCKED = 1,  // congruence output: 16x16-blocked lower triangle, sqrt(2) off-diagonal blocks
@@ -59,6 +59,10 @@ enum HdmRole { HDM_ROLE_GENERIC = 0, HDM_ROLE_CONG1 = 1, HDM_ROLE_CONG2 = 2, HDM
 struct HdmGemmArgs {
     const double *A, *B;
     double *C;
+    // optional second product accumulated into the same tile (SYR2K form): C = alpha (A B^T + A2 B2^T) + beta C,
+    // same shapes, storage classes and K range as the first pair; A2 == nullptr: single product
+    const double *A2, *B2;
+    long lda2, ldb2, strideA2, strideB2;
     long lda, ldb, ldc;
     long strideA, strideB, strideC;  // batch strides (elements) along blockIdx.z (batch) -- 0 = shared
     int M, N, K;

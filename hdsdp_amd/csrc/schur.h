@@ -21,3 +21,6 @@ int hdm_sparse_pairs(const int *rp, const int *ti, const int *tj, const double *
                      const int *rows_global, double *M, long ldm, hipStream_t s);
 int hdm_sparse_dot(const int *rp, const int *ti, const int *tj, const double *tv, const double *Y, long ldy, int mloc,
                    const int *rows_global, double scale, double *out, hipStream_t s);
+int hdm_unpack_low(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s);
+int hdm_synth_fill_low(double *full, long fstride, int n, int ld, int c0, int batch, hipStream_t s);
+int hdm_lower_half(const double *full, double *low, int n, long ld, hipStream_t s);

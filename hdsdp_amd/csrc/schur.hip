@@ -66,6 +66,49 @@ __device__ __forceinline__ void write_sym_tile(const Src &src, double *__restric
     }
 }
 
+// "A_L" form of a symmetric matrix: strict lower triangle + HALF the diagonal, zeros above, so that A = A_L + A_L^T.
+// The congruence kernels multiply with A_L only (triangular times triangular: n^3/3 instead of n^3 flops).
+template <class Src>
+__device__ __forceinline__ void write_low_tile(const Src &src, double *__restrict__ dst, long ld, int n, int ti, int tj) {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int jj = ty; jj < 32; jj += 8) {
+        const int i = ti * 32 + tx, j = tj * 32 + jj;
+        if (i < ld && j < ld) {
+            double v = 0.0;
+            if (i < n && j < n && i >= j) v = (i == j) ? 0.5 * src(i, j) : src(i, j);
+            dst[i + (long) j * ld] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hdm_unpack_low_kernel(const double *__restrict__ packed, long pstride,
+                                                              double *__restrict__ full, long fstride, int n, int ld,
+                                                              int nt) {
+    int t = blockIdx.x, tj = 0;
+    while (t >= nt - tj) { t -= nt - tj; ++tj; }
+    PackedSrc s{packed + (long) blockIdx.y * pstride, n};
+    write_low_tile(s, full + (long) blockIdx.y * fstride, (long) ld, n, tj + t, tj);
+}
+
+__global__ __launch_bounds__(256) void hdm_synth_low_kernel(double *__restrict__ full, long fstride, int n, int ld, int nt,
+                                                             int c0) {
+    int t = blockIdx.x, tj = 0;
+    while (t >= nt - tj) { t -= nt - tj; ++tj; }
+    const uint64_t P = (uint64_t) n * (n + 1) / 2;
+    SynthSrc s{2 * (uint64_t) (c0 + blockIdx.y) * P, n};
+    write_low_tile(s, full + (long) blockIdx.y * fstride, (long) ld, n, tj + t, tj);
+}
+
+// full symmetric -> A_L form (objective matrix)
+__global__ void hdm_lower_half_kernel(const double *__restrict__ full, double *__restrict__ low, int n, long ld) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long) ld * ld) return;
+    int i = (int) (e % ld), j = (int) (e / ld);
+    double v = 0.0;
+    if (i < n && j < n && i >= j) v = (i == j) ? 0.5 * full[e] : full[e];
+    low[e] = v;
+}
+
 __global__ __launch_bounds__(256) void hdm_unpack_sym_kernel(const double *__restrict__ packed, long pstride,
                                                               double *__restrict__ full, long fstride, int n, int ld,
                                                               int nt) {
@@ -179,8 +222,10 @@ __global__ void hdm_sym_combine_kernel(const double *__restrict__ A, long astrid
     int i = (int) (e % n), j = (int) (e / n);
     if (i < j) return;
     long off = i + (long) j * lda;
-    double acc = tau * C[off];
+    double acc = 0.0;
     for (int c = 0; c < m; ++c) acc -= y[c] * A[(long) c * astride + off];
+    if (i == j) acc *= 2.0;  // the constraint matrices are stored in A_L form (half diagonal)
+    acc += tau * C[off];
     if (i == j) acc += eye;
     S[i + (long) j * lds_] = acc;
 }
@@ -305,6 +350,29 @@ __global__ __launch_bounds__(256) void hdm_sparse_dot_kernel(const int *__restri
 // ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
+int hdm_unpack_low(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s) {
+    int nt = (ld + 31) / 32;
+    dim3 grid(nt * (nt + 1) / 2, batch), block(32, 8);
+    hipLaunchKernelGGL(hdm_unpack_low_kernel, grid, block, 0, s, packed, pstride, full, fstride, n, ld, nt);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_synth_fill_low(double *full, long fstride, int n, int ld, int c0, int batch, hipStream_t s) {
+    int nt = (ld + 31) / 32;
+    dim3 grid(nt * (nt + 1) / 2, batch), block(32, 8);
+    hipLaunchKernelGGL(hdm_synth_low_kernel, grid, block, 0, s, full, fstride, n, ld, nt, c0);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_lower_half(const double *full, double *low, int n, long ld, hipStream_t s) {
+    long tot = ld * ld;
+    hipLaunchKernelGGL(hdm_lower_half_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, full, low, n, ld);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int hdm_unpack_sym(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s) {
     int nt = (ld + 31) / 32;
     dim3 grid(nt * (nt + 1) / 2, batch), block(32, 8);
