@@ -269,8 +269,10 @@ int cone_alloc_common(MiCone *c) {
 int cone_alloc_gemm_work(MiCone *c) {
     const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
     // batch size: keep T within ~1 GiB, multiple of 8 for the XCD-aware decode when possible
-    long bc = (long) ((1L << 30) / (double) nn);
-    bc = std::max(1L, std::min(bc, 16L));
+    long bc = (long) ((2L << 30) / (double) nn);
+    long bcmax = 64;
+    if (const char *e = getenv("HDM_BC")) bcmax = atol(e);
+    bc = std::max(1L, std::min(bc, bcmax));
     if (bc >= 8) bc = bc / 8 * 8;
     c->Bc = (int) std::min<long>(bc, std::max(1, c->mloc));
     HDM_HIP_CHECK(hipMalloc((void **) &c->T, nn * (size_t) c->Bc));
