@@ -31,7 +31,11 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X vendor figure for dense fp64 matrix; 256 
 # HBM bytes per launch of the hot kernels from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 for
 # the gfx950 wide-read correction + WRITE_SIZE, separate --pmc runs, n=m=2000): filled in by hand from the summaries,
 # bench.py cannot run the profiler on itself.  None = not measured for the current kernel generation.
-TRAFFIC_BYTES_PER_LAUNCH = {}
+TRAFFIC_BYTES_PER_LAUNCH = {  # profiles/r01_d_summary_pmc_{FETCH,WRITE}_SIZE.txt (counters are in KiB)
+    1: (2 * 4.256e6 + 9.785e5) * 1024,   # congruence step 1, 64 constraints per launch:  9.7 GB
+    2: (2 * 7.519e6 + 9.844e5) * 1024,   # congruence step 2, 64 constraints per launch: 16.4 GB
+    3: (2 * 1.927e8 + 1.014e6) * 1024,   # Gram, whole matrix:                          395.7 GB
+}
 
 
 def survey_flops(n, m):
@@ -176,7 +180,7 @@ def main():
     roofline = {
         "bound": "mfma", "kernel": names[dom],
         "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom),
+        "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom) if (n, m, world) == (2000, 2000, 1) else None,
         "avg_launch_ms": round(float(dom_ms), 4), "launches": int(kln[dom]),
         "flops_per_launch": float(kfl[dom] / max(1, kln[dom])),
         "kernels": {short[r]: {"ms_per_step": round(float(kms[r]) / args.steps, 3),
