@@ -48,7 +48,19 @@ def executed_flops(n, m):
     return m * 1.0 * n ** 3 + 0.5 * (m + 3) * (m + 4) * n * (n + 1) + n ** 3 + m ** 3 / 3.0 + 6.0 * m * m
 
 
-def cpu_baseline(n, m, budget_cols=4):
+def survey_equiv(n, m, world, kms, kln, steps):
+    """achieved TFLOP/s if the work is priced with the reference's operation count; can exceed the
+    MFMA peak because the triangular-factor congruence executes n^3, not 3 n^3, flops per constraint"""
+    rows = (m + world - 1) // world
+    cong_ms = (kms[1] + kms[2]) / steps
+    gram_ms = kms[3] / steps
+    return {"congruence": {"flops_per_unit": 3.0 * n ** 3, "unit": "constraint", "units_per_step": rows,
+                           "tflops": round(3.0 * n ** 3 * rows / max(cong_ms, 1e-9) / 1e9, 2)},
+            "gram": {"flops_per_unit": float(n) * (n + 1), "unit": "row pair", "units_per_step": 0.5 * m * (m + 1) / world,
+                     "tflops": round(0.5 * m * (m + 1) / world * n * (n + 1) / max(gram_ms, 1e-9) / 1e9, 2)}}
+
+
+def cpu_baseline(n, m, budget_cols=8):
     """Time the CPU side on this host: the real reference (oracle/_ref, kind "reference") when it was
     built, else the plain-C restatement (kind "port").  Bounded sample: the same n, `budget_cols`
     constraint matrices; extrapolated to m with the reference's own operation count."""
@@ -183,6 +195,9 @@ def main():
         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom) if (n, m, world) == (2000, 2000, 1) else None,
         "avg_launch_ms": round(float(dom_ms), 4), "launches": int(kln[dom]),
         "flops_per_launch": float(kfl[dom] / max(1, kln[dom])),
+        # the same launch priced with SURVEY 8(d)'s per-unit figure (the reference's M3 count: 3 n^3 per constraint
+        # for S^-1 A S^-1, n(n+1) per row pair for the trace part): congruence = steps 1+2 together
+        "survey_count": survey_equiv(n, m, world, kms, kln, args.steps),
         "kernels": {short[r]: {"ms_per_step": round(float(kms[r]) / args.steps, 3),
                                "tflops": round(float(kfl[r] / max(kms[r], 1e-9) / 1e9), 2),
                                "launches_per_step": int(kln[r] // args.steps)} for r in (1, 2, 3)},

@@ -524,6 +524,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     d.tiles = tl.dev;
     d.ntiles = tl.n;
     d.dbg = (g_dbg && args.role == g_dbg_role) ? g_dbg : nullptr;
+    if (d.dbg && getenv("HDM_DBG_SYNC")) HDM_HIP_CHECK(hipDeviceSynchronize());   // diagnostic: isolate the stamped launch from its neighbours
     const long nwg = (long) tl.n * args.batch;
     dim3 grid((unsigned) nwg), block(256);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -556,6 +557,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
             if (lay == 3) HDM_LAUNCH(true, true, HDM_ROLE_GENERIC, 0);
             else if (lay == 2) HDM_LAUNCH(true, false, HDM_ROLE_GENERIC, 0);
             else if (lay == 1) HDM_LAUNCH(false, true, HDM_ROLE_GENERIC, 0);
+            else if (g_var == 32) HDM_LAUNCH(false, false, HDM_ROLE_GENERIC, 32);   // diagnostic stamps, tools/wg_timeline_gemm.py
             else HDM_LAUNCH(false, false, HDM_ROLE_GENERIC, 0);
     }
 #undef HDM_LAUNCH_V

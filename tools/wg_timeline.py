@@ -24,6 +24,8 @@ lib.HMiDeviceSynchronize()
 d = dbg.cpu().numpy().reshape(nwg, 8)
 d = d[d[:, 0] != 0]
 print("workgroups stamped:", len(d))
+from wg_timeline_gemm import residency
+residency(d, "role %d in the pipeline" % role)
 t0 = d[:, 0].min()
 start, pro, loop, end = (d[:, i] - t0 for i in range(4))
 hw, xcc, nst = d[:, 4], d[:, 5], d[:, 6]
@@ -63,6 +65,17 @@ for lo, hi in ((1, 16), (17, 48), (49, 96), (97, 200)):
     if sel.any():
         print("  tiles with %3d-%3d stages: n=%4d per-stage %.0f  epilogue %.0f  prologue %.0f" % (
             lo, hi, sel.sum(), ps[sel].mean(), (end - loop)[sel].mean(), (pro - start)[sel].mean()))
+# dispatch gap: for every workgroup end, the delay until the next workgroup start on the same CU
+gaps = []
+for c in ucu:
+    sel = cu == c
+    st = np.sort(d[sel][:, 0]); en = np.sort(d[sel][:, 3])
+    j = np.searchsorted(st, en, side="left")
+    ok = j < len(st)
+    gaps.extend((st[j[ok]] - en[ok]).tolist())
+gaps = np.array(gaps)
+print("end -> next start on the same CU (ticks): median %.0f mean %.0f p90 %.0f  (n=%d)" % (
+    np.median(gaps), gaps.mean(), np.percentile(gaps, 90), len(gaps)))
 c = ucu[3]
 sel = np.where(cu == c)[0]
 base = d[sel][:, 0].min()
