@@ -290,6 +290,13 @@ class KKT:
     def build_up_fixed(self, typeKKT, strategy):
         _check(load_library().HKKTBuildUpFixed(self._k, typeKKT, strategy), "HKKTBuildUpFixed")
 
+    def register_psdp(self, primal_mats):
+        """HKKTRegisterPSDP (interface/hdsdp_schur.c:375-380): borrow one n x n column-major primal matrix per cone;
+        build_up(KKT_TYPE_PRIMAL) then runs the builder on them instead of S^-1"""
+        self._psdp = [np.ascontiguousarray(x, dtype=np.float64) for x in primal_mats]
+        self._psdp_arr = (C.POINTER(C.c_double) * len(self._psdp))(*[_dptr(x) for x in self._psdp])
+        load_library().HKKTRegisterPSDP(self._k, C.cast(self._psdp_arr, C.c_void_p))
+
     def factorize(self):
         _check(load_library().HKKTFactorize(self._k), "HKKTFactorize")
 

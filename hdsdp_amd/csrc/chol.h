@@ -19,6 +19,7 @@ struct HdmChol {
     int finish_load(hipStream_t s);
     int factor(hipStream_t s, int *info_host);          // info = 0 ok, j+1 = first non-positive pivot
     int invert_factor(hipStream_t s);                   // builds Linv (idempotent until the next load)
+    int set_reverse_inverse(hipStream_t s);             // primal builds: Linv <- W, W^T W = X, from the factor of J X J
     int get_diag(double *diag_host, hipStream_t s);
     int solve_device(double *b_dev, double *x_dev, int nrhs, long ldv, int which, hipStream_t s);
     int solve_host(const double *rhs, double *sol, int nrhs, int which, hipStream_t s);

@@ -200,6 +200,19 @@ __global__ void hdm_pad_identity_kernel(double *A, long ld, int n, int npad) {
     if (i >= n || j >= n) A[i + (long) j * ld] = (i == j) ? 1.0 : 0.0;
 }
 
+// W[i][j] = F[n-1-j][n-1-i] for i >= j (F = lower factor of the index-reversed matrix J X J = F F^T), zero above the
+// diagonal, identity in the padding: W is lower triangular with W^T W = X.
+__global__ void hdm_reverse_factor_kernel(const double *__restrict__ F, double *__restrict__ W, long ld, int n, int npad) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    long tot = (long) npad * npad;
+    if (e >= tot) return;
+    int i = (int) (e % npad), j = (int) (e / npad);
+    double v;
+    if (i >= n || j >= n) v = (i == j) ? 1.0 : 0.0;
+    else v = (i >= j) ? F[(n - 1 - j) + (long) (n - 1 - i) * ld] : 0.0;
+    W[i + (long) j * ld] = v;
+}
+
 __global__ void hdm_copy_block_kernel(const double *__restrict__ src, long lds_, double *__restrict__ dst, long ldd,
                                       int rows, int cols) {
     long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -344,6 +357,18 @@ int HdmChol::finish_load(hipStream_t s) {
     }
     factored = false;
     have_inv = false;
+    return 0;
+}
+
+int HdmChol::set_reverse_inverse(hipStream_t s) {
+    // valid after factor() of the index-reversed matrix; afterwards Linv holds W (see the kernel) and L is unchanged
+    if (!factored) return 1;
+    if (!Linv) HDM_HIP_CHECK(hipMalloc((void **) &Linv, sizeof(double) * (size_t) npad * npad));
+    long tot = (long) npad * npad;
+    hipLaunchKernelGGL(hdm_reverse_factor_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, L, Linv,
+                       (long) npad, n, npad);
+    HDM_HIP_CHECK(hipGetLastError());
+    have_inv = true;
     return 0;
 }
 

@@ -187,6 +187,7 @@ struct MiCone {
     double *S = nullptr, *Scheck = nullptr;  // n x n (ld n16) dual matrix buffers
     double *ydev = nullptr;
     hdsdp_linsys_fp *dualFactor = nullptr;
+    HdmChol *primal = nullptr; // KKT_TYPE_PRIMAL: factor object of the registered primal matrix (lazy)
     double Rd = 0.0, perturb = 0.0;
     double *trA = nullptr;     // host: tr(A_i) of all m constraints (b of the synthetic family)
     // work space
@@ -426,20 +427,47 @@ int gram_all(MiCone *c) {
     return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, g.stream);
 }
 
-hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
+hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT, HdmChol *chOverride = nullptr);
 hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
 hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
+
+// KKT_TYPE_PRIMAL (hdsdp_conic_sdp.c:1745-1753; driver hdsdp_psdp.c:156,203,420): the builder runs on the registered
+// primal matrix X in place of S^-1.  S^-1 = Linv^T Linv enters every path only through the lower-triangular Linv, so
+// X is brought to the same form: factor the index-reversed matrix J X J = F F^T on the device, then W = J F^T J is
+// lower triangular with W^T W = X and takes Linv's place in the GEMM path (all strategies give the same numbers, and
+// the reference itself re-routes M2 columns for this type, :1782-1788).  X must be positive definite, which a
+// primal interior point is; an indefinite X is reported like a failed dpotrf.
+hdsdp_retcode build_primal(MiCone *c, int iCone, hdsdp_kkt *kkt, MiKKTPriv *pv) {
+    if (!kkt->dPrimalX || !kkt->dPrimalX[iCone]) return HDSDP_RETCODE_FAILED;   // :1747-1750
+    const double *X = kkt->dPrimalX[iCone];
+    const int n = c->n;
+    if (!c->primal) {
+        c->primal = new HdmChol();
+        if (c->primal->init(n)) return HDSDP_RETCODE_MEMORY;
+    }
+    std::vector<double> Xr((size_t) n * n);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) Xr[(size_t) i + (size_t) j * n] = X[(size_t) (n - 1 - i) + (size_t) (n - 1 - j) * n];
+    HdmChol &ch = *c->primal;
+    int info = 0;
+    if (ch.load_host(Xr.data(), n, g.stream)) return HDSDP_RETCODE_FAILED;
+    HIP_RC(hipStreamSynchronize(g.stream));   // Xr is pageable host memory going out of scope
+    if (ch.factor(g.stream, &info)) return HDSDP_RETCODE_FAILED;
+    if (info != 0) {
+        fprintf(stderr, "[hdsdp_mi355x] KKT_TYPE_PRIMAL: the registered primal matrix is not positive definite "
+                        "(pivot %d of the reversed matrix)\n", info);
+        return HDSDP_RETCODE_FAILED;
+    }
+    if (ch.set_reverse_inverse(g.stream)) return HDSDP_RETCODE_FAILED;
+    return build_gemm_path(c, kkt, pv, KKT_TYPE_PRIMAL, &ch);
+}
 
 hdsdp_retcode cone_build_schur(void *cd, int iCone, void *kktv, int typeKKT) {
     (void) iCone;
     MiCone *c = (MiCone *) cd;
     hdsdp_kkt *kkt = (hdsdp_kkt *) kktv;
     MiKKTPriv *pv = priv_of(kkt);
-    if (typeKKT == KKT_TYPE_PRIMAL) {
-        fprintf(stderr, "[hdsdp_mi355x] KKT_TYPE_PRIMAL (primal refinement, off by default in the reference) is "
-                        "not on the accelerated path\n");
-        return HDSDP_RETCODE_FAILED;
-    }
+    if (typeKKT == KKT_TYPE_PRIMAL) return build_primal(c, iCone, kkt, pv);
     MiLin *l = (MiLin *) c->dualFactor->chol;
     if (!l->ch.factored) {
         fprintf(stderr, "[hdsdp_mi355x] BuildSchur: the dual matrix has no valid Cholesky factor\n");
@@ -483,9 +511,9 @@ hdsdp_retcode corrector_components(MiCone *c, HdmChol &ch, MiKKTPriv *pv, int m)
     return HDSDP_RETCODE_OK;
 }
 
-hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT) {
+hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT, HdmChol *chOverride) {
     MiLin *l = (MiLin *) c->dualFactor->chol;
-    HdmChol &ch = l->ch;
+    HdmChol &ch = chOverride ? *chOverride : l->ch;
     const int m = kkt->nRow;
     if (typeKKT == KKT_TYPE_CORRECTOR) return corrector_components(c, ch, pv, m);
     if (!c->work_ready) {
@@ -806,6 +834,7 @@ void cone_destroy_data(void **pcd) {
     if (c->rows_own) (void) hipFree(c->rows_own);
     if (c->trA) free(c->trA);
     HFpLinsysDestroy(&c->dualFactor);
+    if (c->primal) { c->primal->destroy(); delete c->primal; }
     delete c;
     *pcd = nullptr;
 }

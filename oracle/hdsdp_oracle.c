@@ -636,6 +636,7 @@ int orc_kkt_build(const orc_block *b, const double *Sinv, double Rd, int typeKKT
     for (int pos = 0; pos < m && !rc; ++pos) {                                     /* :1770-1804 */
         if (b->rows[b->perm[pos]].type == T_ZERO) continue;
         int s = fixedStrategy >= 0 ? fixedStrategy : b->strategy[pos];
+        if (typeKKT == 3 && fixedStrategy < 0 && s == S_M2) s = S_M5;   /* "primal method cannot use KKT 2", :1782-1788 */
         switch (s) {
             case S_M2: rc = column_m2(&k, pos); break;
             case S_M3: rc = column_m3(&k, pos); break;

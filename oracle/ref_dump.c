@@ -304,6 +304,23 @@ int main(int argc, char **argv) {
     /* fixed-strategy rebuilds: every strategy must give the same M (reference's own invariant) */
     HDSDP_CALL(HKKTBuildUpFixed(kkt, KKT_TYPE_INFEASIBLE, KKT_M3)); dump_d2("M_inf_fixedM3", kkt->kktMatElem, m, m);
     HDSDP_CALL(HKKTBuildUpFixed(kkt, KKT_TYPE_INFEASIBLE, KKT_M4)); dump_d2("M_inf_fixedM4", kkt->kktMatElem, m, m);
+    /* KKT_TYPE_PRIMAL (hdsdp_conic_sdp.c:1745-1753, driver hdsdp_psdp.c:156,203): the same builder on a registered
+       primal matrix X instead of S^-1.  X is a fixed closed form (tests/util.py:primal_X regenerates it). */
+    {
+        double *X = calloc((size_t) n * n, sizeof(double));
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i)
+                X[i + (size_t) j * n] = (i == j) ? 2.0 + 0.01 * (i % 7)
+                                                 : 0.5 / n * cos(0.37 * (double) (i + j) + 0.11 * (double) i * (double) j);
+        double *Xs[1] = { X };
+        HKKTRegisterPSDP(kkt, Xs);
+        HDSDP_CALL(HKKTBuildUp(kkt, KKT_TYPE_PRIMAL));
+        dump_d2("M_pri", kkt->kktMatElem, m, m);
+        dump_d("ASinv_pri", kkt->dASinvVec, m);
+        dump_d("ASinvRdSinv_pri", kkt->dASinvRdSinvVec, m);
+        dump_s("TraceSinv_pri", kkt->dTraceSinv);
+        free(X);
+    }
     printf("ref_dump ok: n=%d m=%d nnz=%ld logdet=%.12e\n", n, m, nnz, logdet);
 exit_cleanup:
     if (retcode != HDSDP_RETCODE_OK) fprintf(stderr, "ref_dump: reference returned %d\n", (int) retcode);

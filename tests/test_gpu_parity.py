@@ -5,7 +5,7 @@ ASinvCSinv; 1e-8 relative 2-norm for the Schur solves; 1e-12 relative for logdet
 import numpy as np
 import pytest
 
-from util import KKT_TOL, check_close, kkt_err, load_golden, lower_mask, y_of
+from util import primal_X, KKT_TOL, check_close, kkt_err, load_golden, lower_mask, y_of
 
 pytestmark = pytest.mark.gpu
 
@@ -79,6 +79,15 @@ def test_schur_against_reference(name):
         # --- fixed-strategy builds give the same matrix (reference invariant, hdsdp_utils.c:536-707)
         kkt.build_up_fixed(api.KKT_TYPE_INFEASIBLE, api.KKT_M4)
         check_close(kkt.M[msk], g["M_inf"][msk], name)
+        # --- KKT_TYPE_PRIMAL: the builder on a registered primal matrix (hdsdp_conic_sdp.c:1745-1753)
+        if "M_pri" in g:
+            kkt.register_psdp([primal_X(n)])
+            kkt.build_up(api.KKT_TYPE_PRIMAL)
+            ex = kkt.export()
+            check_close(kkt.M[msk], g["M_pri"][msk], name + " primal")
+            check_close(ex["ASinv"], g["ASinv_pri"], name + " primal")
+            check_close(ex["ASinvRdSinv"], g["ASinvRdSinv_pri"], name + " primal")
+            check_close([ex["TraceSinv"]], g["TraceSinv_pri"], name + " primal")
         kkt.destroy()
     finally:
         cone.destroy()

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from util import KKT_TOL, check_close, load_golden, lower_mask, y_of
+from util import KKT_TOL, check_close, load_golden, lower_mask, primal_X, y_of
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import oracle_py  # noqa: E402
@@ -62,6 +62,12 @@ def test_oracle_matches_reference(name):
     for strat, key in ((2, "M_inf_fixedM3"), (3, "M_inf_fixedM4")):
         f = blk.kkt_build(Sinv, Rd, 0, fixed=strat)
         check_close(f["M"][mm], g[key][mm], key)
+    # KKT_TYPE_PRIMAL: the same builder on the registered primal matrix (hdsdp_conic_sdp.c:1745-1753)
+    pk = blk.kkt_build(primal_X(n), Rd, 3)
+    check_close(pk["M"][mm], g["M_pri"][mm], "M_pri")
+    check_close(pk["ASinv"], g["ASinv_pri"], "ASinv_pri")
+    check_close(pk["ASinvRdSinv"], g["ASinvRdSinv_pri"], "ASinvRdSinv_pri")
+    check_close([pk["TraceSinv"]], g["TraceSinv_pri"], "TraceSinv_pri")
     # the Schur solves (Jacobi PCG to the reference's tolerances)
     Ms = k["M"].copy()
     Ms[np.arange(m), np.arange(m)] += float(g["diag_add"][0])

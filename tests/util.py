@@ -49,3 +49,13 @@ def load_golden(name):
 
 def y_of(g):
     return np.asarray(g["y"], dtype=np.float64)
+
+
+def primal_X(n):
+    """the fixed symmetric positive definite matrix oracle/ref_dump.c registers with HKKTRegisterPSDP for the
+    KKT_TYPE_PRIMAL goldens (closed form, diagonally dominant)"""
+    i = np.arange(n, dtype=np.float64)
+    I, J = np.meshgrid(i, i, indexing="ij")
+    X = 0.5 / n * np.cos(0.37 * (I + J) + 0.11 * I * J)
+    X[np.arange(n), np.arange(n)] = 2.0 + 0.01 * (np.arange(n) % 7)
+    return np.ascontiguousarray(X)
