@@ -34,6 +34,7 @@ struct HdmGemmDev {
     HdmGemmArgs a;
     const int2 *tiles;
     int ntiles;
+    int edge_off;             // A/B switch (HDM_NO_EDGE=1): bottom-edge tiles take the ordinary quadrant path
     unsigned long long *dbg;  // diagnostic builds only (VAR & 32): 8 words per workgroup
 };
 
@@ -126,15 +127,26 @@ __device__ __forceinline__ double frag(const double *__restrict__ s, int x, int 
 //   wave 0: rows {5,6,7} x cols {0,1,2}   wave 1: rows {5,6,7} x cols {3,4,5}   wave 2: rows {2,3,4} x cols {0,1,2}
 //   wave 3: the three 2x2 lower triangles on the diagonal: (0,0)(1,0)(1,1) (3,3)(4,3)(4,4) (6,6)(7,6)(7,7)
 template <int W> struct DiagCells;
-template <> struct DiagCells<0> { static constexpr int si[9] = {5, 5, 5, 6, 6, 6, 7, 7, 7}, sj[9] = {0, 1, 2, 0, 1, 2, 0, 1, 2}; };
-template <> struct DiagCells<1> { static constexpr int si[9] = {5, 5, 5, 6, 6, 6, 7, 7, 7}, sj[9] = {3, 4, 5, 3, 4, 5, 3, 4, 5}; };
-template <> struct DiagCells<2> { static constexpr int si[9] = {2, 2, 2, 3, 3, 3, 4, 4, 4}, sj[9] = {0, 1, 2, 0, 1, 2, 0, 1, 2}; };
-template <> struct DiagCells<3> { static constexpr int si[9] = {0, 1, 1, 3, 4, 4, 6, 7, 7}, sj[9] = {0, 0, 1, 3, 3, 4, 6, 6, 7}; };
+template <> struct DiagCells<0> { static constexpr int NC = 9, si[16] = {5, 5, 5, 6, 6, 6, 7, 7, 7}, sj[16] = {0, 1, 2, 0, 1, 2, 0, 1, 2}; };
+template <> struct DiagCells<1> { static constexpr int NC = 9, si[16] = {5, 5, 5, 6, 6, 6, 7, 7, 7}, sj[16] = {3, 4, 5, 3, 4, 5, 3, 4, 5}; };
+template <> struct DiagCells<2> { static constexpr int NC = 9, si[16] = {2, 2, 2, 3, 3, 3, 4, 4, 4}, sj[16] = {0, 1, 2, 0, 1, 2, 0, 1, 2}; };
+template <> struct DiagCells<3> { static constexpr int NC = 9, si[16] = {0, 1, 1, 3, 4, 4, 6, 7, 7}, sj[16] = {0, 0, 1, 3, 3, 4, 6, 6, 7}; };
+// Bottom-edge tiles (fewer than 128 valid rows: n = 2000 leaves 80 = 5 sub-tile rows, the Gram operand 88 = 6) keep
+// all 8 sub-tile columns but only rv < 8 sub-tile rows.  The 2x2 quadrant split would run them at the full 16-MFMA
+// cadence (the upper quadrants are full); instead wave w takes sub-tile columns {2w, 2w+1} over RV rows: 2 RV cells
+// per wave, so the tile costs RV/8 of a full one.  RV is a compile-time 4..7 (fewer valid rows run as 4: the extra
+// rows are zeros from the stager and masked by the epilogue); run-time masks would cut the MFMA stream into branches.
+template <int W, int RV> struct EdgeCells {
+    static constexpr int NC = 2 * RV;
+    static constexpr int si[16] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7};
+    static constexpr int sj[16] = {2 * W, 2 * W + 1, 2 * W, 2 * W + 1, 2 * W, 2 * W + 1, 2 * W, 2 * W + 1,
+                                   2 * W, 2 * W + 1, 2 * W, 2 * W + 1, 2 * W, 2 * W + 1, 2 * W, 2 * W + 1};
+};
 
-template <int W, bool AKM, bool BKM>
-__device__ __forceinline__ void diag_compute(const double *__restrict__ cA, const double *__restrict__ cB, int l15, int lq,
+// one BK stage of a cell list
+template <class T, bool AKM, bool BKM>
+__device__ __forceinline__ void cell_compute(const double *__restrict__ cA, const double *__restrict__ cB, int l15, int lq,
                                              hdm_d4 (&acc)[4][4]) {
-    using T = DiagCells<W>;
 #pragma unroll
     for (int kk = 0; kk < HDM_BK; kk += 4) {
         double fr[8], fc[8];   // row / column fragments; only the ones this wave's cells name are ever loaded
@@ -142,28 +154,28 @@ __device__ __forceinline__ void diag_compute(const double *__restrict__ cA, cons
         for (int q = 0; q < 8; ++q) {
             bool ur = false, uc = false;
 #pragma unroll
-            for (int c = 0; c < 9; ++c) { ur |= (T::si[c] == q); uc |= (T::sj[c] == q); }
+            for (int c = 0; c < T::NC; ++c) { ur |= (T::si[c] == q); uc |= (T::sj[c] == q); }
             fr[q] = ur ? frag<AKM>(cA, q * 16 + l15, kk + lq) : 0.0;
             fc[q] = uc ? frag<BKM>(cB, q * 16 + l15, kk + lq) : 0.0;
         }
 #pragma unroll
-        for (int c = 0; c < 9; ++c)
+        for (int c = 0; c < T::NC; ++c)
             acc[c >> 2][c & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fc[T::sj[c]], fr[T::si[c]], acc[c >> 2][c & 3], 0, 0, 0);
     }
 }
 
-template <int W>
-__device__ __forceinline__ void diag_epilogue(const HdmGemmArgs &a, int z, int m0, int n0, int l15, int lq,
+// tri = 1: diagonal tile of a lower-only product (entries above the diagonal are neither scaled nor stored)
+template <class T>
+__device__ __forceinline__ void cell_epilogue(const HdmGemmArgs &a, int z, int m0, int n0, int l15, int lq, int rv, int tri,
                                               const hdm_d4 (&acc)[4][4]) {
-    using T = DiagCells<W>;
     if (a.epilogue == HDM_EPI_BLOCKED) {
         const long rs16 = a.blk_row_stride * 16;
         double *lane_base = a.C + (a.blk_row0 + z) * 16 + l15 + (long) lq * rs16;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
+        for (int c = 0; c < T::NC; ++c) {
             const int bi = (m0 >> 4) + T::si[c], bj = (n0 >> 4) + T::sj[c];
-            if (bi >= a.nblk) continue;
-            const double sc = (T::si[c] == T::sj[c]) ? 1.0 : 1.4142135623730951;
+            if (T::si[c] >= rv || bi >= a.nblk || bj >= a.nblk) continue;
+            const double sc = (bi == bj) ? 1.0 : 1.4142135623730951;
             const long sub = (long) bj * a.nblk - (long) bj * (bj - 1) / 2 + (bi - bj);
             double *q = lane_base + sub * 16 * rs16;
 #pragma unroll
@@ -173,12 +185,13 @@ __device__ __forceinline__ void diag_epilogue(const HdmGemmArgs &a, int z, int m
     }
     double *C = a.C + (a.epilogue == HDM_EPI_SLAB ? (long) z * a.slab_stride : (long) z * a.strideC);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
+    for (int c = 0; c < T::NC; ++c) {
+        if (T::si[c] >= rv) continue;
         const int gi = m0 + T::si[c] * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gj = n0 + T::sj[c] * 16 + lq + 4 * r;
-            if (gi < a.M && gj < a.N && gi >= gj) {
+            if (gi < a.M && gj < a.N && (!tri || gi >= gj)) {
                 double *q = C + gi + (long) gj * a.ldc;
                 double v = a.alpha * acc[c >> 2][c & 3][r];
                 if (a.beta != 0.0) v += a.beta * (*q);
@@ -188,13 +201,13 @@ __device__ __forceinline__ void diag_epilogue(const HdmGemmArgs &a, int z, int m
     }
 }
 
-// whole K loop + epilogue of a diagonal tile for wave W (one-stage look-ahead, 9 accumulators)
-template <int W, bool AKM, bool BKM>
-__device__ __forceinline__ void diag_tile(const HdmGemmArgs &a, Stager<AKM> &stA, Stager<BKM> &stB, double *sA, double *sB,
-                                          int nst, int tid, int z, int m0, int n0, int l15, int lq) {
+// whole K loop + epilogue of a cell-dealt tile (one-stage look-ahead, at most 16 accumulators)
+template <class T, bool AKM, bool BKM>
+__device__ __forceinline__ void cell_tile(const HdmGemmArgs &a, Stager<AKM> &stA, Stager<BKM> &stB, double *sA, double *sB,
+                                          int nst, int tid, int z, int m0, int n0, int l15, int lq, int rv, int tri) {
     hdm_d4 acc[4][4];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) acc[c >> 2][c & 3] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < 16; ++c) acc[c >> 2][c & 3] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
     double2 ra[4], rb[4];
     if (nst > 0) {
         stA.load(ra); stB.load(rb);
@@ -205,7 +218,7 @@ __device__ __forceinline__ void diag_tile(const HdmGemmArgs &a, Stager<AKM> &stA
     for (int t = 0; t < nst; ++t) {
         const bool more = (t + 1 < nst);
         if (more) { stA.load(ra); stB.load(rb); }
-        diag_compute<W, AKM, BKM>(sA + cur * STAGE_DOUBLES, sB + cur * STAGE_DOUBLES, l15, lq, acc);
+        cell_compute<T, AKM, BKM>(sA + cur * STAGE_DOUBLES, sB + cur * STAGE_DOUBLES, l15, lq, acc);
         if (more) {
             r2s<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra);
             r2s<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb);
@@ -213,7 +226,7 @@ __device__ __forceinline__ void diag_tile(const HdmGemmArgs &a, Stager<AKM> &stA
         __syncthreads();
         cur ^= 1;
     }
-    diag_epilogue<W>(a, z, m0, n0, l15, lq, acc);
+    cell_epilogue<T>(a, z, m0, n0, l15, lq, rv, tri, acc);
 }
 
 template <bool AKM, bool BKM, int ROLE, int VAR>
@@ -285,11 +298,26 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     if (a.lower_only && tm == tn) {   // workgroup-uniform: diagonal tile, 36-cell scheme
         const int nst = (kt1 - kt0) * npass;
         switch (wave) {
-            case 0: diag_tile<0, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq); break;
-            case 1: diag_tile<1, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq); break;
-            case 2: diag_tile<2, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq); break;
-            default: diag_tile<3, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq); break;
+            case 0: cell_tile<DiagCells<0>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+            case 1: cell_tile<DiagCells<1>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+            case 2: cell_tile<DiagCells<2>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+            default: cell_tile<DiagCells<3>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
         }
+        return;
+    }
+    if (ROLE != HDM_ROLE_GENERIC && tm != tn && m0 + HDM_TILE > a.M && n0 + HDM_TILE <= a.N && !p.edge_off) {
+        // workgroup-uniform: bottom-edge tile below the diagonal, rv < 8 valid sub-tile rows
+        const int nst = (kt1 - kt0) * npass;
+        const int rv = (a.M - m0 + 15) >> 4;
+#define HDM_EDGE(RV)                                                                                                     \
+    switch (wave) {                                                                                                      \
+        case 0: cell_tile<EdgeCells<0, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rv, 0); break;  \
+        case 1: cell_tile<EdgeCells<1, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rv, 0); break;  \
+        case 2: cell_tile<EdgeCells<2, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rv, 0); break;  \
+        default: cell_tile<EdgeCells<3, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rv, 0); break; \
+    }
+        if (rv <= 4) { HDM_EDGE(4) } else if (rv == 5) { HDM_EDGE(5) } else if (rv == 6) { HDM_EDGE(6) } else { HDM_EDGE(7) }
+#undef HDM_EDGE
         return;
     }
 
@@ -523,6 +551,9 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     if (d.a.b_kblk == 0) d.a.b_kblk = HDM_BK;
     d.tiles = tl.dev;
     d.ntiles = tl.n;
+    static int g_edge_off = -1;
+    if (g_edge_off < 0) { const char *e = getenv("HDM_NO_EDGE"); g_edge_off = (e && atoi(e)) ? 1 : 0; }
+    d.edge_off = g_edge_off;
     d.dbg = (g_dbg && args.role == g_dbg_role) ? g_dbg : nullptr;
     if (d.dbg && getenv("HDM_DBG_SYNC")) HDM_HIP_CHECK(hipDeviceSynchronize());   // diagnostic: isolate the stamped launch from its neighbours
     const long nwg = (long) tl.n * args.batch;
@@ -536,14 +567,13 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
 #define HDM_LAUNCH(AK, BK, R, V) hipLaunchKernelGGL((hdm_gemm_kernel<AK, BK, R, V>), grid, block, 0, stream, d)
 #define HDM_LAUNCH_V(AK, BK, R)                                   \
     switch (g_var) {                                              \
-        case 2: HDM_LAUNCH(AK, BK, R, 2); break;                  \
         case 32: HDM_LAUNCH(AK, BK, R, 32); break;                \
-        case 34: HDM_LAUNCH(AK, BK, R, 34); break;                \
         default: HDM_LAUNCH(AK, BK, R, 0);                        \
     }
     // HDM_VAR selects a kernel variant for A/B runs and diagnostics (tools/var_sweep.sh, tools/wg_timeline.py):
-    //   2 = global loads two stages ahead (measured -2 % on the congruence kernels, +4 % on the Gram kernel; not
-    //   the default: with the diagonal-tile path compiled in, its 64 extra staging VGPRs spill), 32 / 34 = per-workgroup s_memtime stamps on the one- / two-stage loop.
+    //   32 = per-workgroup s_memtime stamps.  (VAR & 2, global loads two stages ahead, is kept in the kernel source but
+    //   no longer instantiated: -2 % on the congruence kernels, +4 % on the Gram kernel when measured, and with the
+    //   cell-dealt tile paths compiled in its 64 extra staging VGPRs spill.)
     //   (The timing-only ablation bits 4/8/16 of VAR -- no staging / no barriers / no LDS reads -- are not
     //   instantiated by default; see DESIGN.md for what they showed.)
     static int g_env_var = -2;
