@@ -276,15 +276,15 @@ int cone_alloc_gemm_work(MiCone *c) {
     bc = std::max(1L, std::min(bc, bcmax));
     if (bc >= 8) bc = bc / 8 * 8;
     c->Bc = (int) std::min<long>(bc, std::max(1, c->mloc));
-    HDM_HIP_CHECK(hipMalloc((void **) &c->T, nn * (size_t) c->Bc));
+    HDM_HIP_CHECK(hipMalloc((void **) &c->T, nn * (size_t) c->Bc + hdm_operand_pad(c->n16)));
     HDM_HIP_CHECK(hdm_memset_sync(c->T, 0, nn * (size_t) c->Bc));  // step 1 writes lower tiles only; the rest must read as 0
     const size_t ahat = sizeof(double) * (size_t) c->world * c->npb_loc * c->Lr * 16;
     if (!c->AhatLoc) {
-        HDM_HIP_CHECK(hipMalloc((void **) &c->AhatLoc, ahat));
+        HDM_HIP_CHECK(hipMalloc((void **) &c->AhatLoc, ahat + sizeof(double) * HDM_OPERAND_PAD_DOUBLES));
         HDM_HIP_CHECK(hdm_memset_sync(c->AhatLoc, 0, ahat));
         if (c->world == 1) c->AhatAll = c->AhatLoc;
         else {
-            HDM_HIP_CHECK(hipMalloc((void **) &c->AhatAll, ahat));
+            HDM_HIP_CHECK(hipMalloc((void **) &c->AhatAll, ahat + sizeof(double) * HDM_OPERAND_PAD_DOUBLES));
             HDM_HIP_CHECK(hdm_memset_sync(c->AhatAll, 0, ahat));
         }
     }
@@ -535,7 +535,7 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
         RC(hdm_launch_gemm(k2, g.stream));
         if (typeKKT == KKT_TYPE_HOMOGENEOUS) {
             if (!c->CL) {
-                HIP_RC(hipMalloc((void **) &c->CL, sizeof(double) * (size_t) nn));
+                HIP_RC(hipMalloc((void **) &c->CL, sizeof(double) * (size_t) nn + hdm_operand_pad(c->n16)));
                 RC(hdm_lower_half(c->Cfull, c->CL, c->n, c->n16, g.stream));
             }
             RC(congruence_rows(c, ch, c->CL, nn, 1, c->mloc + 2));
@@ -1201,7 +1201,7 @@ static int upload_dense_rows(MiCone *c) {
     // densify every owned constraint into a full symmetric n16 x n16 matrix (via packed staging)
     const long P = (long) c->n * (c->n + 1) / 2;
     const long nn = (long) c->n16 * c->n16;
-    HDM_HIP_CHECK(hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) nn * std::max(1, c->mloc)));
+    HDM_HIP_CHECK(hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) nn * std::max(1, c->mloc) + hdm_operand_pad(c->n16)));
     HDM_HIP_CHECK(hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) nn * std::max(1, c->mloc)));
     const int chunk = (int) std::max(1L, std::min<long>(64, (256L << 20) / (P * 8)));
     double *stage_dev = nullptr, *stage_host = nullptr;
@@ -1332,7 +1332,7 @@ hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, in
     c->n = nCol; c->m = nRow; c->rank = rank; c->world = world; c->synthetic = true; c->path = PATH_GEMM;
     if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
     const long nn = (long) c->n16 * c->n16;
-    if (hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) nn * std::max(1, c->mloc)) != hipSuccess) {
+    if (hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) nn * std::max(1, c->mloc) + hdm_operand_pad(c->n16)) != hipSuccess) {
         fprintf(stderr, "[hdsdp_mi355x] cannot allocate %.1f GiB for the constraint matrices\n",
                 (double) nn * c->mloc * 8 / (1 << 30));
         return HDSDP_RETCODE_MEMORY;

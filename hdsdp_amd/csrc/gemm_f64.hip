@@ -98,6 +98,22 @@ struct Stager {
         p += kstep;
         if (--left == 0) { p = p2; qstride = qstride2; kstep = kstep2; }
     }
+    // No row mask: rows past the matrix edge read whatever follows (the engine's operand buffers carry
+    // HDM_OPERAND_PAD bytes of slack, hdm_common.h).  Sound because output element (i, j) depends only on row i of
+    // one operand and row j of the other, and every epilogue masks rows/columns past the edge; it removes the eight
+    // exec-mask branches per stage, so the stage body is one basic block the scheduler can interleave.
+    __device__ __forceinline__ void load_nomask(double2 &r0, double2 &r1, double2 &r2, double2 &r3) {
+        r0 = *reinterpret_cast<const double2 *>(p);
+        r1 = *reinterpret_cast<const double2 *>(p + qstride);
+        r2 = *reinterpret_cast<const double2 *>(p + 2 * qstride);
+        r3 = *reinterpret_cast<const double2 *>(p + 3 * qstride);
+        // `remain` = k blocks not yet loaded: the pointer never moves past the last one, so a look-ahead load issued
+        // beyond the end of the K loop re-reads valid memory instead of running off the matrix (branch-free)
+        remain -= 1;
+        p += (remain > 0) ? kstep : 0;
+        if (--left == 0) { p = p2; qstride = qstride2; kstep = kstep2; }
+    }
+    int remain = 1 << 30;
 };
 
 template <bool KM>
@@ -113,6 +129,24 @@ __device__ __forceinline__ void r2s(double *__restrict__ s, int tid, const doubl
             dst = s + k * LDM + i2;
         }
         *reinterpret_cast<double2 *>(dst) = r[q];
+    }
+}
+
+template <bool KM>
+__device__ __forceinline__ void r2s4(double *__restrict__ s, int tid, const double2 &r0, const double2 &r1, const double2 &r2,
+                                     const double2 &r3) {
+    if (KM) {
+        double *dst = s + (tid >> 3) * LDK + (tid & 7) * 2;
+        *reinterpret_cast<double2 *>(dst) = r0;
+        *reinterpret_cast<double2 *>(dst + 32 * LDK) = r1;
+        *reinterpret_cast<double2 *>(dst + 64 * LDK) = r2;
+        *reinterpret_cast<double2 *>(dst + 96 * LDK) = r3;
+    } else {
+        double *dst = s + (tid >> 6) * LDM + (tid & 63) * 2;
+        *reinterpret_cast<double2 *>(dst) = r0;
+        *reinterpret_cast<double2 *>(dst + 4 * LDM) = r1;
+        *reinterpret_cast<double2 *>(dst + 8 * LDM) = r2;
+        *reinterpret_cast<double2 *>(dst + 12 * LDM) = r3;
     }
 }
 
@@ -201,31 +235,49 @@ __device__ __forceinline__ void cell_epilogue(const HdmGemmArgs &a, int z, int m
     }
 }
 
-// whole K loop + epilogue of a cell-dealt tile (one-stage look-ahead, at most 16 accumulators)
+// REP x { NA instructions of class MA, NB of class MB } for the machine scheduler (classes: 0x8 MFMA, 0x20 VMEM read,
+// 0x100 LDS read, 0x200 LDS write)
+template <int MA, int NA, int MB, int NB, int REP>
+__device__ __forceinline__ void sgb_pairs() {
+    if constexpr (REP > 0) {
+        __builtin_amdgcn_sched_group_barrier(MA, NA, 0);
+        __builtin_amdgcn_sched_group_barrier(MB, NB, 0);
+        sgb_pairs<MA, NA, MB, NB, REP - 1>();
+    }
+}
+
+// whole K loop + epilogue of a cell-dealt tile (one-stage look-ahead, at most 16 accumulators).  Unmasked branch-free
+// staging loads as in the main loop (callers: roles 1-3 only); the eight global loads are issued among the first
+// MFMAs of a stage and the eight LDS writes among the last.
 template <class T, bool AKM, bool BKM>
 __device__ __forceinline__ void cell_tile(const HdmGemmArgs &a, Stager<AKM> &stA, Stager<BKM> &stB, double *sA, double *sB,
                                           int nst, int tid, int z, int m0, int n0, int l15, int lq, int rv, int tri) {
     hdm_d4 acc[4][4];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c >> 2][c & 3] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
-    double2 ra[4], rb[4];
+    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    stA.remain = nst; stB.remain = nst;
     if (nst > 0) {
-        stA.load(ra); stB.load(rb);
-        r2s<AKM>(sA, tid, ra); r2s<BKM>(sB, tid, rb);
+        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);
+        r2s4<AKM>(sA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(sB, tid, rb0, rb1, rb2, rb3);
     }
     __syncthreads();
     int cur = 0;
-    for (int t = 0; t < nst; ++t) {
-        const bool more = (t + 1 < nst);
-        if (more) { stA.load(ra); stB.load(rb); }
+    constexpr int NM = 4 * T::NC;   // MFMAs per stage
+    for (int t = 0; t + 1 < nst; ++t) {
+        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);
         cell_compute<T, AKM, BKM>(sA + cur * STAGE_DOUBLES, sB + cur * STAGE_DOUBLES, l15, lq, acc);
-        if (more) {
-            r2s<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra);
-            r2s<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb);
-        }
+        r2s4<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra0, ra1, ra2, ra3);
+        r2s4<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb0, rb1, rb2, rb3);
+        sgb_pairs<0x8, 1, 0x20, 1, 8>();
+        __builtin_amdgcn_sched_group_barrier(0x8, NM - 16, 0);   // fragment reads are left to the scheduler
+        sgb_pairs<0x8, 1, 0x200, 1, 8>();
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
         cur ^= 1;
     }
+    if (nst > 0) cell_compute<T, AKM, BKM>(sA + cur * STAGE_DOUBLES, sB + cur * STAGE_DOUBLES, l15, lq, acc);
     cell_epilogue<T>(a, z, m0, n0, l15, lq, rv, tri, acc);
 }
 
@@ -288,8 +340,9 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     const int kt0 = (int) (kbeg / HDM_BK), kt1 = (int) (kend / HDM_BK);
     Stager<AKM> stA;
     Stager<BKM> stB;
-    stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, m0, kt0, tid);
-    stB.init(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, n0, kt0, tid);
+    // VAR & 128: timing-only ablation (wrong results): every tile stages rows 0..127, so all operand traffic hits in L2
+    stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, (VAR & 128) ? 0 : m0, kt0, tid);
+    stB.init(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, (VAR & 128) ? 0 : n0, kt0, tid);
     const int npass = a.A2 ? 2 : 1;
     if (a.A2) {
         stA.chain(a.A2 + (long) z * a.strideA2, a.lda2, m0, kt0, tid, kt1 - kt0);
@@ -339,7 +392,80 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         }
     };
 
-    if (VAR & 2) {
+    if (VAR & 64) {
+        // Rotated loop: the barrier sits between the third and the fourth k-step of a stage.  By then the wave holds
+        // the fourth k-step's fragments in registers, so after the barrier it first issues the LDS reads of the NEXT
+        // stage's first k-step and then runs the 16 MFMAs of the fourth k-step, which cover that LDS latency; global
+        // loads (unmasked, branch-free) and the LDS writes of the next stage are spread over the first three k-steps.
+        double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // staging registers, named so they are never an alloca
+        const int nst = (kt1 - kt0) * npass;
+        double fa0[4], fb0[4], fa1[4], fb1[4];   // two fragment sets, named (not indexed) so they stay in registers
+#define HDM_LDF(FA, FB, cA, cB, kk)                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) FB[i] = frag<AKM>(cA, wm * 64 + i * 16 + l15, (kk) + lq); \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) FA[j] = frag<BKM>(cB, wn * 64 + j * 16 + l15, (kk) + lq);
+#define HDM_MMA(FA, FB)                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+            acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[i], acc[j][i], 0, 0, 0);
+        stA.remain = nst; stB.remain = nst;
+        if (nst > 0) {
+            stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);
+            r2s4<AKM>(sA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(sB, tid, rb0, rb1, rb2, rb3);
+            stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   // stage 1, in flight
+        }
+        __syncthreads();
+        if ((VAR & 32) && p.dbg) t_pro = __builtin_amdgcn_s_memtime();
+        int cur = 0;
+        if (nst > 0) { HDM_LDF(fa0, fb0, sA, sB, 0) }
+        // LDS read instructions per fragment set: an M-major operand's four fragments pair up into two ds_read2_b64,
+        // a K-major operand's are 2304 bytes apart and stay four ds_read_b64
+        constexpr int NR = (AKM ? 4 : 2) + (BKM ? 4 : 2);
+        for (int t = 0; t + 1 < nst; ++t) {
+            const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;
+            double *nA = sA + (cur ^ 1) * STAGE_DOUBLES, *nB = sB + (cur ^ 1) * STAGE_DOUBLES;
+            // staging registers hold stage t+1 (loaded after the previous barrier, ~54 MFMAs = 1.5 us before their
+            // LDS writes below)
+            HDM_LDF(fa1, fb1, cA, cB, 4)
+            HDM_MMA(fa0, fb0)
+            HDM_LDF(fa0, fb0, cA, cB, 8)
+            HDM_MMA(fa1, fb1)
+            HDM_LDF(fa1, fb1, cA, cB, 12)
+            r2s4<AKM>(nA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(nB, tid, rb0, rb1, rb2, rb3);
+            HDM_MMA(fa0, fb0)
+            // issue order of the 48 MFMAs before the barrier: 16 with the second k-step's fragment reads, 16 with the
+            // third's, then the fourth's reads and the 8 LDS writes among the last 16
+            sgb_pairs<0x8, 2, 0x100, 1, NR>();
+            __builtin_amdgcn_sched_group_barrier(0x8, 16 - 2 * NR, 0);
+            sgb_pairs<0x8, 2, 0x100, 1, NR>();
+            __builtin_amdgcn_sched_group_barrier(0x8, 16 - 2 * NR, 0);
+            sgb_pairs<0x8, 1, 0x100, NR / 2, 2>();
+            sgb_pairs<0x8, 1, 0x200, 1, 8>();
+            __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            HDM_LDF(fa0, fb0, nA, nB, 0)
+            stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   // stage t+2 (or the last one again)
+            HDM_MMA(fa1, fb1)
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+            sgb_pairs<0x8, 1, 0x20, 1, 8>();
+            __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur ^= 1;
+        }
+        if (nst > 0) {   // last stage: nothing left to stage
+            const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;
+            HDM_LDF(fa1, fb1, cA, cB, 4)
+            HDM_MMA(fa0, fb0)
+            HDM_LDF(fa0, fb0, cA, cB, 8)
+            HDM_MMA(fa1, fb1)
+            HDM_LDF(fa1, fb1, cA, cB, 12)
+            HDM_MMA(fa0, fb0)
+            HDM_MMA(fa1, fb1)
+        }
+#undef HDM_LDF
+#undef HDM_MMA
+    } else if (VAR & 2) {
         // Two k blocks in flight: global loads are issued two stages ahead into two register sets, so a load has
         // two full MFMA stages (~8 us) to land before its ds_write.  With one stage of look-ahead both co-resident
         // workgroups regularly parked on vmcnt together (SQ_WAIT_ANY 14.6 % of wave cycles, MFMA pipe 83.5 %).
@@ -568,7 +694,10 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
 #define HDM_LAUNCH_V(AK, BK, R)                                   \
     switch (g_var) {                                              \
         case 32: HDM_LAUNCH(AK, BK, R, 32); break;                \
-        default: HDM_LAUNCH(AK, BK, R, 0);                        \
+        case 96: HDM_LAUNCH(AK, BK, R, 96); break;                \
+        case 192: HDM_LAUNCH(AK, BK, R, 192); break;              \
+        case 0: HDM_LAUNCH(AK, BK, R, 0); break;                  \
+        default: HDM_LAUNCH(AK, BK, R, 64);                       \
     }
     // HDM_VAR selects a kernel variant for A/B runs and diagnostics (tools/var_sweep.sh, tools/wg_timeline.py):
     //   32 = per-workgroup s_memtime stamps.  (VAR & 2, global loads two stages ahead, is kept in the kernel source but
@@ -578,7 +707,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     //   instantiated by default; see DESIGN.md for what they showed.)
     static int g_env_var = -2;
     if (g_env_var == -2) { const char *e = getenv("HDM_VAR"); g_env_var = e ? atoi(e) : -1; }
-    const int g_var = g_env_var >= 0 ? g_env_var : 0;
+    const int g_var = g_env_var >= 0 ? g_env_var : 64;   // default: the rotated, explicitly interleaved loop
     switch (args.role) {
         case HDM_ROLE_CONG1: HDM_LAUNCH_V(false, true, HDM_ROLE_CONG1); break;   // U = Linv * A_L (A_L k-contiguous)
         case HDM_ROLE_CONG2: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG2); break;  // At = U Linv^T + Linv U^T

@@ -107,9 +107,12 @@ class Exchange:
         lib = api.load_library()
         self.plan = ShardPlan(cone.n, cone.m, self.world)
         count = self.plan.chunk * self.world
-        # torch owns the exchange buffers so RCCL sees registered allocations
-        self.send = torch.zeros(count, dtype=torch.float64, device="cuda")
-        self.recv = torch.zeros(count, dtype=torch.float64, device="cuda") if self.world > 1 else self.send
+        # torch owns the exchange buffers so RCCL sees registered allocations; the engine's Gram kernel reads them
+        # with unmasked tile loads, hence the slack behind the payload (hdm_common.h: HDM_OPERAND_PAD_DOUBLES)
+        pad = 8192
+        self._send_full = torch.zeros(count + pad, dtype=torch.float64, device="cuda")
+        self._recv_full = torch.zeros(count + pad, dtype=torch.float64, device="cuda") if self.world > 1 else self._send_full
+        self.send, self.recv = self._send_full[:count], self._recv_full[:count]
         torch.cuda.synchronize()
         rc = lib.HMiConeSetExchangeBuffers(cone._h, self.send.data_ptr(), self.recv.data_ptr())
         if rc != 0:

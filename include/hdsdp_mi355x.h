@@ -228,7 +228,8 @@ typedef int (*hmi_alltoall_fn)(void *ctx);
 typedef int (*hmi_allreduce_fn)(void *ctx, void *buf, int64_t count);
 void HMiConeSetExchange(hdsdp_cone *cone, hmi_alltoall_fn a2a, hmi_allreduce_fn ar, void *ctx);
 /* exchange buffers (device pointers, `world` chunks of *chunkCount doubles each); the caller may instead
- * supply its own (e.g. torch-allocated) buffers of that size before the first HKKTBuildUp */
+ * supply its own (e.g. torch-allocated) buffers before the first HKKTBuildUp: world * chunkCount doubles of payload
+ * plus 8192 doubles of slack behind it (the Gram kernel stages whole 128-row tiles without a row mask) */
 hdsdp_retcode HMiConeGetExchangeBuffers(hdsdp_cone *cone, void **sendBuf, void **recvBuf, int64_t *chunkCount);
 hdsdp_retcode HMiConeSetExchangeBuffers(hdsdp_cone *cone, void *sendBuf, void *recvBuf);
 void *HMiKKTDeviceMatrix(hdsdp_kkt *HKKT, int64_t *ld);   /* device pointer of M (m x m, lower valid) */
