@@ -173,10 +173,14 @@ def main():
     lib.HMiGetKernelTiming(kms.ctypes.data_as(C.POINTER(C.c_double)), kfl.ctypes.data_as(C.POINTER(C.c_double)),
                            kln.ctypes.data_as(C.POINTER(C.c_int64)))
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank != 0:
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -226,6 +230,9 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
