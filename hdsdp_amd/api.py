@@ -30,7 +30,7 @@ EXPORTS = [
     "HFpLinsysPsdCheck", "HFpLinsysFSolve", "HFpLinsysBSolve", "HFpLinsysSolve", "HFpLinsysGetDiag",
     "HFpLinsysInvert", "HFpLinsysClear", "HFpLinsysDestroy",
     "HMiConeCreateSDP", "HMiConeCreateSynthetic", "HMiConeDestroy", "HMiConeSetStart", "HMiConeUpdate",
-    "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
+    "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
     "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
@@ -104,6 +104,8 @@ def load_library():
         "HMiConeSetStart": (None, [vp, C.c_double]),
         "HMiConeUpdate": (None, [vp, C.c_double, dp]),
         "HMiConeCheckIsInterior": (C.c_int, [vp, C.c_double, dp, ip]),
+        "HMiConeRatioTest": (C.c_int, [vp, C.c_double, dp, C.c_double, C.c_int, dp]),
+        "HMiLanczosStartVector": (None, [C.c_int, dp]),
         "HMiConeGetLogBarrier": (C.c_int, [vp, C.c_double, dp, C.c_int, dp]),
         "HMiConeGetPresolve": (None, [vp, ip, ip, ip, ip, ip, ip]),
         "HMiConeGetDualMatrix": (C.c_int, [vp, dp]),
@@ -169,6 +171,12 @@ def presolve_csc(n, m, beg, idx, val):
     return out
 
 
+def lanczos_start_vector(n):
+    v = np.zeros(n)
+    load_library().HMiLanczosStartVector(int(n), _dptr(v))
+    return v
+
+
 def read_sdpa(fname):
     """SDPA sparse file -> dict(m, b, blocks=[dict(n, beg, idx, val)], n_lp) in the reference's CSC layout"""
     lib = load_library()
@@ -229,6 +237,14 @@ class SDPCone:
         _check(load_library().HMiConeCheckIsInterior(self._h, float(tau), _dptr(y), C.byref(ok)),
                "HConeCheckIsInterior")
         return bool(ok.value)
+
+    def ratio_test(self, dtau_step, dy, ada_ratio=0.0):
+        """HConeRatioTest on BUFFER_DUALVAR: largest step keeping S + step*dS in the cone (inf if unbounded)"""
+        dy = np.ascontiguousarray(dy, dtype=np.float64)
+        out = C.c_double(0.0)
+        _check(load_library().HMiConeRatioTest(self._h, float(dtau_step), _dptr(dy), float(ada_ratio), BUFFER_DUALVAR,
+                                               C.byref(out)), "HConeRatioTest")
+        return out.value
 
     def log_barrier(self, tau, y=None):
         out = C.c_double(0.0)

@@ -17,6 +17,7 @@
 #include "coeff.h"
 #include "hdm_common.h"
 #include "schur.h"
+#include "lanczos.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -188,6 +189,8 @@ struct MiCone {
     double *ydev = nullptr;
     hdsdp_linsys_fp *dualFactor = nullptr;
     HdmChol *primal = nullptr; // KKT_TYPE_PRIMAL: factor object of the registered primal matrix (lazy)
+    HdmLanczos *lanczos = nullptr;  // ratio test state (lazy); dS lives in `dS`
+    double *dS = nullptr;
     double Rd = 0.0, perturb = 0.0;
     double *trA = nullptr;     // host: tr(A_i) of all m constraints (b of the synthetic family)
     // work space
@@ -329,14 +332,14 @@ int64_t cone_getsymnnz(void *cd) { MiCone *c = (MiCone *) cd; return (int64_t) c
 
 // S <- tau*C - sum y_i A_i - Rd*I (+ perturb)   hdsdp_conic_sdp.c:343-402, :1616-1633
 // Sharded: every rank sums its own rows (rank 0 also adds tau*C and the identity term), then all-reduce.
-int cone_assemble(MiCone *c, double tau, const double *y_host, double *target) {
+int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, const double *eye_override = nullptr) {
     std::vector<double> yo(std::max(1, c->mloc));
     bool any = false;
     for (int q = 0; q < c->mloc; ++q) { yo[q] = y_host ? y_host[c->own[q]] : 0.0; any |= (yo[q] != 0.0); }
     HDM_HIP_CHECK(hipMemcpyAsync(c->ydev, yo.data(), sizeof(double) * c->mloc, hipMemcpyHostToDevice, g.stream));
     const double lead = (c->rank == 0) ? 1.0 : 0.0;
     if (hdm_sym_combine(c->Afull, (long) c->n16 * c->n16, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
-                        lead * (-c->Rd + c->perturb), target, c->n, c->n16, c->n16, g.stream)) return 1;
+                        lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)), target, c->n, c->n16, c->n16, g.stream)) return 1;
     if (c->world > 1) {
         HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
         if (!c->allreduce || c->allreduce(c->xctx, target, (int64_t) c->n16 * c->n16)) return 1;
@@ -377,6 +380,43 @@ hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, dou
     double s = 0.0;
     for (int i = 0; i < c->n; ++i) s += log(d[i]);
     *logdet = 2.0 * s;
+    return HDSDP_RETCODE_OK;
+}
+
+// sdpDenseConeRatioTestImpl (hdsdp_conic_sdp.c:1640-1686): dS = dTauStep*C - sum dy_i A_i + dAdaRatio*Rd*I, then the
+// largest alpha with S + alpha dS >= 0 by Lanczos on L^-1 (-dS) L^-T (lanczos.hip).  S is the matrix factored last
+// (BUFFER_DUALVAR); the engine keeps no second "checker" factor, so BUFFER_DUALCHECK is refused.
+hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAdaRatio, int whichBuffer, double *maxStep) {
+    MiCone *c = (MiCone *) cd;
+    if (whichBuffer != 0) {
+        fprintf(stderr, "[hdsdp_mi355x] ratio test: only BUFFER_DUALVAR is resident on the device\n");
+        return HDSDP_RETCODE_FAILED;
+    }
+    MiLin *l = (MiLin *) c->dualFactor->chol;
+    if (!l->ch.factored) return HDSDP_RETCODE_FAILED;
+    const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
+    if (!c->dS) {
+        HIP_RC(hipMalloc((void **) &c->dS, nn));
+        HIP_RC(hdm_memset_sync(c->dS, 0, nn));
+    }
+    const double eye = dAdaRatio * c->Rd;
+    if (cone_assemble(c, dTauStep, dy, c->dS, &eye)) return HDSDP_RETCODE_FAILED;
+    if (c->n == 1) {   // :1668-1675
+        double s0 = 0.0, d0 = 0.0;
+        HIP_RC(hipMemcpyAsync(&d0, c->dS, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        HIP_RC(hipMemcpyAsync(&s0, c->S, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        HIP_RC(hipStreamSynchronize(g.stream));
+        *maxStep = (d0 > 0.0) ? INFINITY : (-s0 / d0);
+        return HDSDP_RETCODE_OK;
+    }
+    RC(hdm_mirror_lower(c->dS, c->n16, c->n, g.stream));
+    RC(l->ch.invert_factor(g.stream));
+    if (!c->lanczos) {
+        c->lanczos = new HdmLanczos();
+        if (c->lanczos->init(c->n)) return HDSDP_RETCODE_MEMORY;
+    }
+    int steps = 0;
+    if (c->lanczos->solve(l->ch.Linv, l->ch.npad, c->dS, c->n16, g.stream, maxStep, &steps)) return HDSDP_RETCODE_FAILED;
     return HDSDP_RETCODE_OK;
 }
 
@@ -838,6 +878,8 @@ void cone_destroy_data(void **pcd) {
     if (c->trA) free(c->trA);
     HFpLinsysDestroy(&c->dualFactor);
     if (c->primal) { c->primal->destroy(); delete c->primal; }
+    if (c->lanczos) { c->lanczos->destroy(); delete c->lanczos; }
+    if (c->dS) (void) hipFree(c->dS);
     delete c;
     *pcd = nullptr;
 }
@@ -855,6 +897,7 @@ hdsdp_cone *new_cone_shell(MiCone *c, int iCone) {
     h->coneBuildSchur = cone_build_schur;
     h->coneBuildSchurFixed = cone_build_schur_fixed;
     h->coneInteriorCheck = cone_interior;
+    h->coneRatioTest = cone_ratio_test;
     h->coneGetBarrier = cone_barrier;
     return h;
 }
@@ -1379,6 +1422,11 @@ hdsdp_retcode HMiConeCheckIsInterior(hdsdp_cone *cone, double tau, double *y, in
 hdsdp_retcode HMiConeGetLogBarrier(hdsdp_cone *cone, double tau, double *y, int whichBuffer, double *logdet) {
     return cone->coneGetBarrier(cone->coneData, tau, y, whichBuffer, logdet);
 }
+hdsdp_retcode HMiConeRatioTest(hdsdp_cone *cone, double dTauStep, double *dy, double dAdaRatio, int whichBuffer,
+                               double *maxStep) {
+    return cone->coneRatioTest(cone->coneData, dTauStep, dy, dAdaRatio, whichBuffer, maxStep);
+}
+void HMiLanczosStartVector(int n, double *v) { hdm_lanczos_start_vector(n, v); }
 void HMiConeGetPresolve(hdsdp_cone *cone, int *coefType, int *coefRank, int *coefNnz, int *kktPerm, int *kktStrategy,
                         int *objType) {
     MiCone *c = (MiCone *) cone->coneData;

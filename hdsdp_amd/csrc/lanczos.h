@@ -1,0 +1,24 @@
+// lanczos.h -- device-resident ratio test (see lanczos.hip)
+#pragma once
+#include <vector>
+#include "hdm_common.h"
+
+struct HdmLanczos {
+    int n = 0, n16 = 0;
+    int maxdim = 30;          // Krylov dimension, hdsdp_conic_sdp.c:1393
+    int nComputed = 0;        // calls so far: the second and later calls warm-start (hdsdp_lanczos.c:166-181)
+    double *V = nullptr;      // n16 x (maxdim + 1) Lanczos basis
+    double *bv = nullptr, *b1 = nullptr, *b2 = nullptr, *bw = nullptr, *bz = nullptr;   // n16 x 8 vector blocks (column 0 used)
+    double *warm = nullptr, *tmp = nullptr, *scal = nullptr;
+    std::vector<double> start;   // the reference's pseudo-random start vector (host)
+
+    int init(int n);
+    void destroy();
+    int apply(const double *Linv, long ldl, const double *dS, long ldd, const double *in, double *out, hipStream_t s);
+    // max step of  S + alpha dS >= 0  given Linv (S = L L^T) and the full symmetric dS; INFINITY if unbounded
+    int solve(const double *Linv, long ldl, const double *dS, long ldd, hipStream_t s, double *maxStep, int *steps);
+};
+
+// HLanczosIPrepare's vector (glibc srand/rand stream reproduced without touching libc state); host only
+void hdm_lanczos_start_vector(int n, double *p);
+int hdm_mirror_lower(double *A, long ld, int n, hipStream_t s);

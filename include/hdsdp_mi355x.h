@@ -198,6 +198,14 @@ void HMiConeUpdate(hdsdp_cone *cone, double barHsdTau, double *rowDual);        
 hdsdp_retcode HMiConeCheckIsInterior(hdsdp_cone *cone, double barHsdTau, double *rowDual, int *isInterior);
 hdsdp_retcode HMiConeGetLogBarrier(hdsdp_cone *cone, double barHsdTau, double *rowDual, int whichBuffer,
                                    double *logdet);
+/* HConeRatioTest (hdsdp_conic.c:270; sdpDenseConeRatioTestImpl hdsdp_conic_sdp.c:1640-1686 + HLanczosSolve
+ * linalg/hdsdp_lanczos.c:161-292) on the device: largest step with S + step * dS >= 0, where
+ * dS = barHsdTauStep*C - sum rowDualStep_i A_i + dAdaRatio*Rd*I and S is the matrix factored last.  whichBuffer
+ * must be BUFFER_DUALVAR (0).  Also reachable through the cone's coneRatioTest slot. */
+hdsdp_retcode HMiConeRatioTest(hdsdp_cone *cone, double barHsdTauStep, double *rowDualStep, double dAdaRatio,
+                               int whichBuffer, double *maxStep);
+/* the pseudo-random Lanczos start vector of the reference (HLanczosIPrepare, hdsdp_lanczos.c:33-42), host only */
+void HMiLanczosStartVector(int n, double *v);
 /* presolve results (classification hdsdp_sdpdata.c:2321-2458, ordering + plan hdsdp_conic_sdp.c:539-676);
  * each output may be NULL; arrays have nRow entries */
 void HMiConeGetPresolve(hdsdp_cone *cone, int *coefType, int *coefRank, int *coefNnz, int *kktPerm,

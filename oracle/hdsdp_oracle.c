@@ -769,3 +769,147 @@ void orc_synth_csc(int n, int m, int **pbeg, int **pidx, double **pval, double *
     *pbeg = beg; *pidx = idx; *pval = val; *pb = b;
 }
 void orc_free_csc(int *beg, int *idx, double *val, double *b) { free(beg); free(idx); free(val); free(b); }
+/* ---------------------------------------------------------------------------------------------------------------
+ * Ratio test: largest alpha with S + alpha dS >= 0 (sdpDenseConeRatioTestImpl hdsdp_conic_sdp.c:1640-1686,
+ * operator sdpDenseConeILanczosMultiply :462-505, solver HLanczosSolve linalg/hdsdp_lanczos.c:161-292).
+ * Same recurrence, same libc-seeded start vector (:33-53), same Ritz check cadence and acceptance rule; the small
+ * dsyevr call (:230) is a cyclic Jacobi here.  `state` carries the warm start between calls like hdsdp_lanczos.
+ * ------------------------------------------------------------------------------------------------------------- */
+struct orc_lanczos_s { int n, nComputed; double *warm; };
+
+orc_lanczos *orc_lanczos_create(int n) {
+    orc_lanczos *st = calloc(1, sizeof(*st));
+    st->n = n; st->warm = calloc(n, sizeof(double));
+    return st;
+}
+void orc_lanczos_free(orc_lanczos *st) { if (st) { free(st->warm); free(st); } }
+
+static void lz_rand_vec(int n, double *v, double scale, int add) {   /* HLanczosIPrepare / HLanczosIPerturb */
+    srand((unsigned int) n);
+    for (int i = 0; i < n; ++i) {
+        srand((unsigned int) rand());
+        double a = sqrt(sqrt((double) (rand() % 1627)));
+        double p = a * (rand() % 2 - 0.5);
+        v[i] = add ? v[i] + scale * p : scale * p;
+    }
+}
+
+static void lz_apply(int n, const double *L, const double *dS, const double *in, double *out, double *t) {
+    /* out = L^-1 ( -dS ( L^-T in ) ), L lower column-major, dS lower-valid column-major */
+    for (int i = n - 1; i >= 0; --i) {               /* backward solve L^T x = in */
+        double s = in[i];
+        for (int k = i + 1; k < n; ++k) s -= L[(size_t) i * n + k] * out[k];
+        out[i] = s / L[(size_t) i * n + i];
+    }
+    for (int i = 0; i < n; ++i) t[i] = 0.0;
+    for (int j = 0; j < n; ++j) {                     /* t = -dS x with the lower triangle only */
+        t[j] -= dS[(size_t) j * n + j] * out[j];
+        for (int i = j + 1; i < n; ++i) {
+            const double a = dS[(size_t) j * n + i];
+            t[i] -= a * out[j];
+            t[j] -= a * out[i];
+        }
+    }
+    for (int i = 0; i < n; ++i) {                     /* forward solve L z = t */
+        double s = t[i];
+        for (int k = 0; k < i; ++k) s -= L[(size_t) k * n + i] * out[k];
+        out[i] = s / L[(size_t) i * n + i];
+    }
+}
+
+static void lz_jacobi(int k, double *A, double *d, double *Y) {  /* A k x k column-major symmetric; ascending d */
+    for (int i = 0; i < k * k; ++i) Y[i] = 0.0;
+    for (int i = 0; i < k; ++i) Y[i * k + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < k; ++p) for (int q = p + 1; q < k; ++q) off += A[q * k + p] * A[q * k + p];
+        if (off < 1e-300) break;
+        for (int p = 0; p < k; ++p) for (int q = p + 1; q < k; ++q) {
+            const double apq = A[q * k + p];
+            if (fabs(apq) < 1e-300) continue;
+            const double th = (A[q * k + q] - A[p * k + p]) / (2.0 * apq);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s_ = t * c;
+            for (int r = 0; r < k; ++r) { double x = A[p * k + r], y = A[q * k + r]; A[p * k + r] = c * x - s_ * y; A[q * k + r] = s_ * x + c * y; }
+            for (int r = 0; r < k; ++r) { double x = A[r * k + p], y = A[r * k + q]; A[r * k + p] = c * x - s_ * y; A[r * k + q] = s_ * x + c * y; }
+            for (int r = 0; r < k; ++r) { double x = Y[p * k + r], y = Y[q * k + r]; Y[p * k + r] = c * x - s_ * y; Y[q * k + r] = s_ * x + c * y; }
+        }
+    }
+    for (int i = 0; i < k; ++i) d[i] = A[i * k + i];
+    for (int i = 0; i < k; ++i) {
+        int mn = i;
+        for (int j = i + 1; j < k; ++j) if (d[j] < d[mn]) mn = j;
+        if (mn != i) {
+            double td = d[i]; d[i] = d[mn]; d[mn] = td;
+            for (int r = 0; r < k; ++r) { double ty = Y[i * k + r]; Y[i * k + r] = Y[mn * k + r]; Y[mn * k + r] = ty; }
+        }
+    }
+}
+
+/* returns 0 and the step (HUGE_VAL if unbounded), or 1 on the reference's failure exit */
+int orc_ratio_test(const orc_block *b, const double *L, double dTauStep, const double *dy, double dEyeCoef,
+                   orc_lanczos *st, double *maxStep) {
+    const int n = b->n, md = 30, nh = md + 1;
+    double *dS = calloc((size_t) n * n, sizeof(double));
+    orc_assemble_S(b, dTauStep, dy, -dEyeCoef, dS);       /* dS = dTau*C - sum dy_i A_i + dEyeCoef*I */
+    double *V = calloc((size_t) n * (md + 1), sizeof(double)), *H = calloc((size_t) nh * nh, sizeof(double));
+    double *v = calloc(n, sizeof(double)), *w = calloc(n, sizeof(double)), *t = calloc(n, sizeof(double));
+    double *z1 = calloc(n, sizeof(double)), *z2 = calloc(n, sizeof(double));
+    double *U = calloc((size_t) md * md, sizeof(double)), *Y = calloc((size_t) md * md, sizeof(double)), *d = calloc(md, sizeof(double));
+    int rc = 0;
+    if (st->nComputed == 0) lz_rand_vec(n, v, 1.0, 0);
+    else { memcpy(v, st->warm, sizeof(double) * n); lz_rand_vec(n, v, 1e-03, 1); }
+    double nv = 0.0; for (int i = 0; i < n; ++i) nv += v[i] * v[i];
+    nv = sqrt(nv); for (int i = 0; i < n; ++i) v[i] /= nv;
+    memcpy(V, v, sizeof(double) * n);
+    int freq = md / 5; if (freq > 3) freq = 3;
+    double step = 0.0;
+#define HH(i, j) H[(size_t) (j) * nh + (i)]
+    for (int k = 0; k < md; ++k) {
+        lz_apply(n, L, dS, v, w, t);
+        if (k > 0) { const double h = HH(k, k - 1); for (int i = 0; i < n; ++i) w[i] -= h * V[(size_t) (k - 1) * n + i]; }
+        double dt = 0.0; for (int i = 0; i < n; ++i) dt += w[i] * V[(size_t) k * n + i];
+        const double alp = -dt;
+        for (int i = 0; i < n; ++i) w[i] += alp * V[(size_t) k * n + i];
+        double nrm = 0.0; for (int i = 0; i < n; ++i) nrm += w[i] * w[i];
+        nrm = sqrt(nrm);
+        HH(k, k) = -alp;
+        if (nrm > 0.0) {
+            for (int i = 0; i < n; ++i) v[i] = w[i] / nrm;
+            memcpy(V + (size_t) (k + 1) * n, v, sizeof(double) * n);
+            HH(k + 1, k) = HH(k, k + 1) = nrm;
+        }
+        if ((k + 1) % freq == 0 || k > md - 1 || nrm == 0.0) {
+            const int kp = k + 1;
+            if (kp < 2) { rc = 1; break; }                 /* the reference's dsyevr(il = 0) abort */
+            for (int j = 0; j < kp; ++j) for (int i = 0; i < kp; ++i) U[j * kp + i] = 0.5 * (HH(i, j) + HH(j, i));
+            lz_jacobi(kp, U, d, Y);
+            const double e1 = d[kp - 1], e2 = d[kp - 2];
+            const double *y1 = Y + (size_t) (kp - 1) * kp, *y2 = Y + (size_t) (kp - 2) * kp;
+            const double resi = fabs(HH(kp, k) * y1[k]);
+            if (resi < 1e-04 || k >= md - 1) {
+                for (int i = 0; i < n; ++i) { double s_ = 0.0; for (int c = 0; c < kp; ++c) s_ += V[(size_t) c * n + i] * y1[c]; z1[i] = s_; }
+                lz_apply(n, L, dS, z1, z2, t);
+                memcpy(st->warm, z2, sizeof(double) * n);
+                double r1 = 0.0; for (int i = 0; i < n; ++i) { double x = z2[i] - e1 * z1[i]; r1 += x * x; }
+                r1 = sqrt(r1);
+                for (int i = 0; i < n; ++i) { double s_ = 0.0; for (int c = 0; c < kp; ++c) s_ += V[(size_t) c * n + i] * y2[c]; z2[i] = s_; }
+                lz_apply(n, L, dS, z2, z1, t);
+                double r2 = 0.0; for (int i = 0; i < n; ++i) { double x = z1[i] - e1 * z2[i]; r2 += x * x; }
+                r2 = sqrt(r2);
+                const double diff = e1 - e2 - r2;
+                double gam = diff > 0 ? diff : 1e-16;
+                const double sq = r1 * r1 / gam;
+                gam = r1 < sq ? r1 : sq;
+                if (gam < 1e-03 || gam + e1 <= 0.5) { step = (gam + e1 <= 0.0) ? HUGE_VAL : 1.0 / (gam + e1); break; }
+                if (nrm == 0.0) { rc = 1; break; }
+                step = 1.0 / (gam + e1);
+            }
+        }
+    }
+#undef HH
+    if (!rc) { st->nComputed += 1; *maxStep = step; }
+    free(dS); free(V); free(H); free(v); free(w); free(t); free(z1); free(z2); free(U); free(Y); free(d);
+    return rc;
+}
+

@@ -36,6 +36,11 @@ def lib():
         L.orc_kkt_build.argtypes = [vp, dp, C.c_double, C.c_int, C.c_int, dp, dp, dp, dp, dp]
         L.orc_pcg_solve.restype = C.c_int
         L.orc_pcg_solve.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_int]
+        L.orc_lanczos_create.restype = vp
+        L.orc_lanczos_create.argtypes = [C.c_int]
+        L.orc_lanczos_free.argtypes = [vp]
+        L.orc_ratio_test.restype = C.c_int
+        L.orc_ratio_test.argtypes = [vp, dp, C.c_double, dp, C.c_double, vp, dp]
         L.orc_synth_csc.argtypes = [C.c_int, C.c_int, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp), C.POINTER(dp)]
         L.orc_free_csc.argtypes = [ip, ip, dp, dp]
         _lib = L
@@ -114,7 +119,22 @@ class Block:
         return {"M": M, "ASinv": a, "ASinvRdSinv": r, "ASinvCSinv": c, "CSinv": scal[0], "CSinvCSinv": scal[1],
                 "CSinvRdSinv": scal[2], "TraceSinv": scal[3]}
 
+    def ratio_test(self, Lf, dtau_step, dy, eye_coef):
+        """largest alpha with S + alpha*dS >= 0 (reference Lanczos estimate); consecutive calls warm-start"""
+        if getattr(self, "_lz", None) is None:
+            self._lz = lib().orc_lanczos_create(self.n)
+        out = C.c_double(0.0)
+        dy = np.ascontiguousarray(dy, dtype=np.float64)
+        rc = lib().orc_ratio_test(self._h, _d(np.ascontiguousarray(Lf)), float(dtau_step), _d(dy), float(eye_coef),
+                                  self._lz, C.byref(out))
+        if rc != 0:
+            raise RuntimeError("orc_ratio_test failed")
+        return out.value
+
     def close(self):
+        if getattr(self, "_lz", None):
+            lib().orc_lanczos_free(self._lz)
+            self._lz = None
         if self._h:
             lib().orc_block_free(self._h)
             self._h = None

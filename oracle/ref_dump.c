@@ -237,6 +237,23 @@ int main(int argc, char **argv) {
     HDSDP_CALL(HConeGetLogBarrier(cone, tau, y, BUFFER_DUALVAR, &logdet));
     dump_s("logdet", logdet);
 
+    /* ratio test (HConeRatioTest -> sdpDenseConeRatioTestImpl hdsdp_conic_sdp.c:1640-1686 -> HLanczosSolve): two calls,
+       the second one warm-started from the first (hdsdp_lanczos.c:166-181).  Dense dual matrices only: with a sparse
+       dual matrix (mcp100) the reference's operator returns the zero vector from this harness state and its own
+       dsyevr call aborts (k = 0 check), so there is nothing to pin. */
+    if (!((hdsdp_cone_sdp_dense *) cone->coneData)->isDualSparse) {
+        double *dy = calloc(m, sizeof(double));
+        double step = 0.0;
+        const double sc = 0.05 * fabs(Rd) / sqrt((double) m);
+        for (int i = 0; i < m; ++i) dy[i] = sc * cos(0.7 * i + 0.2);
+        HDSDP_CALL(HConeRatioTest(cone, 0.0, dy, 0.0, BUFFER_DUALVAR, &step));
+        dump_d("rt_dy1", dy, m); { double pr[2] = {0.0, 0.0}; dump_d("rt_par1", pr, 2); } dump_s("rt_step1", step);
+        for (int i = 0; i < m; ++i) dy[i] = 0.5 * sc * sin(1.3 * i + 0.4);
+        HDSDP_CALL(HConeRatioTest(cone, -0.05, dy, 1.0, BUFFER_DUALVAR, &step));
+        dump_d("rt_dy2", dy, m); { double pr[2] = {-0.05, 1.0}; dump_d("rt_par2", pr, 2); } dump_s("rt_step2", step);
+        free(dy);
+    }
+
     hdsdp_cone_sdp_dense *dc = (hdsdp_cone_sdp_dense *) cone->coneData;
     /* classification, ordering, strategies (hdsdp_conic_sdp.c:602-676, hdsdp_sdpdata.c:2321-2458) */
     {

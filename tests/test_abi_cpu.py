@@ -139,3 +139,21 @@ def test_sdpa_reader_multi_block_and_errors(tmp_path):
     r = api.read_sdpa(str(ragged))
     blk = r["blocks"][0]
     assert list(blk["beg"]) == [0, 1, 2, 3] and list(blk["idx"]) == [0, 1, 5] and list(blk["val"]) == [-2.0, 0.5, -4.0]
+
+
+def test_lanczos_start_vector_matches_libc():
+    """the engine reproduces glibc's srand()/rand() stream for the reference's Lanczos start vector
+    (linalg/hdsdp_lanczos.c:33-42) without touching libc state: compare with libc itself"""
+    import ctypes
+    import math
+    from hdsdp_amd import api
+    libc = ctypes.CDLL("libc.so.6")
+    for n in (3, 50, 257):
+        libc.srand(ctypes.c_uint(n))
+        ref = np.zeros(n)
+        for i in range(n):
+            libc.srand(ctypes.c_uint(libc.rand()))
+            a = libc.rand() % 1627
+            b = libc.rand() % 2
+            ref[i] = math.sqrt(math.sqrt(a)) * (b - 0.5)
+        assert np.array_equal(api.lanczos_start_vector(n), ref)

@@ -5,7 +5,7 @@ ASinvCSinv; 1e-8 relative 2-norm for the Schur solves; 1e-12 relative for logdet
 import numpy as np
 import pytest
 
-from util import primal_X, KKT_TOL, check_close, kkt_err, load_golden, lower_mask, y_of
+from util import primal_X, KKT_TOL, RATIO_TOL, check_close, kkt_err, load_golden, lower_mask, y_of
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +39,14 @@ def test_schur_against_reference(name):
             assert kkt_err(S[msk], g["S"][msk]) < 1e-12
         logdet = cone.log_barrier(tau)
         assert abs(logdet - float(g["logdet"][0])) <= 1e-12 * abs(float(g["logdet"][0]))
+        # --- ratio test on the resident factor (next-row f2): same Lanczos recurrence, start vector and acceptance
+        # rule as HLanczosSolve; the first call starts fresh, the second is warm-started like the reference's
+        if "rt_step1" in g:
+            for tag in ("1", "2"):
+                par = g["rt_par" + tag]
+                step = cone.ratio_test(float(par[0]), g["rt_dy" + tag], float(par[1]))
+                ref = float(g["rt_step" + tag][0])
+                assert abs(step - ref) <= RATIO_TOL * abs(ref), (name, tag, step, ref)
 
         kkt = api.KKT(m, [cone])
         msk = lower_mask(m)
@@ -258,5 +266,28 @@ def test_full_size_known_answers():
         assert np.max(np.abs(exc["ASinv"] - ex4["ASinv"])) <= 1e-10 * np.max(np.abs(ex4["ASinv"]))
         assert np.max(np.abs(exc["ASinvRdSinv"] - ex4["ASinvRdSinv"])) <= 1e-10 * np.max(np.abs(ex4["ASinvRdSinv"]))
         kkt.destroy()
+    finally:
+        cone.destroy()
+
+
+def test_ratio_test_bracket_at_full_dimension():
+    """n = 2000 (the BASELINE dimension; too large for a reference dump in the golden set): the Lanczos step must
+    bracket the cone boundary -- S + 0.99*step*dS is still positive definite, S + 1.05*step*dS is not -- which is
+    checked with the device Cholesky itself (size-independent property of the ratio test)."""
+    from hdsdp_amd import api
+    n, m = 2000, 48
+    cone = api.SDPCone.synthetic(n, m)
+    try:
+        cone.set_start(-10.0 * n)
+        y0 = np.zeros(m)
+        assert cone.check_is_interior(1.0, y0)
+        dy = 40.0 * np.cos(0.7 * np.arange(m) + 0.2)
+        step = cone.ratio_test(0.0, dy, 0.0)
+        assert np.isfinite(step) and step > 0
+        assert cone.check_is_interior(1.0, 0.99 * step * dy)
+        assert not cone.check_is_interior(1.0, 1.05 * step * dy)
+        # a direction that only moves S into the cone is unbounded
+        assert cone.check_is_interior(1.0, y0)
+        assert cone.ratio_test(1.0, np.zeros(m), -1.0) == np.inf or cone.ratio_test(1.0, np.zeros(m), -1.0) > 1e6
     finally:
         cone.destroy()

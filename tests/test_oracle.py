@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from util import KKT_TOL, check_close, load_golden, lower_mask, primal_X, y_of
+from util import KKT_TOL, RATIO_TOL, check_close, load_golden, lower_mask, primal_X, y_of
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import oracle_py  # noqa: E402
@@ -42,6 +42,12 @@ def test_oracle_matches_reference(name):
     assert info == 0
     assert np.allclose(np.diag(Lf), g["Ldiag"], rtol=1e-12)
     assert abs(blk.logdet(Lf) - float(g["logdet"][0])) <= 1e-12 * abs(float(g["logdet"][0]))
+    if "rt_step1" in g:   # ratio test: fresh call, then the warm-started one (dense dual matrices only, see ref_dump.c)
+        for tag in ("1", "2"):
+            par = g["rt_par" + tag]
+            step = blk.ratio_test(Lf, float(par[0]), g["rt_dy" + tag], float(par[1]) * Rd)
+            ref = float(g["rt_step" + tag][0])
+            assert abs(step - ref) <= RATIO_TOL * abs(ref), (tag, step, ref)
     Sinv = blk.inverse(Lf)
     check_close(Sinv, g["Sinv"], "Sinv")
     mm = lower_mask(m)

@@ -19,6 +19,9 @@ def kkt_err(got, ref):
 # The reference's bar has an absolute floor of 1e-4, which is vacuous when S ~ 1e3 I makes every entry
 # of M ~ 1e-6; so every comparison ALSO has to pass a norm-wise relative bound.
 REL_TOL = 1e-10
+# ratio test (Lanczos estimate of the largest feasible step): the reference's own estimate carries a safety term of up
+# to 1e-3 relative (hdsdp_lanczos.c:268-276); two runs of the same recurrence agree far better than that
+RATIO_TOL = 1e-6
 
 
 def rel_err(got, ref):
