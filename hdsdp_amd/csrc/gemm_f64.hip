@@ -374,16 +374,15 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         return;
     }
 
-    double cfa[4] = {1.0 + lane, 2.0, 3.0 - lane, 4.0}, cfb[4] = {0.5, 0.25 * lane, 0.125, 1.0};  // timing-only (VAR & 16)
     auto compute = [&](const double *cA, const double *cB) {
 
 #pragma unroll
         for (int kk = 0; kk < HDM_BK; kk += 4) {
             double fb[4], fa[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fb[i] = (VAR & 16) ? cfb[i] : frag<AKM>(cA, wm * 64 + i * 16 + l15, kk + lq);
+            for (int i = 0; i < 4; ++i) fb[i] = frag<AKM>(cA, wm * 64 + i * 16 + l15, kk + lq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fa[j] = (VAR & 16) ? cfa[j] : frag<BKM>(cB, wn * 64 + j * 16 + l15, kk + lq);
+            for (int j = 0; j < 4; ++j) fa[j] = frag<BKM>(cB, wn * 64 + j * 16 + l15, kk + lq);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -465,35 +464,6 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         }
 #undef HDM_LDF
 #undef HDM_MMA
-    } else if (VAR & 2) {
-        // Two k blocks in flight: global loads are issued two stages ahead into two register sets, so a load has
-        // two full MFMA stages (~8 us) to land before its ds_write.  With one stage of look-ahead both co-resident
-        // workgroups regularly parked on vmcnt together (SQ_WAIT_ANY 14.6 % of wave cycles, MFMA pipe 83.5 %).
-        double2 a0[4], b0[4], a1[4], b1[4];
-        const int nst = (kt1 - kt0) * npass;
-        if (nst > 0) {
-            stA.load(a0); stB.load(b0);
-            r2s<AKM>(sA, tid, a0); r2s<BKM>(sB, tid, b0);
-        }
-        if (nst > 1) { stA.load(a1); stB.load(b1); }
-        if (nst > 2) { stA.load(a0); stB.load(b0); }
-        __syncthreads();
-        if ((VAR & 32) && p.dbg) t_pro = __builtin_amdgcn_s_memtime();
-        for (int t = 0; t < nst; t += 2) {
-            compute(sA, sB);
-            if (t + 1 < nst) {
-                r2s<AKM>(sA + STAGE_DOUBLES, tid, a1); r2s<BKM>(sB + STAGE_DOUBLES, tid, b1);
-                if (t + 3 < nst) { stA.load(a1); stB.load(b1); }
-            }
-            __syncthreads();
-            if (t + 1 >= nst) break;
-            compute(sA + STAGE_DOUBLES, sB + STAGE_DOUBLES);
-            if (t + 2 < nst) {
-                r2s<AKM>(sA, tid, a0); r2s<BKM>(sB, tid, b0);
-                if (t + 4 < nst) { stA.load(a0); stB.load(b0); }
-            }
-            __syncthreads();
-        }
     } else {
         double2 ra[4], rb[4];
         const int kt1x = kt0 + (kt1 - kt0) * npass;
@@ -508,16 +478,16 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         int cur = 0;
         for (int kt = kt0; kt < kt1x; ++kt) {
             const bool more = (kt + 1 < kt1x);
-            if (more && !(VAR & 4)) {
+            if (more) {
                 stA.load(ra);
                 stB.load(rb);
             }
             compute(sA + cur * STAGE_DOUBLES, sB + cur * STAGE_DOUBLES);
-            if (more && !(VAR & 4)) {
+            if (more) {
                 r2s<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra);
                 r2s<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb);
             }
-            if (!(VAR & 8)) __syncthreads();   // VAR & 4/8/16: timing-only ablations (wrong results)
+            __syncthreads();
             cur ^= 1;
         }
     }
@@ -700,11 +670,9 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
         default: HDM_LAUNCH(AK, BK, R, 64);                       \
     }
     // HDM_VAR selects a kernel variant for A/B runs and diagnostics (tools/var_sweep.sh, tools/wg_timeline.py):
-    //   32 = per-workgroup s_memtime stamps.  (VAR & 2, global loads two stages ahead, is kept in the kernel source but
-    //   no longer instantiated: -2 % on the congruence kernels, +4 % on the Gram kernel when measured, and with the
-    //   cell-dealt tile paths compiled in its 64 extra staging VGPRs spill.)
-    //   (The timing-only ablation bits 4/8/16 of VAR -- no staging / no barriers / no LDS reads -- are not
-    //   instantiated by default; see DESIGN.md for what they showed.)
+    //   64 (default) = rotated, explicitly interleaved K loop; 0 = the earlier loop (global loads, 64 MFMAs, LDS
+    //   writes, barrier per stage) kept for same-box A/B runs; +32 = per-workgroup s_memtime stamps;
+    //   192 = 64 + timing-only ablation in which every tile stages rows 0..127 (all operand traffic L2-resident).
     static int g_env_var = -2;
     if (g_env_var == -2) { const char *e = getenv("HDM_VAR"); g_env_var = e ? atoi(e) : -1; }
     const int g_var = g_env_var >= 0 ? g_env_var : 64;   // default: the rotated, explicitly interleaved loop

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""diagnostic (HDM_VAR=32): per-workgroup timeline of one congruence-step-1 launch"""
+"""diagnostic (HDM_VAR=96: stamps on the default loop): per-workgroup timeline of the last launch of one role"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("HDM_VAR", "32")
+os.environ.setdefault("HDM_VAR", "96")
 import torch
 from hdsdp_amd import api
 role = int(sys.argv[1]) if len(sys.argv) > 1 else 1
