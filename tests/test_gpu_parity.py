@@ -291,3 +291,45 @@ def test_ratio_test_bracket_at_full_dimension():
         assert cone.ratio_test(1.0, np.zeros(m), -1.0) == np.inf or cone.ratio_test(1.0, np.zeros(m), -1.0) > 1e6
     finally:
         cone.destroy()
+
+
+def test_many_constraints_known_answers():
+    """the row count of BASELINE config 5 (m = 8000) at a block size that fits one GPU beside it (n = 128): same
+    size-independent known answers as above (S = I at y0 => ASinv = b, M_ij = <A_i, A_j>), sampled over the whole
+    row range, plus the S = 4 I scaling and a host-side residual of the solve"""
+    from hdsdp_amd import api
+    n, m = 128, 8000
+    P = n * (n + 1) // 2
+    y0 = _splitmix_u(np.uint64(2 * m * P) + np.arange(m, dtype=np.uint64))
+    cone = api.SDPCone.synthetic(n, m)
+    try:
+        b = cone.traces()
+        kkt = api.KKT(m, [cone])
+        cone.set_start(0.0)
+        assert cone.check_is_interior(1.0, y0)
+        assert abs(cone.log_barrier(1.0)) < 1e-8
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        ex1 = kkt.export()
+        assert np.max(np.abs(ex1["ASinv"] - b)) <= 1e-10 * np.max(np.abs(b))
+        rows = [0, 1, 127, 128, 4095, 7871, 7999]
+        mats = {i: _synth_matrix(n, i) for i in rows}
+        M1 = kkt.M
+        for i in rows:
+            assert abs(np.trace(mats[i]) - b[i]) < 1e-10
+            for j in rows:
+                ref = float(np.sum(mats[i] * mats[j]))
+                got = M1[min(i, j), max(i, j)]
+                assert abs(got - ref) <= 1e-10 * abs(ref), (i, j, got, ref)
+        d1 = np.diag(M1).copy()
+        cone.set_start(-3.0)
+        assert cone.check_is_interior(1.0, y0)
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        assert np.max(np.abs(np.diag(kkt.M) * 16.0 - d1)) <= 1e-10 * np.max(d1)
+        assert abs(kkt.export()["TraceSinv"] - n / 4.0) < 1e-9
+        kkt.factorize()
+        x = kkt.solve(b)
+        Mfull = np.triu(kkt.M) + np.triu(kkt.M, 1).T
+        assert np.linalg.norm(Mfull @ x - b) <= 1e-9 * np.linalg.norm(b)
+        kkt.destroy()
+    finally:
+        cone.destroy()
