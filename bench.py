@@ -97,6 +97,21 @@ def cpu_baseline(n, m, budget_cols=8):
             "sample_seconds": t_sample}
 
 
+def cpu_baseline_blas3(n, m):
+    """second CPU leg ("for fairness"): the same math as level-3 BLAS on the host cores this box gives us
+    (oracle/blas3_baseline.py, numpy/scipy OpenBLAS), bounded sample, run in a child process"""
+    script = os.path.join(ROOT, "oracle", "blas3_baseline.py")
+    try:
+        out = subprocess.run([sys.executable, script, str(n), str(m), "16", "192"], capture_output=True, text=True,
+                             timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not line:
+            raise RuntimeError(out.stderr[-300:])
+        return json.loads(line[-1])
+    except Exception as e:
+        return {"value": None, "unit": "it/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +242,7 @@ def main():
                                                     "all_reduce": ex.bytes_ar // (args.steps + args.warmup)}
     if not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(n, m)
+        out["cpu_baseline_blas3"] = cpu_baseline_blas3(n, m)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
