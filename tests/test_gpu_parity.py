@@ -333,3 +333,40 @@ def test_many_constraints_known_answers():
         kkt.destroy()
     finally:
         cone.destroy()
+
+
+def test_cones_accumulate_into_one_schur_matrix():
+    """HKKTBuildUp loops over the cones and every cone ADDS its contribution (hdsdp_schur.c:262-264): two blocks with
+    the same row space -- here the same block twice, once on the sparse-gather path and once forced onto the GEMM
+    path -- must give exactly twice the one-block matrix, vectors and scalars"""
+    import os
+    from hdsdp_amd import api
+    g = load_golden("theta1_B")
+    n, m = int(g["dims"][0]), int(g["dims"][1])
+    Rd, tau, y = float(g["Rd"][0]), float(g["tau"][0]), y_of(g)
+    c1 = api.SDPCone.from_csc(n, m, g["csc_beg"], g["csc_idx"], g["csc_val"])
+    os.environ["HDSDP_MI355X_FORCE_GEMM"] = "1"
+    try:
+        c2 = api.SDPCone.from_csc(n, m, g["csc_beg"], g["csc_idx"], g["csc_val"])
+    finally:
+        del os.environ["HDSDP_MI355X_FORCE_GEMM"]
+    try:
+        assert c1.path != c2.path
+        for c in (c1, c2):
+            c.set_start(Rd)
+            assert c.check_is_interior(tau, y)
+        kkt = api.KKT(m, [c1, c2])
+        msk = lower_mask(m)
+        kkt.build_up(api.KKT_TYPE_HOMOGENEOUS)
+        ex = kkt.export()
+        check_close(kkt.M[msk], 2.0 * g["M_hsd"][msk], "two cones: M")
+        check_close(ex["ASinv"], 2.0 * g["ASinv_hsd"], "two cones: ASinv")
+        check_close(ex["ASinvCSinv"], 2.0 * g["ASinvCSinv_hsd"], "two cones: ASinvCSinv")
+        for got, ref in zip((ex["CSinv"], ex["CSinvCSinv"], ex["CSinvRdSinv"], ex["TraceSinv"]), g["hsd_scalars"]):
+            check_close([got], [2.0 * ref], "two cones: scalar")
+        kkt.build_up(api.KKT_TYPE_CORRECTOR)
+        check_close(kkt.export()["ASinvRdSinv"], 2.0 * g["ASinvRdSinv_cor"], "two cones: corrector")
+        kkt.destroy()
+    finally:
+        c1.destroy()
+        c2.destroy()
