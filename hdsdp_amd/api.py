@@ -30,7 +30,7 @@ EXPORTS = [
     "HFpLinsysPsdCheck", "HFpLinsysFSolve", "HFpLinsysBSolve", "HFpLinsysSolve", "HFpLinsysGetDiag",
     "HFpLinsysInvert", "HFpLinsysClear", "HFpLinsysDestroy",
     "HMiConeCreateSDP", "HMiConeCreateSynthetic", "HMiConeDestroy", "HMiConeSetStart", "HMiConeUpdate",
-    "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
+    "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
     "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
@@ -106,6 +106,7 @@ def load_library():
         "HMiConeCheckIsInterior": (C.c_int, [vp, C.c_double, dp, ip]),
         "HMiConeRatioTest": (C.c_int, [vp, C.c_double, dp, C.c_double, C.c_int, dp]),
         "HMiLanczosStartVector": (None, [C.c_int, dp]),
+        "HMiConeGetPrimal": (None, [vp, C.c_double, dp, dp, dp, dp]),
         "HMiConeGetLogBarrier": (C.c_int, [vp, C.c_double, dp, C.c_int, dp]),
         "HMiConeGetPresolve": (None, [vp, ip, ip, ip, ip, ip, ip]),
         "HMiConeGetDualMatrix": (C.c_int, [vp, dp]),
@@ -245,6 +246,14 @@ class SDPCone:
         _check(load_library().HMiConeRatioTest(self._h, float(dtau_step), _dptr(dy), float(ada_ratio), BUFFER_DUALVAR,
                                                C.byref(out)), "HConeRatioTest")
         return out.value
+
+    def get_primal(self, mu, y, dy):
+        """HConeGetPrimal: n x n primal recovery matrix, or None if S(y) is not positive definite"""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        dy = np.ascontiguousarray(dy, dtype=np.float64)
+        X = np.full((self.n, self.n), np.nan)
+        load_library().HMiConeGetPrimal(self._h, float(mu), _dptr(y), _dptr(dy), _dptr(X), None)
+        return None if np.isnan(X[0, 0]) else X
 
     def log_barrier(self, tau, y=None):
         out = C.c_double(0.0)

@@ -190,6 +190,7 @@ struct MiCone {
     hdsdp_linsys_fp *dualFactor = nullptr;
     HdmChol *primal = nullptr; // KKT_TYPE_PRIMAL: factor object of the registered primal matrix (lazy)
     HdmLanczos *lanczos = nullptr;  // ratio test state (lazy); dS lives in `dS`
+    HdmChol *checker = nullptr;     // second factor object (primal recovery works on S without the residual term)
     double *dS = nullptr;
     double Rd = 0.0, perturb = 0.0;
     double *trA = nullptr;     // host: tr(A_i) of all m constraints (b of the synthetic family)
@@ -418,6 +419,60 @@ hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAda
     int steps = 0;
     if (c->lanczos->solve(l->ch.Linv, l->ch.npad, c->dS, c->n16, g.stream, maxStep, &steps)) return HDSDP_RETCODE_FAILED;
     return HDSDP_RETCODE_OK;
+}
+
+// sdpDenseConeGetPrimal (hdsdp_conic_sdp.c:2393-2446), the cone's conePRecover slot:
+//     X = mu * L^-T ( sym( L^-1 dS L^-T ) + I ) L^-1,   S = C - sum y_i A_i = L L^T (no residual term),  dS = sum dy_i A_i.
+// The reference does four triangular solves with n right-hand sides on the checker factor; here S is factored into a
+// second resident factor object, inverted once, and the four products are plain MFMA GEMMs with the explicit Linv.
+// Like the reference, an S that is not positive definite prints a message and leaves the output untouched.
+void cone_precover(void *cd, double dBarrierMu, double *y, double *dy, double *X, double *aux) {
+    (void) aux;
+    MiCone *c = (MiCone *) cd;
+    const double zero = 0.0;
+    const int n = c->n;
+    const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
+    auto fail = [](const char *what) { fprintf(stderr, "[hdsdp_mi355x] primal recovery: %s\n", what); };
+    if (cone_assemble(c, 1.0, y, c->Scheck, &zero)) return fail("S assembly failed");
+    if (!c->checker) {
+        c->checker = new HdmChol();
+        if (c->checker->init(n)) return fail("out of memory");
+    }
+    HdmChol &ch = *c->checker;
+    int info = 0;
+    if (ch.load_device(c->Scheck, c->n16, g.stream) || ch.factor(g.stream, &info)) return fail("factorisation failed");
+    if (info != 0) { printf("Recovery step is infeasible\n"); return; }
+    if (!c->dS) {
+        if (hipMalloc((void **) &c->dS, nn) != hipSuccess || hdm_memset_sync(c->dS, 0, nn) != hipSuccess) return fail("out of memory");
+    }
+    std::vector<double> ndy(c->m);
+    for (int i = 0; i < c->m; ++i) ndy[i] = -dy[i];           // cone_assemble subtracts: dS = + sum dy_i A_i
+    if (cone_assemble(c, 0.0, ndy.data(), c->dS, &zero)) return fail("dS assembly failed");
+    if (hipStreamSynchronize(g.stream) != hipSuccess) return fail("stream");   // ndy is read by an async copy
+    if (hdm_mirror_lower(c->dS, c->n16, n, g.stream)) return fail("mirror");
+    if (ch.invert_factor(g.stream)) return fail("triangular inverse failed");
+    const size_t np2 = sizeof(double) * (size_t) ch.npad * ch.npad;
+    if (!c->Xinv && hipMalloc((void **) &c->Xinv, np2) != hipSuccess) return fail("out of memory");
+    if (!c->Yinv && hipMalloc((void **) &c->Yinv, np2) != hipSuccess) return fail("out of memory");
+    HdmGemmArgs q = {};
+    q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE; q.ldc = ch.npad;
+    // T1 = W dS          (W = Linv)
+    q.A = ch.Linv; q.lda = ch.npad; q.a_kmajor = 0; q.B = c->dS; q.ldb = c->n16; q.b_kmajor = 0; q.C = c->Xinv;
+    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
+    // Z = T1 W^T
+    q.A = c->Xinv; q.lda = ch.npad; q.a_kmajor = 0; q.B = ch.Linv; q.ldb = ch.npad; q.b_kmajor = 0; q.C = c->Yinv;
+    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
+    if (hdm_sym_scale(c->Yinv, ch.npad, c->n16, 1.0, 1.0, g.stream)) return fail("sym");
+    // T2 = W^T Z
+    q.A = ch.Linv; q.lda = ch.npad; q.a_kmajor = 1; q.B = c->Yinv; q.ldb = ch.npad; q.b_kmajor = 0; q.C = c->Xinv;
+    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
+    // X = T2 W
+    q.A = c->Xinv; q.lda = ch.npad; q.a_kmajor = 0; q.B = ch.Linv; q.ldb = ch.npad; q.b_kmajor = 1; q.C = c->Yinv;
+    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
+    if (hdm_sym_scale(c->Yinv, ch.npad, n, 0.0, dBarrierMu, g.stream)) return fail("sym");
+    if (hipMemcpy2DAsync(X, sizeof(double) * n, c->Yinv, sizeof(double) * ch.npad, sizeof(double) * n, n,
+                         hipMemcpyDeviceToHost, g.stream) != hipSuccess) return fail("copy");
+    (void) hipStreamSynchronize(g.stream);
 }
 
 // --- the GPU Schur builder ---------------------------------------------------------------------
@@ -879,6 +934,7 @@ void cone_destroy_data(void **pcd) {
     HFpLinsysDestroy(&c->dualFactor);
     if (c->primal) { c->primal->destroy(); delete c->primal; }
     if (c->lanczos) { c->lanczos->destroy(); delete c->lanczos; }
+    if (c->checker) { c->checker->destroy(); delete c->checker; }
     if (c->dS) (void) hipFree(c->dS);
     delete c;
     *pcd = nullptr;
@@ -898,6 +954,7 @@ hdsdp_cone *new_cone_shell(MiCone *c, int iCone) {
     h->coneBuildSchurFixed = cone_build_schur_fixed;
     h->coneInteriorCheck = cone_interior;
     h->coneRatioTest = cone_ratio_test;
+    h->conePRecover = cone_precover;
     h->coneGetBarrier = cone_barrier;
     return h;
 }
@@ -1427,6 +1484,10 @@ hdsdp_retcode HMiConeRatioTest(hdsdp_cone *cone, double dTauStep, double *dy, do
     return cone->coneRatioTest(cone->coneData, dTauStep, dy, dAdaRatio, whichBuffer, maxStep);
 }
 void HMiLanczosStartVector(int n, double *v) { hdm_lanczos_start_vector(n, v); }
+void HMiConeGetPrimal(hdsdp_cone *cone, double dBarrierMu, double *dRowDual, double *dRowDualStep, double *dConePrimal,
+                      double *dConePrimal2) {
+    cone->conePRecover(cone->coneData, dBarrierMu, dRowDual, dRowDualStep, dConePrimal, dConePrimal2);
+}
 void HMiConeGetPresolve(hdsdp_cone *cone, int *coefType, int *coefRank, int *coefNnz, int *kktPerm, int *kktStrategy,
                         int *objType) {
     MiCone *c = (MiCone *) cone->coneData;

@@ -22,3 +22,4 @@ struct HdmLanczos {
 // HLanczosIPrepare's vector (glibc srand/rand stream reproduced without touching libc state); host only
 void hdm_lanczos_start_vector(int n, double *p);
 int hdm_mirror_lower(double *A, long ld, int n, hipStream_t s);
+int hdm_sym_scale(double *A, long ld, int n, double diag_add, double scale, hipStream_t s);   // A <- scale*(sym(A) + diag_add*I)

@@ -201,6 +201,25 @@ void hdm_lanczos_start_vector(int n, double *p) {
     }
 }
 
+// A <- scale * ( sym(A) + diag_add * I )   (n x n, column-major): the two symmetrisation passes of the primal recovery
+__global__ void hdm_sym_scale_kernel(double *A, long ld, int n, double diag_add, double scale) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long) n * n) return;
+    int i = (int) (e % n), j = (int) (e / n);
+    if (i < j) return;
+    if (i == j) { A[i + (long) i * ld] = scale * (A[i + (long) i * ld] + diag_add); return; }
+    const double v = scale * 0.5 * (A[i + (long) j * ld] + A[j + (long) i * ld]);
+    A[i + (long) j * ld] = v;
+    A[j + (long) i * ld] = v;
+}
+
+int hdm_sym_scale(double *A, long ld, int n, double diag_add, double scale, hipStream_t s) {
+    long tot = (long) n * n;
+    hipLaunchKernelGGL(hdm_sym_scale_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, A, ld, n, diag_add, scale);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int hdm_mirror_lower(double *A, long ld, int n, hipStream_t s) {
     long tot = (long) n * n;
     hipLaunchKernelGGL(hdm_mirror_lower_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, A, ld, n);

@@ -204,6 +204,12 @@ hdsdp_retcode HMiConeGetLogBarrier(hdsdp_cone *cone, double barHsdTau, double *r
  * must be BUFFER_DUALVAR (0).  Also reachable through the cone's coneRatioTest slot. */
 hdsdp_retcode HMiConeRatioTest(hdsdp_cone *cone, double barHsdTauStep, double *rowDualStep, double dAdaRatio,
                                int whichBuffer, double *maxStep);
+/* HConeGetPrimal (hdsdp_conic.c:389; sdpDenseConeGetPrimal hdsdp_conic_sdp.c:2393-2446): primal recovery
+ * X = mu * L^-T (sym(L^-1 dS L^-T) + I) L^-1 with S = C - sum rowDual_i A_i = L L^T and dS = sum rowDualStep_i A_i;
+ * dConePrimal receives the n x n matrix (host, column-major), dConePrimal2 is unused scratch.  If S is not positive
+ * definite a message is printed and dConePrimal is left untouched, like the reference.  Also the conePRecover slot. */
+void HMiConeGetPrimal(hdsdp_cone *cone, double dBarrierMu, double *dRowDual, double *dRowDualStep, double *dConePrimal,
+                      double *dConePrimal2);
 /* the pseudo-random Lanczos start vector of the reference (HLanczosIPrepare, hdsdp_lanczos.c:33-42), host only */
 void HMiLanczosStartVector(int n, double *v);
 /* presolve results (classification hdsdp_sdpdata.c:2321-2458, ordering + plan hdsdp_conic_sdp.c:539-676);

@@ -913,3 +913,56 @@ int orc_ratio_test(const orc_block *b, const double *L, double dTauStep, const d
     return rc;
 }
 
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Primal recovery (sdpDenseConeGetPrimal, hdsdp_conic_sdp.c:2393-2446): S = C - sum y_i A_i (no residual term) = L L^T,
+ * dS = sum dy_i A_i;  two forward solves, "+ I" and symmetrise, two backward solves, symmetrise and scale by mu.
+ * Returns 1 (X untouched) when S is not positive definite -- the reference prints "Recovery step is infeasible".
+ * ------------------------------------------------------------------------------------------------------------- */
+static void pr_fsolve(int n, const double *L, double *B) {          /* B <- L^-1 B, all n columns */
+    for (int c = 0; c < n; ++c) {
+        double *x = B + (size_t) c * n;
+        for (int i = 0; i < n; ++i) {
+            double s_ = x[i];
+            for (int k = 0; k < i; ++k) s_ -= L[(size_t) k * n + i] * x[k];
+            x[i] = s_ / L[(size_t) i * n + i];
+        }
+    }
+}
+static void pr_bsolve(int n, const double *L, double *B) {          /* B <- L^-T B */
+    for (int c = 0; c < n; ++c) {
+        double *x = B + (size_t) c * n;
+        for (int i = n - 1; i >= 0; --i) {
+            double s_ = x[i];
+            for (int k = i + 1; k < n; ++k) s_ -= L[(size_t) i * n + k] * x[k];
+            x[i] = s_ / L[(size_t) i * n + i];
+        }
+    }
+}
+static void pr_transpose(int n, double *A) {
+    for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) { double t = A[(size_t) j * n + i]; A[(size_t) j * n + i] = A[(size_t) i * n + j]; A[(size_t) i * n + j] = t; }
+}
+int orc_get_primal(const orc_block *b, double mu, const double *y, const double *dy, double *X) {
+    const int n = b->n, m = b->m;
+    double *L = calloc((size_t) n * n, sizeof(double)), *W = calloc((size_t) n * n, sizeof(double));
+    double *ndy = malloc(sizeof(double) * (m > 0 ? m : 1));
+    int rc = 0;
+    orc_assemble_S(b, 1.0, y, 0.0, L);
+    if (orc_potrf(n, L) != 0) { rc = 1; goto done; }
+    for (int i = 0; i < m; ++i) ndy[i] = -dy[i];
+    orc_assemble_S(b, 0.0, ndy, 0.0, W);                              /* lower triangle of dS */
+    for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) W[(size_t) i * n + j] = W[(size_t) j * n + i];
+    pr_fsolve(n, L, W); pr_transpose(n, W); pr_fsolve(n, L, W);      /* L^-1 dS L^-T */
+    for (int j = 0; j < n; ++j) {
+        W[(size_t) j * n + j] += 1.0;
+        for (int i = j + 1; i < n; ++i) { double t = 0.5 * (W[(size_t) j * n + i] + W[(size_t) i * n + j]); W[(size_t) j * n + i] = W[(size_t) i * n + j] = t; }
+    }
+    pr_bsolve(n, L, W); pr_transpose(n, W); pr_bsolve(n, L, W);
+    for (int j = 0; j < n; ++j) {
+        X[(size_t) j * n + j] = mu * W[(size_t) j * n + j];
+        for (int i = j + 1; i < n; ++i) { double t = 0.5 * (W[(size_t) j * n + i] + W[(size_t) i * n + j]); X[(size_t) j * n + i] = X[(size_t) i * n + j] = mu * t; }
+    }
+done:
+    free(L); free(W); free(ndy);
+    return rc;
+}

@@ -41,6 +41,8 @@ def lib():
         L.orc_lanczos_free.argtypes = [vp]
         L.orc_ratio_test.restype = C.c_int
         L.orc_ratio_test.argtypes = [vp, dp, C.c_double, dp, C.c_double, vp, dp]
+        L.orc_get_primal.restype = C.c_int
+        L.orc_get_primal.argtypes = [vp, C.c_double, dp, dp, dp]
         L.orc_synth_csc.argtypes = [C.c_int, C.c_int, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp), C.POINTER(dp)]
         L.orc_free_csc.argtypes = [ip, ip, dp, dp]
         _lib = L
@@ -118,6 +120,12 @@ class Block:
             raise RuntimeError("orc_kkt_build: strategy not applicable to this data")
         return {"M": M, "ASinv": a, "ASinvRdSinv": r, "ASinvCSinv": c, "CSinv": scal[0], "CSinvCSinv": scal[1],
                 "CSinvRdSinv": scal[2], "TraceSinv": scal[3]}
+
+    def get_primal(self, mu, y, dy):
+        X = np.zeros((self.n, self.n))
+        rc = lib().orc_get_primal(self._h, float(mu), _d(np.ascontiguousarray(y, dtype=np.float64)),
+                                  _d(np.ascontiguousarray(dy, dtype=np.float64)), _d(X))
+        return None if rc else X
 
     def ratio_test(self, Lf, dtau_step, dy, eye_coef):
         """largest alpha with S + alpha*dS >= 0 (reference Lanczos estimate); consecutive calls warm-start"""

@@ -69,7 +69,7 @@ static double urand(void) {
 }
 
 /* CSC of shape P x (m+1): column 0 = C, column c = A_c, rows = packed-lower col-major index */
-typedef struct { int n, m; int *beg, *idx; double *val; double *b; } csc_prob;
+typedef struct { int n, m; int *beg, *idx; double *val; double *b; double *y0; } csc_prob;
 
 static void gen_syn(csc_prob *p, int n, int m) {
     long P = (long) n * (n + 1) / 2;
@@ -101,7 +101,8 @@ static void gen_syn(csc_prob *p, int n, int m) {
         for (int j = 0; j < n; ++j) { tr += Apk[(size_t) c * P + k]; k += n - j; }
         p->b[c] = tr;
     }
-    free(Apk); free(keep); free(y0); free(Cpk);
+    p->y0 = y0;   /* kept: S(y0) = I is the interior point the primal-recovery dump uses */
+    free(Apk); free(keep); free(Cpk);
 }
 
 /* multi-type mix: row c%6 -> 0 dense, 1 sparse, 2 sparse rank-1, 3 dense rank-1, 4 zero, 5 sparse (diag heavy) */
@@ -321,6 +322,38 @@ int main(int argc, char **argv) {
     /* fixed-strategy rebuilds: every strategy must give the same M (reference's own invariant) */
     HDSDP_CALL(HKKTBuildUpFixed(kkt, KKT_TYPE_INFEASIBLE, KKT_M3)); dump_d2("M_inf_fixedM3", kkt->kktMatElem, m, m);
     HDSDP_CALL(HKKTBuildUpFixed(kkt, KKT_TYPE_INFEASIBLE, KKT_M4)); dump_d2("M_inf_fixedM4", kkt->kktMatElem, m, m);
+    /* primal recovery HConeGetPrimal -> sdpDenseConeGetPrimal (hdsdp_conic_sdp.c:2393-2446): X = mu * L^-T (sym(L^-1 dS L^-T)
+       + I) L^-1 with S = C - sum y_i A_i (no residual term) factored in the checker and dS = sum dy_i A_i.  The point
+       y must make that S positive definite: y0 of the synthetic family (S = I), else the first of two simple
+       candidates the reference's own expert check accepts; no candidate -> nothing dumped. */
+    {
+        double *yr = calloc(m, sizeof(double)), *dyr = calloc(m, sizeof(double));
+        int found = 0;
+        for (int cand = 0; cand < 3 && !found; ++cand) {
+            if (cand == 0) { if (!pb.y0) continue; memcpy(yr, pb.y0, m * sizeof(double)); }
+            if (cand == 1) for (int i = 0; i < m; ++i) yr[i] = -100.0;
+            if (cand == 2) { memset(yr, 0, m * sizeof(double)); yr[0] = -100.0; }
+            int ok = 0;
+            HDSDP_CALL(HConeCheckIsInteriorExpert(cone, 1.0, -1.0, yr, 0.0, BUFFER_DUALCHECK, &ok));
+            found = ok;
+        }
+        if (found) {
+            const double mu = 0.37;
+            for (int i = 0; i < m; ++i) dyr[i] = 0.02 * sin(0.9 * i + 0.1);
+            double *X = calloc((size_t) n * n, sizeof(double)), *aux = calloc((size_t) n * n, sizeof(double));
+            HConeGetPrimal(cone, mu, yr, dyr, X, aux);
+            dump_d("pr_y", yr, m); dump_d("pr_dy", dyr, m); dump_s("pr_mu", mu);
+            dump_d2("pr_X", X, n, n);
+            double tr = 0.0, sm = 0.0, wsum = 0.0;
+            for (int j = 0; j < n; ++j) { tr += X[j + (size_t) j * n]; for (int i = 0; i < n; ++i) { sm += X[i + (size_t) j * n]; wsum += X[i + (size_t) j * n] * cos(0.013 * i + 0.007 * j); } }
+            double cs[3] = { tr, sm, wsum };
+            dump_d("pr_checks", cs, 3);
+            free(X); free(aux);
+            /* the recovery re-factored the checker and overwrote dualStep: restore the state the rest of the dump expects */
+            HDSDP_CALL(HConeCheckIsInterior(cone, tau, y, &isInt));
+        }
+        free(yr); free(dyr);
+    }
     /* KKT_TYPE_PRIMAL (hdsdp_conic_sdp.c:1745-1753, driver hdsdp_psdp.c:156,203): the same builder on a registered
        primal matrix X instead of S^-1.  X is a fixed closed form (tests/util.py:primal_X regenerates it). */
     {

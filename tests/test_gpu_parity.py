@@ -87,6 +87,16 @@ def test_schur_against_reference(name):
         # --- fixed-strategy builds give the same matrix (reference invariant, hdsdp_utils.c:536-707)
         kkt.build_up_fixed(api.KKT_TYPE_INFEASIBLE, api.KKT_M4)
         check_close(kkt.M[msk], g["M_inf"][msk], name)
+        # --- primal recovery X = mu L^-T (sym(L^-1 dS L^-T) + I) L^-1 (next-row f4, hdsdp_conic_sdp.c:2393-2446)
+        if "pr_checks" in g:
+            X = cone.get_primal(float(g["pr_mu"][0]), g["pr_y"], g["pr_dy"])
+            assert X is not None
+            if "pr_X" in g:
+                check_close(X, g["pr_X"], name + " primal recovery")
+            ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")   # X is symmetric: index order is moot
+            got = np.array([np.trace(X), X.sum(), (X * np.cos(0.013 * ii + 0.007 * jj)).sum()])
+            ref = g["pr_checks"]
+            assert np.max(np.abs(got - ref)) <= 1e-9 * np.max(np.abs(ref)), (got, ref)
         # --- KKT_TYPE_PRIMAL: the builder on a registered primal matrix (hdsdp_conic_sdp.c:1745-1753)
         if "M_pri" in g:
             kkt.register_psdp([primal_X(n)])

@@ -68,6 +68,10 @@ def test_oracle_matches_reference(name):
     for strat, key in ((2, "M_inf_fixedM3"), (3, "M_inf_fixedM4")):
         f = blk.kkt_build(Sinv, Rd, 0, fixed=strat)
         check_close(f["M"][mm], g[key][mm], key)
+    if "pr_X" in g:   # primal recovery (hdsdp_conic_sdp.c:2393-2446)
+        X = blk.get_primal(float(g["pr_mu"][0]), g["pr_y"], g["pr_dy"])
+        assert X is not None
+        check_close(X, g["pr_X"], "primal recovery")
     # KKT_TYPE_PRIMAL: the same builder on the registered primal matrix (hdsdp_conic_sdp.c:1745-1753)
     pk = blk.kkt_build(primal_X(n), Rd, 3)
     check_close(pk["M"][mm], g["M_pri"][mm], "M_pri")
