@@ -274,14 +274,14 @@ int cone_alloc_common(MiCone *c) {
 int cone_alloc_gemm_work(MiCone *c) {
     const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
     // batch size: as many constraints per launch as 8 GiB of intermediates allow, at most 256 (each launch pays a
-    // dispatch ramp and a tail: 64 -> 256 per launch measured -1.4 % step time); a multiple of 8 so that the
-    // XCD-local tile decode applies
+    // dispatch ramp and a tail: 64 -> 256 per launch measured -1.4 % step time).  The launches are evened out (2000 rows
+    // -> 8 x 250, a rank's 250 rows -> one launch); the kernel's XCD-local decode pads a batch to a multiple of 8 itself.
     long bc = (long) ((8L << 30) / (double) nn);
     long bcmax = 256;
     if (const char *e = getenv("HDM_BC")) bcmax = atol(e);
     bc = std::max(1L, std::min(bc, bcmax));
-    bc = std::min<long>(bc, std::max(1, c->mloc));
-    if (bc >= 8) bc = bc / 8 * 8;
+    const long rows = std::max(1, c->mloc), launches = (rows + bc - 1) / bc;
+    bc = (rows + launches - 1) / launches;
     c->Bc = (int) bc;
     HDM_HIP_CHECK(hipMalloc((void **) &c->T, nn * (size_t) c->Bc + hdm_operand_pad(c->n16)));
     HDM_HIP_CHECK(hdm_memset_sync(c->T, 0, nn * (size_t) c->Bc));  // step 1 writes lower tiles only; the rest must read as 0

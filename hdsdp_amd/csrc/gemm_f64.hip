@@ -295,10 +295,11 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     const int nb = a.batch;
     const int wg = blockIdx.x;
     int z, t;
-    if ((nb & 7) == 0) {
+    if (nb >= 8) {
         // workgroup ids are dealt round-robin over the 8 XCDs: XCD x walks batch entries x, x+8, ... one after the
         // other and, inside an entry, the tile list in order -- so the ~64 workgroups an XCD runs at any time work
-        // on ONE operand set and on neighbouring tiles, and share their row/column panels in that XCD's L2
+        // on ONE operand set and on neighbouring tiles, and share their row/column panels in that XCD's L2.  The
+        // grid is sized for the batch rounded up to a multiple of 8; the surplus workgroups leave at once.
         const int idx = wg >> 3;
         z = (wg & 7) + 8 * (idx / p.ntiles);
         t = idx % p.ntiles;
@@ -652,7 +653,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     d.edge_off = g_edge_off;
     d.dbg = (g_dbg && args.role == g_dbg_role) ? g_dbg : nullptr;
     if (d.dbg && getenv("HDM_DBG_SYNC")) HDM_HIP_CHECK(hipDeviceSynchronize());   // diagnostic: isolate the stamped launch from its neighbours
-    const long nwg = (long) tl.n * args.batch;
+    const long nwg = (long) tl.n * (args.batch >= 8 ? ((args.batch + 7) & ~7) : args.batch);
     dim3 grid((unsigned) nwg), block(256);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_timing) {
