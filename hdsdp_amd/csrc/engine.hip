@@ -316,6 +316,19 @@ int cone_alloc_gemm_work(MiCone *c) {
         if (cand < 8 && kcap >= 8 && slab_cap >= 8) eff *= 0.5;  // prefer XCD-aligned splits when possible
         if (eff > best + 1e-9) { best = eff; ns = cand; }
     }
+    // Long K ranges: many SHORT splits.  Co-resident workgroups progress at slightly different rates (about 2 %), so
+    // over a long tile they drift out of the few-stage window in which the XCD's L2 still holds a neighbour's operand
+    // panel; with short tiles every round restarts aligned.  Measured Gram kernel at n = m = 2000: 129.9 / 124.6 /
+    // 121.1 / 116.6 ms at 64 / 256 / 512 / 1024 splits.  The price is nsplit x R^2 doubles of slabs (<= 40 GiB).
+    {
+        const long big_cap = (long) ((40LL << 30) / (sizeof(double) * (double) c->R * c->R));
+        const long byk = kblocks / 96;   // >= 96 k blocks (of 16) per workgroup keeps prologue + epilogue under 4 %
+        if (byk >= 128) {
+            const long big = std::min(std::min(1024L, byk), big_cap) & ~7L;
+            if (big > ns) ns = big;
+        }
+    }
+    if (const char *e = getenv("HDM_NSPLIT")) ns = std::max(1L, std::min(atol(e), kblocks / 16));   // A/B knob
     c->nsplit = (int) ns;
     HDM_HIP_CHECK(hipMalloc((void **) &c->slabs, sizeof(double) * (size_t) c->R * c->R * c->nsplit));
     HDM_HIP_CHECK(hipMalloc((void **) &c->Gm, sizeof(double) * (size_t) c->R * c->R));
@@ -522,7 +535,7 @@ int gram_all(MiCone *c) {
         gq.flops = rows * (rows + 1.0) * 0.5 * ((double) c->n * (c->n + 1) * 0.5) * 2.0 / c->world;
     }
     if (hdm_launch_gemm(gq, g.stream)) return 1;
-    return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, g.stream);
+    return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, c->R, g.stream);
 }
 
 hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT, HdmChol *chOverride = nullptr);

@@ -164,13 +164,23 @@ __global__ void hdm_blocked_eye_kernel(double *__restrict__ dst, long row_stride
     dst[(pb * row_stride + row) * 16 + r] = (r == c && g < n) ? 1.0 : 0.0;
 }
 
+// out = sum over the split-K slabs, in slab order (deterministic).  The Gram launch writes lower 128-tiles only, so
+// elements of strictly upper tiles (R > 0: matrices are R x R) are skipped: nothing downstream reads them.
 __global__ void hdm_slab_reduce_kernel(const double *__restrict__ slabs, long slab_stride, int nsplit,
-                                       double *__restrict__ out, long total) {
+                                       double *__restrict__ out, long total, long R) {
     long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += slabs[(long) k * slab_stride + e];
-    out[e] = s;
+    if (R > 0 && ((e / R) >> 7) > ((e % R) >> 7)) return;
+    const double *p = slabs + e;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 3 < nsplit; k += 4) {   // four loads in flight; the sum order is still fixed
+        const double a = p[(long) k * slab_stride], b = p[(long) (k + 1) * slab_stride];
+        const double c = p[(long) (k + 2) * slab_stride], d = p[(long) (k + 3) * slab_stride];
+        s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; k < nsplit; ++k) s0 += p[(long) k * slab_stride];
+    out[e] = (s0 + s1) + (s2 + s3);
 }
 
 // G is the (R x R) augmented Gram matrix in segment order (lower valid, ld = ldg).  rows_seg maps a
@@ -402,9 +412,9 @@ int hdm_blocked_eye(double *dst, long row_stride, long row, int nblk, int n, hip
     return 0;
 }
 
-int hdm_slab_reduce(const double *slabs, long slab_stride, int nsplit, double *out, long total, hipStream_t s) {
+int hdm_slab_reduce(const double *slabs, long slab_stride, int nsplit, double *out, long total, long R, hipStream_t s) {
     hipLaunchKernelGGL(hdm_slab_reduce_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, slabs,
-                       slab_stride, nsplit, out, total);
+                       slab_stride, nsplit, out, total, R);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
