@@ -8,6 +8,7 @@ struct HdmChol {
     double *Linv = nullptr;  // npad x npad, lower triangular inverse (explicit zeros above the diagonal)
     double *Dinv = nullptr;  // nblk x (128 x 128) inverted diagonal blocks
     double *Z = nullptr;     // npad x 128 scratch for invert_factor
+    double *Zd = nullptr;    // npad x npad scratch for the recursive-doubling variant of invert_factor
     double *vec = nullptr;   // 4 * npad scratch vectors
     int *info_dev = nullptr;
     bool factored = false, have_inv = false;

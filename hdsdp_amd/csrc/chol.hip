@@ -213,6 +213,12 @@ __global__ void hdm_reverse_factor_kernel(const double *__restrict__ F, double *
     W[i + (long) j * ld] = v;
 }
 
+// Linv diagonal blocks <- the inverted 128 x 128 diagonal blocks (blockIdx.y = block)
+__global__ void hdm_copy_diag_blocks_kernel(const double *__restrict__ Dinv, double *__restrict__ Linv, long ld) {
+    const int e = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    Linv[(long) k * NB * (ld + 1) + (e & (NB - 1)) + (long) (e >> 7) * ld] = Dinv[(long) k * NB * NB + e];
+}
+
 __global__ void hdm_copy_block_kernel(const double *__restrict__ src, long lds_, double *__restrict__ dst, long ldd,
                                       int rows, int cols) {
     long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,9 +335,10 @@ void HdmChol::destroy() {
     if (Linv) (void) hipFree(Linv);
     if (Dinv) (void) hipFree(Dinv);
     if (Z) (void) hipFree(Z);
+    if (Zd) (void) hipFree(Zd);
     if (info_dev) (void) hipFree(info_dev);
     if (vec) (void) hipFree(vec);
-    L = Linv = Dinv = Z = vec = nullptr;
+    L = Linv = Dinv = Z = Zd = vec = nullptr;
     info_dev = nullptr;
 }
 
@@ -414,6 +421,34 @@ int HdmChol::invert_factor(hipStream_t s) {
     if (!Linv) HDM_HIP_CHECK(hipMalloc((void **) &Linv, mat));
     if (!Z && nblk > 1) HDM_HIP_CHECK(hipMalloc((void **) &Z, sizeof(double) * (size_t) npad * NB));
     HDM_HIP_CHECK(hipMemsetAsync(Linv, 0, mat, s));
+    if (nblk >= 2 && (nblk & (nblk - 1)) == 0) {
+        // Power-of-two block count: recursive doubling instead of the right-to-left sweep.  With the 128-blocks
+        // inverted (Dinv), [[A, 0], [C, B]]^-1 = [[A^-1, 0], [-B^-1 C A^-1, B^-1]] doubles the inverted block size per
+        // level, and all pairs of a level are independent: 2 batched GEMM launches per level, log2(nblk) levels
+        // (8 launches at n = 2000 instead of 30 dependent ones; 2.65 -> ~0.5 ms).
+        if (!Zd) HDM_HIP_CHECK(hipMalloc((void **) &Zd, mat));
+        hipLaunchKernelGGL(hdm_copy_diag_blocks_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, s, Dinv, Linv, ld);
+        HDM_HIP_CHECK(hipGetLastError());
+        for (long sz = NB; sz < npad; sz *= 2) {
+            const int pairs = (int) (npad / (2 * sz));
+            const long pstride = 2 * sz * (ld + 1);
+            HdmGemmArgs g = {};   // T = C * A^-1   (B operand element (j,k) = A^-1(k,j): K-major)
+            g.A = L + sz; g.lda = ld; g.strideA = pstride;
+            g.B = Linv; g.ldb = ld; g.b_kmajor = 1; g.strideB = pstride;
+            g.C = Zd + sz; g.ldc = ld; g.strideC = pstride;
+            g.M = (int) sz; g.N = (int) sz; g.K = (int) sz; g.batch = pairs; g.alpha = 1.0; g.epilogue = HDM_EPI_STORE;
+            if (hdm_launch_gemm(g, s)) return 1;
+            HdmGemmArgs h = {};   // X = -B^-1 * T   (B^-1 lower triangular: K loop cut by the row tile)
+            h.A = Linv + sz * (ld + 1); h.lda = ld; h.strideA = pstride;
+            h.B = Zd + sz; h.ldb = ld; h.b_kmajor = 1; h.strideB = pstride;
+            h.C = Linv + sz; h.ldc = ld; h.strideC = pstride;
+            h.M = (int) sz; h.N = (int) sz; h.K = (int) sz; h.batch = pairs; h.alpha = -1.0;
+            h.klimit = HDM_KLIM_BY_M; h.epilogue = HDM_EPI_STORE;
+            if (hdm_launch_gemm(h, s)) return 1;
+        }
+        have_inv = true;
+        return 0;
+    }
     for (int k = nblk - 1; k >= 0; --k) {
         double *Xkk = Linv + (long) k * NB * (ld + 1);
         hipLaunchKernelGGL(hdm_copy_block_kernel, dim3(NB * NB / 256), dim3(256), 0, s, Dinv + (long) k * NB * NB,

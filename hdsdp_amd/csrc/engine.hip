@@ -329,8 +329,15 @@ int cone_alloc_gemm_work(MiCone *c) {
         }
     }
     if (const char *e = getenv("HDM_NSPLIT")) ns = std::max(1L, std::min(atol(e), kblocks / 16));   // A/B knob
-    c->nsplit = (int) ns;
-    HDM_HIP_CHECK(hipMalloc((void **) &c->slabs, sizeof(double) * (size_t) c->R * c->R * c->nsplit));
+    // the slabs are the one allocation here that is a tuning choice: halve the split count until it fits
+    for (;;) {
+        c->nsplit = (int) ns;
+        if (hipMalloc((void **) &c->slabs, sizeof(double) * (size_t) c->R * c->R * c->nsplit) == hipSuccess) break;
+        (void) hipGetLastError();
+        c->slabs = nullptr;
+        if (ns <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the Gram slabs\n"); return 1; }
+        ns = std::max(8L, (ns / 2) & ~7L);
+    }
     HDM_HIP_CHECK(hipMalloc((void **) &c->Gm, sizeof(double) * (size_t) c->R * c->R));
     // the "S row" (At = I) never changes
     if (c->rank == 0) {
