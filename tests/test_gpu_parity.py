@@ -380,3 +380,53 @@ def test_cones_accumulate_into_one_schur_matrix():
     finally:
         c1.destroy()
         c2.destroy()
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 3), (17, 5), (33, 70), (129, 10), (130, 257), (257, 9)])
+def test_odd_shapes_against_the_oracle(n, m, monkeypatch):
+    """ragged sizes (1 x 1 blocks, dimensions just above a tile boundary, more rows than packed entries) on the GEMM path,
+    checked against the pinned oracle on the synthetic family: edge tiles, single-tile problems, padded batches"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    from hdsdp_amd import api
+    beg, idx, val, b = oracle_py.synth_csc(n, m)
+    blk = oracle_py.Block(n, m, beg, idx, val)
+    monkeypatch.setenv("HDSDP_MI355X_FORCE_GEMM", "1")
+    cone = api.SDPCone.from_csc(n, m, beg, idx, val)
+    try:
+        Rd, tau = -10.0 * n - 5.0, 0.9
+        y = 0.05 * np.cos(np.arange(m) + 0.3)
+        S = blk.assemble_S(tau, y, Rd)
+        Lf, info = blk.factor(S)
+        assert info == 0
+        Sinv = blk.inverse(Lf)
+        cone.set_start(Rd)
+        assert cone.check_is_interior(tau, y)
+        assert abs(cone.log_barrier(tau) - blk.logdet(Lf)) <= 1e-11 * max(1.0, abs(blk.logdet(Lf)))
+        kkt = api.KKT(m, [cone])
+        msk = lower_mask(m)
+        for typ, key in ((api.KKT_TYPE_INFEASIBLE, 0), (api.KKT_TYPE_HOMOGENEOUS, 2)):
+            ref = blk.kkt_build(Sinv, Rd, key)
+            kkt.build_up(typ)
+            ex = kkt.export()
+            check_close(kkt.M[msk], ref["M"][msk], "M %dx%d" % (n, m))
+            check_close(ex["ASinv"], ref["ASinv"], "ASinv")
+            check_close(ex["ASinvRdSinv"], ref["ASinvRdSinv"], "ASinvRdSinv")
+            if key == 2:
+                check_close(ex["ASinvCSinv"], ref["ASinvCSinv"], "ASinvCSinv")
+                for k in ("CSinv", "CSinvCSinv", "CSinvRdSinv", "TraceSinv"):
+                    check_close([ex[k]], [ref[k]], k)
+        ref = blk.kkt_build(Sinv, Rd, 1)
+        kkt.build_up(api.KKT_TYPE_CORRECTOR)
+        check_close(kkt.export()["ASinvRdSinv"], ref["ASinvRdSinv"], "corrector")
+        if n > 1:
+            dy = 3.0 * np.sin(0.7 * np.arange(m) + 0.1)
+            got = cone.ratio_test(-0.02, dy, 0.5)
+            want = blk.ratio_test(Lf, -0.02, dy, 0.5 * Rd)
+            assert abs(got - want) <= RATIO_TOL * abs(want), (got, want)
+        kkt.destroy()
+    finally:
+        cone.destroy()
+        blk.close()
