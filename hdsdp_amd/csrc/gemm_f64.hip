@@ -34,7 +34,6 @@ struct HdmGemmDev {
     HdmGemmArgs a;
     const int2 *tiles;
     int ntiles;
-    int edge_off;             // A/B switch (HDM_NO_EDGE=1): bottom-edge tiles take the ordinary quadrant path
     unsigned long long *dbg;  // diagnostic builds only (VAR & 32): 8 words per workgroup
 };
 
@@ -246,6 +245,23 @@ __device__ __forceinline__ void sgb_pairs() {
     }
 }
 
+// NM MFMAs with NO instructions of class MASK spread between them
+template <int NM, int MASK, int NO>
+__device__ __forceinline__ void sgb_spread() {
+    if constexpr (NM <= 0) {
+        if constexpr (NO > 0) __builtin_amdgcn_sched_group_barrier(MASK, NO, 0);
+    } else if constexpr (NO <= 0) {
+        __builtin_amdgcn_sched_group_barrier(0x8, NM, 0);
+    } else if constexpr (NM >= NO) {
+        constexpr int per = NM / NO;
+        sgb_pairs<0x8, per, MASK, 1, NO>();
+        if constexpr (NM - per * NO > 0) __builtin_amdgcn_sched_group_barrier(0x8, NM - per * NO, 0);
+    } else {
+        constexpr int per = (NO + NM - 1) / NM;
+        sgb_pairs<0x8, 1, MASK, per, NM>();
+    }
+}
+
 // whole K loop + epilogue of a cell-dealt tile (one-stage look-ahead, at most 16 accumulators).  Unmasked branch-free
 // staging loads as in the main loop (callers: roles 1-3 only); the eight global loads are issued among the first
 // MFMAs of a stage and the eight LDS writes among the last.
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         }
         return;
     }
-    if (ROLE != HDM_ROLE_GENERIC && tm != tn && m0 + HDM_TILE > a.M && n0 + HDM_TILE <= a.N && !p.edge_off) {
+    if (ROLE != HDM_ROLE_GENERIC && tm != tn && m0 + HDM_TILE > a.M && n0 + HDM_TILE <= a.N) {
         // workgroup-uniform: bottom-edge tile below the diagonal, rv < 8 valid sub-tile rows
         const int nst = (kt1 - kt0) * npass;
         const int rv = (a.M - m0 + 15) >> 4;
@@ -381,9 +397,9 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         for (int kk = 0; kk < HDM_BK; kk += 4) {
             double fb[4], fa[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fb[i] = frag<AKM>(cA, wm * 64 + i * 16 + l15, kk + lq);
+            for (int i = 0; i < 4; ++i) fb[i] = frag<AKM>(cA, (2 * i + wm) * 16 + l15, kk + lq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fa[j] = frag<BKM>(cB, wn * 64 + j * 16 + l15, kk + lq);
+            for (int j = 0; j < 4; ++j) fa[j] = frag<BKM>(cB, (2 * j + wn) * 16 + l15, kk + lq);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -397,16 +413,80 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         // the fourth k-step's fragments in registers, so after the barrier it first issues the LDS reads of the NEXT
         // stage's first k-step and then runs the 16 MFMAs of the fourth k-step, which cover that LDS latency; global
         // loads (unmasked, branch-free) and the LDS writes of the next stage are spread over the first three k-steps.
+        //
+        // Triangular operands.  In the congruence kernels the K block that lies on an operand's diagonal is half
+        // zeros: for stage s (16 k's) of such a block whole 16-row sub-tiles of the operand are structurally zero
+        //   step 2 (both products, last K block, B side lower triangular): column sub-tiles < s are dead,
+        //   step 1, first K block (A_L on the B side: k >= column): column sub-tiles > s are dead,
+        //   step 1, last K block (Linv on the A side: k <= row): row sub-tiles < s are dead.
+        // The stage body exists in variants that run only the live range [JLO..JHI] x [ILO..3] of a wave's 4 x 4
+        // sub-tiles; with the interleaved ownership the live sub-tiles are spread evenly over the four waves.
         double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // staging registers, named so they are never an alloca
         const int nst = (kt1 - kt0) * npass;
         double fa0[4], fb0[4], fa1[4], fb1[4];   // two fragment sets, named (not indexed) so they stay in registers
 #define HDM_LDF(FA, FB, cA, cB, kk)                                                               \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) FB[i] = frag<AKM>(cA, wm * 64 + i * 16 + l15, (kk) + lq); \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) FA[j] = frag<BKM>(cB, wn * 64 + j * 16 + l15, (kk) + lq);
-#define HDM_MMA(FA, FB)                                                                           \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) FB[i] = frag<AKM>(cA, (2 * i + wm) * 16 + l15, (kk) + lq); \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) FA[j] = frag<BKM>(cB, (2 * j + wn) * 16 + l15, (kk) + lq);
+#define HDM_MMA(FA, FB, JLO, JHI, ILO)                                                            \
+    _Pragma("unroll") for (int j = (JLO); j <= (JHI); ++j)                                        \
+        _Pragma("unroll") for (int i = (ILO); i < 4; ++i)                                         \
             acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[i], acc[j][i], 0, 0, 0);
+        // LDS read instructions per fragment set: an M-major operand's four fragments pair up into two ds_read2_b64,
+        // a K-major operand's are too far apart and stay four ds_read_b64
+        constexpr int NR = (AKM ? 4 : 2) + (BKM ? 4 : 2);
+        // one stage that has a successor: 48 MFMAs, barrier, next stage's first fragments + look-ahead loads, 16 MFMAs
+#define HDM_STAGE(JLO, JHI, ILO)                                                                                     \
+    {                                                                                                                \
+        constexpr int NK = ((JHI) - (JLO) + 1) * (4 - (ILO));   /* live MFMAs per k-step */                          \
+        HDM_LDF(fa1, fb1, cA, cB, 4)                                                                                 \
+        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                                             \
+        HDM_LDF(fa0, fb0, cA, cB, 8)                                                                                 \
+        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                                             \
+        HDM_LDF(fa1, fb1, cA, cB, 12)                                                                                \
+        r2s4<AKM>(nA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(nB, tid, rb0, rb1, rb2, rb3);                              \
+        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                                             \
+        if constexpr (NK == 16) {                                                                                    \
+            /* 16 MFMAs with the second k-step's fragment reads, 16 with the third's, then the fourth's reads and */ \
+            /* the 8 LDS writes among the last 16 */                                                                 \
+            sgb_pairs<0x8, 2, 0x100, 1, NR>();                                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x8, 16 - 2 * NR, 0);                                               \
+            sgb_pairs<0x8, 2, 0x100, 1, NR>();                                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x8, 16 - 2 * NR, 0);                                               \
+            sgb_pairs<0x8, 1, 0x100, NR / 2, 2>();                                                                   \
+            sgb_pairs<0x8, 1, 0x200, 1, 8>();                                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                         \
+        } else {                                                                                                     \
+            sgb_spread<NK, 0x100, NR>();                                                                             \
+            sgb_spread<NK, 0x100, NR>();                                                                             \
+            sgb_spread<NK / 2, 0x100, NR>();                                                                         \
+            sgb_spread<NK - NK / 2, 0x200, 8>();                                                                     \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __syncthreads();                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        HDM_LDF(fa0, fb0, nA, nB, 0)                                                                                 \
+        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   /* stage t+2, or the last again */ \
+        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);                                                          \
+        if constexpr (NK == 16) {                                                                                    \
+            sgb_pairs<0x8, 1, 0x20, 1, 8>();                                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);                                                         \
+        } else {                                                                                                     \
+            sgb_spread<NK, 0x20, 8>();                                                                               \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+        // the last stage: nothing left to stage
+#define HDM_LAST(JLO, JHI, ILO)                                                                   \
+    {                                                                                             \
+        HDM_LDF(fa1, fb1, cA, cB, 4)                                                              \
+        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                          \
+        HDM_LDF(fa0, fb0, cA, cB, 8)                                                              \
+        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                          \
+        HDM_LDF(fa1, fb1, cA, cB, 12)                                                             \
+        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                          \
+        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                          \
+    }
         stA.remain = nst; stB.remain = nst;
         if (nst > 0) {
             stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);
@@ -417,52 +497,49 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         if ((VAR & 32) && p.dbg) t_pro = __builtin_amdgcn_s_memtime();
         int cur = 0;
         if (nst > 0) { HDM_LDF(fa0, fb0, sA, sB, 0) }
-        // LDS read instructions per fragment set: an M-major operand's four fragments pair up into two ds_read2_b64,
-        // a K-major operand's are 2304 bytes apart and stay four ds_read_b64
-        constexpr int NR = (AKM ? 4 : 2) + (BKM ? 4 : 2);
-        for (int t = 0; t + 1 < nst; ++t) {
-            const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;
-            double *nA = sA + (cur ^ 1) * STAGE_DOUBLES, *nB = sB + (cur ^ 1) * STAGE_DOUBLES;
-            // staging registers hold stage t+1 (loaded after the previous barrier, ~54 MFMAs = 1.5 us before their
-            // LDS writes below)
-            HDM_LDF(fa1, fb1, cA, cB, 4)
-            HDM_MMA(fa0, fb0)
-            HDM_LDF(fa0, fb0, cA, cB, 8)
-            HDM_MMA(fa1, fb1)
-            HDM_LDF(fa1, fb1, cA, cB, 12)
-            r2s4<AKM>(nA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(nB, tid, rb0, rb1, rb2, rb3);
-            HDM_MMA(fa0, fb0)
-            // issue order of the 48 MFMAs before the barrier: 16 with the second k-step's fragment reads, 16 with the
-            // third's, then the fourth's reads and the 8 LDS writes among the last 16
-            sgb_pairs<0x8, 2, 0x100, 1, NR>();
-            __builtin_amdgcn_sched_group_barrier(0x8, 16 - 2 * NR, 0);
-            sgb_pairs<0x8, 2, 0x100, 1, NR>();
-            __builtin_amdgcn_sched_group_barrier(0x8, 16 - 2 * NR, 0);
-            sgb_pairs<0x8, 1, 0x100, NR / 2, 2>();
-            sgb_pairs<0x8, 1, 0x200, 1, 8>();
-            __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            HDM_LDF(fa0, fb0, nA, nB, 0)
-            stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   // stage t+2 (or the last one again)
-            HDM_MMA(fa1, fb1)
-            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
-            sgb_pairs<0x8, 1, 0x20, 1, 8>();
-            __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            cur ^= 1;
+        // one stage with a successor / the final stage, on the current LDS buffer
+#define HDM_RUN(JLO, JHI, ILO)                                                                    \
+    {                                                                                             \
+        const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;              \
+        double *nA = sA + (cur ^ 1) * STAGE_DOUBLES, *nB = sB + (cur ^ 1) * STAGE_DOUBLES;        \
+        HDM_STAGE(JLO, JHI, ILO)                                                                  \
+        cur ^= 1;                                                                                 \
+    }
+#define HDM_END(JLO, JHI, ILO)                                                                    \
+    {                                                                                             \
+        const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;              \
+        HDM_LAST(JLO, JHI, ILO)                                                                   \
+    }
+        // The stage sequence of a tile is straight-line: plain loops over the full stages, and the eight stages of a
+        // diagonal K block unrolled with compile-time live ranges (stage s of such a block keeps sub-tiles s/2.. or
+        // ..s/2 of the wave's four: with the interleaved ownership that bound is the same for every wave).  A
+        // run-time switch between stage bodies INSIDE the loop is not an option: two copies of the body under a branch
+        // make the register allocator spill 350-480 VGPRs.
+        if constexpr (ROLE == HDM_ROLE_CONG2) {
+            // (tm > tn, full 128-row tile: diagonal and bottom-edge tiles left through the cell paths above)
+            const int nfull = tn * 8;                       // stages before the B operand's diagonal block, per product
+            for (int t = 0; t < nfull; ++t) HDM_RUN(0, 3, 0)
+            HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0) HDM_RUN(1, 3, 0) HDM_RUN(1, 3, 0)
+            HDM_RUN(2, 3, 0) HDM_RUN(2, 3, 0) HDM_RUN(3, 3, 0) HDM_RUN(3, 3, 0)
+            for (int t = 0; t < nfull; ++t) HDM_RUN(0, 3, 0)
+            HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0) HDM_RUN(1, 3, 0) HDM_RUN(1, 3, 0)
+            HDM_RUN(2, 3, 0) HDM_RUN(2, 3, 0) HDM_RUN(3, 3, 0) HDM_END(3, 3, 0)
+        } else if constexpr (ROLE == HDM_ROLE_CONG1) {
+            // first K block: A_L on the B side, live column sub-tiles <= s; last K block: Linv on the A side, rows >= s
+            HDM_RUN(0, 0, 0) HDM_RUN(0, 0, 0) HDM_RUN(0, 1, 0) HDM_RUN(0, 1, 0)
+            HDM_RUN(0, 2, 0) HDM_RUN(0, 2, 0) HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0)
+            const int nmid = (tm - tn - 1) * 8;
+            for (int t = 0; t < nmid; ++t) HDM_RUN(0, 3, 0)
+            HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 1) HDM_RUN(0, 3, 1)
+            HDM_RUN(0, 3, 2) HDM_RUN(0, 3, 2) HDM_RUN(0, 3, 3) HDM_END(0, 3, 3)
+        } else {
+            for (int t = 0; t + 1 < nst; ++t) HDM_RUN(0, 3, 0)
+            if (nst > 0) HDM_END(0, 3, 0)
         }
-        if (nst > 0) {   // last stage: nothing left to stage
-            const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;
-            HDM_LDF(fa1, fb1, cA, cB, 4)
-            HDM_MMA(fa0, fb0)
-            HDM_LDF(fa0, fb0, cA, cB, 8)
-            HDM_MMA(fa1, fb1)
-            HDM_LDF(fa1, fb1, cA, cB, 12)
-            HDM_MMA(fa0, fb0)
-            HDM_MMA(fa1, fb1)
-        }
+#undef HDM_RUN
+#undef HDM_END
+#undef HDM_LAST
+#undef HDM_STAGE
 #undef HDM_LDF
 #undef HDM_MMA
     } else {
@@ -505,7 +582,9 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         }
     };
     // ---------------------------------------------------------------- epilogue
-    // lane l, reg r of acc[j][i] holds C[m0 + wm*64 + i*16 + l15][n0 + wn*64 + j*16 + lq + 4r]
+    // Sub-tile ownership is INTERLEAVED: wave (wm, wn) owns row sub-tiles 2i + wm and column sub-tiles 2j + wn (i, j = 0..3),
+    // so that when a triangular operand kills the first or last few sub-tiles of a stage the live ones are still spread
+    // evenly over the waves.  lane l, reg r of acc[j][i] holds C[m0 + (2i+wm)*16 + l15][n0 + (2j+wn)*16 + lq + 4r]
     if (a.epilogue == HDM_EPI_BLOCKED) {
         // one base pointer per lane, everything else is wave-uniform 64-bit strides
         const long rs16 = a.blk_row_stride * 16;                       // elements between consecutive p-blocks
@@ -515,8 +594,8 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int bi = (m0 + wm * 64 + i * 16) >> 4;
-                const int bj = (n0 + wn * 64 + j * 16) >> 4;
+                const int bi = (m0 >> 4) + 2 * i + wm;
+                const int bj = (n0 >> 4) + 2 * j + wn;
                 if (bi < bj || bi >= a.nblk) continue;  // (bj <= bi < nblk), wave-uniform
                 const double sc = (bi == bj) ? 1.0 : rt2;
                 const long sub = (long) bj * a.nblk - (long) bj * (bj - 1) / 2 + (bi - bj);
@@ -535,25 +614,25 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     const bool inside = (m0 + HDM_TILE <= a.M) && (n0 + HDM_TILE <= a.N) && !diag_tile;   // wave-uniform
     if (inside) {
         // interior tile: no per-element predicates, one lane pointer, uniform column strides
-        double *lane_c = C + (m0 + wm * 64 + l15) + (long) (n0 + wn * 64 + lq) * a.ldc;
+        double *lane_c = C + (m0 + wm * 16 + l15) + (long) (n0 + wn * 16 + lq) * a.ldc;
         const long c4 = 4 * a.ldc;
         if (a.beta == 0.0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double *q = lane_c + (long) (j * 4 + r) * c4;
+                    double *q = lane_c + (long) (j * 8 + r) * c4;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) q[i * 16] = a.alpha * acc[j][i][r];
+                    for (int i = 0; i < 4; ++i) q[i * 32] = a.alpha * acc[j][i][r];
                 }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double *q = lane_c + (long) (j * 4 + r) * c4;
+                    double *q = lane_c + (long) (j * 8 + r) * c4;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) q[i * 16] = a.alpha * acc[j][i][r] + a.beta * q[i * 16];
+                    for (int i = 0; i < 4; ++i) q[i * 32] = a.alpha * acc[j][i][r] + a.beta * q[i * 32];
                 }
         }
         stamp_end();
@@ -563,10 +642,10 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int gi = m0 + wm * 64 + i * 16 + l15;
+            const int gi = m0 + (2 * i + wm) * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gj = n0 + wn * 64 + j * 16 + lq + 4 * r;
+                const int gj = n0 + (2 * j + wn) * 16 + lq + 4 * r;
                 if (gi < a.M && gj < a.N && !(diag_tile && gi < gj)) {
                     double *c = C + gi + (long) gj * a.ldc;
                     double v = a.alpha * acc[j][i][r];
@@ -648,9 +727,6 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     if (d.a.b_kblk == 0) d.a.b_kblk = HDM_BK;
     d.tiles = tl.dev;
     d.ntiles = tl.n;
-    static int g_edge_off = -1;
-    if (g_edge_off < 0) { const char *e = getenv("HDM_NO_EDGE"); g_edge_off = (e && atoi(e)) ? 1 : 0; }
-    d.edge_off = g_edge_off;
     d.dbg = (g_dbg && args.role == g_dbg_role) ? g_dbg : nullptr;
     if (d.dbg && getenv("HDM_DBG_SYNC")) HDM_HIP_CHECK(hipDeviceSynchronize());   // diagnostic: isolate the stamped launch from its neighbours
     const long nwg = (long) tl.n * (args.batch >= 8 ? ((args.batch + 7) & ~7) : args.batch);
