@@ -176,27 +176,6 @@ template <int W, int RV> struct EdgeCells {
                                    2 * W, 2 * W + 1, 2 * W, 2 * W + 1, 2 * W, 2 * W + 1, 2 * W, 2 * W + 1};
 };
 
-// one BK stage of a cell list
-template <class T, bool AKM, bool BKM>
-__device__ __forceinline__ void cell_compute(const double *__restrict__ cA, const double *__restrict__ cB, int l15, int lq,
-                                             hdm_d4 (&acc)[4][4]) {
-#pragma unroll
-    for (int kk = 0; kk < HDM_BK; kk += 4) {
-        double fr[8], fc[8];   // row / column fragments; only the ones this wave's cells name are ever loaded
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            bool ur = false, uc = false;
-#pragma unroll
-            for (int c = 0; c < T::NC; ++c) { ur |= (T::si[c] == q); uc |= (T::sj[c] == q); }
-            fr[q] = ur ? frag<AKM>(cA, q * 16 + l15, kk + lq) : 0.0;
-            fc[q] = uc ? frag<BKM>(cB, q * 16 + l15, kk + lq) : 0.0;
-        }
-#pragma unroll
-        for (int c = 0; c < T::NC; ++c)
-            acc[c >> 2][c & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fc[T::sj[c]], fr[T::si[c]], acc[c >> 2][c & 3], 0, 0, 0);
-    }
-}
-
 // tri = 1: diagonal tile of a lower-only product (entries above the diagonal are neither scaled nor stored)
 template <class T>
 __device__ __forceinline__ void cell_epilogue(const HdmGemmArgs &a, int z, int m0, int n0, int l15, int lq, int rv, int tri,
@@ -265,6 +244,23 @@ __device__ __forceinline__ void sgb_spread() {
 // whole K loop + epilogue of a cell-dealt tile (one-stage look-ahead, at most 16 accumulators).  Unmasked branch-free
 // staging loads as in the main loop (callers: roles 1-3 only); the eight global loads are issued among the first
 // MFMAs of a stage and the eight LDS writes among the last.
+template <class T> constexpr bool cell_uses_row(int q) {
+    for (int c = 0; c < T::NC; ++c) if (T::si[c] == q) return true;
+    return false;
+}
+template <class T> constexpr bool cell_uses_col(int q) {
+    for (int c = 0; c < T::NC; ++c) if (T::sj[c] == q) return true;
+    return false;
+}
+template <class T> constexpr int cell_frag_count() {
+    int k = 0;
+    for (int q = 0; q < 8; ++q) k += (cell_uses_row<T>(q) ? 1 : 0) + (cell_uses_col<T>(q) ? 1 : 0);
+    return k;
+}
+
+// whole K loop + epilogue of a cell-dealt tile (at most 16 accumulators), same rotated stage as the main loop: the
+// barrier sits before the fourth k-step, whose MFMAs cover the LDS reads of the next stage's first k-step and the issue
+// of the look-ahead global loads; unmasked branch-free staging loads (callers: roles 1-3 only).
 template <class T, bool AKM, bool BKM>
 __device__ __forceinline__ void cell_tile(const HdmGemmArgs &a, Stager<AKM> &stA, Stager<BKM> &stB, double *sA, double *sB,
                                           int nst, int tid, int z, int m0, int n0, int l15, int lq, int rv, int tri) {
@@ -272,28 +268,65 @@ __device__ __forceinline__ void cell_tile(const HdmGemmArgs &a, Stager<AKM> &stA
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c >> 2][c & 3] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
     double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    double fr0[8], fc0[8], fr1[8], fc1[8];   // two fragment sets; only the entries this wave's cells name are ever loaded
+    constexpr int NC = T::NC;                // MFMAs per k-step
+    constexpr int NF = cell_frag_count<T>(); // LDS reads per fragment set (upper bound: the compiler may pair them)
+#define HDM_CLDF(FR, FC, cA, cB, kk)                                                                        \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                         \
+        if constexpr (true) {                                                                               \
+            if (cell_uses_row<T>(q)) FR[q] = frag<AKM>(cA, q * 16 + l15, (kk) + lq);                        \
+            if (cell_uses_col<T>(q)) FC[q] = frag<BKM>(cB, q * 16 + l15, (kk) + lq);                        \
+        }                                                                                                   \
+    }
+#define HDM_CMMA(FR, FC)                                                                                    \
+    _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                          \
+        acc[c >> 2][c & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(FC[T::sj[c]], FR[T::si[c]], acc[c >> 2][c & 3], 0, 0, 0);
     stA.remain = nst; stB.remain = nst;
     if (nst > 0) {
         stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);
         r2s4<AKM>(sA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(sB, tid, rb0, rb1, rb2, rb3);
+        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   // stage 1, in flight
     }
     __syncthreads();
     int cur = 0;
-    constexpr int NM = 4 * T::NC;   // MFMAs per stage
+    if (nst > 0) { HDM_CLDF(fr0, fc0, sA, sB, 0) }
     for (int t = 0; t + 1 < nst; ++t) {
-        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);
-        cell_compute<T, AKM, BKM>(sA + cur * STAGE_DOUBLES, sB + cur * STAGE_DOUBLES, l15, lq, acc);
-        r2s4<AKM>(sA + (cur ^ 1) * STAGE_DOUBLES, tid, ra0, ra1, ra2, ra3);
-        r2s4<BKM>(sB + (cur ^ 1) * STAGE_DOUBLES, tid, rb0, rb1, rb2, rb3);
-        sgb_pairs<0x8, 1, 0x20, 1, 8>();
-        __builtin_amdgcn_sched_group_barrier(0x8, NM - 16, 0);   // fragment reads are left to the scheduler
-        sgb_pairs<0x8, 1, 0x200, 1, 8>();
+        const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;
+        double *nA = sA + (cur ^ 1) * STAGE_DOUBLES, *nB = sB + (cur ^ 1) * STAGE_DOUBLES;
+        HDM_CLDF(fr1, fc1, cA, cB, 4)
+        HDM_CMMA(fr0, fc0)
+        HDM_CLDF(fr0, fc0, cA, cB, 8)
+        HDM_CMMA(fr1, fc1)
+        HDM_CLDF(fr1, fc1, cA, cB, 12)
+        r2s4<AKM>(nA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(nB, tid, rb0, rb1, rb2, rb3);
+        HDM_CMMA(fr0, fc0)
+        sgb_spread<NC, 0x100, NF>();
+        sgb_spread<NC, 0x100, NF>();
+        sgb_spread<NC / 2, 0x100, NF>();
+        sgb_spread<NC - NC / 2, 0x200, 8>();
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
+        HDM_CLDF(fr0, fc0, nA, nB, 0)
+        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   // stage t+2, or the last one again
+        HDM_CMMA(fr1, fc1)
+        __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+        sgb_spread<NC, 0x20, 8>();
+        __builtin_amdgcn_sched_barrier(0);
         cur ^= 1;
     }
-    if (nst > 0) cell_compute<T, AKM, BKM>(sA + cur * STAGE_DOUBLES, sB + cur * STAGE_DOUBLES, l15, lq, acc);
+    if (nst > 0) {
+        const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;
+        HDM_CLDF(fr1, fc1, cA, cB, 4)
+        HDM_CMMA(fr0, fc0)
+        HDM_CLDF(fr0, fc0, cA, cB, 8)
+        HDM_CMMA(fr1, fc1)
+        HDM_CLDF(fr1, fc1, cA, cB, 12)
+        HDM_CMMA(fr0, fc0)
+        HDM_CMMA(fr1, fc1)
+    }
+#undef HDM_CLDF
+#undef HDM_CMMA
     cell_epilogue<T>(a, z, m0, n0, l15, lq, rv, tri, acc);
 }
 
