@@ -17,7 +17,7 @@ KKT_TYPE_INFEASIBLE, KKT_TYPE_CORRECTOR, KKT_TYPE_HOMOGENEOUS, KKT_TYPE_PRIMAL =
 KKT_M1, KKT_M2, KKT_M3, KKT_M4, KKT_M5 = 0, 1, 2, 3, 4
 HDSDP_LINSYS_DENSE_DIRECT, HDSDP_LINSYS_DENSE_ITERATIVE = 0, 5
 RETCODE_OK, RETCODE_FAILED, RETCODE_MEMORY = 0, 1, 2
-BUFFER_DUALVAR = 0
+BUFFER_DUALVAR, BUFFER_DUALCHECK, BUFFER_DUALSTEP = 0, 1, 2   # interface/hdsdp_conic.h:24-26
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libhdsdp_mi355x.so")
@@ -30,7 +30,8 @@ EXPORTS = [
     "HFpLinsysPsdCheck", "HFpLinsysFSolve", "HFpLinsysBSolve", "HFpLinsysSolve", "HFpLinsysGetDiag",
     "HFpLinsysInvert", "HFpLinsysClear", "HFpLinsysDestroy",
     "HMiConeCreateSDP", "HMiConeCreateSynthetic", "HMiConeDestroy", "HMiConeSetStart", "HMiConeUpdate",
-    "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
+    "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeCheckIsInteriorExpert",
+    "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
     "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
@@ -107,6 +108,10 @@ def load_library():
         "HMiConeRatioTest": (C.c_int, [vp, C.c_double, dp, C.c_double, C.c_int, dp]),
         "HMiLanczosStartVector": (None, [C.c_int, dp]),
         "HMiConeGetPrimal": (None, [vp, C.c_double, dp, dp, dp, dp]),
+        "HMiConeCheckIsInteriorExpert": (C.c_int, [vp, C.c_double, C.c_double, dp, C.c_double, C.c_int, ip]),
+        "HMiConeAddStepToBufferAndCheck": (C.c_int, [vp, C.c_double, C.c_int, ip]),
+        "HMiConeReduceResi": (None, [vp, C.c_double]),
+        "HMiConeSetPerturb": (None, [vp, C.c_double]),
         "HMiConeGetLogBarrier": (C.c_int, [vp, C.c_double, dp, C.c_int, dp]),
         "HMiConeGetPresolve": (None, [vp, ip, ip, ip, ip, ip, ip]),
         "HMiConeGetDualMatrix": (C.c_int, [vp, dp]),
@@ -239,13 +244,36 @@ class SDPCone:
                "HConeCheckIsInterior")
         return bool(ok.value)
 
-    def ratio_test(self, dtau_step, dy, ada_ratio=0.0):
-        """HConeRatioTest on BUFFER_DUALVAR: largest step keeping S + step*dS in the cone (inf if unbounded)"""
+    def ratio_test(self, dtau_step, dy, ada_ratio=0.0, buffer=BUFFER_DUALVAR):
+        """HConeRatioTest: largest step keeping S + step*dS in the cone (inf if unbounded); S = the chosen buffer"""
         dy = np.ascontiguousarray(dy, dtype=np.float64)
         out = C.c_double(0.0)
-        _check(load_library().HMiConeRatioTest(self._h, float(dtau_step), _dptr(dy), float(ada_ratio), BUFFER_DUALVAR,
+        _check(load_library().HMiConeRatioTest(self._h, float(dtau_step), _dptr(dy), float(ada_ratio), buffer,
                                                C.byref(out)), "HConeRatioTest")
         return out.value
+
+    def check_is_interior_expert(self, c_coef, a_scal, a_coef, eye_coef, buffer=BUFFER_DUALVAR):
+        a_coef = np.ascontiguousarray(a_coef, dtype=np.float64)
+        ok = C.c_int(0)
+        _check(load_library().HMiConeCheckIsInteriorExpert(self._h, float(c_coef), float(a_scal), _dptr(a_coef),
+                                                           float(eye_coef), buffer, C.byref(ok)), "HConeCheckIsInteriorExpert")
+        return bool(ok.value)
+
+    def axpy_buffer_and_check(self, step, buffer=BUFFER_DUALCHECK):
+        ok = C.c_int(0)
+        _check(load_library().HMiConeAddStepToBufferAndCheck(self._h, float(step), buffer, C.byref(ok)), "HConeAddStepToBufferAndCheck")
+        return bool(ok.value)
+
+    def log_barrier_of(self, buffer):
+        out = C.c_double(0.0)
+        _check(load_library().HMiConeGetLogBarrier(self._h, 0.0, None, buffer, C.byref(out)), "HConeGetLogBarrier")
+        return out.value
+
+    def reduce_resi(self, v):
+        load_library().HMiConeReduceResi(self._h, float(v))
+
+    def set_perturb(self, v):
+        load_library().HMiConeSetPerturb(self._h, float(v))
 
     def get_primal(self, mu, y, dy):
         """HConeGetPrimal: n x n primal recovery matrix, or None if S(y) is not positive definite"""

@@ -380,6 +380,54 @@ hdsdp_retcode cone_factor_S(MiCone *c, int *isPsd) {
     return HDSDP_RETCODE_OK;
 }
 
+// the second factor object ("dualChecker" of the reference, def_hdsdp_conic.h): trial points of the line search and the
+// primal recovery are factored here so that the factor of the current S stays valid
+hdsdp_retcode cone_checker(MiCone *c, HdmChol **out) {
+    if (!c->checker) {
+        c->checker = new HdmChol();
+        if (c->checker->init(c->n)) return HDSDP_RETCODE_MEMORY;
+    }
+    *out = c->checker;
+    return HDSDP_RETCODE_OK;
+}
+
+hdsdp_retcode cone_factor_check(MiCone *c, int *isPsd) {
+    HdmChol *ch = nullptr;
+    RC(cone_checker(c, &ch));
+    int info = 0;
+    if (ch->load_device(c->Scheck, c->n16, g.stream) || ch->factor(g.stream, &info)) return HDSDP_RETCODE_FAILED;
+    if (isPsd) *isPsd = (info == 0);
+    return HDSDP_RETCODE_OK;
+}
+
+// sdpDenseConeInteriorCheckExpert (hdsdp_conic_sdp.c:2192-2207): B = dCCoef*C + dACoefScal*sum_i dACoef_i A_i + dEyeCoef*I
+// (+ the perturbation unless the target is the step buffer, :383-385) into the chosen buffer, then the PSD check
+hdsdp_retcode cone_interior_expert(void *cd, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef,
+                                   int whichBuffer, int *isInterior) {
+    MiCone *c = (MiCone *) cd;
+    std::vector<double> ys(std::max(1, c->m), 0.0);
+    for (int i = 0; i < c->m; ++i) ys[i] = -dACoefScal * (dACoef ? dACoef[i] : 0.0);   // cone_assemble subtracts
+    const double eye = dEyeCoef + c->perturb;
+    double *target = (whichBuffer == 0) ? c->S : c->Scheck;
+    if (cone_assemble(c, dCCoef, ys.data(), target, &eye)) return HDSDP_RETCODE_FAILED;
+    HIP_RC(hipStreamSynchronize(g.stream));   // ys is read by an asynchronous copy
+    return (whichBuffer == 0) ? cone_factor_S(c, isInterior) : cone_factor_check(c, isInterior);
+}
+
+// sdpDenseConeAddStepToBufferAndCheck (hdsdp_conic_sdp.c:2333-2361): S + dStep*dS with the dS of the last ratio test;
+// BUFFER_DUALVAR updates S in place, BUFFER_DUALCHECK leaves S alone and factors the trial point in the checker
+hdsdp_retcode cone_axpy_check(void *cd, double dStep, int whichBuffer, int *isInterior) {
+    MiCone *c = (MiCone *) cd;
+    if (!c->dS) return HDSDP_RETCODE_FAILED;
+    const long cnt = (long) c->n16 * c->n16;
+    double *target = (whichBuffer == 0) ? c->S : c->Scheck;
+    RC(hdm_axpy_mat(target, c->S, c->dS, dStep, cnt, g.stream));
+    return (whichBuffer == 0) ? cone_factor_S(c, isInterior) : cone_factor_check(c, isInterior);
+}
+
+void cone_reduce_resi(void *cd, double resiReduction) { ((MiCone *) cd)->Rd = resiReduction; }   // :2224-2228
+void cone_set_perturb(void *cd, double dDualPerturb) { ((MiCone *) cd)->perturb = dDualPerturb; }  // :2236-2241
+
 // hdsdp_conic_sdp.c:2172-2180
 hdsdp_retcode cone_interior(void *cd, double tau, double *y, int *isInterior) {
     MiCone *c = (MiCone *) cd;
@@ -390,14 +438,17 @@ hdsdp_retcode cone_interior(void *cd, double tau, double *y, int *isInterior) {
 // hdsdp_conic_sdp.c:2252-2291
 hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, double *logdet) {
     MiCone *c = (MiCone *) cd;
-    (void) whichBuffer;
-    if (y) {
+    if (y) {   // only with BUFFER_DUALVAR (the reference asserts it)
         int psd = 0;
         RC(cone_assemble(c, tau, y, c->S));
         if (cone_factor_S(c, &psd) != HDSDP_RETCODE_OK || !psd) return HDSDP_RETCODE_FAILED;
     }
     std::vector<double> d(c->n);
-    if (HFpLinsysGetDiag(c->dualFactor, d.data()) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+    if (whichBuffer == 0) {
+        if (HFpLinsysGetDiag(c->dualFactor, d.data()) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+    } else {
+        if (!c->checker || !c->checker->factored || c->checker->get_diag(d.data(), g.stream)) return HDSDP_RETCODE_FAILED;
+    }
     double s = 0.0;
     for (int i = 0; i < c->n; ++i) s += log(d[i]);
     *logdet = 2.0 * s;
@@ -405,16 +456,13 @@ hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, dou
 }
 
 // sdpDenseConeRatioTestImpl (hdsdp_conic_sdp.c:1640-1686): dS = dTauStep*C - sum dy_i A_i + dAdaRatio*Rd*I, then the
-// largest alpha with S + alpha dS >= 0 by Lanczos on L^-1 (-dS) L^-T (lanczos.hip).  S is the matrix factored last
-// (BUFFER_DUALVAR); the engine keeps no second "checker" factor, so BUFFER_DUALCHECK is refused.
+// largest alpha with S + alpha dS >= 0 by Lanczos on L^-1 (-dS) L^-T (lanczos.hip).  L is the factor of the chosen
+// buffer: the current S (BUFFER_DUALVAR) or the trial point factored last in the checker (BUFFER_DUALCHECK).
 hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAdaRatio, int whichBuffer, double *maxStep) {
     MiCone *c = (MiCone *) cd;
-    if (whichBuffer != 0) {
-        fprintf(stderr, "[hdsdp_mi355x] ratio test: only BUFFER_DUALVAR is resident on the device\n");
-        return HDSDP_RETCODE_FAILED;
-    }
     MiLin *l = (MiLin *) c->dualFactor->chol;
-    if (!l->ch.factored) return HDSDP_RETCODE_FAILED;
+    HdmChol *fac = (whichBuffer == 0) ? &l->ch : c->checker;   // LTarget, :1661-1665
+    if (!fac || !fac->factored) return HDSDP_RETCODE_FAILED;
     const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
     if (!c->dS) {
         HIP_RC(hipMalloc((void **) &c->dS, nn));
@@ -425,19 +473,19 @@ hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAda
     if (c->n == 1) {   // :1668-1675
         double s0 = 0.0, d0 = 0.0;
         HIP_RC(hipMemcpyAsync(&d0, c->dS, sizeof(double), hipMemcpyDeviceToHost, g.stream));
-        HIP_RC(hipMemcpyAsync(&s0, c->S, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        HIP_RC(hipMemcpyAsync(&s0, (whichBuffer == 0) ? c->S : c->Scheck, sizeof(double), hipMemcpyDeviceToHost, g.stream));
         HIP_RC(hipStreamSynchronize(g.stream));
         *maxStep = (d0 > 0.0) ? INFINITY : (-s0 / d0);
         return HDSDP_RETCODE_OK;
     }
     RC(hdm_mirror_lower(c->dS, c->n16, c->n, g.stream));
-    RC(l->ch.invert_factor(g.stream));
+    if (fac->invert_factor(g.stream)) return HDSDP_RETCODE_FAILED;
     if (!c->lanczos) {
         c->lanczos = new HdmLanczos();
         if (c->lanczos->init(c->n)) return HDSDP_RETCODE_MEMORY;
     }
     int steps = 0;
-    if (c->lanczos->solve(l->ch.Linv, l->ch.npad, c->dS, c->n16, g.stream, maxStep, &steps)) return HDSDP_RETCODE_FAILED;
+    if (c->lanczos->solve(fac->Linv, fac->npad, c->dS, c->n16, g.stream, maxStep, &steps)) return HDSDP_RETCODE_FAILED;
     return HDSDP_RETCODE_OK;
 }
 
@@ -454,11 +502,9 @@ void cone_precover(void *cd, double dBarrierMu, double *y, double *dy, double *X
     const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
     auto fail = [](const char *what) { fprintf(stderr, "[hdsdp_mi355x] primal recovery: %s\n", what); };
     if (cone_assemble(c, 1.0, y, c->Scheck, &zero)) return fail("S assembly failed");
-    if (!c->checker) {
-        c->checker = new HdmChol();
-        if (c->checker->init(n)) return fail("out of memory");
-    }
-    HdmChol &ch = *c->checker;
+    HdmChol *chp = nullptr;
+    if (cone_checker(c, &chp) != HDSDP_RETCODE_OK) return fail("out of memory");
+    HdmChol &ch = *chp;
     int info = 0;
     if (ch.load_device(c->Scheck, c->n16, g.stream) || ch.factor(g.stream, &info)) return fail("factorisation failed");
     if (info != 0) { printf("Recovery step is infeasible\n"); return; }
@@ -975,6 +1021,10 @@ hdsdp_cone *new_cone_shell(MiCone *c, int iCone) {
     h->coneInteriorCheck = cone_interior;
     h->coneRatioTest = cone_ratio_test;
     h->conePRecover = cone_precover;
+    h->coneInteriorCheckExpert = cone_interior_expert;
+    h->coneAxpyBufferAndCheck = cone_axpy_check;
+    h->coneReduceResi = cone_reduce_resi;
+    h->coneSetPerturb = cone_set_perturb;
     h->coneGetBarrier = cone_barrier;
     return h;
 }
@@ -1504,6 +1554,15 @@ hdsdp_retcode HMiConeRatioTest(hdsdp_cone *cone, double dTauStep, double *dy, do
     return cone->coneRatioTest(cone->coneData, dTauStep, dy, dAdaRatio, whichBuffer, maxStep);
 }
 void HMiLanczosStartVector(int n, double *v) { hdm_lanczos_start_vector(n, v); }
+hdsdp_retcode HMiConeCheckIsInteriorExpert(hdsdp_cone *cone, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef,
+                                           int whichBuffer, int *isInterior) {
+    return cone->coneInteriorCheckExpert(cone->coneData, dCCoef, dACoefScal, dACoef, dEyeCoef, whichBuffer, isInterior);
+}
+hdsdp_retcode HMiConeAddStepToBufferAndCheck(hdsdp_cone *cone, double dStep, int whichBuffer, int *isInterior) {
+    return cone->coneAxpyBufferAndCheck(cone->coneData, dStep, whichBuffer, isInterior);
+}
+void HMiConeReduceResi(hdsdp_cone *cone, double dResiReduction) { cone->coneReduceResi(cone->coneData, dResiReduction); }
+void HMiConeSetPerturb(hdsdp_cone *cone, double dDualPerturb) { cone->coneSetPerturb(cone->coneData, dDualPerturb); }
 void HMiConeGetPrimal(hdsdp_cone *cone, double dBarrierMu, double *dRowDual, double *dRowDualStep, double *dConePrimal,
                       double *dConePrimal2) {
     cone->conePRecover(cone->coneData, dBarrierMu, dRowDual, dRowDualStep, dConePrimal, dConePrimal2);

@@ -220,6 +220,18 @@ int hdm_sym_scale(double *A, long ld, int n, double diag_add, double scale, hipS
     return 0;
 }
 
+// out = S + step * dS over `count` doubles (out may alias S)
+__global__ void hdm_axpy_mat_kernel(double *out, const double *S, const double *dS, double step, long count) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) out[e] = S[e] + step * dS[e];
+}
+
+int hdm_axpy_mat(double *out, const double *S, const double *dS, double step, long count, hipStream_t s) {
+    hipLaunchKernelGGL(hdm_axpy_mat_kernel, dim3((unsigned) ((count + 255) / 256)), dim3(256), 0, s, out, S, dS, step, count);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int hdm_mirror_lower(double *A, long ld, int n, hipStream_t s) {
     long tot = (long) n * n;
     hipLaunchKernelGGL(hdm_mirror_lower_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, A, ld, n);

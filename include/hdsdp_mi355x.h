@@ -200,10 +200,20 @@ hdsdp_retcode HMiConeGetLogBarrier(hdsdp_cone *cone, double barHsdTau, double *r
                                    double *logdet);
 /* HConeRatioTest (hdsdp_conic.c:270; sdpDenseConeRatioTestImpl hdsdp_conic_sdp.c:1640-1686 + HLanczosSolve
  * linalg/hdsdp_lanczos.c:161-292) on the device: largest step with S + step * dS >= 0, where
- * dS = barHsdTauStep*C - sum rowDualStep_i A_i + dAdaRatio*Rd*I and S is the matrix factored last.  whichBuffer
- * must be BUFFER_DUALVAR (0).  Also reachable through the cone's coneRatioTest slot. */
+ * dS = barHsdTauStep*C - sum rowDualStep_i A_i + dAdaRatio*Rd*I and S is the matrix of the chosen buffer: the current
+ * dual matrix (BUFFER_DUALVAR, 0) or the trial point factored last in the checker (BUFFER_DUALCHECK, 1).  Also reachable
+ * through the cone's coneRatioTest slot. */
 hdsdp_retcode HMiConeRatioTest(hdsdp_cone *cone, double barHsdTauStep, double *rowDualStep, double dAdaRatio,
                                int whichBuffer, double *maxStep);
+/* the rest of the dual line search, device resident (hdsdp_conic.c:350-387, :410-421; hdsdp_conic_sdp.c:2192-2241,
+ * :2333-2361): an interior check of dCCoef*C + dACoefScal*sum dACoef_i A_i + dEyeCoef*I in either buffer, S + dStep*dS
+ * with the dS of the last ratio test (in place for BUFFER_DUALVAR, into the checker for BUFFER_DUALCHECK), and the two
+ * scalar setters.  HMiConeGetLogBarrier(whichBuffer = 1, rowDual = NULL) reads the checker's factor. */
+hdsdp_retcode HMiConeCheckIsInteriorExpert(hdsdp_cone *cone, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef,
+                                           int whichBuffer, int *isInterior);
+hdsdp_retcode HMiConeAddStepToBufferAndCheck(hdsdp_cone *cone, double dStep, int whichBuffer, int *isInterior);
+void HMiConeReduceResi(hdsdp_cone *cone, double dResiReduction);
+void HMiConeSetPerturb(hdsdp_cone *cone, double dDualPerturb);
 /* HConeGetPrimal (hdsdp_conic.c:389; sdpDenseConeGetPrimal hdsdp_conic_sdp.c:2393-2446): primal recovery
  * X = mu * L^-T (sym(L^-1 dS L^-T) + I) L^-1 with S = C - sum rowDual_i A_i = L L^T and dS = sum rowDualStep_i A_i;
  * dConePrimal receives the n x n matrix (host, column-major), dConePrimal2 is unused scratch.  If S is not positive

@@ -252,6 +252,22 @@ int main(int argc, char **argv) {
         for (int i = 0; i < m; ++i) dy[i] = 0.5 * sc * sin(1.3 * i + 0.4);
         HDSDP_CALL(HConeRatioTest(cone, -0.05, dy, 1.0, BUFFER_DUALVAR, &step));
         dump_d("rt_dy2", dy, m); { double pr[2] = {-0.05, 1.0}; dump_d("rt_par2", pr, 2); } dump_s("rt_step2", step);
+        /* the checker buffer of the line search (hdsdp_conic_sdp.c:2333-2361, :2192-2207, :2252-2291): trial point
+           S + 0.5*step*dS factored in the checker, its log-barrier, a ratio test from that trial point (third Lanczos
+           call, warm-started), a trial point beyond the boundary, and an expert check with half the residual */
+        {
+            int ok = 0; double ld = 0.0, st3 = 0.0;
+            HDSDP_CALL(HConeAddStepToBufferAndCheck(cone, 0.5 * step, BUFFER_DUALCHECK, &ok));
+            HDSDP_CALL(HConeGetLogBarrier(cone, 0.0, NULL, BUFFER_DUALCHECK, &ld));
+            HDSDP_CALL(HConeRatioTest(cone, -0.05, dy, 1.0, BUFFER_DUALCHECK, &st3));
+            double r1[3] = { (double) ok, ld, st3 };
+            HDSDP_CALL(HConeAddStepToBufferAndCheck(cone, 1.5 * step, BUFFER_DUALCHECK, &ok));
+            double r2 = (double) ok;
+            HDSDP_CALL(HConeCheckIsInteriorExpert(cone, tau, -1.0, y, -0.5 * Rd, BUFFER_DUALCHECK, &ok));
+            HDSDP_CALL(HConeGetLogBarrier(cone, 0.0, NULL, BUFFER_DUALCHECK, &ld));
+            double r3[2] = { (double) ok, ld };
+            dump_d("ck_axpy_half", r1, 3); dump_s("ck_axpy_beyond", r2); dump_d("ck_expert", r3, 2);
+        }
         free(dy);
     }
 

@@ -47,6 +47,21 @@ def test_schur_against_reference(name):
                 step = cone.ratio_test(float(par[0]), g["rt_dy" + tag], float(par[1]))
                 ref = float(g["rt_step" + tag][0])
                 assert abs(step - ref) <= RATIO_TOL * abs(ref), (name, tag, step, ref)
+            if "ck_axpy_half" in g:
+                # the checker buffer of the line search: trial point S + 0.5*step*dS, its log-barrier, a ratio test
+                # from there (third Lanczos call), a trial point beyond the boundary, an expert check
+                ok_h, ld_h, st3 = g["ck_axpy_half"]
+                assert cone.axpy_buffer_and_check(0.5 * step, api.BUFFER_DUALCHECK) == bool(ok_h)
+                assert abs(cone.log_barrier_of(api.BUFFER_DUALCHECK) - ld_h) <= 1e-11 * abs(ld_h)
+                got3 = cone.ratio_test(float(par[0]), g["rt_dy2"], float(par[1]), api.BUFFER_DUALCHECK)
+                assert abs(got3 - st3) <= RATIO_TOL * abs(st3), (name, got3, st3)
+                assert cone.axpy_buffer_and_check(1.5 * step, api.BUFFER_DUALCHECK) == bool(g["ck_axpy_beyond"][0])
+                ok_e, ld_e = g["ck_expert"]
+                assert cone.check_is_interior_expert(tau, -1.0, y, -0.5 * Rd, api.BUFFER_DUALCHECK) == bool(ok_e)
+                if ok_e:   # (a failed factorisation has no log-barrier: the reference's value is NaN there)
+                    assert abs(cone.log_barrier_of(api.BUFFER_DUALCHECK) - ld_e) <= 1e-11 * abs(ld_e)
+                # none of this may have touched the factor of S itself
+                assert abs(cone.log_barrier_of(api.BUFFER_DUALVAR) - float(g["logdet"][0])) <= 1e-12 * abs(float(g["logdet"][0]))
 
         kkt = api.KKT(m, [cone])
         msk = lower_mask(m)
