@@ -31,7 +31,8 @@ EXPORTS = [
     "HFpLinsysInvert", "HFpLinsysClear", "HFpLinsysDestroy",
     "HMiConeCreateSDP", "HMiConeCreateSynthetic", "HMiConeDestroy", "HMiConeSetStart", "HMiConeUpdate",
     "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeCheckIsInteriorExpert",
-    "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
+    "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetCoeffNorm", "HMiConeGetObjNorm",
+    "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
     "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
@@ -112,6 +113,13 @@ def load_library():
         "HMiConeAddStepToBufferAndCheck": (C.c_int, [vp, C.c_double, C.c_int, ip]),
         "HMiConeReduceResi": (None, [vp, C.c_double]),
         "HMiConeSetPerturb": (None, [vp, C.c_double]),
+        "HMiConeGetCoeffNorm": (C.c_double, [vp, C.c_int]),
+        "HMiConeGetObjNorm": (C.c_double, [vp, C.c_int]),
+        "HMiConeScalByConstant": (None, [vp, C.c_double]),
+        "HMiConeComputeATimesXpy": (None, [vp, dp, dp]),
+        "HMiConeComputeXDotS": (C.c_double, [vp, dp]),
+        "HMiConeComputeTraceCX": (C.c_double, [vp, dp]),
+        "HMiConeGetDual": (None, [vp, dp, dp]),
         "HMiConeGetLogBarrier": (C.c_int, [vp, C.c_double, dp, C.c_int, dp]),
         "HMiConeGetPresolve": (None, [vp, ip, ip, ip, ip, ip, ip]),
         "HMiConeGetDualMatrix": (C.c_int, [vp, dp]),
@@ -268,6 +276,32 @@ class SDPCone:
         out = C.c_double(0.0)
         _check(load_library().HMiConeGetLogBarrier(self._h, 0.0, None, buffer, C.byref(out)), "HConeGetLogBarrier")
         return out.value
+
+    def coeff_norm(self, which):
+        return load_library().HMiConeGetCoeffNorm(self._h, int(which))
+
+    def obj_norm(self, which):
+        return load_library().HMiConeGetObjNorm(self._h, int(which))
+
+    def scal_by_constant(self, s):
+        load_library().HMiConeScalByConstant(self._h, float(s))
+
+    def a_times_x(self, X, y=None):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        out = np.zeros(self.m) if y is None else np.ascontiguousarray(y, dtype=np.float64).copy()
+        load_library().HMiConeComputeATimesXpy(self._h, _dptr(X), _dptr(out))
+        return out
+
+    def x_dot_s(self, X):
+        return load_library().HMiConeComputeXDotS(self._h, _dptr(np.ascontiguousarray(X, dtype=np.float64)))
+
+    def trace_cx(self, X):
+        return load_library().HMiConeComputeTraceCX(self._h, _dptr(np.ascontiguousarray(X, dtype=np.float64)))
+
+    def get_dual(self):
+        S = np.zeros((self.n, self.n))
+        load_library().HMiConeGetDual(self._h, _dptr(S), None)
+        return S
 
     def reduce_resi(self, v):
         load_library().HMiConeReduceResi(self._h, float(v))

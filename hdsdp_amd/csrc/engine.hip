@@ -23,6 +23,15 @@
 #include <cstring>
 #include <vector>
 
+// kernels defined further down in this file (global scope)
+__global__ void mi_low_norms_kernel(const double *__restrict__ A, long astride, int n, long ld, int count, int a_l_form,
+                                    double *__restrict__ out);
+__global__ void mi_scale_kernel(double *__restrict__ A, long count, double s);
+__global__ void mi_lower_dot_kernel(const double *__restrict__ S, long lds_, const double *__restrict__ X, long ldx, int n,
+                                    double *__restrict__ out);
+__global__ void mi_mat_dot_kernel(const double *__restrict__ X, long ldx, const double *__restrict__ Y, long ldy, int n,
+                                  int diag_only, double scale, double *__restrict__ out);
+
 namespace {
 
 struct Ctx {
@@ -190,8 +199,12 @@ struct MiCone {
     hdsdp_linsys_fp *dualFactor = nullptr;
     HdmChol *primal = nullptr; // KKT_TYPE_PRIMAL: factor object of the registered primal matrix (lazy)
     HdmLanczos *lanczos = nullptr;  // ratio test state (lazy); dS lives in `dS`
+    double nrm[4] = {0, 0, 0, 0}; bool norms_ready = false;   // data norms (rows abs / Frobenius, objective abs / Frobenius)
+    double objScal = 1.0;           // product of the coneScal factors applied to C
     HdmChol *checker = nullptr;     // second factor object (primal recovery works on S without the residual term)
     double *dS = nullptr;
+    double *Xup = nullptr;          // uploaded primal matrix of the cone utilities
+    double *Pr1 = nullptr, *Pr2 = nullptr;   // primal recovery scratch (npad x npad each; Xinv / Yinv are sized per builder path)
     double Rd = 0.0, perturb = 0.0;
     double *trA = nullptr;     // host: tr(A_i) of all m constraints (b of the synthetic family)
     // work space
@@ -489,6 +502,148 @@ hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAda
     return HDSDP_RETCODE_OK;
 }
 
+// ---- the remaining cone utilities of the reference's vtable (hdsdp_conic.c:137-153) ------------------------------------
+// norms of the data: |A|_abs = sum |a_ij|, |A|_F over the full symmetric matrices (hdsdp_sdpdata.c:208-309 computes the same
+// numbers per storage class); the synthetic family has no host copy, its norms come from one pass over the device data
+
+static void coeff_norms(const MiCoeff &a, int n, double *abs_, double *fro2) {
+    // raw lower-triangular entries (packed index): diagonal once, off-diagonal twice
+    double sa = 0.0, sf = 0.0;
+    long colstart = 0;
+    int col = 0;
+    for (size_t k = 0; k < a.idx.size(); ++k) {
+        const long pidx = a.idx[k];
+        while (col < n && pidx >= colstart + (n - col)) { colstart += n - col; ++col; }
+        const bool diag = (pidx == colstart);
+        const double v = a.val[k];
+        sa += diag ? fabs(v) : 2.0 * fabs(v);
+        sf += diag ? v * v : 2.0 * v * v;
+    }
+    *abs_ = sa; *fro2 = sf;
+}
+
+int cone_data_norms(MiCone *c, double *rows_abs, double *rows_fro, double *obj_abs, double *obj_fro) {
+    if (c->norms_ready) {
+        *rows_abs = c->nrm[0]; *rows_fro = c->nrm[1]; *obj_abs = c->nrm[2]; *obj_fro = c->nrm[3];
+        return 0;
+    }
+    double ra = 0.0, rf2 = 0.0, oa = 0.0, of2 = 0.0;
+    if (!c->synthetic) {
+        for (int i = 0; i < c->m; ++i) { double a_, f_; coeff_norms(c->blk.rows[i], c->n, &a_, &f_); ra += a_; rf2 += f_; }
+        coeff_norms(c->blk.obj, c->n, &oa, &of2);
+        oa *= c->objScal; of2 *= c->objScal * c->objScal;
+    } else {
+        double *tmp = nullptr;
+        HDM_HIP_CHECK(hipMalloc((void **) &tmp, sizeof(double) * 4));
+        HDM_HIP_CHECK(hipMemsetAsync(tmp, 0, sizeof(double) * 4, g.stream));
+        if (c->mloc > 0)
+            hipLaunchKernelGGL(mi_low_norms_kernel, dim3(c->mloc), dim3(256), 0, g.stream, c->Afull, (long) c->n16 * c->n16,
+                               c->n, (long) c->n16, c->mloc, 1, tmp);
+        hipLaunchKernelGGL(mi_low_norms_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, 0L, c->n, (long) c->n16, 1, 0, tmp + 2);
+        double h[4];
+        HDM_HIP_CHECK(hipMemcpyAsync(h, tmp, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+        HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
+        (void) hipFree(tmp);
+        ra = h[0]; rf2 = h[1]; oa = h[2]; of2 = h[3];
+        if (c->world > 1 && c->allreduce) {   // rows are sharded: sum the two row totals over the ranks
+            double *dv = nullptr;
+            HDM_HIP_CHECK(hipMalloc((void **) &dv, sizeof(double) * 2));
+            double two[2] = {ra, rf2};
+            HDM_HIP_CHECK(hipMemcpy(dv, two, sizeof(two), hipMemcpyHostToDevice));
+            if (c->allreduce(c->xctx, dv, 2)) return 1;
+            HDM_HIP_CHECK(hipMemcpy(two, dv, sizeof(two), hipMemcpyDeviceToHost));
+            (void) hipFree(dv);
+            ra = two[0]; rf2 = two[1];
+        }
+    }
+    c->nrm[0] = ra; c->nrm[1] = sqrt(rf2); c->nrm[2] = oa; c->nrm[3] = sqrt(of2);
+    c->norms_ready = true;
+    return cone_data_norms(c, rows_abs, rows_fro, obj_abs, obj_fro);
+}
+
+double cone_coeff_norm(void *cd, int whichNorm) {   // sdpDenseConeGetCoeffNorm, hdsdp_conic_sdp.c:1568-1586 (ABS_NORM 1, FRO_NORM 2)
+    double v[4];
+    if (cone_data_norms((MiCone *) cd, v, v + 1, v + 2, v + 3)) return NAN;
+    return whichNorm == 1 ? v[0] : v[1];
+}
+double cone_obj_norm(void *cd, int whichNorm) {     // sdpDenseConeGetObjNorm, :1558-1561
+    double v[4];
+    if (cone_data_norms((MiCone *) cd, v, v + 1, v + 2, v + 3)) return NAN;
+    return whichNorm == 1 ? v[2] : v[3];
+}
+void cone_scal(void *cd, double dScal) {             // sdpDenseConeScal, :1604-1614: the objective is scaled, nothing else
+    MiCone *c = (MiCone *) cd;
+    const long cnt = (long) c->n16 * c->n16;
+    hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, g.stream, c->Cfull, cnt, dScal);
+    if (c->CL) hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, g.stream, c->CL, cnt, dScal);
+    c->objScal *= dScal;
+    c->norms_ready = false;
+    (void) hipStreamSynchronize(g.stream);
+}
+
+// X (host, n x n column-major, symmetric) -> the device scratch matrix Xup (ld = npad of the dual factor)
+static int cone_upload_X(MiCone *c, const double *X, long *ldx) {
+    MiLin *l = (MiLin *) c->dualFactor->chol;
+    const long ld = l->ch.npad;
+    const size_t np2 = sizeof(double) * (size_t) ld * ld;
+    if (!c->Xup) HDM_HIP_CHECK(hipMalloc((void **) &c->Xup, np2));   // (Xinv / Yinv belong to the builders, sized per path)
+    HDM_HIP_CHECK(hipMemsetAsync(c->Xup, 0, np2, g.stream));
+    HDM_HIP_CHECK(hipMemcpy2DAsync(c->Xup, sizeof(double) * ld, X, sizeof(double) * c->n, sizeof(double) * c->n, c->n,
+                                   hipMemcpyHostToDevice, g.stream));
+    *ldx = ld;
+    return 0;
+}
+
+void cone_a_times_x(void *cd, double *X, double *ATimesX) {   // sdpDenseConeATimesX, :2470-2477: y_i += <A_i, X>
+    MiCone *c = (MiCone *) cd;
+    long ldx = 0;
+    double *out = nullptr;
+    if (cone_upload_X(c, X, &ldx)) return;
+    if (hipMalloc((void **) &out, sizeof(double) * 2 * (size_t) c->m) != hipSuccess) return;
+    (void) hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t) c->m, g.stream);
+    // A is stored in A_L form: <A, X> = 2 <A_L, X> for symmetric X
+    if (hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Xup, nullptr, ldx, out, out + c->m,
+                     c->rows_own, 2.0, 0.0, g.stream) == 0) {
+        if (c->world > 1 && c->allreduce) { (void) hipStreamSynchronize(g.stream); (void) c->allreduce(c->xctx, out, c->m); }
+        std::vector<double> h(c->m);
+        if (hipMemcpyAsync(h.data(), out, sizeof(double) * c->m, hipMemcpyDeviceToHost, g.stream) == hipSuccess &&
+            hipStreamSynchronize(g.stream) == hipSuccess)
+            for (int i = 0; i < c->m; ++i) ATimesX[i] += h[i];
+    }
+    (void) hipFree(out);
+}
+
+static double cone_dot_with(MiCone *c, const double *dev, long ldd, int lower_valid, double *X) {
+    long ldx = 0;
+    double *out = nullptr, h = NAN;
+    if (cone_upload_X(c, X, &ldx)) return NAN;
+    if (hipMalloc((void **) &out, sizeof(double)) != hipSuccess) return NAN;
+    (void) hipMemsetAsync(out, 0, sizeof(double), g.stream);
+    if (lower_valid) hipLaunchKernelGGL(mi_lower_dot_kernel, dim3(1), dim3(256), 0, g.stream, dev, ldd, c->Xup, ldx, c->n, out);
+    else hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, dev, ldd, c->Xup, ldx, c->n, 0, 1.0, out);
+    if (hipMemcpyAsync(&h, out, sizeof(double), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+        hipStreamSynchronize(g.stream) != hipSuccess) h = NAN;
+    (void) hipFree(out);
+    return h;
+}
+double cone_trace_cx(void *cd, double *X) {   // sdpDenseConeTraceCX, :2520-2523
+    MiCone *c = (MiCone *) cd;
+    return cone_dot_with(c, c->Cfull, c->n16, 0, X);
+}
+double cone_x_dot_s(void *cd, double *X) {    // sdpDenseConeXDotS, :2549-2560 (S is lower-valid: fds_dot_fds, dense_opts.c:134-156)
+    MiCone *c = (MiCone *) cd;
+    return cone_dot_with(c, c->S, c->n16, 1, X);
+}
+void cone_get_dual(void *cd, double *dConeDual, double *dummy) {   // sdpDenseConeGetDual, :2494-2506: S, symmetrised
+    (void) dummy;
+    MiCone *c = (MiCone *) cd;
+    const int n = c->n;
+    if (hipMemcpy2DAsync(dConeDual, sizeof(double) * n, c->S, sizeof(double) * c->n16, sizeof(double) * n, n,
+                         hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) return;
+    for (int j = 0; j < n; ++j)
+        for (int i = j + 1; i < n; ++i) dConeDual[(size_t) j + (size_t) i * n] = dConeDual[(size_t) i + (size_t) j * n];
+}
+
 // sdpDenseConeGetPrimal (hdsdp_conic_sdp.c:2393-2446), the cone's conePRecover slot:
 //     X = mu * L^-T ( sym( L^-1 dS L^-T ) + I ) L^-1,   S = C - sum y_i A_i = L L^T (no residual term),  dS = sum dy_i A_i.
 // The reference does four triangular solves with n right-hand sides on the checker factor; here S is factored into a
@@ -518,25 +673,25 @@ void cone_precover(void *cd, double dBarrierMu, double *y, double *dy, double *X
     if (hdm_mirror_lower(c->dS, c->n16, n, g.stream)) return fail("mirror");
     if (ch.invert_factor(g.stream)) return fail("triangular inverse failed");
     const size_t np2 = sizeof(double) * (size_t) ch.npad * ch.npad;
-    if (!c->Xinv && hipMalloc((void **) &c->Xinv, np2) != hipSuccess) return fail("out of memory");
-    if (!c->Yinv && hipMalloc((void **) &c->Yinv, np2) != hipSuccess) return fail("out of memory");
+    if (!c->Pr1 && hipMalloc((void **) &c->Pr1, np2) != hipSuccess) return fail("out of memory");
+    if (!c->Pr2 && hipMalloc((void **) &c->Pr2, np2) != hipSuccess) return fail("out of memory");
     HdmGemmArgs q = {};
     q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE; q.ldc = ch.npad;
     // T1 = W dS          (W = Linv)
-    q.A = ch.Linv; q.lda = ch.npad; q.a_kmajor = 0; q.B = c->dS; q.ldb = c->n16; q.b_kmajor = 0; q.C = c->Xinv;
+    q.A = ch.Linv; q.lda = ch.npad; q.a_kmajor = 0; q.B = c->dS; q.ldb = c->n16; q.b_kmajor = 0; q.C = c->Pr1;
     if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
     // Z = T1 W^T
-    q.A = c->Xinv; q.lda = ch.npad; q.a_kmajor = 0; q.B = ch.Linv; q.ldb = ch.npad; q.b_kmajor = 0; q.C = c->Yinv;
+    q.A = c->Pr1; q.lda = ch.npad; q.a_kmajor = 0; q.B = ch.Linv; q.ldb = ch.npad; q.b_kmajor = 0; q.C = c->Pr2;
     if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
-    if (hdm_sym_scale(c->Yinv, ch.npad, c->n16, 1.0, 1.0, g.stream)) return fail("sym");
+    if (hdm_sym_scale(c->Pr2, ch.npad, c->n16, 1.0, 1.0, g.stream)) return fail("sym");
     // T2 = W^T Z
-    q.A = ch.Linv; q.lda = ch.npad; q.a_kmajor = 1; q.B = c->Yinv; q.ldb = ch.npad; q.b_kmajor = 0; q.C = c->Xinv;
+    q.A = ch.Linv; q.lda = ch.npad; q.a_kmajor = 1; q.B = c->Pr2; q.ldb = ch.npad; q.b_kmajor = 0; q.C = c->Pr1;
     if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
     // X = T2 W
-    q.A = c->Xinv; q.lda = ch.npad; q.a_kmajor = 0; q.B = ch.Linv; q.ldb = ch.npad; q.b_kmajor = 1; q.C = c->Yinv;
+    q.A = c->Pr1; q.lda = ch.npad; q.a_kmajor = 0; q.B = ch.Linv; q.ldb = ch.npad; q.b_kmajor = 1; q.C = c->Pr2;
     if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
-    if (hdm_sym_scale(c->Yinv, ch.npad, n, 0.0, dBarrierMu, g.stream)) return fail("sym");
-    if (hipMemcpy2DAsync(X, sizeof(double) * n, c->Yinv, sizeof(double) * ch.npad, sizeof(double) * n, n,
+    if (hdm_sym_scale(c->Pr2, ch.npad, n, 0.0, dBarrierMu, g.stream)) return fail("sym");
+    if (hipMemcpy2DAsync(X, sizeof(double) * n, c->Pr2, sizeof(double) * ch.npad, sizeof(double) * n, n,
                          hipMemcpyDeviceToHost, g.stream) != hipSuccess) return fail("copy");
     (void) hipStreamSynchronize(g.stream);
 }
@@ -768,6 +923,52 @@ __global__ void mi_mat_dot_kernel(const double *__restrict__ X, long ldx, const 
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) *out += scale * (red[0] + red[1] + red[2] + red[3]);
+}
+
+// out[0] += sum |A_ij|, out[1] += sum A_ij^2 over the full symmetric matrices given by their lower triangles; a_l_form:
+// the diagonal is stored halved (engine layout of the constraint matrices).  One workgroup per matrix.
+__global__ void mi_low_norms_kernel(const double *__restrict__ A, long astride, int n, long ld, int count, int a_l_form,
+                                    double *__restrict__ out) {
+    __shared__ double ra[4], rf[4];
+    const double *M = A + (long) blockIdx.x * astride;
+    double sa = 0.0, sf = 0.0;
+    for (long e = threadIdx.x; e < (long) n * n; e += 256) {
+        const int i = (int) (e % n), j = (int) (e / n);
+        if (i < j) continue;
+        double v = M[i + (long) j * ld];
+        if (i == j) { if (a_l_form) v *= 2.0; sa += fabs(v); sf += v * v; }
+        else { sa += 2.0 * fabs(v); sf += 2.0 * v * v; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { sa += __shfl_down(sa, off, 64); sf += __shfl_down(sf, off, 64); }
+    if ((threadIdx.x & 63) == 0) { ra[threadIdx.x >> 6] = sa; rf[threadIdx.x >> 6] = sf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(out, ra[0] + ra[1] + ra[2] + ra[3]);
+        atomicAdd(out + 1, rf[0] + rf[1] + rf[2] + rf[3]);
+    }
+    (void) count;
+}
+
+__global__ void mi_scale_kernel(double *__restrict__ A, long count, double s) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) A[e] *= s;
+}
+
+// out += <S, X> with S given by its lower triangle (fds_dot_fds, dense_opts.c:134-156): 2 * (sum_{i>j} + half the diagonal)
+__global__ void mi_lower_dot_kernel(const double *__restrict__ S, long lds_, const double *__restrict__ X, long ldx, int n,
+                                    double *__restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long e = threadIdx.x; e < (long) n * n; e += 256) {
+        const int i = (int) (e % n), j = (int) (e / n);
+        if (i < j) continue;
+        const double v = S[i + (long) j * lds_] * X[i + (long) j * ldx];
+        s += (i == j) ? 0.5 * v : v;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out += 2.0 * (red[0] + red[1] + red[2] + red[3]);
 }
 
 __device__ __forceinline__ double mi_hash_unit(unsigned x) {  // pseudo-random in (-1, 1)
@@ -1002,6 +1203,9 @@ void cone_destroy_data(void **pcd) {
     if (c->lanczos) { c->lanczos->destroy(); delete c->lanczos; }
     if (c->checker) { c->checker->destroy(); delete c->checker; }
     if (c->dS) (void) hipFree(c->dS);
+    if (c->Xup) (void) hipFree(c->Xup);
+    if (c->Pr1) (void) hipFree(c->Pr1);
+    if (c->Pr2) (void) hipFree(c->Pr2);
     delete c;
     *pcd = nullptr;
 }
@@ -1025,6 +1229,13 @@ hdsdp_cone *new_cone_shell(MiCone *c, int iCone) {
     h->coneAxpyBufferAndCheck = cone_axpy_check;
     h->coneReduceResi = cone_reduce_resi;
     h->coneSetPerturb = cone_set_perturb;
+    h->coneGetCoeffNorm = cone_coeff_norm;
+    h->coneGetObjNorm = cone_obj_norm;
+    h->coneScal = cone_scal;
+    h->coneATimesXpy = cone_a_times_x;
+    h->coneTraceCX = cone_trace_cx;
+    h->coneXDotS = cone_x_dot_s;
+    h->coneDRecover = cone_get_dual;
     h->coneGetBarrier = cone_barrier;
     return h;
 }
@@ -1560,6 +1771,17 @@ hdsdp_retcode HMiConeCheckIsInteriorExpert(hdsdp_cone *cone, double dCCoef, doub
 }
 hdsdp_retcode HMiConeAddStepToBufferAndCheck(hdsdp_cone *cone, double dStep, int whichBuffer, int *isInterior) {
     return cone->coneAxpyBufferAndCheck(cone->coneData, dStep, whichBuffer, isInterior);
+}
+double HMiConeGetCoeffNorm(hdsdp_cone *cone, int whichNorm) { return cone->coneGetCoeffNorm(cone->coneData, whichNorm); }
+double HMiConeGetObjNorm(hdsdp_cone *cone, int whichNorm) { return cone->coneGetObjNorm(cone->coneData, whichNorm); }
+void HMiConeScalByConstant(hdsdp_cone *cone, double dScal) { cone->coneScal(cone->coneData, dScal); }
+void HMiConeComputeATimesXpy(hdsdp_cone *cone, double *dConePrimal, double *dATimesX) {
+    cone->coneATimesXpy(cone->coneData, dConePrimal, dATimesX);
+}
+double HMiConeComputeXDotS(hdsdp_cone *cone, double *dConePrimal) { return cone->coneXDotS(cone->coneData, dConePrimal); }
+double HMiConeComputeTraceCX(hdsdp_cone *cone, double *dConePrimal) { return cone->coneTraceCX(cone->coneData, dConePrimal); }
+void HMiConeGetDual(hdsdp_cone *cone, double *dConeDual, double *dConeDual2) {
+    cone->coneDRecover(cone->coneData, dConeDual, dConeDual2);
 }
 void HMiConeReduceResi(hdsdp_cone *cone, double dResiReduction) { cone->coneReduceResi(cone->coneData, dResiReduction); }
 void HMiConeSetPerturb(hdsdp_cone *cone, double dDualPerturb) { cone->coneSetPerturb(cone->coneData, dDualPerturb); }

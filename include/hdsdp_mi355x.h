@@ -214,6 +214,17 @@ hdsdp_retcode HMiConeCheckIsInteriorExpert(hdsdp_cone *cone, double dCCoef, doub
 hdsdp_retcode HMiConeAddStepToBufferAndCheck(hdsdp_cone *cone, double dStep, int whichBuffer, int *isInterior);
 void HMiConeReduceResi(hdsdp_cone *cone, double dResiReduction);
 void HMiConeSetPerturb(hdsdp_cone *cone, double dDualPerturb);
+/* the remaining HCone* utilities of a dense SDP block (hdsdp_conic.h:44-61; hdsdp_conic_sdp.c:1558-1614, :2470-2560):
+ * data norms (whichNorm: ABS_NORM 1 = sum |a_ij|, FRO_NORM 2, over the full symmetric matrices; rows: sum resp. root of the
+ * sum of squares over the constraints), scaling of the objective, and for a primal matrix X (host, n x n, symmetric)
+ * y_i += <A_i, X>, <C, X>, <X, S>; HMiConeGetDual copies S (symmetrised) to the host. */
+double HMiConeGetCoeffNorm(hdsdp_cone *cone, int whichNorm);
+double HMiConeGetObjNorm(hdsdp_cone *cone, int whichNorm);
+void HMiConeScalByConstant(hdsdp_cone *cone, double dScal);
+void HMiConeComputeATimesXpy(hdsdp_cone *cone, double *dConePrimal, double *dATimesX);
+double HMiConeComputeXDotS(hdsdp_cone *cone, double *dConePrimal);
+double HMiConeComputeTraceCX(hdsdp_cone *cone, double *dConePrimal);
+void HMiConeGetDual(hdsdp_cone *cone, double *dConeDual, double *dConeDual2);
 /* HConeGetPrimal (hdsdp_conic.c:389; sdpDenseConeGetPrimal hdsdp_conic_sdp.c:2393-2446): primal recovery
  * X = mu * L^-T (sym(L^-1 dS L^-T) + I) L^-1 with S = C - sum rowDual_i A_i = L L^T and dS = sum rowDualStep_i A_i;
  * dConePrimal receives the n x n matrix (host, column-major), dConePrimal2 is unused scratch.  If S is not positive

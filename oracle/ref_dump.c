@@ -364,9 +364,25 @@ int main(int argc, char **argv) {
             for (int j = 0; j < n; ++j) { tr += X[j + (size_t) j * n]; for (int i = 0; i < n; ++i) { sm += X[i + (size_t) j * n]; wsum += X[i + (size_t) j * n] * cos(0.013 * i + 0.007 * j); } }
             double cs[3] = { tr, sm, wsum };
             dump_d("pr_checks", cs, 3);
-            free(X); free(aux);
             /* the recovery re-factored the checker and overwrote dualStep: restore the state the rest of the dump expects */
             HDSDP_CALL(HConeCheckIsInterior(cone, tau, y, &isInt));
+            /* the remaining cone utilities on that X (hdsdp_conic_sdp.c:1558-1614, :2470-2560) */
+            {
+                double *ax = calloc(m, sizeof(double));
+                for (int i = 0; i < m; ++i) ax[i] = 0.25 * i;
+                HConeComputeATimesXpy(cone, X, ax);
+                dump_d("ut_atimesx", ax, m);
+                double sc[7];
+                sc[0] = HConeComputeTraceCX(cone, X); sc[1] = HConeComputeXDotS(cone, X);
+                sc[2] = HConeGetCoeffNorm(cone, ABS_NORM); sc[3] = HConeGetCoeffNorm(cone, FRO_NORM);
+                sc[4] = HConeGetObjNorm(cone, ABS_NORM); sc[5] = HConeGetObjNorm(cone, FRO_NORM);
+                HConeScalByConstant(cone, 0.5);
+                sc[6] = HConeGetObjNorm(cone, FRO_NORM);
+                HConeScalByConstant(cone, 2.0);
+                dump_d("ut_scalars", sc, 7);
+                free(ax);
+            }
+            free(X); free(aux);
         }
         free(yr); free(dyr);
     }

@@ -112,6 +112,23 @@ def test_schur_against_reference(name):
             got = np.array([np.trace(X), X.sum(), (X * np.cos(0.013 * ii + 0.007 * jj)).sum()])
             ref = g["pr_checks"]
             assert np.max(np.abs(got - ref)) <= 1e-9 * np.max(np.abs(ref)), (got, ref)
+            if "ut_scalars" in g:
+                # the remaining cone utilities on that X: y += A X, <C, X>, <X, S>, data norms, objective scaling
+                ax = cone.a_times_x(g["pr_X"] if "pr_X" in g else X, 0.25 * np.arange(m))
+                check_close(ax, g["ut_atimesx"], name + " A times X")
+                us = g["ut_scalars"]
+                Xr = g["pr_X"] if "pr_X" in g else X
+                for gotv, refv, what in ((cone.trace_cx(Xr), us[0], "tr CX"), (cone.x_dot_s(Xr), us[1], "X.S"),
+                                         (cone.coeff_norm(1), us[2], "rows abs"), (cone.coeff_norm(2), us[3], "rows fro"),
+                                         (cone.obj_norm(1), us[4], "obj abs"), (cone.obj_norm(2), us[5], "obj fro")):
+                    assert abs(gotv - refv) <= 1e-11 * max(abs(refv), 1e-300), (name, what, gotv, refv)
+                cone.scal_by_constant(0.5)
+                assert abs(cone.obj_norm(2) - us[6]) <= 1e-11 * max(abs(us[6]), 1e-300)
+                cone.scal_by_constant(2.0)
+                Sd = cone.get_dual()
+                assert np.array_equal(Sd, Sd.T)
+                if "S" in g:
+                    assert kkt_err(Sd[lower_mask(n)], g["S"][lower_mask(n)]) < 1e-12
         # --- KKT_TYPE_PRIMAL: the builder on a registered primal matrix (hdsdp_conic_sdp.c:1745-1753)
         if "M_pri" in g:
             kkt.register_psdp([primal_X(n)])
