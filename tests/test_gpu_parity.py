@@ -462,3 +462,53 @@ def test_odd_shapes_against_the_oracle(n, m, monkeypatch):
     finally:
         cone.destroy()
         blk.close()
+
+
+@pytest.mark.parametrize("inst,opt,y_start", [("theta1", 23.0, "first"), ("mcp100", 226.1574, "all")])
+def test_dual_barrier_method_reaches_the_sdplib_optimum(inst, opt, y_start):
+    """end to end through the C ABI only: a feasible-start dual barrier method (Newton step dy = M^-1 (b/mu - ASinv),
+    the Phase-B direction of interface/hdsdp_algo.c:1334-1340, step length from the device ratio test) on the reference's
+    own SDPLIB examples, read with the engine's SDPA reader; the dual objective must reach the published optimum
+    (theta1 23, mcp100 226.1574; SURVEY 6 reproduces them with the reference driver).  gpp100 is left out: its primal
+    has no interior (X . 11' = 0), the dual central path runs off to infinity in y_0, and the reference copes with that
+    through its homogeneous embedding and the box on y, which are driver logic outside this engine."""
+    import os
+    from hdsdp_amd import api
+    here = os.path.dirname(os.path.abspath(__file__))
+    prob = api.read_sdpa(os.path.join(here, "golden", inst + ".dat-s"))
+    n, m = prob["blocks"][0]["n"], prob["m"]
+    blk = prob["blocks"][0]
+    cone = api.SDPCone.from_csc(n, m, blk["beg"], blk["idx"], blk["val"])
+    b = np.asarray(prob["b"], dtype=np.float64)
+    try:
+        kkt = api.KKT(m, [cone])
+        cone.set_start(0.0)                       # no dual residual: S = C - sum y_i A_i
+        y = np.zeros(m)
+        if y_start == "first":
+            y[0] = -100.0
+        else:
+            y[:] = -100.0
+        assert cone.check_is_interior(1.0, y)
+        mu = 1.0
+        for outer in range(40):
+            for inner in range(4):
+                assert cone.check_is_interior(1.0, y)
+                kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+                kkt.factorize()
+                ex = kkt.export()
+                dy = kkt.solve(b / mu - ex["ASinv"])
+                step = cone.ratio_test(0.0, dy, 0.0)
+                alpha = min(1.0, 0.9 * step)
+                y = y + alpha * dy
+                # Newton decrement small -> this mu is done
+                if alpha == 1.0 and np.sqrt(abs(np.dot(dy, b / mu - ex["ASinv"]))) < 0.1:
+                    break
+            if n * mu < 1e-8 * opt:
+                break
+            mu *= 0.25
+        assert cone.check_is_interior(1.0, y)
+        dobj = float(np.dot(b, y))
+        assert abs(abs(dobj) - opt) <= 2e-6 * opt, (inst, dobj, opt, mu)
+        kkt.destroy()
+    finally:
+        cone.destroy()
