@@ -9,11 +9,11 @@ from util import check_close, lower_mask
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,m", [(96, 50), (200, 131)])
-def test_two_ranks_match_one(n, m, tmp_path):
+@pytest.mark.parametrize("n,m,world", [(96, 50, 2), (200, 131, 2), (130, 77, 3)])
+def test_sharded_ranks_match_one(n, m, world, tmp_path):
     out1, out2 = str(tmp_path / "w1.npz"), str(tmp_path / "w2.npz")
     launch("gpu", 1, n, m, out1)
-    launch("gpu", 2, n, m, out2)
+    launch("gpu", world, n, m, out2)
     a, b = np.load(out1), np.load(out2)
     msk = lower_mask(m)
     for tag in ("inf", "hsd"):
