@@ -286,17 +286,27 @@ int cone_alloc_common(MiCone *c) {
 
 int cone_alloc_gemm_work(MiCone *c) {
     const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
-    // batch size: as many constraints per launch as 8 GiB of intermediates allow, at most 256 (each launch pays a
-    // dispatch ramp and a tail: 64 -> 256 per launch measured -1.4 % step time).  The launches are evened out (2000 rows
-    // -> 8 x 250, a rank's 250 rows -> one launch); the kernel's XCD-local decode pads a batch to a multiple of 8 itself.
-    long bc = (long) ((8L << 30) / (double) nn);
-    long bcmax = 256;
+    // batch size: as many constraints per launch as 32 GiB of intermediates allow, at most 1024 (each launch pays a
+    // dispatch ramp and a tail: measured step time 400.9 / 396.8 / 393.2 / 393.2 ms at 256 / 512 / 1000 / 2000 per launch on
+    // one box).  The launches are evened out (2000 rows -> 2 x 1000, a rank's 250 rows -> one launch); the kernel's
+    // XCD-local decode pads a batch to a multiple of 8 itself.  If the allocation fails the batch is halved.
+    long tcap = 32;   // GiB of intermediates
+    if (const char *e = getenv("HDM_TCAP_GIB")) tcap = atol(e);
+    long bc = (long) (((double) tcap * (1L << 30)) / (double) nn);
+    long bcmax = 1024;
     if (const char *e = getenv("HDM_BC")) bcmax = atol(e);
     bc = std::max(1L, std::min(bc, bcmax));
-    const long rows = std::max(1, c->mloc), launches = (rows + bc - 1) / bc;
-    bc = (rows + launches - 1) / launches;
-    c->Bc = (int) bc;
-    HDM_HIP_CHECK(hipMalloc((void **) &c->T, nn * (size_t) c->Bc + hdm_operand_pad(c->n16)));
+    const long rows = std::max(1, c->mloc);
+    for (;;) {
+        const long launches = (rows + bc - 1) / bc;
+        bc = (rows + launches - 1) / launches;
+        c->Bc = (int) bc;
+        if (hipMalloc((void **) &c->T, nn * (size_t) c->Bc + hdm_operand_pad(c->n16)) == hipSuccess) break;
+        (void) hipGetLastError();
+        c->T = nullptr;
+        if (bc <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the congruence intermediates\n"); return 1; }
+        bc /= 2;
+    }
     HDM_HIP_CHECK(hdm_memset_sync(c->T, 0, nn * (size_t) c->Bc));  // step 1 writes lower tiles only; the rest must read as 0
     const size_t ahat = sizeof(double) * (size_t) c->world * c->npb_loc * c->Lr * 16;
     if (!c->AhatLoc) {
@@ -312,8 +322,8 @@ int cone_alloc_gemm_work(MiCone *c) {
     // is the fast workgroup index, and workgroups are dealt round-robin over the 8 XCDs: with nsplit a multiple
     // of 8 every XCD keeps to its own K ranges, so the ~64 tiles it runs concurrently share their row/column
     // panels in that XCD's L2 (profiles/r01_a: with nsplit = 15 the Gram kernel fetched 513 GB per launch,
-    // i.e. every tile load went to the fabric).  Among the multiples of 8 pick the one whose last scheduling
-    // round is fullest (136 tiles x 56 = 14.9 rounds at m = 2000).
+    // i.e. every tile load went to the fabric).  Short K ranges (small problems): among the multiples of 8 pick the
+    // one whose last scheduling round is fullest; long K ranges are handled below.
     const long RT = (c->R + HDM_TILE - 1) / HDM_TILE;
     const long tiles = RT * (RT + 1) / 2;
     const long kblocks = c->npb_loc;

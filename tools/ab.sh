@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of environment switches: tools/ab.sh "HDM_NO_EDGE=1" "HDM_NO_EDGE=0" ...  (each run: bench.py --steps 3)
+# same-box A/B of environment switches: tools/ab.sh "HDM_NSPLIT=64" "HDM_NSPLIT=1024" "HDM_VAR=0" ...  (each run: bench.py --steps 3)
 for cfg in "$@"; do
   env $cfg python bench.py --steps 3 --warmup 1 --no-cpu 2>/dev/null | python -c "
 import json,sys

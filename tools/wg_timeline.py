@@ -14,7 +14,7 @@ kkt = api.KKT(m, [cone], host_mirror=False)
 cone.set_start(-10.0 * n)
 assert cone.check_is_interior(1.0, np.zeros(m))
 kkt.build_up(0)
-nwg = 1 << 16
+nwg = 1 << 18
 dbg = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 lib.HMiSetDebugBuffer(dbg.data_ptr(), role)

@@ -37,7 +37,7 @@ if __name__ == "__main__":
     A = torch.randn(K, N, dtype=torch.float64, device="cuda")   # M-major: element (i,k) at i + k*lda
     B = torch.randn(K, N, dtype=torch.float64, device="cuda")
     Cm = torch.zeros(N, N, dtype=torch.float64, device="cuda")
-    nwg = 1 << 16
+    nwg = 1 << 18
     dbg = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     for rep in range(2):
