@@ -7,8 +7,7 @@
 // residuals.  Here the recurrence and the acceptance logic are the same, step for step; what changes is where the
 // work runs:
 //   * the operator is three dense matrix-vector products with the explicit lower-triangular Linv that the Schur
-//     build needs anyway (HBM-bound: 3 x 32 MB at n = 2000) instead of two latency-bound triangular solves; they go
-//     through the MFMA GEMM with an 8-column right-hand block (column 0 is the vector),
+//     build needs anyway (HBM-bound: 2 x 16 + 32 MB at n = 2000) instead of two latency-bound triangular solves,
 //   * one fused single-workgroup kernel per step does the three-term recurrence, both reductions and the
 //     normalisation, and returns (alpha_k, beta_k) -- two doubles cross PCIe per step,
 //   * the (k+1) x (k+1) Ritz problem is solved on the host by cyclic Jacobi (no LAPACK dependency).
@@ -129,6 +128,51 @@ __global__ __launch_bounds__(1024) void hdm_normalize_kernel(const double *__res
     __syncthreads();
     const double inv = bc > 0.0 ? 1.0 / bc : 0.0;
     for (int i = tid; i < n; i += 1024) { double x = v[i] * inv; V0[i] = x; blk[i] = x; }
+}
+
+// y[j] = alpha * sum_i A[i + j*ld] x[i]  (transposed product: one wavefront per column, contiguous reads).
+// lower != 0: A is lower triangular, rows i < j are skipped (half the traffic).
+__global__ __launch_bounds__(256) void hdm_gemv_t_kernel(const double *__restrict__ A, long ld, int n, int lower, double alpha,
+                                                         const double *__restrict__ x, double *__restrict__ y) {
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const double *col = A + (long) j * ld;
+    double s0 = 0.0, s1 = 0.0;
+    int i = (lower ? (j & ~63) : 0) + lane;
+    for (; i + 64 < n; i += 128) {
+        const double a0 = col[i], a1 = col[i + 64];
+        s0 += ((lower && i < j) ? 0.0 : a0) * x[i];
+        s1 += ((lower && i + 64 < j) ? 0.0 : a1) * x[i + 64];
+    }
+    if (i < n) s0 += ((lower && i < j) ? 0.0 : col[i]) * x[i];
+    double s = s0 + s1;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) y[j] = alpha * s;
+}
+
+// part[c][i] = sum over the columns j of chunk c of A[i + j*ld] x[j]  (plain product, rows across lanes: coalesced);
+// lower != 0: A is lower triangular, column j only reaches rows i >= j.  Reduced in chunk order by the kernel below.
+__global__ __launch_bounds__(256) void hdm_gemv_n_kernel(const double *__restrict__ A, long ld, int n, int lower, int nchunk,
+                                                         const double *__restrict__ x, double *__restrict__ part) {
+    const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    const int cw = (n + nchunk - 1) / nchunk, j0 = c * cw, j1 = min(n, j0 + cw);
+    if (i >= n) return;
+    double s0 = 0.0, s1 = 0.0;
+    const int jend = lower ? min(j1, i + 1) : j1;
+    int j = j0;
+    for (; j + 1 < jend; j += 2) {
+        s0 += A[i + (long) j * ld] * x[j];
+        s1 += A[i + (long) (j + 1) * ld] * x[j + 1];
+    }
+    if (j < jend) s0 += A[i + (long) j * ld] * x[j];
+    part[(long) c * n + i] = s0 + s1;
+}
+__global__ void hdm_gemv_n_reduce_kernel(const double *__restrict__ part, int n, int nchunk, double alpha, double *__restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += part[(long) c * n + i];
+    y[i] = alpha * s;
 }
 
 // upper triangle <- lower triangle of an n x n column-major matrix
@@ -252,6 +296,7 @@ int HdmLanczos::init(int n_) {
     HDM_HIP_CHECK(hipMalloc((void **) &warm, sizeof(double) * (size_t) n16));
     HDM_HIP_CHECK(hipMalloc((void **) &tmp, sizeof(double) * (size_t) n16));
     HDM_HIP_CHECK(hipMalloc((void **) &scal, sizeof(double) * 64));
+    HDM_HIP_CHECK(hipMalloc((void **) &part, sizeof(double) * 32 * (size_t) n16));
     for (double *b : {bv, b1, b2, bw, bz}) HDM_HIP_CHECK(hdm_memset_sync(b, 0, blk));
     HDM_HIP_CHECK(hdm_memset_sync(warm, 0, sizeof(double) * (size_t) n16));
     HDM_HIP_CHECK(hdm_memset_sync(tmp, 0, sizeof(double) * (size_t) n16));
@@ -262,25 +307,24 @@ int HdmLanczos::init(int n_) {
 }
 
 void HdmLanczos::destroy() {
-    for (double *b : {V, bv, b1, b2, bw, bz, warm, tmp, scal})
+    for (double *b : {V, bv, b1, b2, bw, bz, warm, tmp, scal, part})
         if (b) (void) hipFree(b);
-    V = bv = b1 = b2 = bw = bz = warm = tmp = scal = nullptr;
+    V = bv = b1 = b2 = bw = bz = warm = tmp = scal = part = nullptr;
 }
 
-// out block (column 0) = Linv * ( -dS * ( Linv^T * in block ) )
+// out (column 0 of a vector block) = Linv * ( -dS * ( Linv^T * in ) ): three HBM-bound matrix-vector products with
+// dedicated kernels (the first version went through the 128 x 128-tile GEMM with an 8-column block: 0.7 ms per
+// application at n = 2000, launch- and tile-latency bound)
 int HdmLanczos::apply(const double *Linv, long ldl, const double *dS, long ldd, const double *in, double *out, hipStream_t s) {
-    HdmGemmArgs q = {};
-    q.M = n16; q.N = 8; q.K = n16; q.batch = 1; q.epilogue = HDM_EPI_STORE; q.beta = 0.0;
-    q.ldb = n16; q.b_kmajor = 1; q.ldc = n16;
-    // t1 = Linv^T v : A(i,k) = Linv[k + i*ldl]
-    q.A = Linv; q.lda = ldl; q.a_kmajor = 1; q.B = in; q.C = b1; q.alpha = 1.0;
-    if (hdm_launch_gemm(q, s)) return 1;
-    // t2 = -dS t1
-    q.A = dS; q.lda = ldd; q.a_kmajor = 0; q.B = b1; q.C = b2; q.alpha = -1.0;
-    if (hdm_launch_gemm(q, s)) return 1;
-    // w = Linv t2
-    q.A = Linv; q.lda = ldl; q.a_kmajor = 0; q.B = b2; q.C = out; q.alpha = 1.0;
-    if (hdm_launch_gemm(q, s)) return 1;
+    const int nchunk = 32;
+    // t1 = Linv^T v            (column dots of the lower-triangular Linv)
+    hipLaunchKernelGGL(hdm_gemv_t_kernel, dim3((n16 + 3) / 4), dim3(256), 0, s, Linv, ldl, n16, 1, 1.0, in, b1);
+    // t2 = -dS t1              (dS is symmetric: column dots again)
+    hipLaunchKernelGGL(hdm_gemv_t_kernel, dim3((n16 + 3) / 4), dim3(256), 0, s, dS, ldd, n16, 0, -1.0, b1, b2);
+    // w = Linv t2              (rows across lanes, 32 column chunks, deterministic two-level sum)
+    hipLaunchKernelGGL(hdm_gemv_n_kernel, dim3((n16 + 255) / 256, nchunk), dim3(256), 0, s, Linv, ldl, n16, 1, nchunk, b2, part);
+    hipLaunchKernelGGL(hdm_gemv_n_reduce_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, part, n16, nchunk, 1.0, out);
+    HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
