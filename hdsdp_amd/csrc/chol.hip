@@ -61,68 +61,56 @@ __global__ __launch_bounds__(256) void hdm_potrf_diag_kernel(double *__restrict_
     for (int p = 0; p < NB / PB; ++p) {
         const int c0 = p * PB;
         if (tid < 64) {
-            // ---- wave 0: Cholesky + in-place inverse of the 32 x 32 diagonal sub-block, LDS resident.
-            // Lane l owns row l (factorisation) / column l (inverse); the wave runs in lockstep, so a
-            // wavefront fence between a store phase and the dependent load phase is all the ordering needed.
+            // ---- wave 0: Cholesky + inverse of the 32 x 32 diagonal sub-block, REGISTER resident: lane l holds row l
+            // of L (then column l of the inverse) in 32 named doubles, and the value every lane needs in a step
+            // (L[k][j], a uniform) is broadcast with v_readlane and consumed at once as the scalar operand of an FMA.
+            // No LDS traffic and no wave barriers inside the 2 x 496 update steps: 32 K cycles per sub-block against
+            // about twice that for the LDS-resident lockstep version this replaces.  Two things keep the SGPR file from
+            // overflowing: the 32 reciprocal pivots are forced into VGPRs, and the rows pass through an opaque asm
+            // before the inverse so that its broadcasts are not CSE'd with (and kept alive since) the factor's.
             const int l = tid & 31;
-            const bool on = tid < PB;
             double *blk = a + c0 + c0 * NB;          // blk[i + k*NB] = element (i, k) of the sub-block
-#define HDM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+            double row[PB], rinv[PB];
+#pragma unroll
+            for (int k = 0; k < PB; ++k) row[k] = blk[l + k * NB];   // (entries above the diagonal are never used)
             int bad = 0;
+#pragma unroll
             for (int j = 0; j < PB; ++j) {
-                double d = blk[j + j * NB];          // pivot (uniform broadcast read)
-                if (!(d > 0.0)) {                    // also catches NaN
+                double d = hdm_readlane_f64(row[j], j);
+                if (!(d > 0.0)) {                    // uniform; also catches NaN
                     if (!bad) bad = j + 1;
                     d = 1.0;
                 }
-                const double piv = sqrt(d), rinv = 1.0 / piv;
-                double v = 0.0;
-                if (on && l >= j) {
-                    v = (l == j) ? piv : blk[l + j * NB] * rinv;
-                    blk[l + j * NB] = v;             // column j of L
-                }
-                HDM_WAVE_SYNC();
-                if (on && l > j) {
-                    // row l, cols j+1..l; iterations are independent: issue the LDS reads in batches of 8
-                    int k = j + 1;
-                    for (; k + 7 <= l; k += 8) {
-                        double t[8], u[8];
+                const double piv = sqrt(d);
+                double ri = 1.0 / piv;
+                asm volatile("" : "+v"(ri));
+                rinv[j] = ri;
+                row[j] = (l == j) ? piv : row[j] * ri;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) { t[q] = blk[l + (k + q) * NB]; u[q] = blk[(k + q) + j * NB]; }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) blk[l + (k + q) * NB] = t[q] - v * u[q];
-                    }
-                    for (; k <= l; ++k) blk[l + k * NB] -= v * blk[k + j * NB];
-                }
-                HDM_WAVE_SYNC();
+                for (int k = j + 1; k < PB; ++k) row[k] -= row[j] * hdm_readlane_f64(row[j], k);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (bad && tid == 0) atomicCAS(info, 0, col0 + c0 + bad);
-            if (on) {
-                for (int k = 0; k <= l; ++k) A[(c0 + l) + (long) (c0 + k) * ld] = blk[l + k * NB];
+            if (tid < PB) {
+#pragma unroll
+                for (int k = 0; k < PB; ++k)
+                    if (k <= l) A[(c0 + l) + (long) (c0 + k) * ld] = row[k];
             }
-            // in-place inverse, row by row: X[i][c] = (delta_ic - sum_{k=c}^{i-1} L[i][k] X[k][c]) / L[i][i];
-            // row i of L is last read in step i, rows < i already hold X
+#pragma unroll
+            for (int k = 0; k < PB; ++k) asm volatile("" : "+v"(row[k]));
+            double x[PB];                            // lane c: column c of X = L^-1
+#pragma unroll
             for (int i = 0; i < PB; ++i) {
-                double s = 0.0;
-                const double dinv = 1.0 / blk[i + i * NB];
-                if (on && l <= i) {
-                    s = (l == i) ? 1.0 : 0.0;
-                    int k = l;
-                    for (; k + 7 < i; k += 8) {
-                        double t[8], u[8];
+                double sacc = (l == i) ? 1.0 : 0.0;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) { t[q] = blk[i + (k + q) * NB]; u[q] = blk[(k + q) + l * NB]; }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) s -= t[q] * u[q];
-                    }
-                    for (; k < i; ++k) s -= blk[i + k * NB] * blk[k + l * NB];
-                    s *= dinv;
-                }
-                HDM_WAVE_SYNC();
-                if (on && l <= i) blk[i + l * NB] = s;
-                HDM_WAVE_SYNC();
+                for (int k = 0; k < i; ++k) sacc -= hdm_readlane_f64(row[k], i) * x[k];
+                x[i] = (l <= i) ? sacc * rinv[i] : 0.0;
+                __builtin_amdgcn_sched_barrier(0);
             }
-#undef HDM_WAVE_SYNC
+            if (tid < PB) {
+#pragma unroll
+                for (int i = 0; i < PB; ++i) blk[i + l * NB] = x[i];   // X[i][l]; zeros above the diagonal
+            }
         }
         __syncthreads();
         const int t0 = c0 + PB, nr = NB - t0;
