@@ -28,6 +28,7 @@
 // L goes to global memory as soon as a piece is final; the inverse is left in LDS and written once.
 // ------------------------------------------------------------------------------------------
 #define PB 32
+#define LDW 98   // row stride of the inverse-assembly scratch W (98 * 8 B = 196 banks: 16 lanes -> 16 distinct bank pairs)
 __device__ __forceinline__ double hdm_readlane_f64(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, lane);
@@ -35,11 +36,55 @@ __device__ __forceinline__ double hdm_readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+typedef double hdm_c4 __attribute__((ext_vector_type(4)));
+
+// Small matrix products between LDS-resident operands on the fp64 MFMA, shared by the four waves of the diagonal-block
+// kernel:  C(m, n) (+)= alpha * sum_k A(m, k) * B(k, n),  A(m, k) = pa[m*ars + k*acs],  B(k, n) = pb[k*brs + n*bcs],
+// C(m, n) = pc[m*crs + n*ccs];  M, N multiples of 16, K of 4.  Work is dealt in units of one 16-row strip with NT (1 or
+// 2) adjacent 16-column tiles; a wave finishes reading a unit's operands before it writes the unit, so an output may
+// alias the A operand as long as units own their rows (the in-place panel).  k_by_row: A is lower triangular relative
+// to the unit's row offset (k <= row), the K loop stops at the strip's last row.  lower_only: units strictly above the
+// diagonal of a square output are skipped.
+// v_mfma_f64_16x16x4_f64(P, Q): lane (l15, lq) supplies P[l15][lq], Q[l15][lq]; it returns D[lq + 4r][l15] = sum_k P[lq+4r][k] Q[l15][k].
+template <int NT>
+__device__ __forceinline__ void hdm_lds_mm(double *pc, int crs, int ccs, const double *pa, int ars, int acs, const double *pb,
+                                           int brs, int bcs, int M, int N, int K, double alpha, int accumulate, int k_by_row,
+                                           int lower_only, int wave, int lane, double *gout, long gld) {
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int mt = M >> 4, nt = (N >> 4) / NT, units = mt * nt;
+    for (int u = wave; u < units; u += 4) {
+        const int ti = u / nt, tj = (u % nt) * NT;
+        if (lower_only && tj > ti) continue;
+        hdm_c4 acc[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[q] = (hdm_c4){0.0, 0.0, 0.0, 0.0};
+        const int kend = k_by_row ? min(K, (ti + 1) * 16) : K;
+        const double *qa = pa + (ti * 16 + l15) * ars + lq * acs;
+        const double *qb = pb + lq * brs + (tj * 16 + l15) * bcs;
+        for (int k0 = 0; k0 < kend; k0 += 4) {
+            const double av = qa[k0 * acs];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(qb[k0 * brs + q * 16 * bcs], av, acc[q], 0, 0, 0);
+        }
+        // lane (l15, lq), register r of acc[q]:  C(ti*16 + l15, (tj + q)*16 + lq + 4r)
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = ti * 16 + l15, n = (tj + q) * 16 + lq + 4 * r;
+                double *c = pc + m * crs + n * ccs;
+                const double v = (accumulate ? *c : 0.0) + alpha * acc[q][r];
+                *c = v;
+                if (gout) gout[m + (long) n * gld] = v;
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void hdm_potrf_diag_kernel(double *__restrict__ A, long ld, double *__restrict__ Dinv,
                                                               int *__restrict__ info, int col0) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *a = sm;             // [NB][NB] column-major: L below the diagonal blocks, inverses on them
-    double *w = sm + NB * NB;   // [96][PB] scratch for the inverse assembly
+    double *w = sm + NB * NB;   // [PB][LDW] scratch for the inverse assembly: W(k, c) = w[k + c * LDW]
     const int tid = threadIdx.x;
     // block load: 16 independent global loads in flight per thread (a conditional load per iteration would
     // serialise 64 global round trips)
@@ -115,66 +160,31 @@ __global__ __launch_bounds__(256) void hdm_potrf_diag_kernel(double *__restrict_
         __syncthreads();
         const int t0 = c0 + PB, nr = NB - t0;
         if (nr <= 0) break;
-        {   // ---- panel: P[r][c] = sum_{k<=c} B[r][k] * X[c][k]   (B = rows t0.. of block column p)
-            const int c = tid & 31;
-            for (int rr = tid >> 5; rr < nr; rr += 8) {
-                const int rg = t0 + rr;
-                const double *brow = a + rg + c0 * NB, *xrow = a + (c0 + c) + c0 * NB;
-                double s = 0.0;
-#pragma unroll 8
-                for (int k = 0; k < PB; ++k) s += brow[k * NB] * xrow[k * NB];
-                // the 32 lanes that share row rg sit in one wave and run in lockstep: every one of them has
-                // finished reading the row before the first of them stores into it
-                __builtin_amdgcn_wave_barrier();
-                a[rg + (c0 + c) * NB] = s;
-                A[rg + (long) (c0 + c) * ld] = s;
-            }
-        }
+        const int wave = tid >> 6, lane = tid & 63;
+        // ---- panel, in place:  P = B * X_pp^T  (B = rows t0.. of block column p; X_pp lower triangular with exact zeros
+        // above its diagonal), written to LDS and to global memory.  Units are 16-row strips of both column tiles.
+        hdm_lds_mm<2>(a + t0 + c0 * NB, 1, NB, a + t0 + c0 * NB, 1, NB, a + c0 + c0 * NB, NB, 1, nr, PB, PB, 1.0, 0, 0, 0, wave,
+                      lane, A + t0 + (long) c0 * ld, ld);
         __syncthreads();
-        {   // ---- trailing update: A22[i][k] -= sum_q P[i][q] * P[k][q],  i >= k
-            const int tx = tid & 15, ty = tid >> 4;
-            for (int kk = ty; kk < nr; kk += 16) {
-                for (int ii = tx + (kk & ~15); ii < nr; ii += 16) {
-                    if (ii < kk) continue;
-                    const int ig = t0 + ii, kg = t0 + kk;
-                    double s = 0.0;
-#pragma unroll 8
-                    for (int q = 0; q < PB; ++q) s += a[ig + (c0 + q) * NB] * a[kg + (c0 + q) * NB];
-                    a[ig + kg * NB] -= s;
-                }
-            }
-        }
+        // ---- trailing update:  A22 -= P P^T  on the lower 16 x 16 tiles
+        hdm_lds_mm<1>(a + t0 + t0 * NB, 1, NB, a + t0 + c0 * NB, 1, NB, a + t0 + c0 * NB, NB, 1, nr, nr, PB, -1.0, 1, 0, 1, wave,
+                      lane, nullptr, 0);
         __syncthreads();
     }
-    // ---- inverse assembly (diagonal sub-blocks of `a` already hold their inverses)
-    for (int j = NB / PB - 2; j >= 0; --j) {
-        const int c0 = j * PB, r0 = c0 + PB, nr = NB - r0;
-        const int rl = tid & 31, cg = tid >> 5;
-        // W = L[r0:, c0:c0+32] * X_jj
-        for (int rb = 0; rb < nr; rb += 32) {
-            const int rg = r0 + rb + rl;
-            const double *lrow = a + rg + c0 * NB;
-            for (int c = cg; c < PB; c += 8) {
-                const double *xcol = a + c0 + (c0 + c) * NB;
-                double s = 0.0;
-#pragma unroll 8
-                for (int k = 0; k < PB; ++k) s += lrow[k * NB] * xcol[k];
-                w[(rb + rl) + c * 96] = s;
-            }
+    // ---- inverse assembly (diagonal sub-blocks of `a` already hold their inverses), block column by block column,
+    // right to left:  W = L[r0:, c0:c0+32] * X_jj  into the scratch (k-contiguous, row stride LDW: conflict-free as the
+    // next product's B operand), then  X[r0:, c0:c0+32] = -X[r0:, r0:] * W  with the K loop cut at the row (lower triangular)
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int j = NB / PB - 2; j >= 0; --j) {
+            const int c0 = j * PB, r0 = c0 + PB, nr = NB - r0;
+            hdm_lds_mm<2>(w, 1, LDW, a + r0 + c0 * NB, 1, NB, a + c0 + c0 * NB, 1, NB, nr, PB, PB, 1.0, 0, 0, 0, wave, lane,
+                          nullptr, 0);
+            __syncthreads();
+            hdm_lds_mm<2>(a + r0 + c0 * NB, 1, NB, a + r0 + r0 * NB, 1, NB, w, 1, LDW, nr, PB, nr, -1.0, 0, 1, 0, wave, lane,
+                          nullptr, 0);
+            __syncthreads();
         }
-        __syncthreads();
-        // X[r0:, c0:c0+32] = -Xtrail * W   (Xtrail = a[r0:, r0:], lower triangular with exact zeros above)
-        for (int rb = 0; rb < nr; rb += 32) {
-            const int rg = r0 + rb + rl;
-            for (int c = cg; c < PB; c += 8) {
-                double s = 0.0;
-                const int kmax = (rb + 32 < nr) ? rb + 32 : nr;
-#pragma unroll 8
-                for (int k = 0; k < kmax; ++k) s += a[rg + (r0 + k) * NB] * w[k + c * 96];
-                a[rg + (c0 + c) * NB] = -s;
-            }
-        }
-        __syncthreads();
     }
     for (int e = tid; e < NB * NB; e += 256) Dinv[e] = a[e];
 }
@@ -314,7 +324,7 @@ int HdmChol::init(int n_) {
     HDM_HIP_CHECK(hipMalloc((void **) &vec, sizeof(double) * (size_t) npad * 4));
     HDM_HIP_CHECK(hdm_memset_sync(L, 0, mat));
     HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (NB * NB + 96 * 32 + 64) * (int) sizeof(double)));
+                                      (NB * NB + LDW * PB) * (int) sizeof(double)));
     return 0;
 }
 
@@ -370,7 +380,7 @@ int HdmChol::set_reverse_inverse(hipStream_t s) {
 int HdmChol::factor(hipStream_t s, int *info_host) {
     HDM_HIP_CHECK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
     const long ld = npad;
-    const size_t shm = (NB * NB + 96 * 32 + 64) * sizeof(double);
+    const size_t shm = (NB * NB + LDW * PB) * sizeof(double);
     for (int k = 0; k < nblk; ++k) {
         double *Akk = L + (long) k * NB * (ld + 1);
         hipLaunchKernelGGL(hdm_potrf_diag_kernel, dim3(1), dim3(256), shm, s, Akk, ld, Dinv + (long) k * NB * NB,
