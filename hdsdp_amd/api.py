@@ -33,7 +33,7 @@ EXPORTS = [
     "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeCheckIsInteriorExpert",
     "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetCoeffNorm", "HMiConeGetObjNorm",
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
-    "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange",
+    "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
     "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
@@ -127,6 +127,7 @@ def load_library():
         "HMiConeGetPath": (C.c_int, [vp]),
         "HMiKKTSetHostMirror": (None, [kp, C.c_int]),
         "HMiConeSetExchange": (None, [vp, vp, vp, vp]),
+        "HMiConeSetExchangePieces": (None, [vp, vp, vp, C.c_int]),
         "HMiConeGetExchangeBuffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]),
         "HMiConeSetExchangeBuffers": (C.c_int, [vp, vp, vp]),
         "HMiKKTDeviceMatrix": (vp, [kp, C.POINTER(C.c_int64)]),

@@ -221,6 +221,9 @@ struct MiCone {
     double *U = nullptr, *V = nullptr, *Gr1 = nullptr, *Ct = nullptr, *W = nullptr, *Xinv = nullptr, *Yinv = nullptr;
     // exchange hooks (world > 1)
     hmi_alltoall_fn alltoall = nullptr;
+    hmi_alltoall_piece_fn a2a_start = nullptr;   // piecewise exchange overlapped with the Gram product (optional)
+    hmi_alltoall_wait_fn a2a_wait = nullptr;
+    int a2a_pieces = 1;
     hmi_allreduce_fn allreduce = nullptr;
     void *xctx = nullptr;
     bool work_ready = false;
@@ -738,22 +741,65 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, in
     return 0;
 }
 
-int gram_all(MiCone *c) {
-    // Gm(lower) = sum over this rank's p-range of Ahat * Ahat^T, rows in segment order
+// Gram partial sums of the K splits [z0, z0 + nz): slabs z0.. <- Ahat * Ahat^T over their share of this rank's p-range
+int gram_splits(MiCone *c, int z0, int nz) {
     HdmGemmArgs gq = {};
     gq.A = c->AhatAll; gq.B = c->AhatAll; gq.a_kmajor = 1; gq.b_kmajor = 1;
     gq.lda = 16; gq.ldb = 16; gq.a_kblk = (long) c->Lr * 16; gq.b_kblk = (long) c->Lr * 16;
     if (c->world > 1) { gq.seg_rows = c->Lr; gq.seg_extra = c->npb_loc * c->Lr * 16 - (long) c->Lr * 16; }
-    gq.C = c->slabs; gq.ldc = c->R; gq.M = (int) c->R; gq.N = (int) c->R; gq.K = (int) (c->npb_loc * 16);
-    gq.lower_only = 1; gq.epilogue = HDM_EPI_SLAB; gq.batch = c->nsplit;
-    long chunk = (c->npb_loc + c->nsplit - 1) / c->nsplit;
+    gq.ldc = c->R; gq.M = (int) c->R; gq.N = (int) c->R; gq.K = (int) (c->npb_loc * 16);
+    gq.lower_only = 1; gq.epilogue = HDM_EPI_SLAB; gq.batch = nz;
+    const long chunk = (c->npb_loc + c->nsplit - 1) / c->nsplit;
     gq.k_chunk = chunk * 16; gq.slab_stride = c->R * c->R; gq.alpha = 1.0; gq.role = HDM_ROLE_GRAM;
+    gq.k_base = (long) z0 * gq.k_chunk;
+    gq.C = c->slabs + (long) z0 * gq.slab_stride;
     {   // (m+3)(m+4)/2 inner products of length n(n+1)/2 (this rank's share), 2 flops each
         const double rows = (double) c->m + 3.0;
-        gq.flops = rows * (rows + 1.0) * 0.5 * ((double) c->n * (c->n + 1) * 0.5) * 2.0 / c->world;
+        gq.flops = rows * (rows + 1.0) * 0.5 * ((double) c->n * (c->n + 1) * 0.5) * 2.0 / c->world * ((double) nz / c->nsplit);
     }
-    if (hdm_launch_gemm(gq, g.stream)) return 1;
+    return hdm_launch_gemm(gq, g.stream);
+}
+
+int gram_all(MiCone *c) {
+    // Gm(lower) = sum over this rank's p-range of Ahat * Ahat^T, rows in segment order
+    if (gram_splits(c, 0, c->nsplit)) return 1;
     return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, c->R, g.stream);
+}
+
+// world > 1: the all-to-all that re-shards Ahat from "by constraint" to "by packed-index range", and the Gram product.
+// With the piecewise hooks registered the exchange runs in pieces along the packed index and the Gram splits of a piece
+// start as soon as it has arrived, while the later pieces are still on the links.
+hdsdp_retcode exchange_and_gram(MiCone *c) {
+    if (!c->alltoall && !(c->a2a_start && c->a2a_wait)) {
+        fprintf(stderr, "[hdsdp_mi355x] world > 1 but no exchange hook registered\n");
+        return HDSDP_RETCODE_FAILED;
+    }
+    HIP_RC(hipStreamSynchronize(g.stream));
+    int P = (c->a2a_start && c->a2a_wait) ? c->a2a_pieces : 1;
+    if (const char *e = getenv("HDSDP_MI355X_A2A_PIECES")) P = std::max(1, atoi(e));
+    if (!(c->a2a_start && c->a2a_wait)) P = 1;
+    while (P > 1 && (c->nsplit % P)) --P;            // pieces are whole groups of K splits
+    if (P <= 1) {
+        if (c->alltoall) { if (c->alltoall(c->xctx)) return HDSDP_RETCODE_FAILED; }
+        else {
+            if (c->a2a_start(c->xctx, 0, (int64_t) c->npb_loc * c->Lr * 16, 0) || c->a2a_wait(c->xctx, 0)) return HDSDP_RETCODE_FAILED;
+        }
+        return gram_all(c) ? HDSDP_RETCODE_FAILED : HDSDP_RETCODE_OK;
+    }
+    const long chunk = (c->npb_loc + c->nsplit - 1) / c->nsplit;   // p-blocks per split
+    const int zper = c->nsplit / P;
+    const int64_t total = (int64_t) c->npb_loc * c->Lr * 16;       // doubles per (source, destination) chunk
+    for (int k = 0; k < P; ++k) {
+        const int64_t off = std::min<int64_t>(total, (int64_t) k * zper * chunk * c->Lr * 16);
+        const int64_t end = (k == P - 1) ? total : std::min<int64_t>(total, (int64_t) (k + 1) * zper * chunk * c->Lr * 16);
+        if (c->a2a_start(c->xctx, off, end - off, k)) return HDSDP_RETCODE_FAILED;
+    }
+    for (int k = 0; k < P; ++k) {
+        if (c->a2a_wait(c->xctx, k)) return HDSDP_RETCODE_FAILED;
+        if (gram_splits(c, k * zper, zper)) return HDSDP_RETCODE_FAILED;
+    }
+    return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, c->R, g.stream) ? HDSDP_RETCODE_FAILED
+                                                                                                 : HDSDP_RETCODE_OK;
 }
 
 hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT, HdmChol *chOverride = nullptr);
@@ -871,15 +917,8 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
         }
     }
     HIP_RC(hipEventRecord(g.ev[2], g.stream));
-    if (c->world > 1) {
-        if (!c->alltoall) {
-            fprintf(stderr, "[hdsdp_mi355x] world > 1 but no exchange hook registered\n");
-            return HDSDP_RETCODE_FAILED;
-        }
-        HIP_RC(hipStreamSynchronize(g.stream));
-        if (c->alltoall(c->xctx)) return HDSDP_RETCODE_FAILED;
-    }
-    RC(gram_all(c));
+    if (c->world > 1) { RC(exchange_and_gram(c)); }
+    else { RC(gram_all(c)); }
     HIP_RC(hipEventRecord(g.ev[3], g.stream));
     if (c->world > 1) {
         HIP_RC(hipStreamSynchronize(g.stream));
@@ -1561,6 +1600,10 @@ void HKKTDestroy(hdsdp_kkt **pHKKT) {
 }
 
 void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM) { priv_of(HKKT)->mirror = mirrorM; }
+void HMiConeSetExchangePieces(hdsdp_cone *cone, hmi_alltoall_piece_fn start, hmi_alltoall_wait_fn wait, int npieces) {
+    MiCone *c = (MiCone *) cone->coneData;
+    c->a2a_start = start; c->a2a_wait = wait; c->a2a_pieces = std::max(1, npieces);
+}
 void HMiConeSetExchange(hdsdp_cone *cone, hmi_alltoall_fn a2a, hmi_allreduce_fn ar, void *ctx) {
     MiCone *c = (MiCone *) cone->coneData;
     c->alltoall = a2a; c->allreduce = ar; c->xctx = ctx;

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     if (a.klimit == HDM_KLIM_BAND) { kbeg = (long) tn * HDM_TILE; kend = min((long) a.K, (long) (tm + 1) * HDM_TILE); }
     const double *A = a.A, *B = a.B;
     if (a.epilogue == HDM_EPI_SLAB) {
-        kbeg = (long) z * a.k_chunk;
+        kbeg = a.k_base + (long) z * a.k_chunk;
         kend = min(kend, kbeg + a.k_chunk);
     } else {
         A += (long) z * a.strideA;

@@ -91,6 +91,7 @@ struct HdmGemmArgs {
     int nblk;             // n/16: sub-blocks per matrix edge
     // SLAB epilogue / split-K
     long k_chunk;         // K range per split (multiple of HDM_BK)
+    long k_base;          // first k of split 0 (a launch may cover a sub-range of the splits; C then points at its first slab)
     long slab_stride;     // elements between slabs
 };
 

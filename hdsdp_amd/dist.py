@@ -97,7 +97,7 @@ class Exchange:
     backend "gloo": device buffers are staged through host memory (used to rehearse world > 1 with every
     rank on one GPU, and on CPU-only boxes for the layout tests)."""
 
-    def __init__(self, cone, group=None):
+    def __init__(self, cone, group=None, pieces=4):
         import torch
         import torch.distributed as dist
         from . import api
@@ -120,6 +120,14 @@ class Exchange:
         self._a2a = C.CFUNCTYPE(C.c_int, C.c_void_p)(self._alltoall)
         self._ar = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)(self._allreduce)
         lib.HMiConeSetExchange(cone._h, C.cast(self._a2a, C.c_void_p), C.cast(self._ar, C.c_void_p), None)
+        # piecewise exchange: the engine starts all pieces, then waits for piece k and launches the Gram splits of its
+        # index range while pieces k+1.. are still on the links (RCCL runs them on its own stream)
+        self._a2a_start = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int)(self._alltoall_piece)
+        self._a2a_wait = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)(self._alltoall_wait)
+        self._works = {}
+        self._comm = torch.cuda.Stream() if self.backend != "gloo" else None
+        lib.HMiConeSetExchangePieces(cone._h, C.cast(self._a2a_start, C.c_void_p), C.cast(self._a2a_wait, C.c_void_p),
+                                     pieces if self.world > 1 else 1)
         self.bytes_a2a = 0
         self.bytes_ar = 0
 
@@ -137,6 +145,40 @@ class Exchange:
             return 0
         except Exception as e:  # a Python exception must not unwind through the C frame
             print("[hdsdp_amd.dist] all_to_all failed:", e, flush=True)
+            return 1
+
+    def _alltoall_piece(self, ctx, off, cnt, piece):
+        try:
+            chunk = self.plan.chunk
+            ins = [self.send[d * chunk + off:d * chunk + off + cnt] for d in range(self.world)]
+            outs = [self.recv[s * chunk + off:s * chunk + off + cnt] for s in range(self.world)]
+            if self.backend == "gloo":
+                si = self.torch.cat([t.cpu() for t in ins])
+                ro = self.torch.empty_like(si)
+                self.dist.all_to_all_single(ro, si, group=self.group)
+                for s_, t in enumerate(outs):
+                    t.copy_(ro[s_ * cnt:(s_ + 1) * cnt])
+                self.torch.cuda.synchronize()
+                self._works[piece] = None
+            else:
+                with self.torch.cuda.stream(self._comm):
+                    self._works[piece] = self.dist.all_to_all(outs, ins, group=self.group, async_op=True)
+            self.bytes_a2a += int(cnt) * 8 * self.world
+            return 0
+        except Exception as e:
+            print("[hdsdp_amd.dist] all_to_all piece failed:", e, flush=True)
+            return 1
+
+    def _alltoall_wait(self, ctx, piece):
+        try:
+            w = self._works.pop(piece, None)
+            if w is not None:
+                with self.torch.cuda.stream(self._comm):
+                    w.wait()
+                self._comm.synchronize()
+            return 0
+        except Exception as e:
+            print("[hdsdp_amd.dist] all_to_all wait failed:", e, flush=True)
             return 1
 
     def _allreduce(self, ctx, buf, count):

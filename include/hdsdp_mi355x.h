@@ -262,6 +262,14 @@ void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM);   /* default 1: kktMatEl
 typedef int (*hmi_alltoall_fn)(void *ctx);
 typedef int (*hmi_allreduce_fn)(void *ctx, void *buf, int64_t count);
 void HMiConeSetExchange(hdsdp_cone *cone, hmi_alltoall_fn a2a, hmi_allreduce_fn ar, void *ctx);
+/* optional: the all-to-all in `npieces` pieces along the packed index, so that the Gram product over a piece's index
+ * range runs while the later pieces are still in flight.  start(ctx, offset, count, piece): begin exchanging the `count`
+ * doubles at `offset` of EVERY chunk (send chunk r -> rank r, into recv chunk <source rank> at the same offset), may
+ * return before the data has arrived; wait(ctx, piece): return once that piece is in place.  Called with the engine
+ * stream idle (the congruence is complete), pieces are started in order 0..npieces-1 and waited for in that order. */
+typedef int (*hmi_alltoall_piece_fn)(void *ctx, int64_t offset, int64_t count, int piece);
+typedef int (*hmi_alltoall_wait_fn)(void *ctx, int piece);
+void HMiConeSetExchangePieces(hdsdp_cone *cone, hmi_alltoall_piece_fn start, hmi_alltoall_wait_fn wait, int npieces);
 /* exchange buffers (device pointers, `world` chunks of *chunkCount doubles each); the caller may instead
  * supply its own (e.g. torch-allocated) buffers before the first HKKTBuildUp: world * chunkCount doubles of payload
  * plus 8192 doubles of slack behind it (the Gram kernel stages whole 128-row tiles without a row mask) */

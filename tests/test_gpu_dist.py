@@ -47,6 +47,11 @@ assert ex.backend == "nccl" and ex.world == 1
 ex.send.copy_(torch.arange(ex.send.numel(), dtype=torch.float64, device="cuda"))
 assert ex._alltoall(None) == 0
 assert torch.equal(ex.recv, ex.send)
+# the piecewise flavour (list all_to_all, asynchronous on the side stream): two pieces of the one chunk
+half = ex.plan.chunk // 2
+assert ex._alltoall_piece(None, 0, half, 0) == 0 and ex._alltoall_piece(None, half, ex.plan.chunk - half, 1) == 0
+assert ex._alltoall_wait(None, 0) == 0 and ex._alltoall_wait(None, 1) == 0
+assert torch.equal(ex.recv, ex.send)
 buf = torch.full((1000,), 2.5, dtype=torch.float64, device="cuda")
 assert ex._allreduce(None, buf.data_ptr(), 1000) == 0
 assert float(buf.sum()) == 2500.0
