@@ -64,9 +64,10 @@ def test_gemm_triangular_k_limits():
     assert np.all(got[~msk] == 0.0)  # lower_only leaves the strict upper part untouched
 
 
-@pytest.mark.parametrize("n", [50, 128, 300, 517])
+@pytest.mark.parametrize("n", [50, 128, 300, 400, 517, 1000])
 def test_dense_direct_linsys(n):
-    """HFpLinsys* dense-direct surface vs LAPACK semantics (linalg/hdsdp_linsolver.c:1082-1260)"""
+    """HFpLinsys* dense-direct surface vs LAPACK semantics (linalg/hdsdp_linsolver.c:1082-1260); 1, 2, 3, 4, 5 and 8
+    diagonal blocks: the triangular inverse runs by recursive doubling for 2, 4, 8 and by the block-column sweep otherwise"""
     from hdsdp_amd import api
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n, n))
