@@ -792,7 +792,16 @@ hdsdp_retcode exchange_and_gram(MiCone *c) {
     for (int k = 0; k < P; ++k) {
         const int64_t off = std::min<int64_t>(total, (int64_t) k * zper * chunk * c->Lr * 16);
         const int64_t end = (k == P - 1) ? total : std::min<int64_t>(total, (int64_t) (k + 1) * zper * chunk * c->Lr * 16);
-        if (c->a2a_start(c->xctx, off, end - off, k)) return HDSDP_RETCODE_FAILED;
+        if (c->a2a_start(c->xctx, off, end - off, k)) {
+            if (k == 0 && c->alltoall) {
+                // the piecewise flavour is not available in this process group: one blocking exchange from now on
+                fprintf(stderr, "[hdsdp_mi355x] piecewise all-to-all failed to start; using the blocking exchange\n");
+                c->a2a_pieces = 1; c->a2a_start = nullptr; c->a2a_wait = nullptr;
+                if (c->alltoall(c->xctx)) return HDSDP_RETCODE_FAILED;
+                return gram_all(c) ? HDSDP_RETCODE_FAILED : HDSDP_RETCODE_OK;
+            }
+            return HDSDP_RETCODE_FAILED;
+        }
     }
     for (int k = 0; k < P; ++k) {
         if (c->a2a_wait(c->xctx, k)) return HDSDP_RETCODE_FAILED;
