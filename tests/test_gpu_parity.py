@@ -512,3 +512,57 @@ def test_dual_barrier_method_reaches_the_sdplib_optimum(inst, opt, y_start):
         kkt.destroy()
     finally:
         cone.destroy()
+
+
+def test_cpu_extra_cone_writes_through_the_host_mirror():
+    """the driver's HKKTBuildUpExtraCone (hdsdp_algo.c:1087,:1735): a CPU cone -- here a stand-in for the y-box cone of
+    interface/hdsdp_conic_bound.c:201-249 -- adds to diag(M) through kktDiag[] and to dASinvVec on the HOST fields after
+    the device cones have been pulled back; HKKTFactorize must then factor the host matrix, not the stale device copy"""
+    import ctypes as C
+    from hdsdp_amd import api
+    g = load_golden("syn64")
+    n, m = int(g["dims"][0]), int(g["dims"][1])
+    cone = api.SDPCone.synthetic(n, m)
+    lib = api.load_library()
+
+    class HostCone(C.Structure):   # hdsdp_cone, interface/def_hdsdp_conic.h:60-100: 2 ints, 2 pointers, 30 slots
+        _fields_ = [("iCone", C.c_int), ("cone", C.c_int), ("usrData", C.c_void_p), ("coneData", C.c_void_p),
+                    ("slots", C.c_void_p * 30)]
+    add_diag = 0.125 + 0.01 * np.arange(m)
+    add_asinv = np.cos(np.arange(m))
+    calls = []
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int)
+    def build_schur(cone_data, icone, kkt_ptr, type_kkt):
+        k = C.cast(kkt_ptr, C.POINTER(api.hdsdp_kkt)).contents
+        for i in range(k.nRow):
+            k.kktDiag[i][0] += add_diag[i]
+            k.dASinvVec[i] += add_asinv[i]
+        calls.append((icone, type_kkt))
+        return 0
+    extra = HostCone()
+    extra.iCone = 7
+    extra.slots[11] = C.cast(build_schur, C.c_void_p)   # coneBuildSchur is the 12th slot
+    try:
+        kkt = api.KKT(m, [cone])                          # host mirror on: the reference boundary
+        cone.set_start(float(g["Rd"][0]))
+        assert cone.check_is_interior(float(g["tau"][0]), y_of(g))
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        M0 = kkt.M.copy()
+        a0 = kkt.export()["ASinv"].copy()
+        assert lib.HKKTBuildUpExtraCone(kkt._k, C.cast(C.pointer(extra), C.c_void_p), api.KKT_TYPE_INFEASIBLE) == 0
+        assert calls == [(7, api.KKT_TYPE_INFEASIBLE)]
+        M1 = kkt.M
+        assert np.allclose(np.diag(M1) - np.diag(M0), add_diag, rtol=0, atol=1e-15)
+        assert np.allclose(kkt.export()["ASinv"] - a0, add_asinv, rtol=0, atol=1e-15)
+        kkt.factorize()
+        rhs = np.sin(np.arange(m) + 1.0)
+        x = kkt.solve(rhs)
+        Mfull = np.triu(M1) + np.triu(M1, 1).T
+        assert np.linalg.norm(Mfull @ x - rhs) <= 1e-11 * np.linalg.norm(rhs)
+        # and it is the modified matrix that was factored: the unmodified one gives a different answer
+        M0full = np.triu(M0) + np.triu(M0, 1).T
+        assert np.linalg.norm(M0full @ x - rhs) > 1e-6 * np.linalg.norm(rhs)
+        kkt.destroy()
+    finally:
+        cone.destroy()
