@@ -566,3 +566,26 @@ def test_cpu_extra_cone_writes_through_the_host_mirror():
         kkt.destroy()
     finally:
         cone.destroy()
+
+
+def test_regularize_follows_the_reference_rule():
+    """HKKTRegularize (interface/hdsdp_schur.c:348-373): diag(M) += min(reg * min diag(M), 1e-5), nothing below 1e-14"""
+    from hdsdp_amd import api
+    g = load_golden("syn64")
+    n, m = int(g["dims"][0]), int(g["dims"][1])
+    cone = api.SDPCone.synthetic(n, m)
+    try:
+        kkt = api.KKT(m, [cone])
+        cone.set_start(float(g["Rd"][0]))
+        assert cone.check_is_interior(float(g["tau"][0]), y_of(g))
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        for reg in (1e-6, 1e3, 1e12):
+            d0 = np.diag(kkt.M).copy()
+            want = min(reg * d0.min(), 1e-5)
+            if want < 1e-14:
+                want = 0.0
+            kkt.regularize(reg)
+            assert np.array_equal(np.diag(kkt.M), d0 + want)
+        kkt.destroy()
+    finally:
+        cone.destroy()
