@@ -167,6 +167,62 @@ int main(int argc, char **argv) {
     csc_prob pb; memset(&pb, 0, sizeof(pb));
     double Rd, tau, yscale;
 
+    if (!strcmp(mode, "sdpam")) {
+        /* multi-block SDPA instance (truss1: six 2x2 blocks and a 1x1): one dense-SDP cone per block in ONE Schur
+           operator -- HKKTBuildUp loops over the cones and every cone adds its part (hdsdp_schur.c:256-268) */
+        int nConstrs = 0, nBlks = 0, *BlkDims = NULL, nCols = 0, nLpCols = 0, nElem = 0;
+        int **cBeg = NULL, **cIdx = NULL, *LpBeg = NULL, *LpIdx = NULL;
+        double **cElem = NULL, *rowRHS = NULL, *LpElem = NULL;
+        HDSDP_CALL(HReadSDPA(argv[3], &nConstrs, &nBlks, &BlkDims, &rowRHS, &cBeg, &cIdx, &cElem,
+                             &nCols, &nLpCols, &LpBeg, &LpIdx, &LpElem, &nElem));
+        if (nLpCols != 0) { fprintf(stderr, "harness handles SDP blocks only\n"); return 2; }
+        const int mm = nConstrs;
+        Rd = atof(argv[4]); tau = atof(argv[5]); yscale = atof(argv[6]);
+        double *yy = calloc(mm, sizeof(double));
+        for (int i = 0; i < mm; ++i) yy[i] = yscale * sin(1.7 * (i + 1));
+        { int dm[2] = {nBlks, mm}; dump_i("mb_dims", dm, 2); dump_i("mb_blkdims", BlkDims, nBlks); }
+        dump_d("b", rowRHS, mm); dump_d("y", yy, mm); dump_s("Rd", Rd); dump_s("tau", tau);
+        hdsdp_cone **cones = calloc(nBlks, sizeof(hdsdp_cone *));
+        char nm[64];
+        double ldsum = 0.0;
+        for (int k = 0; k < nBlks; ++k) {
+            user_data *udk = NULL;
+            long nz = cBeg[k][mm + 1];
+            snprintf(nm, 64, "mb%d_beg", k); dump_i(nm, cBeg[k], mm + 2);
+            snprintf(nm, 64, "mb%d_idx", k); dump_i(nm, cIdx[k], nz);
+            snprintf(nm, 64, "mb%d_val", k); dump_d(nm, cElem[k], nz);
+            HDSDP_CALL(HUserDataCreate(&udk));
+            HUserDataSetConeData(udk, HDSDP_CONETYPE_DENSE_SDP, mm, BlkDims[k], cBeg[k], cIdx[k], cElem[k]);
+            HDSDP_CALL(HConeCreate(&cones[k], k));
+            HDSDP_CALL(HConeSetData(cones[k], udk));
+            HDSDP_CALL(HConeProcData(cones[k]));
+            HDSDP_CALL(HConePresolveData(cones[k]));
+            HConeSetStart(cones[k], Rd);
+            int ok = 0; double ld = 0.0;
+            HDSDP_CALL(HConeCheckIsInterior(cones[k], tau, yy, &ok));
+            if (!ok) { fprintf(stderr, "block %d not interior\n", k); return 3; }
+            HDSDP_CALL(HConeGetLogBarrier(cones[k], tau, yy, BUFFER_DUALVAR, &ld));
+            ldsum += ld;
+        }
+        dump_s("logdet", ldsum);
+        hdsdp_kkt *kk = NULL;
+        HDSDP_CALL(HKKTCreate(&kk));
+        HDSDP_CALL(HKKTInit(kk, mm, nBlks, cones));
+        if (kk->isKKTSparse) { fprintf(stderr, "sparse Schur: harness dumps dense M only\n"); return 4; }
+        HDSDP_CALL(HKKTBuildUp(kk, KKT_TYPE_HOMOGENEOUS));
+        dump_d2("M_hsd", kk->kktMatElem, mm, mm);
+        dump_d("ASinv_hsd", kk->dASinvVec, mm); dump_d("ASinvRdSinv_hsd", kk->dASinvRdSinvVec, mm);
+        dump_d("ASinvCSinv_hsd", kk->dASinvCSinvVec, mm);
+        { double sc[4] = { kk->dCSinv, kk->dCSinvCSinv, kk->dCSinvRdSinv, kk->dTraceSinv }; dump_d("hsd_scalars", sc, 4); }
+        HDSDP_CALL(HKKTBuildUp(kk, KKT_TYPE_INFEASIBLE));
+        dump_d2("M_inf", kk->kktMatElem, mm, mm);
+        dump_d("ASinv_inf", kk->dASinvVec, mm); dump_d("ASinvRdSinv_inf", kk->dASinvRdSinvVec, mm);
+        double *so = calloc(mm, sizeof(double));
+        HDSDP_CALL(HKKTFactorize(kk));
+        HDSDP_CALL(HKKTSolve(kk, rowRHS, so)); dump_d("sol_b", so, mm);
+        printf("ref_dump ok: blocks=%d m=%d logdet=%.12e\n", nBlks, mm, ldsum);
+        return 0;
+    }
     if (!strcmp(mode, "sdpa")) {
         int nConstrs = 0, nBlks = 0, *BlkDims = NULL, nCols = 0, nLpCols = 0, nElem = 0;
         int **cBeg = NULL, **cIdx = NULL, *LpBeg = NULL, *LpIdx = NULL;

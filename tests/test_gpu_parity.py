@@ -589,3 +589,47 @@ def test_regularize_follows_the_reference_rule():
         kkt.destroy()
     finally:
         cone.destroy()
+
+
+def test_multi_block_instance_against_reference():
+    """truss1 through the engine's own SDPA reader: seven cones (2 x 2 blocks and a 1 x 1) in one KKT object, against the
+    reference's numbers for the same instance (golden truss1_A: the reference run with one dense-SDP cone per block)"""
+    import os
+    from hdsdp_amd import api
+    g = load_golden("truss1_A")
+    nb, m = int(g["mb_dims"][0]), int(g["mb_dims"][1])
+    Rd, tau, y = float(g["Rd"][0]), float(g["tau"][0]), y_of(g)
+    prob = api.read_sdpa(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "truss1.dat-s"))
+    assert prob["m"] == m and len(prob["blocks"]) == nb
+    assert np.array_equal(prob["b"], g["b"])
+    cones = []
+    try:
+        for k, blk in enumerate(prob["blocks"]):
+            assert blk["n"] == int(g["mb_blkdims"][k])
+            assert np.array_equal(blk["beg"], g["mb%d_beg" % k]) and np.array_equal(blk["idx"], g["mb%d_idx" % k])
+            assert np.array_equal(blk["val"], g["mb%d_val" % k])
+            cones.append(api.SDPCone.from_csc(blk["n"], m, blk["beg"], blk["idx"], blk["val"], iCone=k))
+        ld = 0.0
+        for c in cones:
+            c.set_start(Rd)
+            assert c.check_is_interior(tau, y)
+            ld += c.log_barrier(tau)
+        assert abs(ld - float(g["logdet"][0])) <= 1e-12 * abs(float(g["logdet"][0]))
+        kkt = api.KKT(m, cones)
+        msk = lower_mask(m)
+        kkt.build_up(api.KKT_TYPE_HOMOGENEOUS)
+        ex = kkt.export()
+        check_close(kkt.M[msk], g["M_hsd"][msk], "truss1 M_hsd")
+        check_close(ex["ASinv"], g["ASinv_hsd"], "truss1 ASinv")
+        check_close(ex["ASinvRdSinv"], g["ASinvRdSinv_hsd"], "truss1 ASinvRdSinv")
+        check_close(ex["ASinvCSinv"], g["ASinvCSinv_hsd"], "truss1 ASinvCSinv")
+        check_close([ex["CSinv"], ex["CSinvCSinv"], ex["CSinvRdSinv"], ex["TraceSinv"]], g["hsd_scalars"], "truss1 scalars")
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        check_close(kkt.M[msk], g["M_inf"][msk], "truss1 M_inf")
+        kkt.factorize()
+        x = kkt.solve(g["b"])
+        assert np.linalg.norm(x - g["sol_b"]) <= 1e-8 * np.linalg.norm(g["sol_b"])
+        kkt.destroy()
+    finally:
+        for c in cones:
+            c.destroy()
