@@ -15,7 +15,7 @@ import numpy as np
 
 KKT_TYPE_INFEASIBLE, KKT_TYPE_CORRECTOR, KKT_TYPE_HOMOGENEOUS, KKT_TYPE_PRIMAL = 0, 1, 2, 3
 KKT_M1, KKT_M2, KKT_M3, KKT_M4, KKT_M5 = 0, 1, 2, 3, 4
-HDSDP_LINSYS_DENSE_DIRECT, HDSDP_LINSYS_DENSE_ITERATIVE = 0, 5
+HDSDP_LINSYS_DENSE_DIRECT, HDSDP_LINSYS_DENSE_ITERATIVE, HDSDP_LINSYS_DENSE_INDEFINITE = 0, 5, 6
 RETCODE_OK, RETCODE_FAILED, RETCODE_MEMORY = 0, 1, 2
 BUFFER_DUALVAR, BUFFER_DUALCHECK, BUFFER_DUALSTEP = 0, 1, 2   # interface/hdsdp_conic.h:24-26
 
@@ -58,6 +58,14 @@ class hdsdp_kkt(C.Structure):  # interface/def_hdsdp_schur.h:32-68
         ("dCSinvCSinv", C.c_double), ("dCSinvRdSinv", C.c_double), ("dCSinv", C.c_double),
         ("dTraceSinv", C.c_double), ("dPrimalX", C.c_void_p),
     ]
+
+
+class hdsdp_linsys_head(C.Structure):  # linalg/def_hdsdp_linsolver.h:40-63, the fields callers read
+    _fields_ = [("nCol", C.c_int), ("chol", C.c_void_p), ("LinType", C.c_int)]
+
+
+def _lin_type(ptr):
+    return C.cast(ptr, C.POINTER(hdsdp_linsys_head)).contents.LinType
 
 
 _lib = None
@@ -400,6 +408,12 @@ class KKT:
     def regularize(self, reg):
         load_library().HKKTRegularize(self._k, float(reg))
 
+    @property
+    def lin_type(self):
+        """kktM->LinType: DENSE_ITERATIVE until a factorisation fails, DENSE_INDEFINITE afterwards
+        (HFpLinsysSwitchToIndefinite, linalg/hdsdp_linsolver.c:1827-1857)"""
+        return _lin_type(self._k.contents.kktM)
+
     def export(self):
         m = self.m
         a, r, c = (np.zeros(m) for _ in range(3))
@@ -444,6 +458,10 @@ class LinSys:
     def numeric(self, A):
         A = np.ascontiguousarray(A, dtype=np.float64)
         _check(load_library().HFpLinsysNumeric(self._h, None, None, _dptr(A)), "HFpLinsysNumeric")
+
+    @property
+    def lin_type(self):
+        return _lin_type(self._h)
 
     def psd_check(self, A):
         A = np.ascontiguousarray(A, dtype=np.float64)

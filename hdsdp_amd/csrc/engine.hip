@@ -18,6 +18,7 @@
 #include "hdm_common.h"
 #include "schur.h"
 #include "lanczos.h"
+#include "lu.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -86,6 +87,12 @@ struct MiLin {
     int maxIter = -1;
     // Schur systems: M lives here (device, ld = ch.npad) before factorisation
     double *Mdev = nullptr;
+    // symmetric-indefinite fallback (HFpLinsysSwitchToIndefinite, hdsdp_linsolver.c:1827-1857): once switched, every
+    // later factorisation goes through the pivoted solver, like the reference's replaced vtable
+    HdmLu *lu = nullptr;
+    bool indef = false;
+    const double *srcHost = nullptr, *srcDev = nullptr;   // where the last factorised matrix came from (lower valid)
+    long srcLd = 0;
 };
 
 hdsdp_retcode lin_create(void **pchol, int nCol) {
@@ -104,16 +111,40 @@ hdsdp_retcode lin_factor_host(MiLin *l, const double *A, int *info) {
     RC(l->ch.factor(g.stream, info));
     return HDSDP_RETCODE_OK;
 }
+// lapackIndefiniteLinSolverNumeric (hdsdp_linsolver.c:1706-1727): copy + pivoted factorisation; a singular matrix fails
+hdsdp_retcode lin_factor_indef(MiLin *l) {
+    if (!l->lu) {
+        l->lu = new HdmLu();
+        if (l->lu->init(l->n)) { l->lu->destroy(); delete l->lu; l->lu = nullptr; return HDSDP_RETCODE_MEMORY; }
+    }
+    if (l->srcDev) RC(l->lu->load_device_lower(l->srcDev, l->srcLd, g.stream));
+    else if (l->srcHost) RC(l->lu->load_host_lower(l->srcHost, l->srcLd, g.stream));
+    else return HDSDP_RETCODE_FAILED;
+    int info = 0;
+    RC(l->lu->factor(g.stream, &info));
+    return info == 0 ? HDSDP_RETCODE_OK : HDSDP_RETCODE_FAILED;
+}
 // linalg/hdsdp_linsolver.c:1082-1110 (copy + dpotrf; info != 0 is a failure here)
 hdsdp_retcode lin_numeric(void *chol, int *, int *, double *colMatElem) {
     MiLin *l = (MiLin *) chol;
+    l->srcHost = colMatElem; l->srcDev = nullptr; l->srcLd = l->n;
+    if (l->indef) return lin_factor_indef(l);
     int info = 0;
     if (lin_factor_host(l, colMatElem, &info) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
     return info == 0 ? HDSDP_RETCODE_OK : HDSDP_RETCODE_FAILED;
 }
+// HFpLinsysSwitchToIndefinite (hdsdp_linsolver.c:1827-1857): only the Schur system (DENSE_ITERATIVE) has this way out;
+// the matrix is re-read from where the failed factorisation took it
+hdsdp_retcode lin_switch_indefinite(hdsdp_linsys_fp *HLin) {
+    MiLin *l = (MiLin *) HLin->chol;
+    HLin->LinType = HDSDP_LINSYS_DENSE_INDEFINITE;
+    l->indef = true;
+    return lin_factor_indef(l);
+}
 // linalg/hdsdp_linsolver.c:1112-1144 (info > 0 => "not PSD" is a value, not an error)
 hdsdp_retcode lin_psdcheck(void *chol, int *, int *, double *colMatElem, int *isPsd) {
     MiLin *l = (MiLin *) chol;
+    if (l->indef) return HDSDP_RETCODE_FAILED;   // :1729-1739, no PSD check on the pivoted factor
     int info = 0;
     if (lin_factor_host(l, colMatElem, &info) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
     *isPsd = (info == 0) ? 1 : 0;
@@ -122,15 +153,22 @@ hdsdp_retcode lin_psdcheck(void *chol, int *, int *, double *colMatElem, int *is
 // :1146-1196 dtrsm with L / L^T ; solVec == NULL => in place
 void lin_fsolve(void *chol, int nRhs, double *rhs, double *sol) {
     MiLin *l = (MiLin *) chol;
+    if (l->indef) return;                        // :1741-1759, no half solves with the pivoted factor
     l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 1, g.stream);
 }
 void lin_bsolve(void *chol, int nRhs, double *rhs, double *sol) {
     MiLin *l = (MiLin *) chol;
+    if (l->indef) return;
     l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 2, g.stream);
 }
 // :1198-1225 dpotrs
 hdsdp_retcode lin_solve(void *chol, int nRhs, double *rhs, double *sol) {
     MiLin *l = (MiLin *) chol;
+    if (l->indef) {                              // :1761-1780 dsytrs
+        if (!l->lu || !l->lu->factored) return HDSDP_RETCODE_FAILED;
+        RC(l->lu->solve_host(rhs, sol ? sol : rhs, nRhs, g.stream));
+        return HDSDP_RETCODE_OK;
+    }
     if (!l->ch.factored) return HDSDP_RETCODE_FAILED;
     RC(l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 0, g.stream));
     return HDSDP_RETCODE_OK;
@@ -138,12 +176,14 @@ hdsdp_retcode lin_solve(void *chol, int nRhs, double *rhs, double *sol) {
 // :1227-1236
 hdsdp_retcode lin_getdiag(void *chol, double *diag) {
     MiLin *l = (MiLin *) chol;
+    if (l->indef) return HDSDP_RETCODE_FAILED;   // :1782-1788
     RC(l->ch.get_diag(diag, g.stream));
     return HDSDP_RETCODE_OK;
 }
 // :1238-1260 dpotri + HUtilMatSymmetrize: full symmetric inverse into dFullMatrix (n x n)
 void lin_invert(void *chol, double *dFull, double *) {
     MiLin *l = (MiLin *) chol;
+    if (l->indef) return;                        // :1790-1797
     HdmChol &c = l->ch;
     if (!l->work) {
         if (hipMalloc((void **) &l->work, sizeof(double) * (size_t) c.npad * c.npad) != hipSuccess) return;
@@ -157,6 +197,7 @@ void lin_destroy(void **pchol) {
     if (!pchol || !*pchol) return;
     MiLin *l = (MiLin *) *pchol;
     l->ch.destroy();
+    if (l->lu) { l->lu->destroy(); delete l->lu; }
     if (l->work) (void) hipFree(l->work);
     if (l->Mdev) (void) hipFree(l->Mdev);
     delete l;
@@ -1343,7 +1384,7 @@ hdsdp_retcode HFpLinsysCreate(hdsdp_linsys_fp **pHLin, int nCol, linsys_type Lty
             break;                          // than the reference's PCG to 1e-12, hdsdp_linsolver.c:1446-1588)
         default:
             fprintf(stderr, "[hdsdp_mi355x] HFpLinsysCreate: linsys_type %d is not on the accelerated path "
-                            "(sparse / small / indefinite backends stay with the CPU reference)\n", (int) Ltype);
+                            "(sparse / small backends stay with the CPU reference; DENSE_INDEFINITE is only reached by switching)\n", (int) Ltype);
             return HDSDP_RETCODE_FAILED;
     }
     hdsdp_linsys_fp *h = (hdsdp_linsys_fp *) calloc(1, sizeof(hdsdp_linsys_fp));
@@ -1376,8 +1417,14 @@ hdsdp_retcode HFpLinsysSymbolic(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colM
     return HLin->cholSymbolic(HLin->chol, colMatBeg, colMatIdx);
 }
 hdsdp_retcode HFpLinsysNumeric(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx, double *colMatElem) {
+    // hdsdp_linsolver.c:2029-2044: a failed factorisation of the Schur system switches to the indefinite solver
     HLin->nFactorizes += 1;
-    return HLin->cholNumeric(HLin->chol, colMatBeg, colMatIdx, colMatElem);
+    hdsdp_retcode rc = HLin->cholNumeric(HLin->chol, colMatBeg, colMatIdx, colMatElem);
+    if (rc == HDSDP_RETCODE_FAILED && HLin->LinType == HDSDP_LINSYS_DENSE_ITERATIVE) {
+        fprintf(stderr, "[hdsdp_mi355x] KKT system is almost indefinite. Switch to the pivoted (LDL-equivalent) solver.\n");
+        rc = lin_switch_indefinite(HLin);
+    }
+    return rc;
 }
 hdsdp_retcode HFpLinsysSwitchToBackUp(hdsdp_linsys_fp *HLin) { (void) HLin; return HDSDP_RETCODE_OK; }
 hdsdp_retcode HFpLinsysPsdCheck(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx, double *colMatElem, int *isPsd) {
@@ -1393,8 +1440,18 @@ void HFpLinsysBSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *so
     HLin->cholBSolve(HLin->chol, nRhs, rhsVec, solVec);
 }
 hdsdp_retcode HFpLinsysSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec) {
+    // hdsdp_linsolver.c:2085-2110: NaN in the solution (or the right-hand side) counts as a failure, and a failed solve
+    // of the Schur system switches to the indefinite solver and solves again
+    hdsdp_retcode rc = HLin->cholSolve(HLin->chol, nRhs, rhsVec, solVec);
+    if (solVec && solVec[0] != solVec[0]) rc = HDSDP_RETCODE_FAILED;
+    if (rhsVec[0] != rhsVec[0]) rc = HDSDP_RETCODE_FAILED;
+    if (rc != HDSDP_RETCODE_OK && HLin->LinType == HDSDP_LINSYS_DENSE_ITERATIVE) {
+        fprintf(stderr, "[hdsdp_mi355x] KKT system is unstable. Switch to the pivoted (LDL-equivalent) solver.\n");
+        if (lin_switch_indefinite(HLin) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+        return HFpLinsysSolve(HLin, nRhs, rhsVec, solVec);
+    }
     HLin->nSolves += 1;
-    return HLin->cholSolve(HLin->chol, nRhs, rhsVec, solVec);
+    return rc;
 }
 hdsdp_retcode HFpLinsysGetDiag(hdsdp_linsys_fp *HLin, double *diagElem) { return HLin->cholGetDiag(HLin->chol, diagElem); }
 void HFpLinsysInvert(hdsdp_linsys_fp *HLin, double *dFullMatrix, double *dAuxiMatrix) {
@@ -1562,15 +1619,23 @@ hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
     HKKT->kktM->nFactorizes += 1;
     int info = 0;
     if (pv->mirror) {
-        if (l->ch.load_host(HKKT->kktMatElem, HKKT->nRow, g.stream)) return HDSDP_RETCODE_FAILED;
+        l->srcHost = HKKT->kktMatElem; l->srcDev = nullptr; l->srcLd = HKKT->nRow;
     } else {
         if (!pv->Mdev_valid) return HDSDP_RETCODE_FAILED;
+        l->srcHost = nullptr; l->srcDev = l->Mdev; l->srcLd = l->ch.npad;
+    }
+    if (l->indef) return lin_factor_indef(l);     // switched earlier: stays switched (hdsdp_linsolver.c:1838)
+    if (pv->mirror) {
+        if (l->ch.load_host(HKKT->kktMatElem, HKKT->nRow, g.stream)) return HDSDP_RETCODE_FAILED;
+    } else {
         if (l->ch.load_device(l->Mdev, l->ch.npad, g.stream)) return HDSDP_RETCODE_FAILED;
     }
     if (l->ch.factor(g.stream, &info)) return HDSDP_RETCODE_FAILED;
     if (info != 0) {
-        fprintf(stderr, "[hdsdp_mi355x] HKKTFactorize: Schur matrix is not positive definite (pivot %d)\n", info);
-        return HDSDP_RETCODE_FAILED;
+        // hdsdp_linsolver.c:2034-2039: the Schur system falls back to the symmetric-indefinite solver
+        fprintf(stderr, "[hdsdp_mi355x] HKKTFactorize: Schur matrix is not positive definite (pivot %d). "
+                        "Switch to the pivoted (LDL-equivalent) solver.\n", info);
+        return lin_switch_indefinite(HKKT->kktM);
     }
     return HDSDP_RETCODE_OK;
 }

@@ -1,0 +1,360 @@
+// lu.hip -- the Schur system's last-resort solver on the device.
+//
+// Reference behaviour being replaced (linalg/hdsdp_linsolver.c): when the Schur matrix M stops being numerically
+// positive definite -- PCG stalls (:1543-1546), its Cholesky preconditioner dpotrf fails (:1558-1567) or the solution
+// comes back NaN (:2085-2103) -- HFpLinsysSwitchToIndefinite (:1827-1857) replaces the solver object by LAPACK's
+// symmetric-indefinite pair dsytrf / dsytrs (:1706-1780) for the rest of the run.  LAPACK is a third-party dependency
+// of the reference (not in its tree); what the caller observes is "a backward-stable direct solve of M x = b with M
+// symmetric, possibly indefinite".  Nothing downstream reads the Bunch-Kaufman pivots or the inertia.
+//
+// Here: partial-pivot LU of the mirrored full matrix, blocked right-looking with 32-wide panels --
+//   panel   one workgroup: column-by-column pivot search (first maximum, like idamax), row exchange, scaling by the
+//           reciprocal pivot, rank-one update of the rest of the panel; the panel stays in L2
+//   swap    the panel's row exchanges applied to every other column
+//   trsm    U12 = L11^-1 A12, one thread per column, the 32 x 32 unit triangle in LDS
+//   update  A22 -= L21 U12 on the fp64 MFMA GEMM (generic role)
+// and a single-workgroup solve per right-hand side (x in LDS, 32-blocked substitution).  Same solution as dsytrs to
+// rounding (both are backward stable; tests pin it against the reference's own LDL^T solves); 2/3 m^3 flops instead
+// of 1/3 m^3, which is irrelevant: this path runs a handful of times at the very end of a hard solve, if ever.
+#include "lu.h"
+
+#include <vector>
+
+namespace {
+constexpr int LNB = 32;
+constexpr int LPT = 512;   // threads of the panel kernel (a thread keeps one 32-wide row in registers)
+
+// lower triangle -> full symmetric inside n x n, identity in the padding, piv = identity
+__global__ void hdm_lu_mirror_pad_kernel(double *A, long ld, int n, int npad, int *piv) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < npad) piv[e] = (int) e;
+    long tot = (long) npad * npad;
+    if (e >= tot) return;
+    int i = (int) (e % npad), j = (int) (e / npad);
+    if (i >= n || j >= n) A[i + (long) j * ld] = (i == j) ? 1.0 : 0.0;
+    else if (i < j) A[i + (long) j * ld] = A[j + (long) i * ld];
+}
+
+// unblocked partial-pivot elimination of the panel A[j0:nrows, j0:j0+32).  Per column: pivot search (the candidates of
+// the next column are tracked while the rank-one update has them in registers, so only the first column is read for
+// it), row exchange inside the panel, scaling, rank-one update of the columns to the right -- each thread loads its
+// row of the panel with independent loads, updates in registers and stores, so a step costs one memory round trip.
+__global__ __launch_bounds__(LPT) void hdm_lu_panel_kernel(double *__restrict__ A, long ld, int nrows, int j0,
+                                                            int *__restrict__ piv, int *__restrict__ info) {
+    __shared__ double s_val[LPT / 64];
+    __shared__ int s_idx[LPT / 64];
+    __shared__ double s_row[LNB];
+    __shared__ int s_p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double best = -1.0;
+    int bi = j0;
+    for (int i = j0 + tid; i < nrows; i += LPT) {
+        const double v = fabs(A[i + (long) j0 * ld]);
+        if (v > best) { best = v; bi = i; }
+    }
+    for (int c = 0; c < LNB; ++c) {
+        const int jc = j0 + c;
+        for (int off = 32; off; off >>= 1) {
+            const double ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double b = s_val[0];
+            int p = s_idx[0];
+            for (int w = 1; w < LPT / 64; ++w)
+                if (s_val[w] > b || (s_val[w] == b && s_idx[w] < p)) { b = s_val[w]; p = s_idx[w]; }
+            if (!(b > 0.0)) {          // zero (or NaN) column: nothing to eliminate with, report like dgetrf's info
+                p = jc;
+                if (*info == 0) *info = jc + 1;
+            }
+            s_p = p;
+            piv[jc] = p;
+        }
+        __syncthreads();
+        const int p = s_p;
+        if (tid < LNB) {               // exchange rows jc and p inside the panel; keep the pivot row in LDS
+            double *e = A + (long) (j0 + tid) * ld;
+            const double a = e[jc], b = e[p];
+            e[jc] = b;
+            e[p] = a;
+            s_row[tid] = b;
+        }
+        __syncthreads();
+        const double pv = s_row[c];
+        const bool elim = (pv != 0.0 && pv == pv);
+        const double rinv = elim ? 1.0 / pv : 0.0;
+        best = -1.0;
+        bi = jc + 1;
+        for (int i = jc + 1 + tid; i < nrows; i += LPT) {
+            double *row = A + i + (long) j0 * ld;
+            double t[LNB];
+#pragma unroll
+            for (int cc = 0; cc < LNB; ++cc) t[cc] = (cc >= c) ? row[(long) cc * ld] : 0.0;
+            double l = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < LNB; ++cc) if (cc == c) l = t[cc] * rinv;
+            if (elim) {
+#pragma unroll
+                for (int cc = 0; cc < LNB; ++cc) {
+                    if (cc == c) row[(long) cc * ld] = l;
+                    if (cc > c) { t[cc] -= l * s_row[cc]; row[(long) cc * ld] = t[cc]; }
+                }
+            }
+            if (c + 1 < LNB) {
+                double nv = 0.0;
+#pragma unroll
+                for (int cc = 1; cc < LNB; ++cc) if (cc == c + 1) nv = fabs(t[cc]);
+                if (nv > best) { best = nv; bi = i; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// The panel's row exchanges on all columns outside the panel.  The 32 exchanges touch at most 64 rows; one thread
+// replays them on an index map in LDS, then every thread moves its column's (<= 64) values with independent loads.
+__global__ __launch_bounds__(256) void hdm_lu_swap_kernel(double *__restrict__ A, long ld, int ncols, int j0,
+                                                          const int *__restrict__ piv) {
+    __shared__ int s_rows[2 * LNB], s_src[2 * LNB], s_cnt;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int cnt = LNB;
+        for (int k = 0; k < LNB; ++k) { s_rows[k] = j0 + k; s_src[k] = j0 + k; }
+        for (int k = 0; k < LNB; ++k) {
+            const int p = piv[j0 + k];
+            if (p == j0 + k) continue;
+            int q = -1;
+            for (int t = 0; t < cnt; ++t) if (s_rows[t] == p) { q = t; break; }
+            if (q < 0) { q = cnt++; s_rows[q] = p; s_src[q] = p; }
+            const int t = s_src[k]; s_src[k] = s_src[q]; s_src[q] = t;
+        }
+        s_cnt = cnt;
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 256 + tid;
+    if (j >= ncols || (j >= j0 && j < j0 + LNB)) return;
+    double *c = A + (long) j * ld;
+    const int cnt = s_cnt;
+    double v[2 * LNB];
+#pragma unroll
+    for (int q = 0; q < 2 * LNB; ++q) v[q] = (q < cnt) ? c[s_src[q]] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 2 * LNB; ++q) if (q < cnt && s_src[q] != s_rows[q]) c[s_rows[q]] = v[q];
+}
+
+// U12 = L11^-1 A12 (L11 unit lower, 32 x 32): one thread per column of A12
+__global__ __launch_bounds__(256) void hdm_lu_trsm_kernel(double *__restrict__ A, long ld, int ncols, int j0) {
+    __shared__ double Ls[LNB * LNB];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < LNB * LNB; e += 256) Ls[e] = A[(j0 + (e & 31)) + (long) (j0 + (e >> 5)) * ld];
+    __syncthreads();
+    const int j = j0 + LNB + blockIdx.x * 256 + tid;
+    if (j >= ncols) return;
+    hdm_d4 *c4 = (hdm_d4 *) (A + j0 + (long) j * ld);   // j0 % 32 == 0 and ld % 128 == 0: 32-byte aligned
+    double x[LNB];
+#pragma unroll
+    for (int q = 0; q < LNB / 4; ++q) {
+        hdm_d4 v = c4[q];
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < LNB - 1; ++k)
+#pragma unroll
+        for (int i = k + 1; i < LNB; ++i) x[i] -= Ls[i + LNB * k] * x[k];
+#pragma unroll
+    for (int q = 0; q < LNB / 4; ++q) {
+        hdm_d4 v;
+        v.x = x[4 * q]; v.y = x[4 * q + 1]; v.z = x[4 * q + 2]; v.w = x[4 * q + 3];
+        c4[q] = v;
+    }
+}
+
+// x = U^-1 L^-1 P b for one right-hand side per workgroup; the vector lives in LDS, substitution in 32-blocks:
+// the 32 x 32 triangle by one wave (shuffles), the rest of the column block by all threads
+__global__ __launch_bounds__(1024) void hdm_lu_solve_kernel(const double *__restrict__ A, long ld, int n, int nn,
+                                                            const int *__restrict__ perm, const double *__restrict__ b,
+                                                            double *__restrict__ x, long ldv) {
+    extern __shared__ double xs[];
+    const int tid = threadIdx.x;
+    const double *bb = b + (long) blockIdx.x * ldv;
+    double *xx = x + (long) blockIdx.x * ldv;
+    for (int i = tid; i < nn; i += 1024) xs[i] = (i < n) ? bb[perm[i]] : 0.0;
+    __syncthreads();
+    for (int kb = 0; kb < nn; kb += LNB) {           // L y = P b, unit diagonal
+        if (tid < 64) {
+            const int r = tid & 31;                  // both halves of the wave carry the same rows
+            const double *Lc = A + (kb + r) + (long) kb * ld;
+            double l[LNB];
+#pragma unroll
+            for (int k = 0; k < LNB; ++k) l[k] = Lc[(long) k * ld];
+            double v = xs[kb + r];
+#pragma unroll
+            for (int k = 0; k < LNB - 1; ++k) {
+                const double xk = __shfl(v, k, 64);
+                if (r > k) v -= l[k] * xk;
+            }
+            if (tid < 32) xs[kb + r] = v;
+        }
+        __syncthreads();
+        for (int i = kb + LNB + tid; i < nn; i += 1024) {
+            const double *Lr = A + i + (long) kb * ld;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < LNB; ++k) acc += Lr[(long) k * ld] * xs[kb + k];
+            xs[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int kb = nn - LNB; kb >= 0; kb -= LNB) {    // U x = y
+        if (tid < 64) {
+            const int r = tid & 31;
+            const double *Uc = A + (kb + r) + (long) kb * ld;
+            double u[LNB];
+#pragma unroll
+            for (int k = 0; k < LNB; ++k) u[k] = Uc[(long) k * ld];
+            double v = xs[kb + r];
+#pragma unroll
+            for (int k = LNB - 1; k >= 0; --k) {
+                const double d = __shfl(u[k], k, 64);
+                const double xk = __shfl(v, k, 64) / d;
+                if (r == k) v = xk;
+                if (r < k) v -= u[k] * xk;
+            }
+            if (tid < 32) xs[kb + r] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < kb; i += 1024) {
+            const double *Ur = A + i + (long) kb * ld;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < LNB; ++k) acc += Ur[(long) k * ld] * xs[kb + k];
+            xs[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 1024) xx[i] = xs[i];
+}
+}  // namespace
+
+int HdmLu::init(int n_) {
+    n = n_;
+    npad = (int) hdm_roundup(n, HDM_TILE);
+    size_t mat = sizeof(double) * (size_t) npad * npad;
+    HDM_HIP_CHECK(hipMalloc((void **) &A, mat + hdm_operand_pad(npad)));
+    HDM_HIP_CHECK(hipMalloc((void **) &piv, sizeof(int) * (size_t) npad));
+    HDM_HIP_CHECK(hipMalloc((void **) &perm, sizeof(int) * (size_t) npad));
+    HDM_HIP_CHECK(hipMalloc((void **) &vec, sizeof(double) * (size_t) npad * 4));
+    HDM_HIP_CHECK(hipMalloc((void **) &info_dev, sizeof(int)));
+    HDM_HIP_CHECK(hdm_memset_sync(A, 0, mat + hdm_operand_pad(npad)));
+    // the LDS limit of the solve kernel is a per-function attribute: only ever raise it
+    static int lds_limit = 48 * 1024;
+    const int need = (int) (hdm_roundup(n, LNB) * sizeof(double));
+    if (need > lds_limit && need <= 156 * 1024) {
+        HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_lu_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need));
+        lds_limit = need;
+    }
+    return 0;
+}
+
+void HdmLu::destroy() {
+    if (A) (void) hipFree(A);
+    if (piv) (void) hipFree(piv);
+    if (perm) (void) hipFree(perm);
+    if (vec) (void) hipFree(vec);
+    if (info_dev) (void) hipFree(info_dev);
+    A = vec = nullptr;
+    piv = perm = info_dev = nullptr;
+}
+
+static int lu_finish_load(HdmLu *lu, hipStream_t s) {
+    long tot = (long) lu->npad * lu->npad;
+    hipLaunchKernelGGL(hdm_lu_mirror_pad_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, lu->A,
+                       (long) lu->npad, lu->n, lu->npad, lu->piv);
+    HDM_HIP_CHECK(hipGetLastError());
+    lu->factored = false;
+    return 0;
+}
+
+int HdmLu::load_host_lower(const double *M, long ldm, hipStream_t s) {
+    HDM_HIP_CHECK(hipMemcpy2DAsync(A, sizeof(double) * npad, M, sizeof(double) * ldm, sizeof(double) * n, n,
+                                   hipMemcpyHostToDevice, s));
+    return lu_finish_load(this, s);
+}
+
+int HdmLu::load_device_lower(const double *M, long ldm, hipStream_t s) {
+    HDM_HIP_CHECK(hipMemcpy2DAsync(A, sizeof(double) * npad, M, sizeof(double) * ldm, sizeof(double) * n, n,
+                                   hipMemcpyDeviceToDevice, s));
+    return lu_finish_load(this, s);
+}
+
+int HdmLu::factor(hipStream_t s, int *info_host) {
+    HDM_HIP_CHECK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    const long ld = npad;
+    const int nn = (int) hdm_roundup(n, LNB);     // everything behind nn is identity padding
+    for (int j0 = 0; j0 < nn; j0 += LNB) {
+        hipLaunchKernelGGL(hdm_lu_panel_kernel, dim3(1), dim3(LPT), 0, s, A, ld, nn, j0, piv, info_dev);
+        HDM_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(hdm_lu_swap_kernel, dim3((nn + 255) / 256), dim3(256), 0, s, A, ld, nn, j0, piv);
+        HDM_HIP_CHECK(hipGetLastError());
+        const int rem = nn - j0 - LNB;
+        if (rem <= 0) break;
+        hipLaunchKernelGGL(hdm_lu_trsm_kernel, dim3((rem + 255) / 256), dim3(256), 0, s, A, ld, nn, j0);
+        HDM_HIP_CHECK(hipGetLastError());
+        HdmGemmArgs g = {};    // A22 -= L21 * U12   (B operand element (j,k) = U12(k,j): K-major)
+        g.A = A + (j0 + LNB) + (long) j0 * ld; g.lda = ld;
+        g.B = A + j0 + (long) (j0 + LNB) * ld; g.ldb = ld; g.b_kmajor = 1;
+        g.C = A + (long) (j0 + LNB) * (ld + 1); g.ldc = ld;
+        g.M = rem; g.N = rem; g.K = LNB; g.batch = 1; g.alpha = -1.0; g.beta = 1.0; g.epilogue = HDM_EPI_STORE;
+        if (hdm_launch_gemm(g, s)) return 1;
+    }
+    int info = 0;
+    std::vector<int> hp(npad), hperm(npad);
+    HDM_HIP_CHECK(hipMemcpyAsync(&info, info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    HDM_HIP_CHECK(hipMemcpyAsync(hp.data(), piv, sizeof(int) * (size_t) npad, hipMemcpyDeviceToHost, s));
+    HDM_HIP_CHECK(hipStreamSynchronize(s));
+    // index bookkeeping: the sequence of row exchanges as one gather
+    for (int i = 0; i < npad; ++i) hperm[i] = i;
+    for (int j = 0; j < nn; ++j) {
+        const int p = hp[j];
+        if (p < 0 || p >= npad) return 1;
+        if (p != j) std::swap(hperm[j], hperm[p]);
+    }
+    for (int i = 0; i < n; ++i)
+        if (hperm[i] >= n) info = info ? info : n;   // a padding row was pulled in: the matrix is singular
+    HDM_HIP_CHECK(hipMemcpyAsync(perm, hperm.data(), sizeof(int) * (size_t) npad, hipMemcpyHostToDevice, s));
+    HDM_HIP_CHECK(hipStreamSynchronize(s));
+    if (info_host) *info_host = info;
+    factored = (info == 0);
+    return 0;
+}
+
+int HdmLu::solve_device(const double *b_dev, double *x_dev, int nrhs, long ldv, hipStream_t s) {
+    if (!factored) return 1;
+    const int nn = (int) hdm_roundup(n, LNB);
+    const size_t shm = (size_t) nn * sizeof(double);
+    if (shm > 156 * 1024) {
+        fprintf(stderr, "[hdsdp_mi355x] indefinite solve: %d unknowns do not fit the LDS-resident solve\n", n);
+        return 1;
+    }
+    hipLaunchKernelGGL(hdm_lu_solve_kernel, dim3(nrhs), dim3(1024), shm, s, A, (long) npad, n, nn, perm, b_dev, x_dev, ldv);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int HdmLu::solve_host(const double *rhs, double *sol, int nrhs, hipStream_t s) {
+    const int chunk = 2;  // vec holds 4 * npad doubles: chunk rhs + chunk sol
+    for (int c0 = 0; c0 < nrhs; c0 += chunk) {
+        const int nc = (nrhs - c0 < chunk) ? nrhs - c0 : chunk;
+        double *b = vec, *x = vec + 2L * npad;
+        HDM_HIP_CHECK(hipMemcpy2DAsync(b, sizeof(double) * npad, rhs + (long) c0 * n, sizeof(double) * n,
+                                       sizeof(double) * n, nc, hipMemcpyHostToDevice, s));
+        if (solve_device(b, x, nc, npad, s)) return 1;
+        HDM_HIP_CHECK(hipMemcpy2DAsync(sol + (long) c0 * n, sizeof(double) * n, x, sizeof(double) * npad,
+                                       sizeof(double) * n, nc, hipMemcpyDeviceToHost, s));
+        HDM_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return 0;
+}

@@ -162,7 +162,15 @@ void HKKTRegisterPSDP(hdsdp_kkt *HKKT, double **dPrimalScalX);                  
 void HKKTClear(hdsdp_kkt *HKKT);                                                          /* :382 */
 void HKKTDestroy(hdsdp_kkt **pHKKT);                                                      /* :408 */
 
-/* ==================  linear-system operator: linalg/hdsdp_linsolver.h:16-28  ================ */
+/* ==================  linear-system operator: linalg/hdsdp_linsolver.h:16-28  ================
+ * DENSE_DIRECT (the dual matrix S): blocked Cholesky on the device; "not positive definite" is a value of PsdCheck
+ * and a failure of Numeric, as in lapackLinSolver* (hdsdp_linsolver.c:1082-1144).
+ * DENSE_ITERATIVE (the Schur matrix M): the same direct Cholesky instead of the reference's PCG.  When M is not
+ * numerically positive definite -- Numeric's factorisation fails, or Solve returns NaN -- the object switches itself to
+ * DENSE_INDEFINITE like HFpLinsysSwitchToIndefinite (hdsdp_linsolver.c:1827-1857, called at :2034-2039 and :2098-2103)
+ * and from then on factors with a pivoted device factorisation (csrc/lu.hip; same solutions as the reference's
+ * dsytrf/dsytrs to rounding); LinType reads DENSE_INDEFINITE afterwards, PsdCheck / GetDiag fail and FSolve / BSolve /
+ * Invert do nothing on such an object (:1729-1797). */
 hdsdp_retcode HFpLinsysCreate(hdsdp_linsys_fp **pHLin, int nCol, linsys_type Ltype);      /* hdsdp_linsolver.c:1859 */
 void HFpLinsysSetParam(hdsdp_linsys_fp *HLin, double relTol, double absTol, int nThreads, int maxIter,
                        int nRestartFreq);                                                 /* :2000 */

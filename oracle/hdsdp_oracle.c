@@ -734,6 +734,121 @@ int orc_pcg_solve(int m, const double *M, const double *rhs, double *x, double r
     return it;
 }
 
+/* ---------------------------------------------------------------- symmetric-indefinite fallback
+ * The reference switches the Schur system to LAPACK dsytrf / dsytrs (hdsdp_linsolver.c:1706-1780) when its PCG gives
+ * up.  LAPACK is a third-party dependency that is not in the reference tree (any conforming build; MKL in this image);
+ * below is its published algorithm, the unblocked Bunch-Kaufman LDL^T with partial pivoting of dsytf2 (lower storage,
+ * alpha = (1+sqrt(17))/8) and the matching dsytrs substitution.  ipiv: >= 0 one-by-one pivot exchanged with that row;
+ * < 0: two-by-two pivot in (k, k+1), row k+1 exchanged with -ipiv-1.  Returns 0, or j+1 for an exactly zero pivot. */
+int orc_sytrf(int n, double *A, int *ipiv) {
+    const double alpha = (1.0 + sqrt(17.0)) / 8.0;
+    int info = 0, k = 0;
+    while (k < n) {
+        int kstep = 1, kp = k, imax = k;
+        double absakk = fabs(FE(A, n, k, k)), colmax = 0.0;
+        for (int i = k + 1; i < n; ++i) if (fabs(FE(A, n, i, k)) > colmax) { colmax = fabs(FE(A, n, i, k)); imax = i; }
+        if (fmax(absakk, colmax) == 0.0) {
+            if (!info) info = k + 1;
+        } else {
+            if (absakk >= alpha * colmax) kp = k;
+            else {
+                double rowmax = 0.0;
+                for (int j = k; j < imax; ++j) rowmax = fmax(rowmax, fabs(FE(A, n, imax, j)));
+                for (int i = imax + 1; i < n; ++i) rowmax = fmax(rowmax, fabs(FE(A, n, i, imax)));
+                if (absakk >= alpha * colmax * (colmax / rowmax)) kp = k;
+                else if (fabs(FE(A, n, imax, imax)) >= alpha * rowmax) kp = imax;
+                else { kp = imax; kstep = 2; }
+            }
+            const int kk = k + kstep - 1;
+            if (kp != kk) {      /* symmetric exchange of rows/columns kk and kp inside the trailing block */
+                double t;
+                for (int i = kp + 1; i < n; ++i) { t = FE(A, n, i, kk); FE(A, n, i, kk) = FE(A, n, i, kp); FE(A, n, i, kp) = t; }
+                for (int i = kk + 1; i < kp; ++i) { t = FE(A, n, i, kk); FE(A, n, i, kk) = FE(A, n, kp, i); FE(A, n, kp, i) = t; }
+                t = FE(A, n, kk, kk); FE(A, n, kk, kk) = FE(A, n, kp, kp); FE(A, n, kp, kp) = t;
+                if (kstep == 2) { t = FE(A, n, k + 1, k); FE(A, n, k + 1, k) = FE(A, n, kp, k); FE(A, n, kp, k) = t; }
+            }
+            if (kstep == 1) {
+                const double d = 1.0 / FE(A, n, k, k);
+                for (int j = k + 1; j < n; ++j) {
+                    const double w = -d * FE(A, n, j, k);
+                    if (w != 0.0) for (int i = j; i < n; ++i) FE(A, n, i, j) += FE(A, n, i, k) * w;
+                }
+                for (int i = k + 1; i < n; ++i) FE(A, n, i, k) *= d;
+            } else if (k < n - 2) {
+                double d21 = FE(A, n, k + 1, k);
+                const double d11 = FE(A, n, k + 1, k + 1) / d21, d22 = FE(A, n, k, k) / d21;
+                const double t = 1.0 / (d11 * d22 - 1.0);
+                d21 = t / d21;
+                for (int j = k + 2; j < n; ++j) {
+                    const double wk = d21 * (d11 * FE(A, n, j, k) - FE(A, n, j, k + 1));
+                    const double wk1 = d21 * (d22 * FE(A, n, j, k + 1) - FE(A, n, j, k));
+                    for (int i = j; i < n; ++i) FE(A, n, i, j) -= FE(A, n, i, k) * wk + FE(A, n, i, k + 1) * wk1;
+                    FE(A, n, j, k) = wk;
+                    FE(A, n, j, k + 1) = wk1;
+                }
+            }
+        }
+        if (kstep == 1) ipiv[k] = kp;
+        else ipiv[k] = ipiv[k + 1] = -kp - 1;
+        k += kstep;
+    }
+    return info;
+}
+void orc_sytrs(int n, const double *A, const int *ipiv, double *b) {
+    double t;
+    int k = 0;
+    while (k < n) {                       /* b <- D^-1 L^-1 P^T b */
+        if (ipiv[k] >= 0) {
+            const int kp = ipiv[k];
+            if (kp != k) { t = b[k]; b[k] = b[kp]; b[kp] = t; }
+            for (int i = k + 1; i < n; ++i) b[i] -= FE(A, n, i, k) * b[k];
+            b[k] /= FE(A, n, k, k);
+            k += 1;
+        } else {
+            const int kp = -ipiv[k] - 1;
+            if (kp != k + 1) { t = b[k + 1]; b[k + 1] = b[kp]; b[kp] = t; }
+            for (int i = k + 2; i < n; ++i) b[i] -= FE(A, n, i, k) * b[k] + FE(A, n, i, k + 1) * b[k + 1];
+            const double akm1k = FE(A, n, k + 1, k), akm1 = FE(A, n, k, k) / akm1k, ak = FE(A, n, k + 1, k + 1) / akm1k;
+            const double denom = akm1 * ak - 1.0, bkm1 = b[k] / akm1k, bk = b[k + 1] / akm1k;
+            b[k] = (ak * bkm1 - bk) / denom;
+            b[k + 1] = (akm1 * bk - bkm1) / denom;
+            k += 2;
+        }
+    }
+    k = n - 1;
+    while (k >= 0) {                      /* b <- P L^-T b */
+        if (ipiv[k] >= 0) {
+            for (int i = k + 1; i < n; ++i) b[k] -= FE(A, n, i, k) * b[i];
+            const int kp = ipiv[k];
+            if (kp != k) { t = b[k]; b[k] = b[kp]; b[kp] = t; }
+            k -= 1;
+        } else {
+            for (int i = k + 1; i < n; ++i) { b[k] -= FE(A, n, i, k) * b[i]; b[k - 1] -= FE(A, n, i, k - 1) * b[i]; }
+            const int kp = -ipiv[k] - 1;
+            if (kp != k) { t = b[k]; b[k] = b[kp]; b[kp] = t; }
+            k -= 2;
+        }
+    }
+}
+/* HFpLinsysNumeric + HFpLinsysSolve on the Schur system object (hdsdp_linsolver.c:2029-2044, 2085-2110): *linType is
+ * the object's solver class, 5 = DENSE_ITERATIVE (PCG) or 6 = DENSE_INDEFINITE; a failed PCG (or a NaN result)
+ * switches the object to 6 for good and solves again with LDL^T.  Returns 0, or 1 for a failed solve. */
+int orc_schur_solve(int m, const double *M, const double *rhs, double *x, double relTol, double absTol, int maxIter,
+                    int *linType) {
+    if (*linType == 5) {
+        int it = orc_pcg_solve(m, M, rhs, x, relTol, absTol, maxIter);
+        if (it >= 0 && x[0] == x[0] && rhs[0] == rhs[0]) return 0;
+        *linType = 6;
+    }
+    double *F = malloc(sizeof(double) * (size_t) m * m);
+    int *ipiv = malloc(sizeof(int) * (size_t) m);
+    memcpy(F, M, sizeof(double) * (size_t) m * m);
+    int info = orc_sytrf(m, F, ipiv);
+    if (!info) { memcpy(x, rhs, sizeof(double) * m); orc_sytrs(m, F, ipiv, x); }
+    free(F); free(ipiv);
+    return (info || x[0] != x[0]) ? 1 : 0;
+}
+
 /* ---------------------------------------------------------------- SURVEY.md 8(d) generator */
 static uint64_t g_state;
 static double draw(void) {

@@ -36,6 +36,8 @@ def lib():
         L.orc_kkt_build.argtypes = [vp, dp, C.c_double, C.c_int, C.c_int, dp, dp, dp, dp, dp]
         L.orc_pcg_solve.restype = C.c_int
         L.orc_pcg_solve.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_int]
+        L.orc_schur_solve.restype = C.c_int
+        L.orc_schur_solve.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_int, ip]
         L.orc_lanczos_create.restype = vp
         L.orc_lanczos_create.argtypes = [C.c_int]
         L.orc_lanczos_free.argtypes = [vp]
@@ -157,6 +159,17 @@ def pcg_solve(M, rhs, relTol=5e-12, absTol=1e-12, maxIter=-1):
     if it < 0:
         raise RuntimeError("orc_pcg_solve failed")
     return x
+
+
+def schur_solve(M, rhs, lin_type=5, relTol=5e-12, absTol=1e-12, maxIter=-1):
+    """factor + solve on the Schur system object with the reference's switch to LDL^T; returns (x, lin_type_after)"""
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+    x = np.zeros_like(rhs)
+    lt = C.c_int(lin_type)
+    if lib().orc_schur_solve(M.shape[0], _d(M), _d(rhs), _d(x), relTol, absTol, maxIter, C.byref(lt)):
+        raise RuntimeError("orc_schur_solve failed")
+    return x, lt.value
 
 
 def bench_sample(n, sample_m):

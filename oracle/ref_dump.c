@@ -16,6 +16,9 @@
  *        ref_dump <outdir> mix  <n> <m>      <Rd> <tau> <yscale>     (all five coefficient types)
  *        ref_dump -        bench <n> <m>     <Rd> <tau> <yscale>     (CPU baseline: prints one JSON line
  *                                                                     with stage timings, dumps nothing)
+ *        ref_dump <outdir> indef <m> <kind> <shift> 0 0              (Schur-system solver on a matrix that is not
+ *                                                                     positive definite: the LDL^T fallback,
+ *                                                                     linalg/hdsdp_linsolver.c:1827-1857, 2029-2110)
  */
 #include "interface/hdsdp.h"
 #include "interface/hdsdp_utils.h"
@@ -24,6 +27,7 @@
 #include "interface/hdsdp_conic.h"
 #include "interface/hdsdp_schur.h"
 #include "linalg/hdsdp_sdpdata.h"
+#include "linalg/hdsdp_linsolver.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -167,6 +171,52 @@ int main(int argc, char **argv) {
     csc_prob pb; memset(&pb, 0, sizeof(pb));
     double Rd, tau, yscale;
 
+    if (!strcmp(mode, "indef")) {
+        /* the Schur system object exactly as HKKTIAllocDenseKKT sets it up (hdsdp_schur.c:11-44), fed with a symmetric
+           matrix that is not positive definite.  kind 0: uniform(-1,1) entries + shift on the diagonal (strongly
+           indefinite for shift 0); kind 1: G G^T / m + shift I with shift < 0 pushing the small eigenvalues below zero
+           ("almost indefinite").  Two factor+solve rounds: the second one shows that the object stays switched. */
+        const int mm = atoi(argv[3]), kind = atoi(argv[4]);
+        const double shift = atof(argv[5]);
+        double *Mm = calloc((size_t) mm * mm, sizeof(double)), *bb = calloc(mm, sizeof(double));
+        double *x1 = calloc(mm, sizeof(double)), *x2 = calloc(mm, sizeof(double));
+        if (kind == 0) {
+            for (int j = 0; j < mm; ++j)
+                for (int i = j; i < mm; ++i) Mm[i + (size_t) j * mm] = urand();
+        } else {
+            double *G = calloc((size_t) mm * mm, sizeof(double));
+            for (size_t e = 0; e < (size_t) mm * mm; ++e) G[e] = urand();
+            for (int j = 0; j < mm; ++j)
+                for (int i = j; i < mm; ++i) {
+                    double acc = 0.0;
+                    for (int k = 0; k < mm; ++k) acc += G[i + (size_t) k * mm] * G[j + (size_t) k * mm];
+                    Mm[i + (size_t) j * mm] = acc / mm;
+                }
+            free(G);
+        }
+        for (int j = 0; j < mm; ++j) Mm[j + (size_t) j * mm] += shift;
+        for (int i = 0; i < mm; ++i) bb[i] = urand();
+        { int dm[2] = {mm, kind}; dump_i("indef_dims", dm, 2); }
+        dump_d2("indef_M", Mm, mm, mm); dump_d("indef_b", bb, mm);
+        hdsdp_linsys_fp *lin = NULL;
+        HDSDP_CALL(HFpLinsysCreate(&lin, mm, HDSDP_LINSYS_DENSE_ITERATIVE));
+        HFpLinsysSetParam(lin, 5.0 * KKT_ACCURACY, KKT_ACCURACY, -1, -1, -1);
+        int codes[6] = {0, 0, 0, 0, 0, 0};
+        codes[0] = (int) HFpLinsysNumeric(lin, NULL, NULL, Mm);
+        codes[1] = (int) HFpLinsysSolve(lin, 1, bb, x1);
+        codes[2] = (int) lin->LinType;
+        dump_d("indef_x1", x1, mm);
+        /* second round on a modified matrix (what the next IPM iteration does) */
+        for (int j = 0; j < mm; ++j) Mm[j + (size_t) j * mm] += 0.125;
+        codes[3] = (int) HFpLinsysNumeric(lin, NULL, NULL, Mm);
+        codes[4] = (int) HFpLinsysSolve(lin, 1, bb, x2);
+        codes[5] = (int) lin->LinType;
+        dump_d("indef_x2", x2, mm);
+        dump_i("indef_codes", codes, 6);
+        printf("ref_dump ok: indef m=%d kind=%d codes=%d %d %d | %d %d %d\n", mm, kind, codes[0], codes[1], codes[2],
+               codes[3], codes[4], codes[5]);
+        return 0;
+    }
     if (!strcmp(mode, "sdpam")) {
         /* multi-block SDPA instance (truss1: six 2x2 blocks and a 1x1): one dense-SDP cone per block in ONE Schur
            operator -- HKKTBuildUp loops over the cones and every cone adds its part (hdsdp_schur.c:256-268) */

@@ -103,3 +103,114 @@ def test_mfma_probe_reports_a_rate():
     tf = api.load_library().HMiMfmaPeakProbe(20000)
     print("fp64 MFMA register-loop rate: %.1f TFLOP/s" % tf)
     assert tf > 10.0
+
+
+@pytest.mark.parametrize("name", ["indef96", "indef150"])
+def test_schur_system_indefinite_fallback_matches_reference(name):
+    """HFpLinsysNumeric / HFpLinsysSolve on the Schur system object (DENSE_ITERATIVE) with a matrix that is not
+    positive definite: the object switches to the symmetric-indefinite solver and stays switched
+    (linalg/hdsdp_linsolver.c:1827-1857, 2029-2110); values against the reference's own LDL^T solves.
+    Tolerance 1e-9 relative (the reference's bar for Schur solves is 1e-8)."""
+    import os
+    from hdsdp_amd import api
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")))
+    M, b = g["indef_M"], g["indef_b"]
+    m = M.shape[0]
+    ls = api.LinSys(m, api.HDSDP_LINSYS_DENSE_ITERATIVE)
+    try:
+        assert ls.lin_type == api.HDSDP_LINSYS_DENSE_ITERATIVE
+        ls.numeric(M)
+        assert ls.lin_type == int(g["indef_codes"][2]) == api.HDSDP_LINSYS_DENSE_INDEFINITE
+        x1 = ls.solve(b)
+        assert np.linalg.norm(x1 - g["indef_x1"]) <= 1e-9 * np.linalg.norm(g["indef_x1"])
+        M2 = M.copy()
+        i = np.arange(m)
+        M2[i, i] += 0.125
+        ls.numeric(M2)
+        assert ls.lin_type == int(g["indef_codes"][5])
+        x2 = ls.solve(b)
+        assert np.linalg.norm(x2 - g["indef_x2"]) <= 1e-9 * np.linalg.norm(g["indef_x2"])
+        # in-place solve and several right-hand sides
+        rhs = np.stack([b, 2.0 * b, b[::-1].copy()])
+        xs = ls.solve(rhs)
+        assert np.linalg.norm(xs[1] - 2.0 * x2) <= 1e-9 * np.linalg.norm(xs[1])
+        A2 = np.triu(M2) + np.triu(M2, 1).T
+        assert np.linalg.norm(A2 @ xs[2] - rhs[2]) <= 1e-10 * np.linalg.norm(rhs[2]) * np.linalg.cond(A2)
+        # the pivoted object is no PSD oracle and has no half solves (hdsdp_linsolver.c:1729-1797)
+        with pytest.raises(api.HDSDPError):
+            ls.get_diag()
+    finally:
+        ls.destroy()
+    # the dual-matrix object (DENSE_DIRECT) has no such way out: not positive definite is a failure there
+    ld = api.LinSys(m, api.HDSDP_LINSYS_DENSE_DIRECT)
+    try:
+        with pytest.raises(api.HDSDPError):
+            ld.numeric(M)
+        assert ld.lin_type == api.HDSDP_LINSYS_DENSE_DIRECT
+    finally:
+        ld.destroy()
+
+
+@pytest.mark.parametrize("m", [33, 500, 2000])
+def test_schur_system_indefinite_fallback_sizes(m):
+    """size-independent property at sizes the goldens do not cover (one panel + identity padding, several panels, the
+    bench size): M x = b to rounding for a symmetric indefinite M, against numpy's LAPACK solve; a singular matrix
+    fails like dsytrf's info > 0"""
+    from hdsdp_amd import api
+    rng = np.random.default_rng(m)
+    G = rng.uniform(-1, 1, (m, m))
+    A = 0.5 * (G + G.T)
+    b = rng.uniform(-1, 1, m)
+    ls = api.LinSys(m, api.HDSDP_LINSYS_DENSE_ITERATIVE)
+    try:
+        ls.numeric(np.triu(A))
+        assert ls.lin_type == api.HDSDP_LINSYS_DENSE_INDEFINITE
+        x = ls.solve(b)
+        ref = np.linalg.solve(A, b)
+        cond = np.linalg.cond(A)
+        assert np.linalg.norm(x - ref) <= 1e-13 * cond * np.linalg.norm(ref)
+        assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(A, 2) * np.linalg.norm(x)
+        Z = A.copy()
+        Z[:, 5] = 0.0
+        Z[5, :] = 0.0
+        with pytest.raises(api.HDSDPError):
+            ls.numeric(np.triu(Z))
+    finally:
+        ls.destroy()
+
+
+def test_kkt_factorize_falls_back_when_the_schur_matrix_is_indefinite():
+    """HKKTFactorize / HKKTSolve with a Schur matrix pushed indefinite through kktDiag (what a cone or the driver can do
+    to the host matrix): the operator keeps solving, through the pivoted solver, and stays on it afterwards"""
+    from hdsdp_amd import api
+    n = m = 64
+    cone = api.SDPCone.synthetic(n, m)
+    kkt = api.KKT(m, [cone])
+    try:
+        cone.set_start(-10.0 * n)
+        assert cone.check_is_interior(1.0, np.zeros(m))
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        assert kkt.lin_type == api.HDSDP_LINSYS_DENSE_ITERATIVE
+        Mh = kkt.M
+        A = np.triu(Mh) + np.triu(Mh, 1).T
+        shift = -0.5 * (np.linalg.eigvalsh(A)[0] + np.linalg.eigvalsh(A)[-1])
+        kkt.add_to_diag(shift)                      # eigenvalues now straddle zero
+        A = A + shift * np.eye(m)
+        assert np.linalg.eigvalsh(A)[0] < 0 < np.linalg.eigvalsh(A)[-1]
+        kkt.factorize()
+        assert kkt.lin_type == api.HDSDP_LINSYS_DENSE_INDEFINITE
+        b = cone.traces()
+        x = kkt.solve(b)
+        ref = np.linalg.solve(A, b)
+        assert np.linalg.norm(x - ref) <= 1e-12 * np.linalg.cond(A) * np.linalg.norm(ref)
+        # next iteration: a positive definite matrix again, the object stays on the pivoted solver and is still right
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        kkt.factorize()
+        assert kkt.lin_type == api.HDSDP_LINSYS_DENSE_INDEFINITE
+        Mh = kkt.M
+        A = np.triu(Mh) + np.triu(Mh, 1).T
+        x = kkt.solve(b)
+        assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(b)
+    finally:
+        kkt.destroy()
+        cone.destroy()

@@ -144,3 +144,29 @@ def test_oracle_multi_block_matches_reference():
     check_close(ai, g["ASinv_inf"], "ASinv_inf"); check_close(ri, g["ASinvRdSinv_inf"], "ASinvRdSinv_inf")
     x = oracle_py.pcg_solve(Mi, g["b"])
     assert np.linalg.norm(x - g["sol_b"]) <= 1e-8 * np.linalg.norm(g["sol_b"])
+
+
+@pytest.mark.parametrize("name", ["indef96", "indef150"])
+def test_oracle_indefinite_schur_fallback_matches_reference(name):
+    """the Schur system object on a matrix that is not positive definite (strongly indefinite; a few eigenvalues just
+    below zero): the reference's PCG gives up, HFpLinsysSwitchToIndefinite replaces it by LDL^T for good
+    (linalg/hdsdp_linsolver.c:1827-1857, 2029-2110); the restatement must take the same way and land on the same
+    solution, in the first round and in the next one"""
+    g = load_golden(name)
+    M, b = g["indef_M"], g["indef_b"]
+    rc_num, rc_sol, lt, rc_num2, rc_sol2, lt2 = (int(v) for v in g["indef_codes"])
+    assert (rc_num, rc_sol, rc_num2, rc_sol2) == (0, 0, 0, 0) and lt == 6 and lt2 == 6
+    x, lin_type = oracle_py.schur_solve(M, b, lin_type=5)
+    assert lin_type == lt
+    assert np.linalg.norm(x - g["indef_x1"]) <= 1e-11 * np.linalg.norm(g["indef_x1"])
+    M2 = M.copy()
+    i = np.arange(M.shape[0])
+    M2[i, i] += 0.125
+    x2, lin_type = oracle_py.schur_solve(M2, b, lin_type=lin_type)
+    assert lin_type == lt2
+    assert np.linalg.norm(x2 - g["indef_x2"]) <= 1e-11 * np.linalg.norm(g["indef_x2"])
+    # a positive definite matrix does not switch
+    A = np.triu(M) + np.triu(M, 1).T
+    P = A @ A.T / M.shape[0] + np.eye(M.shape[0])
+    xp, lin_type = oracle_py.schur_solve(np.triu(P), b, lin_type=5)
+    assert lin_type == 5 and np.linalg.norm(P @ xp - b) <= 1e-9 * np.linalg.norm(b)
