@@ -317,8 +317,10 @@ int main(int argc, char **argv) {
         HDSDP_CALL(HKKTSolve(kkt, d2, NULL));
         HDSDP_CALL(HKKTSolve(kkt, d3, NULL));
         double t4 = HUtilGetTimeStamp();
-        printf("{\"n\": %d, \"m\": %d, \"interior\": %d, \"chol_s\": %.6f, \"buildup_s\": %.6f, \"factor_s\": %.6f, \"solve3_s\": %.6f}\n",
-               n, m, isInt, t1 - t0, t2 - t1, t3 - t2, t4 - t3);
+        double sum_d2 = 0.0;
+        for (int i = 0; i < m; ++i) sum_d2 += d2[i];
+        printf("{\"n\": %d, \"m\": %d, \"interior\": %d, \"chol_s\": %.6f, \"buildup_s\": %.6f, \"factor_s\": %.6f, \"solve3_s\": %.6f, \"sum_d2\": %.15e}\n",
+               n, m, isInt, t1 - t0, t2 - t1, t3 - t2, t4 - t3, sum_d2);
         return 0;
     }
     dump_i("csc_beg", pb.beg, m + 2); dump_i("csc_idx", pb.idx, nnz); dump_d("csc_val", pb.val, nnz);
