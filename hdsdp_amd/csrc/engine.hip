@@ -1645,6 +1645,25 @@ hdsdp_retcode HKKTSolve(hdsdp_kkt *HKKT, double *dRhsVec, double *dLhsVec) {
 }
 
 void HKKTRegularize(hdsdp_kkt *HKKT, double dKKTReg) {  // hdsdp_schur.c:348-373
+    MiKKTPriv *pv = priv_of(HKKT);
+    if (!pv->mirror) {
+        // device-resident M (HMiKKTSetHostMirror(.., 0)): same rule on the device copy; the diagonal (m doubles)
+        // makes the round trip, the matrix does not
+        MiLin *l = (MiLin *) HKKT->kktM->chol;
+        if (!pv->Mdev_valid || !l->Mdev) return;
+        const int m = HKKT->nRow;
+        const size_t pitch = sizeof(double) * ((size_t) l->ch.npad + 1);
+        std::vector<double> d(m);
+        if (hipStreamSynchronize(g.stream) != hipSuccess) return;
+        if (hipMemcpy2D(d.data(), sizeof(double), l->Mdev, pitch, sizeof(double), m, hipMemcpyDeviceToHost) != hipSuccess) return;
+        double mn = INFINITY;
+        for (int i = 0; i < m; ++i) mn = std::min(mn, d[i]);
+        double reg = std::min(dKKTReg * mn, 1e-05);
+        if (reg < 1e-14) return;
+        for (int i = 0; i < m; ++i) d[i] += reg;
+        (void) hipMemcpy2D(l->Mdev, pitch, d.data(), sizeof(double), sizeof(double), m, hipMemcpyHostToDevice);
+        return;
+    }
     double mn = INFINITY;
     for (int i = 0; i < HKKT->nRow; ++i) mn = std::min(mn, *HKKT->kktDiag[i]);
     dKKTReg = std::min(dKKTReg * mn, 1e-05);

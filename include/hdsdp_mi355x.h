@@ -258,7 +258,8 @@ int HMiConeGetPath(hdsdp_cone *cone);
 /* ===============================  device-resident fast path  ===============================
  * The reference boundary hands host buffers (S in, M out).  For benchmarking with inputs resident in
  * HBM, these keep M on the device between BuildUp / Factorize / Solve (no PCIe round trip of M).  */
-void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM);   /* default 1: kktMatElem is refreshed after BuildUp */
+void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM);   /* default 1: kktMatElem is refreshed after BuildUp; with 0
+                                                              HKKTRegularize / Factorize / Solve act on the device copy */
 /* multi-GPU (world > 1): constraint rows are sharded (row i on rank i % world).  Each rank congruence-
  * transforms its own rows, a transpose (all-to-all) re-shards the transformed data from "by constraint"
  * to "by packed-index range", each rank forms the Gram partial sum over its range, and an all-reduce

@@ -586,6 +586,24 @@ def test_regularize_follows_the_reference_rule():
                 want = 0.0
             kkt.regularize(reg)
             assert np.array_equal(np.diag(kkt.M), d0 + want)
+        # the device-resident flavour (host mirror off) applies the same rule to the device copy of M: seen through
+        # the solve, against the mirrored operator regularised the same way
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        kkt.regularize(1e3)
+        Mh = kkt.M
+        A = np.triu(Mh) + np.triu(Mh, 1).T
+        b = cone.traces()
+        kdev = api.KKT(m, [cone], host_mirror=False)
+        kdev.build_up(api.KKT_TYPE_INFEASIBLE)
+        kdev.factorize()
+        x_plain = kdev.solve(b)
+        kdev.regularize(1e3)
+        kdev.factorize()
+        x_reg = kdev.solve(b)
+        ref = np.linalg.solve(A, b)
+        assert np.linalg.norm(x_reg - ref) <= 1e-10 * np.linalg.norm(ref)
+        assert np.linalg.norm(x_plain - ref) > 1e-6 * np.linalg.norm(ref)   # the shift is visible in the solution
+        kdev.destroy()
         kkt.destroy()
     finally:
         cone.destroy()
