@@ -10,6 +10,7 @@ the HIP extension and an MI355X.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -79,6 +80,16 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise HDSDPError(f"{LIB_PATH} is missing: run `python -m hdsdp_amd.build` (hipcc, gfx950). "
                          "There is no CPU fallback for the Schur path.")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7 and loads it by path, the engine
+    # links the system one by soname.  Engine first, torch later = two runtimes in one process, and torch then finds
+    # "No HIP GPUs"; torch first = the engine's DT_NEEDED resolves to the copy torch already loaded.  So when torch is
+    # around (tests, bench, the RCCL exchange), let it load first.  HDSDP_MI355X_NO_TORCH=1 skips this for processes
+    # that never touch torch (the C ABI itself has no torch dependency).
+    if "torch" not in sys.modules and os.environ.get("HDSDP_MI355X_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
     kp = C.POINTER(hdsdp_kkt)

@@ -12,6 +12,14 @@ struct HdmChol {
     double *vec = nullptr;   // 4 * npad scratch vectors
     int *info_dev = nullptr;
     bool factored = false, have_inv = false;
+    // The factorisation (3 launches per 128-block) and the block substitutions (2 launches per block) are chains of
+    // short dependent launches with fixed arguments: after one eager run they can be captured into a hipGraph and
+    // replayed (policy and measurements: hdm_graph_level in chol.hip).  A failed capture falls back to eager launches.
+    struct Replay { const void *b = nullptr, *x = nullptr; int nrhs = 0, which = 0; long ldv = 0; hipGraphExec_t exec = nullptr; };
+    hipGraphExec_t factor_graph = nullptr;
+    Replay solves[4];
+    int nsolves = 0, factor_runs = 0, solve_runs = 0;
+    bool graphs_ok = true;
 
     int init(int n);
     void destroy();
@@ -23,6 +31,8 @@ struct HdmChol {
     int set_reverse_inverse(hipStream_t s);             // primal builds: Linv <- W, W^T W = X, from the factor of J X J
     int get_diag(double *diag_host, hipStream_t s);
     int solve_device(double *b_dev, double *x_dev, int nrhs, long ldv, int which, hipStream_t s);
+    int enqueue_factor(hipStream_t s);
+    int enqueue_solve(double *b_dev, double *x_dev, int nrhs, long ldv, int which, hipStream_t s);
     int solve_host(const double *rhs, double *sol, int nrhs, int which, hipStream_t s);
     int inverse_full(double *out_dev, long ldo, hipStream_t s);
 };

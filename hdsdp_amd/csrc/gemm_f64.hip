@@ -697,6 +697,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
 namespace {
 struct TimedLaunch { hipEvent_t e0, e1; int role; double flops; };
 bool g_timing = false;
+bool g_capturing = false;
 std::vector<TimedLaunch> g_timed;
 unsigned long long *g_dbg = nullptr;
 int g_dbg_role = -1;
@@ -761,11 +762,12 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     d.tiles = tl.dev;
     d.ntiles = tl.n;
     d.dbg = (g_dbg && args.role == g_dbg_role) ? g_dbg : nullptr;
-    if (d.dbg && getenv("HDM_DBG_SYNC")) HDM_HIP_CHECK(hipDeviceSynchronize());   // diagnostic: isolate the stamped launch from its neighbours
+    if (d.dbg && !g_capturing && getenv("HDM_DBG_SYNC")) HDM_HIP_CHECK(hipDeviceSynchronize());   // diagnostic: isolate the stamped launch from its neighbours
     const long nwg = (long) tl.n * (args.batch >= 8 ? ((args.batch + 7) & ~7) : args.batch);
     dim3 grid((unsigned) nwg), block(256);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (g_timing) {
+    const bool timed = g_timing && !g_capturing;
+    if (timed) {
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
         HDM_HIP_CHECK(hipEventRecord(e0, stream));
     }
@@ -799,7 +801,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     }
 #undef HDM_LAUNCH_V
 #undef HDM_LAUNCH
-    if (g_timing) {
+    if (timed) {
         HDM_HIP_CHECK(hipEventRecord(e1, stream));
         std::lock_guard<std::mutex> lk(g_tl_mutex);
         g_timed.push_back({e0, e1, args.role, args.flops});
@@ -809,6 +811,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
 }
 
 void hdm_timing_enable(int on) { g_timing = (on != 0); }
+void hdm_gemm_capture_mode(int on) { g_capturing = (on != 0); }
 
 int hdm_timing_collect(double *ms, double *flops, long *launches) {
     for (int r = 0; r < HDM_NROLES; ++r) { ms[r] = 0.0; flops[r] = 0.0; launches[r] = 0; }

@@ -96,6 +96,8 @@ struct HdmGemmArgs {
 };
 
 int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream);
+// while a stream capture is recording the launches (chol.hip), the launcher must not record timing events
+void hdm_gemm_capture_mode(int on);
 // per-role live timing with HIP events on the launch stream (off by default)
 void hdm_timing_enable(int on);
 void hdm_set_debug_buffer(unsigned long long *dev, int role);
