@@ -34,7 +34,7 @@ EXPORTS = [
     "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeCheckIsInteriorExpert",
     "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetCoeffNorm", "HMiConeGetObjNorm",
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
-    "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces",
+    "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
     "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
@@ -147,6 +147,7 @@ def load_library():
         "HMiKKTSetHostMirror": (None, [kp, C.c_int]),
         "HMiConeSetExchange": (None, [vp, vp, vp, vp]),
         "HMiConeSetExchangePieces": (None, [vp, vp, vp, C.c_int]),
+        "HMiConeGetExchangeStats": (None, [vp, ip, ip]),
         "HMiConeGetExchangeBuffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]),
         "HMiConeSetExchangeBuffers": (C.c_int, [vp, vp, vp]),
         "HMiKKTDeviceMatrix": (vp, [kp, C.POINTER(C.c_int64)]),
@@ -346,6 +347,12 @@ class SDPCone:
         _check(load_library().HMiConeGetLogBarrier(self._h, float(tau), yp, BUFFER_DUALVAR, C.byref(out)),
                "HConeGetLogBarrier")
         return out.value
+
+    def exchange_stats(self):
+        """(pieces of the last build's all-to-all, launches the staged second congruence step was cut into)"""
+        p, s = C.c_int(0), C.c_int(0)
+        load_library().HMiConeGetExchangeStats(self._h, C.byref(p), C.byref(s))
+        return p.value, s.value
 
     def presolve(self):
         m = self.m

@@ -265,6 +265,8 @@ struct MiCone {
     hmi_alltoall_piece_fn a2a_start = nullptr;   // piecewise exchange overlapped with the Gram product (optional)
     hmi_alltoall_wait_fn a2a_wait = nullptr;
     int a2a_pieces = 1;
+    hipEvent_t piece_ev[64] = {};                // staged exchange: congruence step 2 finished the p-blocks of piece k
+    int last_pieces = 1, last_staged = 0;        // HMiConeGetExchangeStats
     hmi_allreduce_fn allreduce = nullptr;
     void *xctx = nullptr;
     bool work_ready = false;
@@ -751,7 +753,23 @@ void cone_precover(void *cd, double dBarrierMu, double *y, double *dy, double *X
 }
 
 // --- the GPU Schur builder ---------------------------------------------------------------------
-int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, int count, long row0) {
+// share of step 2's work that falls into the tile columns of `mask` (tile (tm, tn), tm >= tn, runs tn + 1 K blocks)
+double cong2_mask_share(int NT, unsigned long long mask) {
+    if (!mask || NT > 64) return 1.0;
+    double all = 0.0, sel = 0.0;
+    for (int tn = 0; tn < NT; ++tn) {
+        const double w = (double) (NT - tn) * (tn + 1);
+        all += w;
+        if ((mask >> tn) & 1ULL) sel += w;
+    }
+    return all > 0.0 ? sel / all : 1.0;
+}
+
+// phase 0: both steps; 1: step 1 only; 2: step 2 only (count <= Bc, T still holds step 1's output), optionally only the
+// output tiles of the tile columns in `colmask` -- the multi-GPU build runs step 2 by packed-index range so that the
+// finished ranges can leave for the other ranks while the rest is still being computed
+int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, int count, long row0, int phase = 0,
+                    unsigned long long colmask = 0) {
     // rows row0 .. row0+count-1 of AhatLoc  <-  blocked( Linv * A * Linv^T ),  A = A_L + A_L^T given in A_L form:
     //   step 1  U  = Linv * A_L                 (lower x lower = lower triangular: k in [col tile, row tile], n^3/3)
     //   step 2  At = U * Linv^T + Linv * U^T    (SYR2K form, lower tiles, k <= col tile, 2n^3/3)
@@ -767,7 +785,8 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, in
         k1.M = c->n16; k1.N = c->n16; k1.K = c->n16; k1.batch = nb; k1.alpha = 1.0;
         k1.klimit = HDM_KLIM_BAND; k1.lower_only = 1; k1.epilogue = HDM_EPI_STORE; k1.role = HDM_ROLE_CONG1;
         k1.flops = (double) nb * n3 / 3.0;
-        if (hdm_launch_gemm(k1, g.stream)) return 1;
+        if (phase != 2 && hdm_launch_gemm(k1, g.stream)) return 1;
+        if (phase == 1) continue;
         HdmGemmArgs k2 = {};
         k2.A = c->T; k2.lda = c->n16; k2.strideA = nn;
         k2.B = ch.Linv; k2.ldb = ch.npad; k2.strideB = 0;
@@ -776,7 +795,8 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, in
         k2.C = c->AhatLoc; k2.M = c->n16; k2.N = c->n16; k2.K = c->n16; k2.batch = nb; k2.alpha = 1.0;
         k2.klimit = HDM_KLIM_BY_N; k2.lower_only = 1; k2.epilogue = HDM_EPI_BLOCKED;
         k2.blk_row_stride = c->Lr; k2.blk_row0 = row0 + b0; k2.nblk = c->nblk; k2.role = HDM_ROLE_CONG2;
-        k2.flops = (double) nb * n3 * 2.0 / 3.0;
+        k2.tile_col_mask = colmask;
+        k2.flops = (double) nb * n3 * 2.0 / 3.0 * cong2_mask_share((c->n16 + HDM_TILE - 1) / HDM_TILE, colmask);
         if (hdm_launch_gemm(k2, g.stream)) return 1;
     }
     return 0;
@@ -810,34 +830,71 @@ int gram_all(MiCone *c) {
 // world > 1: the all-to-all that re-shards Ahat from "by constraint" to "by packed-index range", and the Gram product.
 // With the piecewise hooks registered the exchange runs in pieces along the packed index and the Gram splits of a piece
 // start as soon as it has arrived, while the later pieces are still on the links.
-hdsdp_retcode exchange_and_gram(MiCone *c) {
+// number of pieces of the piecewise exchange (whole groups of Gram K splits)
+int exchange_pieces(const MiCone *c) {
+    int P = (c->a2a_start && c->a2a_wait) ? c->a2a_pieces : 1;
+    if (const char *e = getenv("HDSDP_MI355X_A2A_PIECES")) P = std::max(1, atoi(e));
+    if (!(c->a2a_start && c->a2a_wait)) P = 1;
+    while (P > 1 && (c->nsplit % P)) --P;
+    return P;
+}
+// p-blocks [lo, hi) of every destination's chunk that piece k of P carries
+void piece_range(const MiCone *c, int k, int P, long *lo, long *hi) {
+    const long chunk = (c->npb_loc + c->nsplit - 1) / c->nsplit;   // p-blocks per split
+    const int zper = c->nsplit / P;
+    *lo = std::min<long>(c->npb_loc, (long) k * zper * chunk);
+    *hi = (k == P - 1) ? c->npb_loc : std::min<long>(c->npb_loc, (long) (k + 1) * zper * chunk);
+}
+// Tile columns of congruence step 2 whose output piece k needs.  P-block q belongs to the 16 x 16 sub-block q / 16 of the
+// blocked lower triangle, sub-blocks are numbered column by column (column bj starts at bj*nblk - bj(bj-1)/2), and tile
+// column tn produces the sub-block columns 8 tn .. 8 tn + 7: a range of p-blocks is a range of tile columns.
+unsigned long long piece_tile_cols(const MiCone *c, int k, int P) {
+    long lo, hi;
+    piece_range(c, k, P, &lo, &hi);
+    auto col_of = [&](long sub) {
+        int bj = 0;
+        while (bj + 1 < c->nblk && (long) (bj + 1) * c->nblk - (long) (bj + 1) * bj / 2 <= sub) ++bj;
+        return bj;
+    };
+    unsigned long long mask = 0;
+    for (int d = 0; d < c->world; ++d) {
+        const long g0 = (long) d * c->npb_loc + lo, g1 = std::min<long>(c->npb, (long) d * c->npb_loc + hi);
+        if (g0 >= g1) continue;
+        for (int tn = col_of(g0 / 16) / 8; tn <= col_of((g1 - 1) / 16) / 8; ++tn) mask |= 1ULL << tn;
+    }
+    return mask;
+}
+
+// `staged`: congruence step 2 was launched piece by piece and c->piece_ev[k] marks the point where piece k's p-blocks
+// are final, so piece k can leave while the later tile columns are still being computed; otherwise the whole stream
+// is drained first.
+hdsdp_retcode exchange_and_gram(MiCone *c, bool staged = false) {
     if (!c->alltoall && !(c->a2a_start && c->a2a_wait)) {
         fprintf(stderr, "[hdsdp_mi355x] world > 1 but no exchange hook registered\n");
         return HDSDP_RETCODE_FAILED;
     }
-    HIP_RC(hipStreamSynchronize(g.stream));
-    int P = (c->a2a_start && c->a2a_wait) ? c->a2a_pieces : 1;
-    if (const char *e = getenv("HDSDP_MI355X_A2A_PIECES")) P = std::max(1, atoi(e));
-    if (!(c->a2a_start && c->a2a_wait)) P = 1;
-    while (P > 1 && (c->nsplit % P)) --P;            // pieces are whole groups of K splits
+    if (!staged) HIP_RC(hipStreamSynchronize(g.stream));
+    const int P = exchange_pieces(c);
     if (P <= 1) {
+        if (staged) HIP_RC(hipStreamSynchronize(g.stream));
         if (c->alltoall) { if (c->alltoall(c->xctx)) return HDSDP_RETCODE_FAILED; }
         else {
             if (c->a2a_start(c->xctx, 0, (int64_t) c->npb_loc * c->Lr * 16, 0) || c->a2a_wait(c->xctx, 0)) return HDSDP_RETCODE_FAILED;
         }
         return gram_all(c) ? HDSDP_RETCODE_FAILED : HDSDP_RETCODE_OK;
     }
-    const long chunk = (c->npb_loc + c->nsplit - 1) / c->nsplit;   // p-blocks per split
     const int zper = c->nsplit / P;
-    const int64_t total = (int64_t) c->npb_loc * c->Lr * 16;       // doubles per (source, destination) chunk
     for (int k = 0; k < P; ++k) {
-        const int64_t off = std::min<int64_t>(total, (int64_t) k * zper * chunk * c->Lr * 16);
-        const int64_t end = (k == P - 1) ? total : std::min<int64_t>(total, (int64_t) (k + 1) * zper * chunk * c->Lr * 16);
+        long lo, hi;
+        piece_range(c, k, P, &lo, &hi);
+        const int64_t off = (int64_t) lo * c->Lr * 16, end = (int64_t) hi * c->Lr * 16;   // doubles inside a chunk
+        if (staged) HIP_RC(hipEventSynchronize(c->piece_ev[k]));
         if (c->a2a_start(c->xctx, off, end - off, k)) {
             if (k == 0 && c->alltoall) {
                 // the piecewise flavour is not available in this process group: one blocking exchange from now on
                 fprintf(stderr, "[hdsdp_mi355x] piecewise all-to-all failed to start; using the blocking exchange\n");
                 c->a2a_pieces = 1; c->a2a_start = nullptr; c->a2a_wait = nullptr;
+                HIP_RC(hipStreamSynchronize(g.stream));
                 if (c->alltoall(c->xctx)) return HDSDP_RETCODE_FAILED;
                 return gram_all(c) ? HDSDP_RETCODE_FAILED : HDSDP_RETCODE_OK;
             }
@@ -949,7 +1006,16 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     RC(ch.invert_factor(g.stream));
     HIP_RC(hipEventRecord(g.ev[1], g.stream));
     const long nn = (long) c->n16 * c->n16;
-    RC(congruence_rows(c, ch, c->Afull, nn, c->mloc, 0));
+    // Multi-GPU: run step 2 of the owned rows by packed-index range, in the order of the exchange pieces, so that a piece
+    // crosses the links while the later ranges are still being computed (at two ranks the all-to-all moves 8 GB per
+    // rank over a single link, more than the Gram product alone can hide).  Needs the piecewise exchange hooks, all
+    // owned rows in one launch group and at most 64 tile columns.  HDSDP_MI355X_STAGED_A2A=0: drain, then exchange.
+    const int NT = (c->n16 + HDM_TILE - 1) / HDM_TILE;
+    int P = (c->world > 1) ? exchange_pieces(c) : 1;
+    bool staged = c->world > 1 && P > 1 && P <= 64 && c->mloc <= c->Bc && NT <= 64;
+    if (const char *e = getenv("HDSDP_MI355X_STAGED_A2A")) staged = staged && atoi(e) != 0;
+    c->last_pieces = P; c->last_staged = 0;
+    if (!staged) RC(congruence_rows(c, ch, c->Afull, nn, c->mloc, 0));
     if (c->rank == 0) {
         // "I row": A = I => T = Linv, At = Linv Linv^T.  Reuse step 2 with T := Linv.
         HdmGemmArgs k2 = {};
@@ -966,8 +1032,20 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
             RC(congruence_rows(c, ch, c->CL, nn, 1, c->mloc + 2));
         }
     }
+    if (staged) {
+        RC(congruence_rows(c, ch, c->Afull, nn, c->mloc, 0, 1));
+        const unsigned long long all = (NT >= 64) ? ~0ULL : ((1ULL << NT) - 1);
+        unsigned long long done = 0;
+        for (int k = 0; k < P; ++k) {
+            unsigned long long mk = (k == P - 1 ? all : piece_tile_cols(c, k, P)) & all & ~done;
+            if (mk) { RC(congruence_rows(c, ch, c->Afull, nn, c->mloc, 0, 2, mk)); c->last_staged += 1; }
+            done |= mk;
+            if (!c->piece_ev[k]) HIP_RC(hipEventCreateWithFlags(&c->piece_ev[k], hipEventDisableTiming));
+            HIP_RC(hipEventRecord(c->piece_ev[k], g.stream));
+        }
+    }
     HIP_RC(hipEventRecord(g.ev[2], g.stream));
-    if (c->world > 1) { RC(exchange_and_gram(c)); }
+    if (c->world > 1) { RC(exchange_and_gram(c, staged)); }
     else { RC(gram_all(c)); }
     HIP_RC(hipEventRecord(g.ev[3], g.stream));
     if (c->world > 1) {
@@ -1301,6 +1379,7 @@ void cone_destroy_data(void **pcd) {
     if (c->primal) { c->primal->destroy(); delete c->primal; }
     if (c->lanczos) { c->lanczos->destroy(); delete c->lanczos; }
     if (c->checker) { c->checker->destroy(); delete c->checker; }
+    for (hipEvent_t e : c->piece_ev) if (e) (void) hipEventDestroy(e);
     if (c->dS) (void) hipFree(c->dS);
     if (c->Xup) (void) hipFree(c->Xup);
     if (c->Pr1) (void) hipFree(c->Pr1);
@@ -1696,6 +1775,11 @@ void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM) { priv_of(HKKT)->mirror =
 void HMiConeSetExchangePieces(hdsdp_cone *cone, hmi_alltoall_piece_fn start, hmi_alltoall_wait_fn wait, int npieces) {
     MiCone *c = (MiCone *) cone->coneData;
     c->a2a_start = start; c->a2a_wait = wait; c->a2a_pieces = std::max(1, npieces);
+}
+void HMiConeGetExchangeStats(hdsdp_cone *cone, int *pieces, int *stagedLaunches) {
+    MiCone *c = (MiCone *) cone->coneData;
+    if (pieces) *pieces = c->last_pieces;
+    if (stagedLaunches) *stagedLaunches = c->last_staged;
 }
 void HMiConeSetExchange(hdsdp_cone *cone, hmi_alltoall_fn a2a, hmi_allreduce_fn ar, void *ctx) {
     MiCone *c = (MiCone *) cone->coneData;

@@ -706,13 +706,14 @@ struct TileList {
     int n = 0;
 };
 std::mutex g_tl_mutex;
-std::map<std::tuple<int, int, int, int, int>, TileList> g_tl_cache;
+std::map<std::tuple<int, int, int, int, int, unsigned long long>, TileList> g_tl_cache;
 
-int get_tiles(int MT, int NT, int klimit, int lower_only, TileList &out) {
+int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long colmask, TileList &out) {
     int dev = 0;
     HDM_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_tl_mutex);
-    auto key = std::make_tuple(dev, MT, NT, klimit, lower_only);
+    if (NT > 64) colmask = 0;
+    auto key = std::make_tuple(dev, MT, NT, klimit, lower_only, colmask);
     auto it = g_tl_cache.find(key);
     if (it != g_tl_cache.end()) {
         out = it->second;
@@ -722,6 +723,7 @@ int get_tiles(int MT, int NT, int klimit, int lower_only, TileList &out) {
     for (int tm = 0; tm < MT; ++tm)
         for (int tn = 0; tn < NT; ++tn) {
             if (lower_only && tm < tn) continue;
+            if (colmask && !((colmask >> tn) & 1ULL)) continue;
             long w = 1;
             if (klimit == HDM_KLIM_BY_M) w = tm + 1;
             if (klimit == HDM_KLIM_BY_N) w = tn + 1;
@@ -754,7 +756,8 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     }
     const int MT = (args.M + HDM_TILE - 1) / HDM_TILE, NT = (args.N + HDM_TILE - 1) / HDM_TILE;
     TileList tl;
-    if (get_tiles(MT, NT, args.klimit, args.lower_only, tl)) return 1;
+    if (get_tiles(MT, NT, args.klimit, args.lower_only, args.tile_col_mask, tl)) return 1;
+    if (tl.n == 0) return 0;
     HdmGemmDev d;
     d.a = args;
     if (d.a.a_kblk == 0) d.a.a_kblk = HDM_BK;

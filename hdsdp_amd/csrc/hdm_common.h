@@ -80,6 +80,8 @@ struct HdmGemmArgs {
     long seg_rows, seg_extra;
     int klimit;       // HdmKLimit: triangular operand => shorter K loop for early tiles
     int lower_only;   // only tiles with tile_m >= tile_n are computed (C symmetric / lower)
+    unsigned long long tile_col_mask;  // != 0: only tile columns whose bit is set are computed (N <= 64 tiles; multi-GPU
+                                       // builds run congruence step 2 by packed-index range, see engine.hip)
     int epilogue;     // HdmEpilogue
     int batch;        // number of batch entries (grid z for STORE/BLOCKED), or #K-splits for SLAB
     double alpha, beta;

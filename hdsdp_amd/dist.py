@@ -97,7 +97,7 @@ class Exchange:
     backend "gloo": device buffers are staged through host memory (used to rehearse world > 1 with every
     rank on one GPU, and on CPU-only boxes for the layout tests)."""
 
-    def __init__(self, cone, group=None, pieces=4):
+    def __init__(self, cone, group=None, pieces=8):
         import torch
         import torch.distributed as dist
         from . import api
@@ -120,8 +120,9 @@ class Exchange:
         self._a2a = C.CFUNCTYPE(C.c_int, C.c_void_p)(self._alltoall)
         self._ar = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)(self._allreduce)
         lib.HMiConeSetExchange(cone._h, C.cast(self._a2a, C.c_void_p), C.cast(self._ar, C.c_void_p), None)
-        # piecewise exchange: the engine starts all pieces, then waits for piece k and launches the Gram splits of its
-        # index range while pieces k+1.. are still on the links (RCCL runs them on its own stream)
+        # piecewise exchange: the engine starts piece k as soon as the congruence has finished that piece's index range
+        # (the later ranges are still being computed), then waits for piece k and launches the Gram splits of its
+        # range while pieces k+1.. are still on the links (RCCL runs them on its own stream)
         self._a2a_start = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int)(self._alltoall_piece)
         self._a2a_wait = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)(self._alltoall_wait)
         self._works = {}

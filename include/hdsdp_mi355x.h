@@ -274,11 +274,17 @@ void HMiConeSetExchange(hdsdp_cone *cone, hmi_alltoall_fn a2a, hmi_allreduce_fn 
 /* optional: the all-to-all in `npieces` pieces along the packed index, so that the Gram product over a piece's index
  * range runs while the later pieces are still in flight.  start(ctx, offset, count, piece): begin exchanging the `count`
  * doubles at `offset` of EVERY chunk (send chunk r -> rank r, into recv chunk <source rank> at the same offset), may
- * return before the data has arrived; wait(ctx, piece): return once that piece is in place.  Called with the engine
- * stream idle (the congruence is complete), pieces are started in order 0..npieces-1 and waited for in that order. */
+ * return before the data has arrived; wait(ctx, piece): return once that piece is in place.  Pieces are started in
+ * order 0..npieces-1 and waited for in that order.  start(.., piece) is called once the send ranges of that piece are
+ * final; the engine stream may still be computing the ranges of LATER pieces (the congruence's second step runs by
+ * packed-index range in piece order, so the exchange also overlaps the congruence; HDSDP_MI355X_STAGED_A2A=0 restores
+ * "congruence complete, stream idle, then exchange"), so start() must only touch the ranges it is given. */
 typedef int (*hmi_alltoall_piece_fn)(void *ctx, int64_t offset, int64_t count, int piece);
 typedef int (*hmi_alltoall_wait_fn)(void *ctx, int piece);
 void HMiConeSetExchangePieces(hdsdp_cone *cone, hmi_alltoall_piece_fn start, hmi_alltoall_wait_fn wait, int npieces);
+/* what the last HKKTBuildUp did: pieces of the exchange (1 = one blocking all-to-all) and, when the congruence's second
+ * step was staged by packed-index range, the number of launches it was cut into (0 = not staged) */
+void HMiConeGetExchangeStats(hdsdp_cone *cone, int *pieces, int *stagedLaunches);
 /* exchange buffers (device pointers, `world` chunks of *chunkCount doubles each); the caller may instead
  * supply its own (e.g. torch-allocated) buffers before the first HKKTBuildUp: world * chunkCount doubles of payload
  * plus 8192 doubles of slack behind it (the Gram kernel stages whole 128-row tiles without a row mask) */

@@ -95,6 +95,7 @@ def run_gpu(rank, world, n, m, out):
             res[k + "_" + tag] = e[k]
         res["scal_" + tag] = np.array([e["CSinv"], e["CSinvCSinv"], e["CSinvRdSinv"], e["TraceSinv"]])
     kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+    res["xstats"] = np.array(cone.exchange_stats())
     kkt.factorize()
     res["sol"] = kkt.solve(cone.traces())
     res["S"] = cone.dual_matrix()
