@@ -31,7 +31,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X vendor figure for dense fp64 matrix; 256 
 # HBM bytes per launch of the hot kernels from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 for
 # the gfx950 wide-read correction + WRITE_SIZE, separate --pmc runs, n=m=2000): filled in by hand from the summaries,
 # bench.py cannot run the profiler on itself.  None = not measured for the current kernel generation.
-TRAFFIC_BYTES_PER_LAUNCH = {  # profiles/r01_h_summary_pmc_{FETCH,WRITE}_SIZE.txt (counters are in KiB; mean over the launches)
+TRAFFIC_BYTES_PER_LAUNCH = {  # profiles/r01_h_summary_pmc_{FETCH,WRITE}_SIZE.txt (counters are in KiB; mean over the launches;
+                             # re-measured with the same values in r01_i and r01_j)
     1: (2 * 7.525e7 + 1.566e7) * 1024,   # congruence step 1, 1000 constraints per launch: 170 GB
     2: (2 * 1.418e8 + 1.575e7) * 1024,   # congruence step 2, 1000 constraints per launch: 307 GB
     3: (2 * 1.824e8 + 1.641e7) * 1024,   # Gram, whole matrix, 1024 K splits:            390 GB
