@@ -151,7 +151,7 @@ def test_schur_system_indefinite_fallback_matches_reference(name):
         ld.destroy()
 
 
-@pytest.mark.parametrize("m", [33, 500, 2000])
+@pytest.mark.parametrize("m", [1, 2, 33, 129, 500, 2000])
 def test_schur_system_indefinite_fallback_sizes(m):
     """size-independent property at sizes the goldens do not cover (one panel + identity padding, several panels, the
     bench size): M x = b to rounding for a symmetric indefinite M, against numpy's LAPACK solve; a singular matrix
@@ -160,6 +160,7 @@ def test_schur_system_indefinite_fallback_sizes(m):
     rng = np.random.default_rng(m)
     G = rng.uniform(-1, 1, (m, m))
     A = 0.5 * (G + G.T)
+    A[0, 0] = -abs(A[0, 0]) - 0.1          # never positive definite, also at m = 1
     b = rng.uniform(-1, 1, m)
     ls = api.LinSys(m, api.HDSDP_LINSYS_DENSE_ITERATIVE)
     try:
@@ -171,8 +172,8 @@ def test_schur_system_indefinite_fallback_sizes(m):
         assert np.linalg.norm(x - ref) <= 1e-13 * cond * np.linalg.norm(ref)
         assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(A, 2) * np.linalg.norm(x)
         Z = A.copy()
-        Z[:, 5] = 0.0
-        Z[5, :] = 0.0
+        Z[:, m // 2] = 0.0
+        Z[m // 2, :] = 0.0
         with pytest.raises(api.HDSDPError):
             ls.numeric(np.triu(Z))
     finally:
