@@ -20,6 +20,11 @@ struct HdmChol {
     Replay solves[4];
     int nsolves = 0, factor_runs = 0, solve_runs = 0;
     bool graphs_ok = true;
+    // single-launch block substitution (hdm_trsv_flow_kernel): per (rhs, direction, block) publication flags + error word
+    int *flow_flags = nullptr;
+    int *flow_err = nullptr;     // mapped host word: a workgroup gave up waiting
+    int flow_epoch = 0;
+    bool flow_ok = true, flow_pending = false;
 
     int init(int n);
     void destroy();

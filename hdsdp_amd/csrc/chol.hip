@@ -311,6 +311,126 @@ __global__ __launch_bounds__(256) void hdm_trsv_bwd_step(const double *__restric
 }
 
 // ------------------------------------------------------------------------------------------
+// The same block substitution as ONE launch: workgroup i owns block row i and consumes the solved blocks of the others
+// as they are published (a flag per block, release/acquire at agent scope), so the chain costs one hand-off per block
+// instead of one kernel launch per block (n = 2000: 32 launches -> 1).
+//   forward : acc = b_i - sum_{k<i} L[i,k] y_k (k ascending) ;  y_i = Dinv_i acc          -> published in `y`
+//   backward: acc = y_i - sum_{k>i} L[k,i]^T x_k (k descending) ;  x_i = Dinv_i^T acc     -> published in `x`
+// The accumulation order is fixed, so the result does not depend on timing.  Forward waits only on lower-numbered
+// workgroups (dispatched earlier), backward on higher-numbered ones, which the host guarantees to be co-resident
+// (nblk * nrhs <= 256 workgroups on 256 CUs); every wait is bounded -- a workgroup that gives up raises *err and the
+// host repeats the solve with the per-block launches.  `epoch` distinguishes this launch's flags from older ones.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool hdm_flow_wait(const int *flag, int epoch) {
+    for (int it = 0; it < (1 << 22); ++it) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+// out[r] = sum_c Mb[r + c*ld] * v[c] over the 128 x 128 block, two threads per row (the halves meet in `part`); 16 loads
+// in flight per thread -- a load, wait, multiply loop would spend the whole hand-off in memory latency
+__device__ __forceinline__ double hdm_row_dot_half(const double *__restrict__ Mb, long ld, const double *v, int tid) {
+    const int r = tid & (NB - 1), h = tid >> 7;
+    const double *q = Mb + r + (long) (h * 64) * ld;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 16
+    for (int c = 0; c < 64; c += 2) {
+        s0 += q[(long) c * ld] * v[h * 64 + c];
+        s1 += q[(long) (c + 1) * ld] * v[h * 64 + c + 1];
+    }
+    return s0 + s1;
+}
+// out[c] -= (or =) sum_r Mb[r + c*ld] * v[r]: lanes run along r (coalesced), each wave owns 32 columns, eight columns
+// (16 loads) in flight, reductions by shuffles
+template <bool SUBTRACT>
+__device__ __forceinline__ void hdm_col_dots(const double *__restrict__ Mb, long ld, const double *v, double *out, int wave,
+                                             int lane) {
+    const double v0 = v[lane], v1 = v[lane + 64];
+    for (int cc = 0; cc < 32; cc += 8) {
+        double sacc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double *col = Mb + (long) (wave * 32 + cc + q) * ld;
+            sacc[q] = col[lane] * v0 + col[lane + 64] * v1;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sacc[q] += __shfl_down(sacc[q], off, 64);
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (SUBTRACT) out[wave * 32 + cc + q] -= sacc[q];
+                else out[wave * 32 + cc + q] = sacc[q];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hdm_trsv_flow_kernel(const double *__restrict__ L, long ld,
+                                                             const double *__restrict__ Dinv, const double *b, double *y,
+                                                             double *x, int nblk, long ldv, int *flags, int epoch,
+                                                             int which, volatile int *err) {
+    __shared__ double v[NB];
+    __shared__ double acc[NB];
+    __shared__ double part[256];
+    __shared__ int ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x, rhs = blockIdx.y;
+    const double *bb = b + (long) rhs * ldv;
+    double *yy = y + (long) rhs * ldv, *xx = x + (long) rhs * ldv;
+    int *ff = flags + (long) rhs * 2 * nblk, *fb = ff + nblk;
+    const double *D = Dinv + (long) i * NB * NB;    // lower triangular, explicit zeros above the diagonal
+    if (tid < NB) acc[tid] = bb[i * NB + tid];
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    if (which != 2) {
+        for (int k = 0; k < i; ++k) {
+            if (tid == 0 && !hdm_flow_wait(ff + k, epoch)) ok = 0;
+            __syncthreads();
+            if (!ok) { if (tid == 0) *err = 1; return; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (tid < NB) v[tid] = __builtin_nontemporal_load(yy + k * NB + tid);
+            __syncthreads();
+            part[tid] = hdm_row_dot_half(L + (long) i * NB + (long) k * NB * ld, ld, v, tid);
+            __syncthreads();
+            if (tid < NB) acc[tid] -= part[tid] + part[tid + NB];
+            __syncthreads();
+        }
+        part[tid] = hdm_row_dot_half(D, NB, acc, tid);     // y_i = Dinv_i acc
+        __syncthreads();
+        if (tid < NB) {
+            const double val = part[tid] + part[tid + NB];
+            acc[tid] = val;
+            yy[i * NB + tid] = val;
+            if (which == 1) xx[i * NB + tid] = val;
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ff + i, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (which == 1) return;
+    }
+    for (int k = nblk - 1; k > i; --k) {
+        if (tid == 0 && !hdm_flow_wait(fb + k, epoch)) ok = 0;
+        __syncthreads();
+        if (!ok) { if (tid == 0) *err = 1; return; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tid < NB) v[tid] = __builtin_nontemporal_load(xx + k * NB + tid);
+        __syncthreads();
+        hdm_col_dots<true>(L + (long) k * NB + (long) i * NB * ld, ld, v, acc, wave, lane);   // acc -= L[k,i]^T x_k
+        __syncthreads();
+    }
+    hdm_col_dots<false>(D, NB, acc, part, wave, lane);      // x_i = Dinv_i^T acc
+    __syncthreads();
+    if (tid < NB) xx[i * NB + tid] = part[tid];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(fb + i, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------
 // host drivers
 // ------------------------------------------------------------------------------------------
 int HdmChol::init(int n_) {
@@ -336,6 +456,9 @@ void HdmChol::destroy() {
     if (Zd) (void) hipFree(Zd);
     if (info_dev) (void) hipFree(info_dev);
     if (vec) (void) hipFree(vec);
+    if (flow_flags) (void) hipFree(flow_flags);
+    if (flow_err) (void) hipHostFree(flow_err);
+    flow_flags = nullptr; flow_err = nullptr;
     if (factor_graph) (void) hipGraphExecDestroy(factor_graph);
     for (int i = 0; i < nsolves; ++i) if (solves[i].exec) (void) hipGraphExecDestroy(solves[i].exec);
     factor_graph = nullptr; nsolves = 0;
@@ -514,10 +637,17 @@ int HdmChol::get_diag(double *diag_host, hipStream_t s) {
     return 0;
 }
 
+// HDM_TRSV_FLOW=0: always the per-block launches
+static bool hdm_flow_enabled() {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("HDM_TRSV_FLOW"); on = (e && atoi(e) == 0) ? 0 : 1; }
+    return on == 1;
+}
+
 int HdmChol::solve_device(double *b_dev, double *x_dev, int nrhs, long ldv, int which, hipStream_t s) {
     // replay the launch chain of an earlier call with the same buffers when there is one (the C-ABI solves always
     // come through the object's own scratch vectors, so this is the common case)
-    if (hdm_graph_level() >= 2 && graphs_ok) {
+    if (hdm_graph_level() >= 2 && graphs_ok && !(hdm_flow_enabled() && flow_ok)) {   // (a replayed launch would reuse its epoch)
         Replay *r = nullptr;
         for (int i = 0; i < nsolves; ++i)
             if (solves[i].b == b_dev && solves[i].x == x_dev && solves[i].nrhs == nrhs && solves[i].which == which &&
@@ -540,6 +670,23 @@ int HdmChol::enqueue_solve(double *b_dev, double *x_dev, int nrhs, long ldv, int
     // which: 0 = full solve (L L^T x = b), 1 = forward only (L x = b), 2 = backward only (L^T x = b)
     // b_dev is overwritten (workspace); vectors have npad entries (zero padded)
     const long ld = npad;
+    if (hdm_flow_enabled() && flow_ok && nrhs <= 2 && (long) nblk * nrhs <= 256) {
+        if (!flow_flags) {
+            HDM_HIP_CHECK(hipMalloc((void **) &flow_flags, sizeof(int) * 4 * (size_t) nblk));
+            HDM_HIP_CHECK(hdm_memset_sync(flow_flags, 0, sizeof(int) * 4 * (size_t) nblk));
+            // the give-up word lives in mapped host memory: the host reads it after its usual synchronisation, no extra copy
+            HDM_HIP_CHECK(hipHostMalloc((void **) &flow_err, sizeof(int), hipHostMallocMapped));
+            *flow_err = 0;
+        }
+        int *err_dev = nullptr;
+        HDM_HIP_CHECK(hipHostGetDevicePointer((void **) &err_dev, flow_err, 0));
+        ++flow_epoch;
+        hipLaunchKernelGGL(hdm_trsv_flow_kernel, dim3(nblk, nrhs), dim3(256), 0, s, L, ld, Dinv, b_dev, b_dev, x_dev, nblk,
+                           ldv, flow_flags, flow_epoch, which, err_dev);
+        HDM_HIP_CHECK(hipGetLastError());
+        flow_pending = true;
+        return 0;
+    }
     double *cur = b_dev;
     if (which == 0 || which == 1) {
         for (int k = 0; k < nblk; ++k) {
@@ -571,6 +718,16 @@ int HdmChol::solve_host(const double *rhs, double *sol, int nrhs, int which, hip
         HDM_HIP_CHECK(hipMemcpy2DAsync(sol + (long) c0 * n, sizeof(double) * n, x, sizeof(double) * npad,
                                        sizeof(double) * n, nc, hipMemcpyDeviceToHost, s));
         HDM_HIP_CHECK(hipStreamSynchronize(s));
+        const bool gave_up = flow_pending && flow_err && *(volatile int *) flow_err != 0;
+        flow_pending = false;
+        if (gave_up) {
+            // a workgroup of the single-launch substitution gave up waiting (never seen; it would mean the workgroups
+            // were not co-resident): per-block launches from now on, and this chunk again
+            fprintf(stderr, "[hdsdp_mi355x] single-launch substitution timed out; using per-block launches\n");
+            flow_ok = false;
+            *flow_err = 0;
+            c0 -= chunk;
+        }
     }
     return 0;
 }
