@@ -12,6 +12,7 @@
 // triangular inverse Linv (needed by the congruence kernels) is assembled from them by GEMMs.
 #include "hdm_common.h"
 #include "chol.h"
+#include <algorithm>
 
 #define NB 128
 
@@ -670,7 +671,19 @@ int HdmChol::enqueue_solve(double *b_dev, double *x_dev, int nrhs, long ldv, int
     // which: 0 = full solve (L L^T x = b), 1 = forward only (L x = b), 2 = backward only (L^T x = b)
     // b_dev is overwritten (workspace); vectors have npad entries (zero padded)
     const long ld = npad;
-    if (hdm_flow_enabled() && flow_ok && nrhs <= 2 && (long) nblk * nrhs <= 256) {
+    // co-residency bound of the single-launch substitution on this device (partitioned GPUs have far fewer CUs)
+    static int flow_cap = -1;
+    if (flow_cap < 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hdm_trsv_flow_kernel, 256, 0) == hipSuccess)
+            flow_cap = cus * std::max(1, per_cu);
+        else
+            flow_cap = 0;
+        (void) hipGetLastError();
+    }
+    if (hdm_flow_enabled() && flow_ok && nrhs <= 2 && (long) nblk * nrhs <= flow_cap) {
         if (!flow_flags) {
             HDM_HIP_CHECK(hipMalloc((void **) &flow_flags, sizeof(int) * 4 * (size_t) nblk));
             HDM_HIP_CHECK(hdm_memset_sync(flow_flags, 0, sizeof(int) * 4 * (size_t) nblk));
