@@ -305,9 +305,15 @@ int cone_alloc_common(MiCone *c) {
     c->npb = (long) c->nblk * (c->nblk + 1) / 2 * 16;
     c->npb_loc = (c->npb + c->world - 1) / c->world;
     c->own.clear();
-    for (int i = c->rank; i < c->m; i += c->world) c->own.push_back(i);
+    // One GPU: constraints that are zero on this block (most of them in a many-block problem; the reference's
+    // "sparse SDP cone", hdsdp_conic_sdp.c:1814-1886, loops over the non-zero ones only) are left out of the device
+    // data altogether: no congruence, no Gram rows, nothing written to their rows of M.  Sharded blocks keep the plain
+    // cyclic deal (row i on rank i % world) that the exchange layout is built on.
+    const bool compact = (c->world == 1 && !c->synthetic && (int) c->blk.rows.size() == c->m);
+    for (int i = c->rank; i < c->m; i += c->world)
+        if (!compact || c->blk.rows[i].type != MI_COEFF_ZERO) c->own.push_back(i);
     c->mloc = (int) c->own.size();
-    int maxloc = (c->m + c->world - 1) / c->world;
+    int maxloc = compact ? c->mloc : (c->m + c->world - 1) / c->world;
     c->Lr = (c->world == 1) ? (int) hdm_roundup(maxloc + 3, 8) : (int) hdm_roundup(maxloc + 3, HDM_TILE);
     c->R = (long) c->world * c->Lr;
     const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
@@ -319,7 +325,8 @@ int cone_alloc_common(MiCone *c) {
     std::vector<int> rs((size_t) c->R, -1);
     for (int gq = 0; gq < c->world; ++gq) {
         int cnt = 0;
-        for (int i = gq; i < c->m; i += c->world) rs[(size_t) gq * c->Lr + cnt++] = i;
+        if (compact) { for (int i : c->own) rs[cnt++] = i; }
+        else for (int i = gq; i < c->m; i += c->world) rs[(size_t) gq * c->Lr + cnt++] = i;
         if (gq == 0) { rs[cnt] = -2; rs[cnt + 1] = -3; rs[cnt + 2] = -4; }  // I, S, C rows
     }
     HDM_HIP_CHECK(hipMalloc((void **) &c->rows_seg, sizeof(int) * (size_t) c->R));
@@ -1055,7 +1062,7 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     long ldm = 0;
     double *Mdev = kkt_Mdev(kkt, &ldm);
     const int hsd = (typeKKT == KKT_TYPE_HOMOGENEOUS);
-    const long pI = (c->m + c->world - 1) / c->world;  // rows owned by rank 0 = position of the "I row"
+    const long pI = (c->world == 1) ? c->mloc : (c->m + c->world - 1) / c->world;  // rows owned by rank 0 = position of the "I row"
     RC(hdm_extract(c->Gm, c->R, c->R, pI, c->rows_seg, Mdev, ldm, pv->vecs, pv->vecs + m, pv->vecs + 2 * m,
                    pv->vecs + 3 * m, c->Rd, hsd, g.stream));
     HIP_RC(hipEventRecord(g.ev[4], g.stream));
@@ -1884,6 +1891,7 @@ hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol
     if (force && atoi(force)) c->path = PATH_GEMM;
     const char *forcesp = getenv("HDSDP_MI355X_FORCE_PATH");
     if (forcesp && world == 1) c->path = atoi(forcesp);
+    if (c->mloc == 0) c->path = PATH_GEMM;   // no constraint touches this block: only the objective's scalars remain
     if (upload_dense_rows(c)) return HDSDP_RETCODE_MEMORY;   // dense copies also feed the S assembly
     if (c->path == PATH_R1) {
         c->mloc16 = (int) hdm_roundup(std::max(1, c->mloc), 16);

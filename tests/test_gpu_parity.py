@@ -651,3 +651,67 @@ def test_multi_block_instance_against_reference():
     finally:
         for c in cones:
             c.destroy()
+
+
+@pytest.mark.parametrize("path", [0, 1, 2])
+@pytest.mark.parametrize("keep", [(), (4,), (0, 3, 4, 11, 29)])
+def test_constraints_that_are_zero_on_a_block(path, keep, monkeypatch):
+    """a block on which most constraints vanish (what every block of a many-block SDP looks like; the reference's sparse
+    SDP cone loops over the non-zero ones only, interface/hdsdp_conic_sdp.c:1814-1886): the engine leaves the zero
+    rows out of its device data, and their rows of M, ASinv, ... must come out exactly zero -- on every device path,
+    also when NO constraint touches the block (then only the objective's HSD scalars are non-zero)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    from hdsdp_amd import api
+    n, m = 40, 30
+    beg0, idx0, val0, _ = oracle_py.synth_csc(n, m)
+    beg, idx, val = [0], [], []
+    for col in range(m + 1):                      # column 0 = C, column i = A_i
+        lo, hi = int(beg0[col]), int(beg0[col + 1])
+        if col == 0 or (col - 1) in keep:
+            if path != 0 and col > 0:             # rank-one / sparse paths need sparse data: keep 3 diagonal-ish entries
+                sel = [k for k in range(lo, hi) if idx0[k] in (0, n, 2 * n - 1)]
+                if path == 1:
+                    sel = sel[:1]                 # one diagonal entry = rank one
+                idx += [int(idx0[k]) for k in sel]; val += [float(val0[k]) for k in sel]
+            else:
+                idx += [int(v) for v in idx0[lo:hi]]; val += [float(v) for v in val0[lo:hi]]
+        beg.append(len(idx))
+    beg, idx, val = np.array(beg, dtype=np.int32), np.array(idx, dtype=np.int32), np.array(val)
+    blk = oracle_py.Block(n, m, beg, idx, val)
+    monkeypatch.setenv("HDSDP_MI355X_FORCE_PATH", str(path))
+    cone = api.SDPCone.from_csc(n, m, beg, idx, val)
+    kkt = api.KKT(m, [cone])
+    try:
+        Rd, tau = -10.0 * n, 0.9
+        y = 0.05 * np.cos(np.arange(m) + 0.3)
+        S = blk.assemble_S(tau, y, Rd)
+        Lf, info = blk.factor(S)
+        assert info == 0
+        Sinv = blk.inverse(Lf)
+        cone.set_start(Rd)
+        assert cone.check_is_interior(tau, y)
+        check_close(cone.dual_matrix()[lower_mask(n)], S[lower_mask(n)], "S")
+        msk = lower_mask(m)
+        zero = np.array([i not in keep for i in range(m)])
+        for typ, key in ((api.KKT_TYPE_INFEASIBLE, 0), (api.KKT_TYPE_HOMOGENEOUS, 2), (api.KKT_TYPE_CORRECTOR, 1)):
+            ref = blk.kkt_build(Sinv, Rd, key)
+            kkt.build_up(typ)
+            ex = kkt.export()
+            if key != 1:
+                M = kkt.M
+                check_close(M[msk], ref["M"][msk], "M")
+                assert not M[zero, :].any() and not M[:, zero].any()
+            check_close(ex["ASinv"], ref["ASinv"], "ASinv")
+            check_close(ex["ASinvRdSinv"], ref["ASinvRdSinv"], "ASinvRdSinv")
+            assert not ex["ASinv"][zero].any() and not ex["ASinvRdSinv"][zero].any()
+            if key == 2:
+                check_close(ex["ASinvCSinv"], ref["ASinvCSinv"], "ASinvCSinv")
+                for k in ("CSinv", "CSinvCSinv", "CSinvRdSinv", "TraceSinv"):
+                    check_close([ex[k]], [ref[k]], k)
+    finally:
+        kkt.destroy()
+        cone.destroy()
+        blk.close()
