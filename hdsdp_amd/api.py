@@ -21,7 +21,7 @@ RETCODE_OK, RETCODE_FAILED, RETCODE_MEMORY = 0, 1, 2
 BUFFER_DUALVAR, BUFFER_DUALCHECK, BUFFER_DUALSTEP = 0, 1, 2   # interface/hdsdp_conic.h:24-26
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libhdsdp_mi355x.so")
+LIB_PATH = os.environ.get("HDSDP_MI355X_LIB") or os.path.join(_PKG, "libhdsdp_mi355x.so")   # override: same-box A/B of two builds
 
 # every symbol include/hdsdp_mi355x.h declares
 EXPORTS = [
