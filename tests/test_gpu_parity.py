@@ -609,15 +609,18 @@ def test_regularize_follows_the_reference_rule():
         cone.destroy()
 
 
-def test_multi_block_instance_against_reference():
-    """truss1 through the engine's own SDPA reader: seven cones (2 x 2 blocks and a 1 x 1) in one KKT object, against the
-    reference's numbers for the same instance (golden truss1_A: the reference run with one dense-SDP cone per block)"""
+@pytest.mark.parametrize("name,fname", [("truss1_A", "truss1.dat-s"), ("blocks3_A", "blocks3.dat-s")])
+def test_multi_block_instance_against_reference(name, fname):
+    """multi-block instances through the engine's own SDPA reader, all cones in one KKT object, against the reference's
+    numbers for the same file (the reference run with one dense-SDP cone per block): truss1 (2 x 2 blocks and a 1 x 1),
+    and blocks3 (21 / 34 / 9), where most constraints are zero on each block and the three blocks take the three
+    different device paths"""
     import os
     from hdsdp_amd import api
-    g = load_golden("truss1_A")
+    g = load_golden(name)
     nb, m = int(g["mb_dims"][0]), int(g["mb_dims"][1])
     Rd, tau, y = float(g["Rd"][0]), float(g["tau"][0]), y_of(g)
-    prob = api.read_sdpa(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "truss1.dat-s"))
+    prob = api.read_sdpa(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fname))
     assert prob["m"] == m and len(prob["blocks"]) == nb
     assert np.array_equal(prob["b"], g["b"])
     cones = []
@@ -627,6 +630,8 @@ def test_multi_block_instance_against_reference():
             assert np.array_equal(blk["beg"], g["mb%d_beg" % k]) and np.array_equal(blk["idx"], g["mb%d_idx" % k])
             assert np.array_equal(blk["val"], g["mb%d_val" % k])
             cones.append(api.SDPCone.from_csc(blk["n"], m, blk["beg"], blk["idx"], blk["val"], iCone=k))
+        if name == "blocks3_A":
+            assert [c.path for c in cones] == [2, 0, 1]    # sparse gather, congruence + Gram, rank one
         ld = 0.0
         for c in cones:
             c.set_start(Rd)
@@ -637,7 +642,7 @@ def test_multi_block_instance_against_reference():
         msk = lower_mask(m)
         kkt.build_up(api.KKT_TYPE_HOMOGENEOUS)
         ex = kkt.export()
-        check_close(kkt.M[msk], g["M_hsd"][msk], "truss1 M_hsd")
+        check_close(kkt.M[msk], g["M_hsd"][msk], name + " M_hsd")
         check_close(ex["ASinv"], g["ASinv_hsd"], "truss1 ASinv")
         check_close(ex["ASinvRdSinv"], g["ASinvRdSinv_hsd"], "truss1 ASinvRdSinv")
         check_close(ex["ASinvCSinv"], g["ASinvCSinv_hsd"], "truss1 ASinvCSinv")

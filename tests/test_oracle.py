@@ -113,10 +113,12 @@ def test_potrf_reports_first_bad_pivot():
     assert info == 8
 
 
-def test_oracle_multi_block_matches_reference():
-    """truss1 (six 2 x 2 blocks and a 1 x 1): the Schur operator is the SUM of the per-cone contributions
-    (interface/hdsdp_schur.c:256-268); the oracle builds each block and the parts are added here"""
-    g = load_golden("truss1_A")
+@pytest.mark.parametrize("name", ["truss1_A", "blocks3_A"])
+def test_oracle_multi_block_matches_reference(name):
+    """truss1 (six 2 x 2 blocks and a 1 x 1) and blocks3 (21 / 34 / 9, most constraints zero on each block): the Schur
+    operator is the SUM of the per-cone contributions (interface/hdsdp_schur.c:256-268); the oracle builds each block
+    and the parts are added here"""
+    g = load_golden(name)
     nb, m = int(g["mb_dims"][0]), int(g["mb_dims"][1])
     Rd, tau, y = float(g["Rd"][0]), float(g["tau"][0]), y_of(g)
     M = np.zeros((m, m)); a = np.zeros(m); r = np.zeros(m); c = np.zeros(m); sc = np.zeros(4); ld = 0.0
