@@ -277,6 +277,10 @@ struct MiKKTPriv {
     double *vecs = nullptr;   // device: ASinv[m], ASinvRdSinv[m], ASinvCSinv[m], scal[4]
     double *rhs = nullptr;
     bool Mdev_valid = false;  // device M holds the result of the last BuildUp
+    // cones of HKKT->cones[] whose coneBuildSchur is this engine's (they accumulate on the device) and the others (the
+    // reference's CPU cones: they accumulate into the host fields, hdsdp_conic_*.c)
+    int n_engine = 0, n_foreign = 0;
+    double *Mtmp = nullptr;   // pinned m x m staging buffer for the mixed case (device part added to the host part)
 };
 
 // the kkt private state hangs off kktM->chol's MiLin (Mdev) plus a side struct keyed by the kkt pointer
@@ -293,6 +297,7 @@ void priv_drop(hdsdp_kkt *k) {
         if (g_priv[i].first == k) {
             if (g_priv[i].second->vecs) (void) hipFree(g_priv[i].second->vecs);
             if (g_priv[i].second->rhs) (void) hipFree(g_priv[i].second->rhs);
+            if (g_priv[i].second->Mtmp) (void) hipHostFree(g_priv[i].second->Mtmp);
             delete g_priv[i].second;
             g_priv.erase(g_priv.begin() + i);
             return;
@@ -1604,6 +1609,11 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
     if (hdm_memset_sync(l->Mdev, 0, mm) != hipSuccess) return HDSDP_RETCODE_FAILED;
     MiKKTPriv *pv = priv_of(HKKT);
     if (hipMalloc((void **) &pv->vecs, sizeof(double) * (3 * (size_t) nRow + 4)) != hipSuccess) return HDSDP_RETCODE_MEMORY;
+    pv->n_engine = pv->n_foreign = 0;
+    for (int i = 0; i < nCones; ++i) {
+        if (cones[i]->coneBuildSchur == cone_build_schur) pv->n_engine += 1;
+        else pv->n_foreign += 1;
+    }
     HKKT->dPrimalX = nullptr;
     return HDSDP_RETCODE_OK;
 }
@@ -1635,14 +1645,27 @@ static hdsdp_retcode kkt_pull(hdsdp_kkt *HKKT, int typeKKT) {
     std::vector<double> h(3 * (size_t) m + 4);
     if (hipMemcpyAsync(h.data(), pv->vecs, sizeof(double) * h.size(), hipMemcpyDeviceToHost, g.stream) != hipSuccess)
         return HDSDP_RETCODE_FAILED;
-    if (typeKKT != KKT_TYPE_CORRECTOR && pv->mirror) {
+    // M: every cone ACCUMULATES (hdsdp_schur.c:256-268).  The engine's cones did so on the device, foreign (CPU) cones
+    // straight into kktMatElem: with only engine cones the device matrix simply replaces the (zeroed) host one, with
+    // only foreign cones there is nothing to bring back, and in the mixed case the device part is added to the host part.
+    bool add_M = false;
+    if (typeKKT != KKT_TYPE_CORRECTOR && pv->mirror && pv->n_engine > 0) {
         long ld = 0;
         double *Mdev = kkt_Mdev(HKKT, &ld);
-        if (hipMemcpy2DAsync(HKKT->kktMatElem, sizeof(double) * m, Mdev, sizeof(double) * ld, sizeof(double) * m, m,
+        double *dst = HKKT->kktMatElem;
+        if (pv->n_foreign > 0) {
+            if (!pv->Mtmp && hipHostMalloc((void **) &pv->Mtmp, sizeof(double) * (size_t) m * m) != hipSuccess) return HDSDP_RETCODE_MEMORY;
+            dst = pv->Mtmp;
+            add_M = true;
+        }
+        if (hipMemcpy2DAsync(dst, sizeof(double) * m, Mdev, sizeof(double) * ld, sizeof(double) * m, m,
                              hipMemcpyDeviceToHost, g.stream) != hipSuccess)
             return HDSDP_RETCODE_FAILED;
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    if (add_M)
+        for (int j = 0; j < m; ++j)                    // lower triangle, column-major
+            for (int i = j; i < m; ++i) HKKT->kktMatElem[i + (size_t) j * m] += pv->Mtmp[i + (size_t) j * m];
     for (int i = 0; i < m; ++i) {
         HKKT->dASinvVec[i] += h[i];
         HKKT->dASinvRdSinvVec[i] += h[m + i];
@@ -1778,7 +1801,15 @@ void HKKTDestroy(hdsdp_kkt **pHKKT) {
     *pHKKT = nullptr;
 }
 
-void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM) { priv_of(HKKT)->mirror = mirrorM; }
+void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM) {
+    MiKKTPriv *pv = priv_of(HKKT);
+    if (!mirrorM && pv->n_foreign > 0) {
+        fprintf(stderr, "[hdsdp_mi355x] HMiKKTSetHostMirror(0) ignored: %d cone(s) of this operator accumulate on the host\n",
+                pv->n_foreign);
+        return;
+    }
+    pv->mirror = mirrorM;
+}
 void HMiConeSetExchangePieces(hdsdp_cone *cone, hmi_alltoall_piece_fn start, hmi_alltoall_wait_fn wait, int npieces) {
     MiCone *c = (MiCone *) cone->coneData;
     c->a2a_start = start; c->a2a_wait = wait; c->a2a_pieces = std::max(1, npieces);

@@ -720,3 +720,80 @@ def test_constraints_that_are_zero_on_a_block(path, keep, monkeypatch):
         kkt.destroy()
         cone.destroy()
         blk.close()
+
+
+def test_cpu_cone_inside_the_operator_accumulates_with_the_engine_cones():
+    """HKKTBuildUp lets EVERY cone of HKKT->cones[] accumulate (interface/hdsdp_schur.c:256-268).  A cone that is not
+    the engine's -- the reference's own CPU cones in a partly converted solver; here a stand-in that adds a known
+    symmetric matrix and vector to the host fields -- must end up summed with the device-built part, whatever its
+    position in the array; with only such cones the operator is still a working Schur system (the engine then only
+    factors and solves).  This is what the reference's unmodified driver relies on (tests/test_gpu_reference_driver.py)."""
+    import ctypes as C
+    from hdsdp_amd import api
+    g = load_golden("syn64")
+    n, m = int(g["dims"][0]), int(g["dims"][1])
+    lib = api.load_library()
+
+    class HostCone(C.Structure):   # hdsdp_cone, interface/def_hdsdp_conic.h:60-100: 2 ints, 2 pointers, 30 slots
+        _fields_ = [("iCone", C.c_int), ("cone", C.c_int), ("usrData", C.c_void_p), ("coneData", C.c_void_p),
+                    ("slots", C.c_void_p * 30)]
+    rng = np.random.default_rng(5)
+    G = rng.uniform(-1, 1, (m, m))
+    P = G @ G.T / m + np.eye(m)                       # what the CPU cone adds to M (lower triangle, column-major)
+    add_asinv = np.cos(np.arange(m))
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int)
+    def build_schur(cone_data, icone, kkt_ptr, type_kkt):
+        k = C.cast(kkt_ptr, C.POINTER(api.hdsdp_kkt)).contents
+        Mh = np.ctypeslib.as_array(k.kktMatElem, shape=(m, m))       # C-order view: Mh[j, i] = element (row i, col j)
+        if type_kkt != api.KKT_TYPE_CORRECTOR:
+            Mh += np.triu(P)
+        for i in range(k.nRow):
+            k.dASinvVec[i] += add_asinv[i]
+        return 0
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p)
+    def get_dim(cone_data):
+        return 3
+
+    @C.CFUNCTYPE(C.c_int64, C.c_void_p)
+    def get_nnz(cone_data):
+        return m * m
+    host = HostCone()
+    host.iCone = 1
+    host.slots[7] = C.cast(get_nnz, C.c_void_p)       # coneGetSymNnz
+    host.slots[8] = C.cast(get_dim, C.c_void_p)       # coneGetDim
+    host.slots[11] = C.cast(build_schur, C.c_void_p)  # coneBuildSchur
+    host_ptr = C.cast(C.pointer(host), C.c_void_p).value
+    cone = api.SDPCone.synthetic(n, m)
+    msk = lower_mask(m)
+    try:
+        cone.set_start(float(g["Rd"][0]))
+        assert cone.check_is_interior(float(g["tau"][0]), y_of(g))
+        ref = api.KKT(m, [cone])
+        ref.build_up(api.KKT_TYPE_INFEASIBLE)
+        M0, a0 = ref.M.copy(), ref.export()["ASinv"].copy()
+        ref.destroy()
+        for order in ("engine first", "host first", "host only"):
+            k = C.POINTER(api.hdsdp_kkt)()
+            assert lib.HKKTCreate(C.byref(k)) == 0
+            ptrs = {"engine first": [cone._h, host_ptr], "host first": [host_ptr, cone._h], "host only": [host_ptr]}[order]
+            arr = (C.c_void_p * len(ptrs))(*ptrs)
+            assert lib.HKKTInit(k, m, len(ptrs), arr) == 0
+            lib.HMiKKTSetHostMirror(k, 0)             # must be refused: a host cone is in the operator
+            assert lib.HKKTBuildUp(k, api.KKT_TYPE_INFEASIBLE) == 0
+            Mh = np.ctypeslib.as_array(k.contents.kktMatElem, shape=(m, m)).copy()
+            asinv = np.ctypeslib.as_array(k.contents.dASinvVec, shape=(m,)).copy()
+            want_M = np.triu(P) + (M0 * np.triu(np.ones((m, m))) if order != "host only" else 0.0)
+            want_a = add_asinv + (a0 if order != "host only" else 0.0)
+            assert np.allclose(Mh[msk], want_M[msk], rtol=1e-14, atol=1e-300), order
+            assert np.allclose(asinv, want_a, rtol=1e-14, atol=1e-300), order
+            assert lib.HKKTFactorize(k) == 0
+            rhs = np.sin(np.arange(m) + 1.0)
+            x = np.zeros(m)
+            assert lib.HKKTSolve(k, api._dptr(rhs), api._dptr(x)) == 0
+            full = np.triu(want_M) + np.triu(want_M, 1).T
+            assert np.linalg.norm(full @ x - rhs) <= 1e-11 * np.linalg.norm(rhs), order
+            lib.HKKTDestroy(C.byref(k))
+    finally:
+        cone.destroy()

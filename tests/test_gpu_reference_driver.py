@@ -1,0 +1,46 @@
+"""The reference's OWN solver driver on top of the product library (GPU box).
+
+`make -C oracle drop` (run by __graft_entry__.build() in the build container, where /root/reference lives) links the
+reference WITHOUT its interface/hdsdp_schur.c and linalg/hdsdp_linsolver.c against hdsdp_amd/libhdsdp_mi355x.so and puts
+the reference's solver main (tests/sdpasolve.c) on top: oracle/_ref/sdpasolve_mi355x.  Nothing of the reference is patched:
+its IPM driver, presolve, CPU cones and Lanczos call HKKT* / HFpLinsys* exactly as they call their own -- 33 call sites
+in interface/hdsdp_algo.c alone -- and here those calls land in the HIP engine: the Schur operator object (the cones
+accumulate into its host fields, the engine factors and solves M on the device) and every dense factorisation, PSD check,
+triangular solve and inverse of the dual matrix S.  Instances with a dense dual matrix only: a sparse S asks for
+HDSDP_LINSYS_SPARSE_DIRECT, which stays with the reference's CPU solver behind the dispatcher of INTEGRATION.md.
+The compiled binary is test infrastructure under oracle/_ref/ (git-ignored, travels to the GPU box like the other built
+files); the test is skipped where it was not built."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "sdpasolve_mi355x")
+
+# instance -> (SDPLIB optimum as the driver prints it, iterations of the unmodified reference on the same file)
+CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None)}
+
+
+@pytest.mark.parametrize("inst", sorted(CASES))
+def test_reference_driver_runs_on_the_engine(inst):
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/sdpasolve_mi355x not built (needs /root/reference at build time: make -C oracle drop)")
+    opt, ref_iters = CASES[inst]
+    r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden", inst + ".dat-s")], capture_output=True, text=True,
+                       timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert "SDP Status: Primal dual optimal" in out, out[-3000:]
+    pobj = float(re.search(r"pObj\s+([-+0-9.eE]+)", out).group(1))
+    dobj = float(re.search(r"dObj\s+([-+0-9.eE]+)", out).group(1))
+    assert abs(dobj - opt) <= 1e-4 * abs(opt), (dobj, opt)
+    assert abs(pobj - dobj) <= 1e-4 * abs(opt), (pobj, dobj)
+    # the Schur system never had to leave the Cholesky path on these instances
+    assert "Switch to the pivoted" not in out
+    if ref_iters is not None:
+        its = [int(m.group(1)) for m in re.finditer(r"^\s+(\d+)\s+[-+]\d\.\d+e[-+]\d+\s+[-+]\d\.\d+e[-+]\d+", out, re.M)]
+        assert its and abs(max(its) - ref_iters) <= 2, (max(its) if its else None, ref_iters)
