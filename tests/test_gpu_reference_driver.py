@@ -6,7 +6,11 @@ the reference's solver main (tests/sdpasolve.c) on top: oracle/_ref/sdpasolve_mi
 its IPM driver, presolve, CPU cones and Lanczos call HKKT* / HFpLinsys* exactly as they call their own -- 33 call sites
 in interface/hdsdp_algo.c alone -- and here those calls land in the HIP engine: the Schur operator object (the cones
 accumulate into its host fields, the engine factors and solves M on the device) and every dense factorisation, PSD check,
-triangular solve and inverse of the dual matrix S.  Instances with a dense dual matrix only: a sparse S asks for
+triangular solve and inverse of the dual matrix S.  In the second mode the harness (oracle/drop_attach.c, the glue of
+INTEGRATION.md 2(b) injected by symbol interposition, no reference file is touched) also hands every dense SDP block to the
+engine's cone at presolve time, and the same unmodified driver then runs its whole conic work -- S assembly, interior
+checks, ratio tests, Schur builds of every type, barrier, line search, primal recovery -- on the GPU through the
+reference's own cone interface.  Instances with a dense dual matrix only: a sparse S asks for
 HDSDP_LINSYS_SPARSE_DIRECT, which stays with the reference's CPU solver behind the dispatcher of INTEGRATION.md.
 The compiled binary is test infrastructure under oracle/_ref/ (git-ignored, travels to the GPU box like the other built
 files); the test is skipped where it was not built."""
@@ -25,15 +29,17 @@ EXE = os.path.join(ROOT, "oracle", "_ref", "sdpasolve_mi355x")
 CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None)}
 
 
+@pytest.mark.parametrize("attach", ["0", "1"], ids=["cpu-cones+engine-operator", "engine-cones"])
 @pytest.mark.parametrize("inst", sorted(CASES))
-def test_reference_driver_runs_on_the_engine(inst):
+def test_reference_driver_runs_on_the_engine(inst, attach):
     if not os.path.exists(EXE):
         pytest.skip("oracle/_ref/sdpasolve_mi355x not built (needs /root/reference at build time: make -C oracle drop)")
     opt, ref_iters = CASES[inst]
     r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden", inst + ".dat-s")], capture_output=True, text=True,
-                       timeout=600)
+                       timeout=600, env=dict(os.environ, HDSDP_DROP_ATTACH=attach))
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
+    assert ("attached to the MI355X engine" in out) == (attach == "1")
     assert "SDP Status: Primal dual optimal" in out, out[-3000:]
     pobj = float(re.search(r"pObj\s+([-+0-9.eE]+)", out).group(1))
     dobj = float(re.search(r"dObj\s+([-+0-9.eE]+)", out).group(1))
