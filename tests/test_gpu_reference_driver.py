@@ -30,7 +30,9 @@ EXE = os.path.join(ROOT, "oracle", "_ref", "sdpasolve_mi355x")
 # n = m = 120, written as an SDPA file at test time (tools/synth_sdpa.py): the congruence + Gram path, i.e. the kernels
 # of the headline benchmark, under the real driver.  Its optimum is the pure reference's on the same file (-36.746433644,
 # also SURVEY.md section 6).
-CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None), "syn120": (-36.746433644, None),
+# truss1: seven blocks; the reference makes six dense SDP cones (attached to the engine in the second mode) and one sparse
+# SDP cone (stays a CPU cone): engine and CPU cones accumulate into one Schur operator.
+CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None), "truss1": (8.999996, None), "syn120": (-36.746433644, None),
          "syn200": (23.898531410, None)}   # n = m = 200 (28 s for the pure reference on a host core): engine cones only
 
 
