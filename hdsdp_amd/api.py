@@ -16,7 +16,7 @@ import numpy as np
 
 KKT_TYPE_INFEASIBLE, KKT_TYPE_CORRECTOR, KKT_TYPE_HOMOGENEOUS, KKT_TYPE_PRIMAL = 0, 1, 2, 3
 KKT_M1, KKT_M2, KKT_M3, KKT_M4, KKT_M5 = 0, 1, 2, 3, 4
-HDSDP_LINSYS_DENSE_DIRECT, HDSDP_LINSYS_DENSE_ITERATIVE, HDSDP_LINSYS_DENSE_INDEFINITE = 0, 5, 6
+HDSDP_LINSYS_DENSE_DIRECT, HDSDP_LINSYS_SPARSE_DIRECT, HDSDP_LINSYS_DENSE_ITERATIVE, HDSDP_LINSYS_DENSE_INDEFINITE = 0, 2, 5, 6
 RETCODE_OK, RETCODE_FAILED, RETCODE_MEMORY = 0, 1, 2
 BUFFER_DUALVAR, BUFFER_DUALCHECK, BUFFER_DUALSTEP = 0, 1, 2   # interface/hdsdp_conic.h:24-26
 
@@ -480,6 +480,19 @@ class LinSys:
     @property
     def lin_type(self):
         return _lin_type(self._h)
+
+    def symbolic(self, beg, idx):
+        """HFpLinsysSymbolic: the lower-triangular CSC pattern of a SPARSE_DIRECT object"""
+        self._beg = np.ascontiguousarray(beg, dtype=np.int32)
+        self._idx = np.ascontiguousarray(idx, dtype=np.int32)
+        _check(load_library().HFpLinsysSymbolic(self._h, _iptr(self._beg), _iptr(self._idx)), "HFpLinsysSymbolic")
+
+    def psd_check_csc(self, val):
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        ok = C.c_int(0)
+        _check(load_library().HFpLinsysPsdCheck(self._h, _iptr(self._beg), _iptr(self._idx), _dptr(val), C.byref(ok)),
+               "HFpLinsysPsdCheck")
+        return bool(ok.value)
 
     def psd_check(self, A):
         A = np.ascontiguousarray(A, dtype=np.float64)

@@ -93,6 +93,14 @@ struct MiLin {
     bool indef = false;
     const double *srcHost = nullptr, *srcDev = nullptr;   // where the last factorised matrix came from (lower valid)
     long srcLd = 0;
+    // HDSDP_LINSYS_SPARSE_DIRECT (the reference's QDLDL backend for a sparse dual matrix, hdsdp_linsolver.c:509-809):
+    // the matrix arrives as a lower-triangular CSC and is factored densely on the device.  Result-equivalent for every
+    // caller: QDLDL's forward / backward solves carry the D^-1/2 scaling (:669-721), i.e. they ARE the Cholesky factor's,
+    // GetDiag returns sqrt(D) (:746-756), Invert the full inverse (:758-772); a fill-reducing order only changes the
+    // factor by an orthogonal similarity, which neither logdet nor the Lanczos spectrum sees.
+    bool csc_in = false;
+    std::vector<int> cscBeg, cscIdx;
+    std::vector<double> dense;
 };
 
 hdsdp_retcode lin_create(void **pchol, int nCol) {
@@ -104,7 +112,29 @@ hdsdp_retcode lin_create(void **pchol, int nCol) {
     return HDSDP_RETCODE_OK;
 }
 void lin_setparam(void *chol, void *param) { (void) chol; (void) param; }
-hdsdp_retcode lin_symbolic(void *, int *, int *) { return HDSDP_RETCODE_OK; }
+hdsdp_retcode lin_symbolic(void *chol, int *colMatBeg, int *colMatIdx) {
+    MiLin *l = (MiLin *) chol;
+    if (l->csc_in && colMatBeg && colMatIdx) {   // keep the pattern: later calls may pass it again or not at all
+        l->cscBeg.assign(colMatBeg, colMatBeg + l->n + 1);
+        l->cscIdx.assign(colMatIdx, colMatIdx + colMatBeg[l->n]);
+    }
+    return HDSDP_RETCODE_OK;
+}
+// lower-triangular CSC -> dense n x n column-major (lower triangle valid), on the host: a format conversion of n^2 doubles
+const double *lin_densify(MiLin *l, const int *colMatBeg, const int *colMatIdx, const double *colMatElem) {
+    const int *beg = colMatBeg ? colMatBeg : (l->cscBeg.empty() ? nullptr : l->cscBeg.data());
+    const int *idx = colMatIdx ? colMatIdx : (l->cscIdx.empty() ? nullptr : l->cscIdx.data());
+    if (!beg || !idx || !colMatElem) return nullptr;
+    const size_t n = (size_t) l->n;
+    l->dense.assign(n * n, 0.0);
+    for (size_t j = 0; j < n; ++j)
+        for (int p = beg[j]; p < beg[j + 1]; ++p) {
+            const size_t i = (size_t) idx[p];
+            if (i >= j) l->dense[i + j * n] = colMatElem[p];
+            else l->dense[j + i * n] = colMatElem[p];     // an upper entry, should a caller hand one over
+        }
+    return l->dense.data();
+}
 
 hdsdp_retcode lin_factor_host(MiLin *l, const double *A, int *info) {
     RC(l->ch.load_host(A, l->n, g.stream));
@@ -125,8 +155,12 @@ hdsdp_retcode lin_factor_indef(MiLin *l) {
     return info == 0 ? HDSDP_RETCODE_OK : HDSDP_RETCODE_FAILED;
 }
 // linalg/hdsdp_linsolver.c:1082-1110 (copy + dpotrf; info != 0 is a failure here)
-hdsdp_retcode lin_numeric(void *chol, int *, int *, double *colMatElem) {
+hdsdp_retcode lin_numeric(void *chol, int *colMatBeg, int *colMatIdx, double *colMatElem) {
     MiLin *l = (MiLin *) chol;
+    if (l->csc_in) {
+        colMatElem = const_cast<double *>(lin_densify(l, colMatBeg, colMatIdx, colMatElem));
+        if (!colMatElem) return HDSDP_RETCODE_FAILED;
+    }
     l->srcHost = colMatElem; l->srcDev = nullptr; l->srcLd = l->n;
     if (l->indef) return lin_factor_indef(l);
     int info = 0;
@@ -142,8 +176,12 @@ hdsdp_retcode lin_switch_indefinite(hdsdp_linsys_fp *HLin) {
     return lin_factor_indef(l);
 }
 // linalg/hdsdp_linsolver.c:1112-1144 (info > 0 => "not PSD" is a value, not an error)
-hdsdp_retcode lin_psdcheck(void *chol, int *, int *, double *colMatElem, int *isPsd) {
+hdsdp_retcode lin_psdcheck(void *chol, int *colMatBeg, int *colMatIdx, double *colMatElem, int *isPsd) {
     MiLin *l = (MiLin *) chol;
+    if (l->csc_in) {
+        colMatElem = const_cast<double *>(lin_densify(l, colMatBeg, colMatIdx, colMatElem));
+        if (!colMatElem) return HDSDP_RETCODE_FAILED;
+    }
     if (l->indef) return HDSDP_RETCODE_FAILED;   // :1729-1739, no PSD check on the pivoted factor
     int info = 0;
     if (lin_factor_host(l, colMatElem, &info) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
@@ -1473,9 +1511,11 @@ hdsdp_retcode HFpLinsysCreate(hdsdp_linsys_fp **pHLin, int nCol, linsys_type Lty
         case HDSDP_LINSYS_DENSE_DIRECT:
         case HDSDP_LINSYS_DENSE_ITERATIVE:  // Schur system: solved by a direct blocked Cholesky here (stricter
             break;                          // than the reference's PCG to 1e-12, hdsdp_linsolver.c:1446-1588)
+        case HDSDP_LINSYS_SPARSE_DIRECT:    // sparse dual matrix: CSC in, dense factorisation on the device (see MiLin)
+            break;
         default:
             fprintf(stderr, "[hdsdp_mi355x] HFpLinsysCreate: linsys_type %d is not on the accelerated path "
-                            "(sparse / small backends stay with the CPU reference; DENSE_INDEFINITE is only reached by switching)\n", (int) Ltype);
+                            "(sparse indefinite / iterative backends stay with the CPU reference; DENSE_INDEFINITE is only reached by switching)\n", (int) Ltype);
             return HDSDP_RETCODE_FAILED;
     }
     hdsdp_linsys_fp *h = (hdsdp_linsys_fp *) calloc(1, sizeof(hdsdp_linsys_fp));
@@ -1496,6 +1536,7 @@ hdsdp_retcode HFpLinsysCreate(hdsdp_linsys_fp **pHLin, int nCol, linsys_type Lty
     hdsdp_retcode rc = h->cholCreate(&h->chol, nCol);
     if (rc != HDSDP_RETCODE_OK) { free(h); return rc; }
     ((MiLin *) h->chol)->type = Ltype;
+    ((MiLin *) h->chol)->csc_in = (Ltype == HDSDP_LINSYS_SPARSE_DIRECT);
     *pHLin = h;
     return HDSDP_RETCODE_OK;
 }

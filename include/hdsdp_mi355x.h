@@ -165,6 +165,9 @@ void HKKTDestroy(hdsdp_kkt **pHKKT);                                            
 /* ==================  linear-system operator: linalg/hdsdp_linsolver.h:16-28  ================
  * DENSE_DIRECT (the dual matrix S): blocked Cholesky on the device; "not positive definite" is a value of PsdCheck
  * and a failure of Numeric, as in lapackLinSolver* (hdsdp_linsolver.c:1082-1144).
+ * SPARSE_DIRECT (a sparse dual matrix S; QDLDL in the reference, hdsdp_linsolver.c:509-809): Symbolic takes the lower-
+ * triangular CSC pattern, Numeric / PsdCheck the values; the matrix is factored densely on the device.  Result-equivalent:
+ * QDLDL's forward / backward solves carry the D^-1/2 scaling, GetDiag returns sqrt(D), Invert the full inverse.
  * DENSE_ITERATIVE (the Schur matrix M): the same direct Cholesky instead of the reference's PCG.  When M is not
  * numerically positive definite -- Numeric's factorisation fails, or Solve returns NaN -- the object switches itself to
  * DENSE_INDEFINITE like HFpLinsysSwitchToIndefinite (hdsdp_linsolver.c:1827-1857, called at :2034-2039 and :2098-2103)

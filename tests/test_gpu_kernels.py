@@ -215,3 +215,40 @@ def test_kkt_factorize_falls_back_when_the_schur_matrix_is_indefinite():
     finally:
         kkt.destroy()
         cone.destroy()
+
+
+def test_sparse_direct_linsys_takes_a_csc_and_behaves_like_the_cholesky_backend():
+    """HDSDP_LINSYS_SPARSE_DIRECT (the reference's QDLDL backend for a sparse dual matrix, hdsdp_linsolver.c:509-809): a
+    lower-triangular CSC goes in; every observable -- diag (sqrt(D) there), forward / backward solves (with the
+    D^-1/2 scaling there), solve, full inverse, the PSD verdict -- equals the dense Cholesky object's on the same matrix"""
+    from hdsdp_amd import api
+    n = 150
+    rng = np.random.default_rng(3)
+    A = np.zeros((n, n))
+    for _ in range(5 * n):                             # a sparse symmetric pattern + a dominant diagonal
+        i, j = rng.integers(0, n, 2)
+        A[max(i, j), min(i, j)] += rng.uniform(-1, 1)
+    A = np.tril(A, -1)
+    S = A + A.T + np.diag(4.0 + np.abs(A).sum(0) + np.abs(A).sum(1))
+    beg, idx, val = [0], [], []
+    for j in range(n):
+        rows = [i for i in range(j, n) if S[i, j] != 0.0]
+        idx += rows; val += [S[i, j] for i in rows]; beg.append(len(idx))
+    sp = api.LinSys(n, api.HDSDP_LINSYS_SPARSE_DIRECT)
+    de = api.LinSys(n, api.HDSDP_LINSYS_DENSE_DIRECT)
+    try:
+        sp.symbolic(beg, idx)
+        assert sp.psd_check_csc(val) and de.psd_check(np.triu(S))
+        assert sp.lin_type == api.HDSDP_LINSYS_SPARSE_DIRECT      # callers branch on it (hdsdp_sdpdata.c:1035)
+        assert np.array_equal(sp.get_diag(), de.get_diag())
+        b = rng.uniform(-1, 1, n)
+        for f in ("solve", "fsolve", "bsolve"):
+            assert np.array_equal(getattr(sp, f)(b), getattr(de, f)(b)), f
+        assert np.array_equal(sp.invert(), de.invert())
+        assert np.linalg.norm(S @ sp.solve(b) - b) <= 1e-12 * np.linalg.norm(b) * np.linalg.cond(S)
+        bad = np.array(val)
+        bad[beg[n // 2]] = -1.0                                    # a negative diagonal entry
+        assert sp.psd_check_csc(bad) is False
+    finally:
+        sp.destroy()
+        de.destroy()

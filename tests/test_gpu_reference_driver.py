@@ -6,12 +6,11 @@ the reference's solver main (tests/sdpasolve.c) on top: oracle/_ref/sdpasolve_mi
 its IPM driver, presolve, CPU cones and Lanczos call HKKT* / HFpLinsys* exactly as they call their own -- 33 call sites
 in interface/hdsdp_algo.c alone -- and here those calls land in the HIP engine: the Schur operator object (the cones
 accumulate into its host fields, the engine factors and solves M on the device) and every dense factorisation, PSD check,
-triangular solve and inverse of the dual matrix S.  In the second mode the harness (oracle/drop_attach.c, the glue of
+triangular solve and inverse of the dual matrix S (dense, or handed over as a CSC).  In the second mode the harness (oracle/drop_attach.c, the glue of
 INTEGRATION.md 2(b) injected by symbol interposition, no reference file is touched) also hands every dense SDP block to the
 engine's cone at presolve time, and the same unmodified driver then runs its whole conic work -- S assembly, interior
 checks, ratio tests, Schur builds of every type, barrier, line search, primal recovery -- on the GPU through the
-reference's own cone interface.  Instances with a dense dual matrix only: a sparse S asks for
-HDSDP_LINSYS_SPARSE_DIRECT, which stays with the reference's CPU solver behind the dispatcher of INTEGRATION.md.
+reference's own cone interface.
 The compiled binary is test infrastructure under oracle/_ref/ (git-ignored, travels to the GPU box like the other built
 files); the test is skipped where it was not built."""
 import os
@@ -32,7 +31,9 @@ EXE = os.path.join(ROOT, "oracle", "_ref", "sdpasolve_mi355x")
 # also SURVEY.md section 6).
 # truss1: seven blocks; the reference makes six dense SDP cones (attached to the engine in the second mode) and one sparse
 # SDP cone (stays a CPU cone): engine and CPU cones accumulate into one Schur operator.
-CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None), "truss1": (8.999996, None), "syn120": (-36.746433644, None),
+# mcp100: sparse dual matrix -- the reference asks for HDSDP_LINSYS_SPARSE_DIRECT objects, which the library factors densely.
+CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None), "mcp100": (-226.15735, None), "truss1": (8.999996, None),
+         "syn120": (-36.746433644, None),
          "syn200": (23.898531410, None)}   # n = m = 200 (28 s for the pure reference on a host core): engine cones only
 
 
