@@ -34,7 +34,7 @@ EXPORTS = [
     "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeCheckIsInteriorExpert",
     "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetCoeffNorm", "HMiConeGetObjNorm",
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
-    "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats",
+    "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
     "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
@@ -148,6 +148,7 @@ def load_library():
         "HMiConeSetExchange": (None, [vp, vp, vp, vp]),
         "HMiConeSetExchangePieces": (None, [vp, vp, vp, C.c_int]),
         "HMiConeGetExchangeStats": (None, [vp, ip, ip]),
+        "HMiConeBuildPrimalXSXDirection": (None, [vp, dp, dp, C.c_int]),
         "HMiConeGetExchangeBuffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]),
         "HMiConeSetExchangeBuffers": (C.c_int, [vp, vp, vp]),
         "HMiKKTDeviceMatrix": (vp, [kp, C.POINTER(C.c_int64)]),
@@ -347,6 +348,13 @@ class SDPCone:
         _check(load_library().HMiConeGetLogBarrier(self._h, float(tau), yp, BUFFER_DUALVAR, C.byref(out)),
                "HConeGetLogBarrier")
         return out.value
+
+    def build_primal_xsx(self, X, XSX, dual_matrix=True):
+        """XSX += X^T D X with D = the dual matrix S (dual_matrix) or the dual step of the last ratio test"""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        assert XSX.flags.c_contiguous and XSX.dtype == np.float64
+        load_library().HMiConeBuildPrimalXSXDirection(self._h, _dptr(X), _dptr(XSX), 1 if dual_matrix else 0)
+        return XSX
 
     def exchange_stats(self):
         """(pieces of the last build's all-to-all, launches the staged second congruence step was cut into)"""

@@ -28,6 +28,7 @@
 __global__ void mi_low_norms_kernel(const double *__restrict__ A, long astride, int n, long ld, int count, int a_l_form,
                                     double *__restrict__ out);
 __global__ void mi_scale_kernel(double *__restrict__ A, long count, double s);
+__global__ void mi_put_row_kernel(double *__restrict__ M, long ldm, int i, const double *__restrict__ v, int m);
 __global__ void mi_lower_dot_kernel(const double *__restrict__ S, long lds_, const double *__restrict__ X, long ldx, int n,
                                     double *__restrict__ out);
 __global__ void mi_mat_dot_kernel(const double *__restrict__ X, long ldx, const double *__restrict__ Y, long ldy, int n,
@@ -700,6 +701,41 @@ static int cone_upload_X(MiCone *c, const double *X, long *ldx) {
     return 0;
 }
 
+// sdpDenseConeBuildPrimalXSXDirection (hdsdp_conic_sdp.c:2021-2040 -> fds_trimultiply, dense_opts.c:102-132), the cone's
+// coneBuildPrimalDirection slot used by the primal refinement (hdsdp_psdp.c:236,295):  XSX += X^T D X  (full symmetric
+// n x n, host), D = the dual matrix (iDualMat != 0) or the dual step dS of the last ratio test, both resident.  Two
+// plain MFMA GEMMs on the device; only X goes up and the n x n product comes back.
+void cone_build_primal_dir(void *cd, void *kktv, double *X, double *XSX, int iDualMat) {
+    (void) kktv;
+    MiCone *c = (MiCone *) cd;
+    const int n = c->n;
+    long ldx = 0;
+    const double *D = iDualMat ? c->S : c->dS;
+    if (!D) { fprintf(stderr, "[hdsdp_mi355x] primal direction: no dual step has been formed yet\n"); return; }
+    if (cone_upload_X(c, X, &ldx)) return;
+    const size_t np2 = sizeof(double) * (size_t) ldx * ldx;
+    if (!c->Pr1 && hipMalloc((void **) &c->Pr1, np2) != hipSuccess) return;
+    if (!c->Pr2 && hipMalloc((void **) &c->Pr2, np2) != hipSuccess) return;
+    // Pr1 <- D as a full symmetric matrix (the resident copy has its lower triangle valid), zero padded
+    if (hipMemsetAsync(c->Pr1, 0, np2, g.stream) != hipSuccess) return;
+    if (hipMemcpy2DAsync(c->Pr1, sizeof(double) * ldx, D, sizeof(double) * c->n16, sizeof(double) * n, n,
+                         hipMemcpyDeviceToDevice, g.stream) != hipSuccess) return;
+    if (hdm_mirror_lower(c->Pr1, ldx, n, g.stream)) return;
+    HdmGemmArgs q = {};
+    q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE; q.ldc = ldx;
+    // T = D X   (B operand element (j, k) = X(k, j): K-major)
+    q.A = c->Pr1; q.lda = ldx; q.a_kmajor = 0; q.B = c->Xup; q.ldb = ldx; q.b_kmajor = 1; q.C = c->Pr2;
+    if (hdm_launch_gemm(q, g.stream)) return;
+    // P = X^T T   (A operand element (i, k) = X(k, i): K-major; B operand element (j, k) = T(k, j): K-major)
+    q.A = c->Xup; q.lda = ldx; q.a_kmajor = 1; q.B = c->Pr2; q.ldb = ldx; q.b_kmajor = 1; q.C = c->Pr1;
+    if (hdm_launch_gemm(q, g.stream)) return;
+    std::vector<double> h((size_t) n * n);
+    if (hipMemcpy2DAsync(h.data(), sizeof(double) * n, c->Pr1, sizeof(double) * ldx, sizeof(double) * n, n,
+                         hipMemcpyDeviceToHost, g.stream) != hipSuccess) return;
+    if (hipStreamSynchronize(g.stream) != hipSuccess) return;
+    for (size_t e = 0; e < h.size(); ++e) XSX[e] += h[e];
+}
+
 void cone_a_times_x(void *cd, double *X, double *ATimesX) {   // sdpDenseConeATimesX, :2470-2477: y_i += <A_i, X>
     MiCone *c = (MiCone *) cd;
     long ldx = 0;
@@ -960,6 +996,7 @@ hdsdp_retcode exchange_and_gram(MiCone *c, bool staged = false) {
 }
 
 hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT, HdmChol *chOverride = nullptr);
+double *kkt_Mdev(hdsdp_kkt *kkt, long *ld);
 hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
 hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
 
@@ -969,6 +1006,60 @@ hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int ty
 // lower triangular with W^T W = X and takes Linv's place in the GEMM path (all strategies give the same numbers, and
 // the reference itself re-routes M2 columns for this type, :1782-1788).  X must be positive definite, which a
 // primal interior point is; an indefinite X is reported like a failed dpotrf.
+// KKT_TYPE_PRIMAL with a registered matrix that is NOT positive definite (the primal refinement does hand such iterates
+// over, hdsdp_psdp.c:203,420; the reference's trace formulas do not care): no triangular factor exists, so the product is
+// formed the way the reference's M3 column does it, one owned row at a time:  B_i = X A_i X  (three plain MFMA GEMMs on
+// the A_L form: X A = X A_L + X A_L^T),  then  M_ij = <A_j, B_i>  for all j in one pass over the resident constraint data.
+// 4 n^3 + m n^2 flops per row instead of the congruence path's n^3 + m n^2 / 2: a fallback, used only on this condition.
+hdsdp_retcode build_primal_general(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, const double *X) {
+    if (c->world > 1) {
+        fprintf(stderr, "[hdsdp_mi355x] KKT_TYPE_PRIMAL: an indefinite primal matrix is not supported on a sharded block\n");
+        return HDSDP_RETCODE_FAILED;
+    }
+    const int n = c->n, m = kkt->nRow;
+    long ldx = 0, ldm = 0;
+    RC(cone_upload_X(c, X, &ldx));
+    const size_t np2 = sizeof(double) * (size_t) ldx * ldx;
+    if (!c->Pr1) HIP_RC(hipMalloc((void **) &c->Pr1, np2));
+    if (!c->Pr2) HIP_RC(hipMalloc((void **) &c->Pr2, np2));
+    double *Mdev = kkt_Mdev(kkt, &ldm), *row = nullptr;
+    HIP_RC(hipMalloc((void **) &row, sizeof(double) * (size_t) m));
+    HdmGemmArgs q = {};
+    q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE; q.ldc = ldx;
+    // vectors: ASinv_i = <A_i, X>, ASinvRdSinv_i = Rd <A_i, X^2>   (Pr2 <- X X^T)
+    q.A = c->Xup; q.lda = ldx; q.B = c->Xup; q.ldb = ldx; q.C = c->Pr2;
+    hdsdp_retcode rc = HDSDP_RETCODE_OK;
+    if (hdm_launch_gemm(q, g.stream) ||
+        hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Xup, c->Pr2, ldx, pv->vecs, pv->vecs + m,
+                     c->rows_own, 2.0, 2.0 * c->Rd, g.stream))
+        rc = HDSDP_RETCODE_FAILED;
+    for (int qi = 0; qi < c->mloc && rc == HDSDP_RETCODE_OK; ++qi) {
+        const double *AL = c->Afull + (long) qi * c->n16 * c->n16;
+        // Pr1 = X A_L            (B operand element (j, k) = A_L(k, j): K-major)
+        q.A = c->Xup; q.lda = ldx; q.a_kmajor = 0; q.B = AL; q.ldb = c->n16; q.b_kmajor = 1; q.C = c->Pr1; q.beta = 0.0;
+        if (hdm_launch_gemm(q, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
+        // Pr1 += X A_L^T         (B operand element (j, k) = A_L(j, k): M-major)
+        q.b_kmajor = 0; q.beta = 1.0;
+        if (hdm_launch_gemm(q, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
+        // Pr2 = Pr1 X            (B operand element (j, k) = X(k, j): K-major)
+        q.A = c->Pr1; q.lda = ldx; q.B = c->Xup; q.ldb = ldx; q.b_kmajor = 1; q.C = c->Pr2; q.beta = 0.0;
+        if (hdm_launch_gemm(q, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
+        if (hipMemsetAsync(row, 0, sizeof(double) * (size_t) m, g.stream) != hipSuccess ||
+            hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Pr2, nullptr, ldx, row, row,
+                         c->rows_own, 2.0, 0.0, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
+        hipLaunchKernelGGL(mi_put_row_kernel, dim3((m + 255) / 256), dim3(256), 0, g.stream, Mdev, ldm, c->own[qi], row, m);
+    }
+    if (hipStreamSynchronize(g.stream) != hipSuccess) rc = HDSDP_RETCODE_FAILED;
+    (void) hipFree(row);
+    if (rc != HDSDP_RETCODE_OK) return rc;
+    if (c->Rd != 0.0) {                      // dTraceSinv += tr X (hdsdp_conic_sdp.c:1767-1769)
+        double tr = 0.0;
+        for (int i = 0; i < n; ++i) tr += X[(size_t) i * (n + 1)];
+        kkt->dTraceSinv += tr;
+    }
+    return HDSDP_RETCODE_OK;
+}
+
 hdsdp_retcode build_primal(MiCone *c, int iCone, hdsdp_kkt *kkt, MiKKTPriv *pv) {
     if (!kkt->dPrimalX || !kkt->dPrimalX[iCone]) return HDSDP_RETCODE_FAILED;   // :1747-1750
     const double *X = kkt->dPrimalX[iCone];
@@ -985,11 +1076,7 @@ hdsdp_retcode build_primal(MiCone *c, int iCone, hdsdp_kkt *kkt, MiKKTPriv *pv) 
     if (ch.load_host(Xr.data(), n, g.stream)) return HDSDP_RETCODE_FAILED;
     HIP_RC(hipStreamSynchronize(g.stream));   // Xr is pageable host memory going out of scope
     if (ch.factor(g.stream, &info)) return HDSDP_RETCODE_FAILED;
-    if (info != 0) {
-        fprintf(stderr, "[hdsdp_mi355x] KKT_TYPE_PRIMAL: the registered primal matrix is not positive definite "
-                        "(pivot %d of the reversed matrix)\n", info);
-        return HDSDP_RETCODE_FAILED;
-    }
+    if (info != 0) return build_primal_general(c, kkt, pv, X);   // X is not positive definite: no factor to lean on
     if (ch.set_reverse_inverse(g.stream)) return HDSDP_RETCODE_FAILED;
     return build_gemm_path(c, kkt, pv, KKT_TYPE_PRIMAL, &ch);
 }
@@ -1121,6 +1208,12 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
 }  // namespace
 
 // kernels local to this file -------------------------------------------------------------------
+// row i of the lower triangle of M (column-major, ld): M[i, j] += v[j] for j <= i
+__global__ void mi_put_row_kernel(double *__restrict__ M, long ldm, int i, const double *__restrict__ v, int m) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < m && j <= i) M[i + (long) j * ldm] += v[j];
+}
+
 __global__ void mi_col_dot_kernel(const double *__restrict__ X, const double *__restrict__ Y, long ld, int n,
                                   const double *__restrict__ sgn, const int *__restrict__ rows, int count,
                                   double *__restrict__ out) {
@@ -1450,6 +1543,7 @@ hdsdp_cone *new_cone_shell(MiCone *c, int iCone) {
     h->coneGetDim = cone_getdim;
     h->coneBuildSchur = cone_build_schur;
     h->coneBuildSchurFixed = cone_build_schur_fixed;
+    h->coneBuildPrimalDirection = cone_build_primal_dir;
     h->coneInteriorCheck = cone_interior;
     h->coneRatioTest = cone_ratio_test;
     h->conePRecover = cone_precover;
@@ -1854,6 +1948,9 @@ void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM) {
 void HMiConeSetExchangePieces(hdsdp_cone *cone, hmi_alltoall_piece_fn start, hmi_alltoall_wait_fn wait, int npieces) {
     MiCone *c = (MiCone *) cone->coneData;
     c->a2a_start = start; c->a2a_wait = wait; c->a2a_pieces = std::max(1, npieces);
+}
+void HMiConeBuildPrimalXSXDirection(hdsdp_cone *cone, double *dPrimalScalMatrix, double *dPrimalXSXBuffer, int iDualMat) {
+    cone->coneBuildPrimalDirection(cone->coneData, nullptr, dPrimalScalMatrix, dPrimalXSXBuffer, iDualMat);
 }
 void HMiConeGetExchangeStats(hdsdp_cone *cone, int *pieces, int *stagedLaunches) {
     MiCone *c = (MiCone *) cone->coneData;

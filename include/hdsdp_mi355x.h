@@ -285,6 +285,10 @@ void HMiConeSetExchange(hdsdp_cone *cone, hmi_alltoall_fn a2a, hmi_allreduce_fn 
 typedef int (*hmi_alltoall_piece_fn)(void *ctx, int64_t offset, int64_t count, int piece);
 typedef int (*hmi_alltoall_wait_fn)(void *ctx, int piece);
 void HMiConeSetExchangePieces(hdsdp_cone *cone, hmi_alltoall_piece_fn start, hmi_alltoall_wait_fn wait, int npieces);
+/* HConeBuildPrimalXSXDirection (interface/hdsdp_conic.c:335-338; the cone's coneBuildPrimalDirection slot, used by the primal
+ * refinement hdsdp_psdp.c:236,295): XSX += X^T D X, D = the resident dual matrix (iDualMat != 0) or the dual step of the last
+ * ratio test; X and XSX are n x n column-major host matrices */
+void HMiConeBuildPrimalXSXDirection(hdsdp_cone *cone, double *dPrimalScalMatrix, double *dPrimalXSXBuffer, int iDualMat);
 /* what the last HKKTBuildUp did: pieces of the exchange (1 = one blocking all-to-all) and, when the congruence's second
  * step was staged by packed-index range, the number of launches it was cut into (0 = not staged) */
 void HMiConeGetExchangeStats(hdsdp_cone *cone, int *pieces, int *stagedLaunches);

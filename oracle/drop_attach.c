@@ -59,6 +59,7 @@ hdsdp_retcode HConePresolveData(hdsdp_cone *HCone) {
     HCone->coneRatioTest = g->coneRatioTest;
     HCone->coneGetSymNnz = g->coneGetSymNnz;                   HCone->coneGetDim = g->coneGetDim;
     HCone->coneBuildSchur = g->coneBuildSchur;                 HCone->coneBuildSchurFixed = g->coneBuildSchurFixed;
+    HCone->coneBuildPrimalDirection = g->coneBuildPrimalDirection;
     HCone->coneInteriorCheck = g->coneInteriorCheck;           HCone->coneInteriorCheckExpert = g->coneInteriorCheckExpert;
     HCone->coneGetBarrier = g->coneGetBarrier;                 HCone->coneAxpyBufferAndCheck = g->coneAxpyBufferAndCheck;
     HCone->coneReduceResi = g->coneReduceResi;                 HCone->coneSetPerturb = g->coneSetPerturb;

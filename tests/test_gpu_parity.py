@@ -797,3 +797,96 @@ def test_cpu_cone_inside_the_operator_accumulates_with_the_engine_cones():
             lib.HKKTDestroy(C.byref(k))
     finally:
         cone.destroy()
+
+
+@pytest.mark.parametrize("name", ["theta1_B", "mix40_B"])
+def test_primal_xsx_direction(name):
+    """the cone's coneBuildPrimalDirection slot (sdpDenseConeBuildPrimalXSXDirection, interface/hdsdp_conic_sdp.c:2021-2040
+    -> fds_trimultiply, linalg/dense_opts.c:102-132): XSX += X^T D X, accumulated into the caller's buffer, with D the
+    dual matrix or the dual step of the last ratio test; checked against the same product in numpy on the oracle's S"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    from hdsdp_amd import api
+    g = load_golden(name)
+    n, m = int(g["dims"][0]), int(g["dims"][1])
+    Rd, tau, y = float(g["Rd"][0]), float(g["tau"][0]), y_of(g)
+    blk = oracle_py.Block(n, m, g["csc_beg"], g["csc_idx"], g["csc_val"])
+    cone = api.SDPCone.from_csc(n, m, g["csc_beg"], g["csc_idx"], g["csc_val"])
+    try:
+        cone.set_start(Rd)
+        assert cone.check_is_interior(tau, y)
+        def full(T):    # the oracle's matrices are column-major with the lower triangle valid = numpy's upper triangle
+            T = np.asarray(T)
+            return np.triu(T) + np.triu(T, 1).T
+        S = full(blk.assemble_S(tau, y, Rd))
+        rng = np.random.default_rng(n)
+        G = rng.uniform(-1, 1, (n, n))
+        X = G + 0.3 * G.T                                        # not symmetric on purpose: X^T D X, not X D X
+        out = np.full((n, n), 0.25)
+        cone.build_primal_xsx(X.T.copy(), out, dual_matrix=True)  # column-major X == C-order X^T
+        want = X.T @ S @ X
+        assert np.allclose(out.T - 0.25, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+        # the dual step of the last ratio test: dS = dtau * C - sum dy_i A_i
+        dy = 3.0 * np.sin(0.7 * np.arange(m) + 0.1)
+        cone.ratio_test(0.0, dy, 0.0)
+        D = full(blk.assemble_S(0.0, dy, 0.0))
+        out2 = np.zeros((n, n))
+        cone.build_primal_xsx(X.T.copy(), out2, dual_matrix=False)
+        want2 = X.T @ D @ X
+        assert np.allclose(out2.T, want2, rtol=1e-12, atol=1e-12 * np.abs(want2).max())
+    finally:
+        cone.destroy()
+        blk.close()
+
+
+@pytest.mark.parametrize("name", ["theta1_B", "mix40_A", "syn64"])
+def test_primal_build_with_an_indefinite_registered_matrix(name):
+    """KKT_TYPE_PRIMAL when the registered matrix is NOT positive definite -- the primal refinement does hand such iterates
+    over (seen with the reference's driver on the synthetic family at n = 30, m = 100), and the reference's formulas
+    M_ij = tr(A_i X A_j X) do not care.  The engine then has no triangular factor of X to lean on and falls back to the
+    row-by-row product X A_i X; checked against the pinned oracle run with X in S^-1's place (its typeKKT = 3 branch,
+    pinned for positive definite X by the M_pri goldens)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    from hdsdp_amd import api
+    g = load_golden(name)
+    n, m = int(g["dims"][0]), int(g["dims"][1])
+    if "csc_beg" in g:
+        beg, idx, val = g["csc_beg"], g["csc_idx"], g["csc_val"]
+    else:
+        beg, idx, val, _ = oracle_py.synth_csc(n, m)
+    blk = oracle_py.Block(n, m, beg, idx, val)
+    cone = api.SDPCone.from_csc(n, m, beg, idx, val)
+    kkt = api.KKT(m, [cone])
+    try:
+        Rd = float(g["Rd"][0])
+        cone.set_start(Rd)
+        assert cone.check_is_interior(float(g["tau"][0]), y_of(g))
+        rng = np.random.default_rng(n + m)
+        G = rng.uniform(-1, 1, (n, n))
+        X = 0.5 * (G + G.T)                       # symmetric, eigenvalues of both signs
+        w = np.linalg.eigvalsh(X)
+        assert w[0] < -0.1 and w[-1] > 0.1
+        ref = blk.kkt_build(X, Rd, 3)
+        kkt.register_psdp([X])
+        kkt.build_up(api.KKT_TYPE_PRIMAL)
+        ex = kkt.export()
+        msk = lower_mask(m)
+        check_close(kkt.M[msk], ref["M"][msk], name + " M, indefinite X")
+        check_close(ex["ASinv"], ref["ASinv"], "ASinv")
+        check_close(ex["ASinvRdSinv"], ref["ASinvRdSinv"], "ASinvRdSinv")
+        check_close([ex["TraceSinv"]], [ref["TraceSinv"]], "TraceSinv")
+        # and a positive definite matrix still takes the congruence path and gives the oracle's numbers too
+        P = X @ X + np.eye(n)
+        ref = blk.kkt_build(P, Rd, 3)
+        kkt.register_psdp([P])
+        kkt.build_up(api.KKT_TYPE_PRIMAL)
+        check_close(kkt.M[msk], ref["M"][msk], name + " M, definite X")
+    finally:
+        kkt.destroy()
+        cone.destroy()
+        blk.close()

@@ -34,7 +34,11 @@ EXE = os.path.join(ROOT, "oracle", "_ref", "sdpasolve_mi355x")
 # mcp100: sparse dual matrix -- the reference asks for HDSDP_LINSYS_SPARSE_DIRECT objects, which the library factors densely.
 CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None), "mcp100": (-226.15735, None), "truss1": (8.999996, None),
          "syn120": (-36.746433644, None),
-         "syn200": (23.898531410, None)}   # n = m = 200 (28 s for the pure reference on a host core): engine cones only
+         "syn200": (23.898531410, None),   # n = m = 200 (28 s for the pure reference on a host core): engine cones only
+         # n = 30, m = 100: the driver turns its primal refinement on (hdsdp.c:156) -- KKT_TYPE_PRIMAL builds on registered
+         # primal iterates (which are not always positive definite), the primal XSX direction, and, when that Schur matrix
+         # is indefinite, the switch of the Schur system to the pivoted solver
+         "syn30x100": (-2.76541492, None)}
 
 
 @pytest.mark.parametrize("attach", ["0", "1"], ids=["cpu-cones+engine-operator", "engine-cones"])
@@ -50,9 +54,9 @@ def test_reference_driver_runs_on_the_engine(inst, attach, tmp_path):
         import sys
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from synth_sdpa import write_synth_sdpa
-        nm = int(inst[3:])
+        dims = [int(v) for v in inst[3:].split("x")]
         fname = str(tmp_path / (inst + ".dat-s"))
-        write_synth_sdpa(nm, nm, fname)
+        write_synth_sdpa(dims[0], dims[-1], fname)
     r = subprocess.run([EXE, fname], capture_output=True, text=True,
                        timeout=600, env=dict(os.environ, HDSDP_DROP_ATTACH=attach))
     out = r.stdout + r.stderr
@@ -63,8 +67,10 @@ def test_reference_driver_runs_on_the_engine(inst, attach, tmp_path):
     dobj = float(re.search(r"dObj\s+([-+0-9.eE]+)", out).group(1))
     assert abs(dobj - opt) <= (1e-6 if inst.startswith("syn") else 1e-4) * abs(opt), (dobj, opt)
     assert abs(pobj - dobj) <= 1e-4 * abs(opt), (pobj, dobj)
-    # the Schur system never had to leave the Cholesky path on these instances
-    assert "Switch to the pivoted" not in out
+    if inst != "syn30x100":     # the Schur system never had to leave the Cholesky path on the other instances
+        assert "Switch to the pivoted" not in out
+    else:
+        assert "Primal refinement starts" in out
     if ref_iters is not None:
         its = [int(m.group(1)) for m in re.finditer(r"^\s+(\d+)\s+[-+]\d\.\d+e[-+]\d+\s+[-+]\d\.\d+e[-+]\d+", out, re.M)]
         assert its and abs(max(its) - ref_iters) <= 2, (max(its) if its else None, ref_iters)
