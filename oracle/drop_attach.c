@@ -13,6 +13,9 @@
  * This file contains none of the reference's source; it includes its headers from where they lie, like ref_dump.c. */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -26,6 +29,21 @@
 /* the engine's constructor (include/hdsdp_mi355x.h; its hdsdp_cone is binary-compatible with the reference's) */
 extern hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *coneMatBeg,
                                       const int *coneMatIdx, const double *coneMatElem, int rank, int world);
+
+/* a crash inside the driver (the reference aborts in a few places, e.g. an undersized dsyevr work array) should say where */
+static void crash_backtrace(int sig) {
+    void *frames[48];
+    const int nf = backtrace(frames, 48);
+    const char msg[] = "drop_attach: fatal signal, backtrace:\n";
+    (void) !write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, nf, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+__attribute__((constructor)) static void install_crash_handler(void) {
+    signal(SIGABRT, crash_backtrace);
+    signal(SIGSEGV, crash_backtrace);
+}
 
 #define MAX_ATTACHED 256
 static struct { void *engineData; void *cpuData; void (*cpuGetstat)(void *, double *, int[20], double[20]); } g_tab[MAX_ATTACHED];
