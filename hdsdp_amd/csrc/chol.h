@@ -1,6 +1,7 @@
 // chol.h -- device-resident blocked Cholesky object (see chol.hip)
 #pragma once
 #include "hdm_common.h"
+#include <vector>
 
 struct HdmChol {
     int n = 0, npad = 0, nblk = 0;
@@ -25,6 +26,8 @@ struct HdmChol {
     int *flow_err = nullptr;     // mapped host word: a workgroup gave up waiting
     int flow_epoch = 0;
     bool flow_ok = true, flow_pending = false;
+    int flow_cap = -1;           // co-residency bound on this object's device (workgroups), computed at the first solve
+    std::vector<double> host_stage;   // solve_host: solutions land here first (in-place solves, retry after a give-up)
 
     int init(int n);
     void destroy();

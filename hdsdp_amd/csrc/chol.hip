@@ -13,6 +13,7 @@
 #include "hdm_common.h"
 #include "chol.h"
 #include <algorithm>
+#include <cstring>
 
 #define NB 128
 
@@ -671,8 +672,8 @@ int HdmChol::enqueue_solve(double *b_dev, double *x_dev, int nrhs, long ldv, int
     // which: 0 = full solve (L L^T x = b), 1 = forward only (L x = b), 2 = backward only (L^T x = b)
     // b_dev is overwritten (workspace); vectors have npad entries (zero padded)
     const long ld = npad;
-    // co-residency bound of the single-launch substitution on this device (partitioned GPUs have far fewer CUs)
-    static int flow_cap = -1;
+    // co-residency bound of the single-launch substitution on the device this object lives on (partitioned GPUs have
+    // far fewer CUs); several engine instances sharing one device (multi-shard rehearsals) cannot rely on it at all
     if (flow_cap < 0) {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
@@ -718,9 +719,21 @@ int HdmChol::enqueue_solve(double *b_dev, double *x_dev, int nrhs, long ldv, int
     return 0;
 }
 
+// HDM_TRSV_FLOW_FAIL_ONCE=1 (tests): the first single-launch substitution of the process is treated as timed out and its
+// result is thrown away, so that the retry below is exercised
+static bool hdm_flow_fail_once() {
+    static int left = -1;
+    if (left < 0) { const char *e = getenv("HDM_TRSV_FLOW_FAIL_ONCE"); left = (e && atoi(e) != 0) ? 1 : 0; }
+    if (left == 1) { left = 0; return true; }
+    return false;
+}
+
 int HdmChol::solve_host(const double *rhs, double *sol, int nrhs, int which, hipStream_t s) {
-    // nrhs columns of length n (column-major, ld = n) on the host
+    // nrhs columns of length n (column-major, ld = n) on the host.  `sol` may be `rhs` (the reference solves in place
+    // almost everywhere, hdsdp_algo.c:452-454): a chunk's solution goes through a host staging buffer and reaches `sol`
+    // only once the launch is known to be good, so a retry always starts from the caller's intact right-hand side.
     const int chunk = 2;  // vec holds 4 * npad doubles: chunk rhs + chunk sol
+    if (host_stage.size() < (size_t) chunk * n) host_stage.resize((size_t) chunk * n);
     for (int c0 = 0; c0 < nrhs; c0 += chunk) {
         int nc = (nrhs - c0 < chunk) ? nrhs - c0 : chunk;
         double *b = vec, *x = vec + 2L * npad;
@@ -728,19 +741,22 @@ int HdmChol::solve_host(const double *rhs, double *sol, int nrhs, int which, hip
         HDM_HIP_CHECK(hipMemcpy2DAsync(b, sizeof(double) * npad, rhs + (long) c0 * n, sizeof(double) * n,
                                        sizeof(double) * n, nc, hipMemcpyHostToDevice, s));
         if (solve_device(b, x, nc, npad, which, s)) return 1;
-        HDM_HIP_CHECK(hipMemcpy2DAsync(sol + (long) c0 * n, sizeof(double) * n, x, sizeof(double) * npad,
+        HDM_HIP_CHECK(hipMemcpy2DAsync(host_stage.data(), sizeof(double) * n, x, sizeof(double) * npad,
                                        sizeof(double) * n, nc, hipMemcpyDeviceToHost, s));
         HDM_HIP_CHECK(hipStreamSynchronize(s));
-        const bool gave_up = flow_pending && flow_err && *(volatile int *) flow_err != 0;
+        bool gave_up = flow_pending && flow_err && *(volatile int *) flow_err != 0;
+        if (flow_pending && hdm_flow_fail_once()) gave_up = true;
         flow_pending = false;
         if (gave_up) {
-            // a workgroup of the single-launch substitution gave up waiting (never seen; it would mean the workgroups
-            // were not co-resident): per-block launches from now on, and this chunk again
+            // a workgroup of the single-launch substitution gave up waiting (it would mean the workgroups were not
+            // co-resident): per-block launches from now on, and this chunk again from the untouched right-hand side
             fprintf(stderr, "[hdsdp_mi355x] single-launch substitution timed out; using per-block launches\n");
             flow_ok = false;
-            *flow_err = 0;
+            if (flow_err) *flow_err = 0;
             c0 -= chunk;
+            continue;
         }
+        memcpy(sol + (long) c0 * n, host_stage.data(), sizeof(double) * (size_t) n * nc);
     }
     return 0;
 }

@@ -193,12 +193,20 @@ hdsdp_retcode lin_psdcheck(void *chol, int *colMatBeg, int *colMatIdx, double *c
 void lin_fsolve(void *chol, int nRhs, double *rhs, double *sol) {
     MiLin *l = (MiLin *) chol;
     if (l->indef) return;                        // :1741-1759, no half solves with the pivoted factor
-    l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 1, g.stream);
+    // the slot returns void (hdsdp_linsolver.h:22): a device failure can only be reported, and poisons the output so that
+    // the caller's next NaN check (e.g. HFpLinsysSolve, :2085-2110) sees it
+    if (l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 1, g.stream)) {
+        fprintf(stderr, "[hdsdp_mi355x] forward substitution failed on the device\n");
+        (sol ? sol : rhs)[0] = NAN;
+    }
 }
 void lin_bsolve(void *chol, int nRhs, double *rhs, double *sol) {
     MiLin *l = (MiLin *) chol;
     if (l->indef) return;
-    l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 2, g.stream);
+    if (l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 2, g.stream)) {
+        fprintf(stderr, "[hdsdp_mi355x] backward substitution failed on the device\n");
+        (sol ? sol : rhs)[0] = NAN;
+    }
 }
 // :1198-1225 dpotrs
 hdsdp_retcode lin_solve(void *chol, int nRhs, double *rhs, double *sol) {
@@ -276,6 +284,8 @@ struct MiCone {
     int *rows_own = nullptr;   // mloc: owned row -> global constraint
     double *S = nullptr, *Scheck = nullptr;  // n x n (ld n16) dual matrix buffers
     double *ydev = nullptr;
+    double *yhost = nullptr;   // pinned staging of the owned multipliers (the upload is asynchronous)
+    double *corr = nullptr;    // sharded corrector build: this cone's 2m dot products before they join the operator's
     hdsdp_linsys_fp *dualFactor = nullptr;
     HdmChol *primal = nullptr; // KKT_TYPE_PRIMAL: factor object of the registered primal matrix (lazy)
     HdmLanczos *lanczos = nullptr;  // ratio test state (lazy); dS lives in `dS`
@@ -474,10 +484,14 @@ int64_t cone_getsymnnz(void *cd) { MiCone *c = (MiCone *) cd; return (int64_t) c
 // S <- tau*C - sum y_i A_i - Rd*I (+ perturb)   hdsdp_conic_sdp.c:343-402, :1616-1633
 // Sharded: every rank sums its own rows (rank 0 also adds tau*C and the identity term), then all-reduce.
 int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, const double *eye_override = nullptr) {
-    std::vector<double> yo(std::max(1, c->mloc));
+    // the upload below is asynchronous: the source is a pinned buffer of the cone, and the previous upload from it has
+    // been consumed by the time it is rewritten (every caller synchronises on the factorisation that follows)
+    if (!c->yhost) HDM_HIP_CHECK(hipHostMalloc((void **) &c->yhost, sizeof(double) * (size_t) std::max(1, c->mloc), hipHostMallocDefault));
+    HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
+    double *yo = c->yhost;
     bool any = false;
     for (int q = 0; q < c->mloc; ++q) { yo[q] = y_host ? y_host[c->own[q]] : 0.0; any |= (yo[q] != 0.0); }
-    HDM_HIP_CHECK(hipMemcpyAsync(c->ydev, yo.data(), sizeof(double) * c->mloc, hipMemcpyHostToDevice, g.stream));
+    HDM_HIP_CHECK(hipMemcpyAsync(c->ydev, yo, sizeof(double) * c->mloc, hipMemcpyHostToDevice, g.stream));
     const double lead = (c->rank == 0) ? 1.0 : 0.0;
     if (hdm_sym_combine(c->Afull, (long) c->n16 * c->n16, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
                         lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)), target, c->n, c->n16, c->n16, g.stream)) return 1;
@@ -1121,12 +1135,22 @@ hdsdp_retcode corrector_components(MiCone *c, HdmChol &ch, MiKKTPriv *pv, int m)
         RC(hdm_launch_gemm(q, g.stream));
         Y = c->Yinv;
     }
-    RC(hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, pv->vecs,
-                    pv->vecs + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));   // A is stored in A_L form: <A, X> = 2 <A_L, X>
-    if (c->world > 1) {
-        HIP_RC(hipStreamSynchronize(g.stream));
-        if (!c->allreduce || c->allreduce(c->xctx, pv->vecs, (int64_t) 2 * m)) return HDSDP_RETCODE_FAILED;
+    // A is stored in A_L form: <A, X> = 2 <A_L, X>
+    if (c->world == 1) {
+        RC(hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, pv->vecs,
+                        pv->vecs + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));
+        return HDSDP_RETCODE_OK;
     }
+    // Sharded block: pv->vecs is the accumulator of the whole operator (every engine cone adds into it), so the sum
+    // over the ranks runs on this cone's own contribution only and is added afterwards; reducing pv->vecs itself would
+    // multiply what the cones before this one have put there by the number of ranks.
+    if (!c->corr) HIP_RC(hipMalloc((void **) &c->corr, sizeof(double) * 2 * (size_t) m));
+    HIP_RC(hipMemsetAsync(c->corr, 0, sizeof(double) * 2 * (size_t) m, g.stream));
+    RC(hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, c->corr,
+                    c->corr + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));
+    HIP_RC(hipStreamSynchronize(g.stream));
+    if (!c->allreduce || c->allreduce(c->xctx, c->corr, (int64_t) 2 * m)) return HDSDP_RETCODE_FAILED;
+    RC(hdm_axpy_mat(pv->vecs, pv->vecs, c->corr, 1.0, 2L * m, g.stream));
     return HDSDP_RETCODE_OK;
 }
 
@@ -1518,6 +1542,8 @@ void cone_destroy_data(void **pcd) {
     if (c->rows_seg) (void) hipFree(c->rows_seg);
     if (c->rows_own) (void) hipFree(c->rows_own);
     if (c->trA) free(c->trA);
+    if (c->yhost) (void) hipHostFree(c->yhost);
+    if (c->corr) (void) hipFree(c->corr);
     HFpLinsysDestroy(&c->dualFactor);
     if (c->primal) { c->primal->destroy(); delete c->primal; }
     if (c->lanczos) { c->lanczos->destroy(); delete c->lanczos; }

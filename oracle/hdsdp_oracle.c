@@ -884,6 +884,50 @@ void orc_synth_csc(int n, int m, int **pbeg, int **pidx, double **pval, double *
     *pbeg = beg; *pidx = idx; *pval = val; *pb = b;
 }
 void orc_free_csc(int *beg, int *idx, double *val, double *b) { free(beg); free(idx); free(val); free(b); }
+
+/* The same family WITHOUT the CSC (the int32 CSC cannot hold n = m = 2000): draw number t (0-based) of the one splitmix64
+ * stream is a pure function of t, so single matrices and the objective can be generated on their own.  Used by the
+ * full-size parity tests (tests/test_gpu_parity.py) to form host-side fp64 answers at the BASELINE sizes. */
+static double draw_at(uint64_t t) {
+    uint64_t z = 0x9E3779B97F4A7C15ULL * (t + 2);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return 2.0 * ((double) (z >> 11) / 9007199254740992.0) - 1.0;
+}
+/* constraint matrix c (0-based) as a full symmetric n x n matrix */
+void orc_synth_matrix(int n, int c, double *A) {
+    const uint64_t P = (uint64_t) n * (n + 1) / 2;
+    uint64_t t = 2 * (uint64_t) c * P;
+    for (int j = 0; j < n; ++j)
+        for (int i = j; i < n; ++i, t += 2) {
+            const double v = draw_at(t);
+            const int kp = draw_at(t + 1) >= 0.2;
+            const double a = (i == j || kp) ? v : 0.0;
+            A[(size_t) j * n + i] = a; A[(size_t) i * n + j] = a;
+        }
+}
+/* y0 (m multipliers) and the objective C = I + sum_c y0_c A_c as a full symmetric matrix; `threads` host threads */
+void orc_synth_objective(int n, int m, double *y0, double *C, int threads) {
+    const uint64_t P = (uint64_t) n * (n + 1) / 2;
+    for (int c = 0; c < m; ++c) y0[c] = draw_at(2 * (uint64_t) m * P + (uint64_t) c);
+    if (threads < 1) threads = 1;
+    /* every entry sums its m terms in constraint order starting from the identity's, exactly like orc_synth_csc, whatever
+     * the thread count: bit-reproducible */
+    #pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+    for (int j = 0; j < n; ++j) {
+        long k = PK(n, j, j);
+        for (int i = j; i < n; ++i, ++k) {
+            double acc = (i == j) ? 1.0 : 0.0;
+            for (int c = 0; c < m; ++c) {
+                const uint64_t t = 2 * ((uint64_t) c * P + (uint64_t) k);
+                const double v = draw_at(t);
+                if (i == j || draw_at(t + 1) >= 0.2) acc += y0[c] * v;
+            }
+            C[(size_t) j * n + i] = acc; C[(size_t) i * n + j] = acc;
+        }
+    }
+}
 /* ---------------------------------------------------------------------------------------------------------------
  * Ratio test: largest alpha with S + alpha dS >= 0 (sdpDenseConeRatioTestImpl hdsdp_conic_sdp.c:1640-1686,
  * operator sdpDenseConeILanczosMultiply :462-505, solver HLanczosSolve linalg/hdsdp_lanczos.c:161-292).

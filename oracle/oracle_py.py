@@ -47,6 +47,8 @@ def lib():
         L.orc_get_primal.argtypes = [vp, C.c_double, dp, dp, dp]
         L.orc_synth_csc.argtypes = [C.c_int, C.c_int, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp), C.POINTER(dp)]
         L.orc_free_csc.argtypes = [ip, ip, dp, dp]
+        L.orc_synth_matrix.argtypes = [C.c_int, C.c_int, dp]
+        L.orc_synth_objective.argtypes = [C.c_int, C.c_int, dp, dp, C.c_int]
         _lib = L
     return _lib
 
@@ -71,6 +73,21 @@ def synth_csc(n, m):
     b = np.ctypeslib.as_array(pbb, shape=(m,)).copy()
     L.orc_free_csc(pb, pi, pv, pbb)
     return beg, idx, val, b
+
+
+def synth_matrix(n, c):
+    """constraint matrix c (0-based) of the synthetic family, full symmetric; no CSC involved (any n)"""
+    A = np.empty((n, n))
+    lib().orc_synth_matrix(n, c, _d(A))
+    return A
+
+
+def synth_objective(n, m, threads=0):
+    """(y0, C) of the synthetic family, C = I + sum y0_c A_c full symmetric; streams over the m matrices"""
+    import os
+    y0, Cm = np.empty(m), np.empty((n, n))
+    lib().orc_synth_objective(n, m, _d(y0), _d(Cm), threads or min(16, os.cpu_count() or 1))
+    return y0, Cm
 
 
 class Block:

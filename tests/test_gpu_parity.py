@@ -312,6 +312,70 @@ def test_full_size_known_answers():
         cone.destroy()
 
 
+def check_full_size_state(cone, kkt, g, st, tol_scale=1.0):
+    """one state of tests/golden/full2000.npz (host BLAS-3 fp64 answers at n = m = 2000, oracle/full_size_golden.py)
+    against the engine: 16 full rows of M spread over every 128-row tile (tile edges 127|128, 1919|1920 and the ragged
+    last tile included), the whole diagonal, checksums and four dense bilinear probes over the WHOLE lower triangle,
+    both vectors, log det S, tr S^-1 and the three Phase-A solutions."""
+    from hdsdp_amd import api
+    m = int(g["m"])
+    y, Rd = np.asarray(g[st + "_y"]), float(g[st + "_Rd"])
+    cone.set_start(Rd)
+    assert cone.check_is_interior(1.0, y), st
+    ld = cone.log_barrier(1.0)
+    assert abs(ld - float(g[st + "_logdetS"])) <= 1e-12 * abs(float(g[st + "_logdetS"])) * tol_scale + 1e-9, st
+    kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+    ex = kkt.export()
+    Mc = kkt.M                                    # C-order view of the column-major matrix: lower triangle at [col, row]
+    Mf = np.triu(Mc) + np.triu(Mc, 1).T           # full symmetric
+    rows = np.asarray(g[st + "_rows"])
+    check_close(Mf[rows, :], g[st + "_M_rows"], st + " sampled rows of M")
+    check_close(np.diag(Mf), g[st + "_diag_M"], st + " diag M")
+    check_close(ex["ASinv"], g[st + "_ASinv"], st + " ASinv")
+    check_close(ex["ASinvRdSinv"], g[st + "_ASinvRdSinv"], st + " ASinvRdSinv")
+    assert abs(ex["TraceSinv"] - float(g[st + "_TraceSinv"])) <= 1e-10 * abs(float(g[st + "_TraceSinv"])), st
+    low = np.tril(Mf)
+    assert abs(np.sum(low) - float(g[st + "_sum_M_lower"])) <= 1e-10 * np.sum(np.abs(low)), st
+    assert abs(np.sum(low ** 2) - float(g[st + "_sumsq_M_lower"])) <= 1e-10 * float(g[st + "_sumsq_M_lower"]), st
+    for k in range(4):
+        rng = np.random.RandomState(20260 + k)    # oracle/full_size_golden.py: probe_vectors
+        u, v = rng.uniform(-1.0, 1.0, m), rng.uniform(-1.0, 1.0, m)
+        got = float(u @ Mf @ v)
+        assert abs(got - float(g[st + "_probes"][k])) <= 1e-10 * float(np.abs(u) @ np.abs(Mf) @ np.abs(v)), (st, k)
+    kkt.factorize()
+    sols = [kkt.solve(np.asarray(g[st + "_b"])), kkt.solve(ex["ASinv"]), kkt.solve(ex["ASinvRdSinv"])]
+    for x, name in zip(sols, ("d1", "d2", "d3")):
+        ref = np.asarray(g[st + "_" + name])
+        assert np.linalg.norm(x - ref) <= 1e-8 * np.linalg.norm(ref), (st, name)
+    return {"sum_d2": float(np.sum(sols[1])), "sum_d1w": float(np.dot(np.arange(1, m + 1), sols[0]))}
+
+
+def test_full_size_against_host_fp64_at_nontrivial_states():
+    """BASELINE configs[3], n = m = 2000, at two states whose dual matrix is NOT a multiple of the identity: the state
+    bench.py times (y = 0, Rd = -10 n: S = C + 20000 I with the dense objective C) and a harder one (non-zero y, Rd just
+    below the smallest eigenvalue of C - sum y_i A_i: cond(S) ~ 1e3).  The expected values are an independent host
+    computation in fp64 (tests/golden/full2000.npz, generated by oracle/full_size_golden.py from the oracle's restatement
+    of the SURVEY 8(d) generator: level-3 BLAS congruence + Gram, 15 min on 8 cores); tolerances are the tests/util.py
+    bars.  Also pins bench.py's `checksum` (sum_d2, sum_d1w at the bench state) to that independent value."""
+    from hdsdp_amd import api
+    g = load_golden("full2000")
+    n, m = int(g["n"]), int(g["m"])
+    cone = api.SDPCone.synthetic(n, m)
+    try:
+        kkt = api.KKT(m, [cone])
+        b = cone.traces()
+        assert np.max(np.abs(b - g["bench_b"])) <= 1e-12 * np.max(np.abs(b))
+        cs = check_full_size_state(cone, kkt, g, "bench")
+        # bench.py prints these two numbers as its `checksum`; BENCH_r01.json carried sum_d2 = -0.7590183915452648
+        assert abs(cs["sum_d2"] - float(g["bench_sum_d2"])) <= 1e-9 * abs(float(g["bench_sum_d2"]))
+        assert abs(cs["sum_d1w"] - float(g["bench_sum_d1w"])) <= 1e-9 * abs(float(g["bench_sum_d1w"]))
+        assert abs(float(g["bench_sum_d2"]) - (-0.7590183915452648)) <= 1e-9
+        check_full_size_state(cone, kkt, g, "hard")
+        kkt.destroy()
+    finally:
+        cone.destroy()
+
+
 def test_ratio_test_bracket_at_full_dimension():
     """n = 2000 (the BASELINE dimension; too large for a reference dump in the golden set): the Lanczos step must
     bracket the cone boundary -- S + 0.99*step*dS is still positive definite, S + 1.05*step*dS is not -- which is

@@ -41,9 +41,10 @@ CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None), "mcp100": (-226.15735
          "syn30x100": (-2.76541492, None),
          # tools/blocks_sdpa.py: three SDP blocks (the reference makes two dense SDP cones -- attached to the engine -- and
          # one sparse SDP cone, which stays on the CPU), without and with an LP block (a CPU LP cone): engine and CPU cones
-         # of three kinds in one Schur operator.  Engine-cone mode only: with its own CPU cones the reference aborts
-         # in its final solution check on the first instance (HDSDPCheckSolution hands dsyevr a 2-element eigenvalue
-         # array, interface/hdsdp.c:811; whether MKL overruns it depends on the last digits of the iterate).
+         # of three kinds in one Schur operator.  Both modes: the abort round 1 saw in the CPU-cone mode was the
+         # reference's own final solution check overrunning a 2-element eigenvalue array (interface/hdsdp.c:811 ->
+         # dsyevr); the harness now hands that call an array of the size LAPACK documents (oracle/syev_guard.c, which
+         # also reports on stderr whenever dsyevr writes past the reference's two entries), so nothing is skipped.
          "blocks": (9.4410357041, None), "blockslp": (10.616269973, None)}
 
 
@@ -55,8 +56,6 @@ def test_reference_driver_runs_on_the_engine(inst, attach, tmp_path):
     opt, ref_iters = CASES[inst]
     fname = os.path.join(ROOT, "tests", "golden", inst + ".dat-s")
     if inst.startswith("blocks"):
-        if attach == "0":
-            pytest.skip("see CASES: the reference's own solution check is fragile on this instance")
         import sys
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from blocks_sdpa import write_blocks_sdpa
@@ -74,10 +73,9 @@ def test_reference_driver_runs_on_the_engine(inst, attach, tmp_path):
     r = subprocess.run([EXE, fname], capture_output=True, text=True,
                        timeout=600, env=dict(os.environ, HDSDP_DROP_ATTACH=attach))
     out = r.stdout + r.stderr
-    if r.returncode != 0 and "HDSDPCheckSolution" in out and "backtrace" in out:
-        # the harness prints a backtrace on a fatal signal: an abort on return from the reference's final solution check
-        # is the reference's own defect (a 2-element eigenvalue array handed to dsyevr, interface/hdsdp.c:811), not a result
-        pytest.skip("the reference's own HDSDPCheckSolution aborted after the solve (known defect of the reference)")
+    for line in out.splitlines():
+        if "OVERRUN" in line:
+            print(line)     # informational: dsyevr used more of W than the reference's caller provides
     assert r.returncode == 0, out[-3000:]
     assert ("attached to the MI355X engine" in out) == (attach == "1")
     assert "SDP Status: Primal dual optimal" in out, out[-3000:]

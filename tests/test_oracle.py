@@ -172,3 +172,57 @@ def test_oracle_indefinite_schur_fallback_matches_reference(name):
     P = A @ A.T / M.shape[0] + np.eye(M.shape[0])
     xp, lin_type = oracle_py.schur_solve(np.triu(P), b, lin_type=5)
     assert lin_type == 5 and np.linalg.norm(P @ xp - b) <= 1e-9 * np.linalg.norm(b)
+
+
+def test_streamed_generator_is_the_csc_generator():
+    """orc_synth_matrix / orc_synth_objective (no CSC: they serve the sizes the int32 CSC cannot hold) are bit-equal to
+    orc_synth_csc where both exist -- which in turn is pinned to the compiled reference by the syn* goldens"""
+    n, m = 37, 23
+    beg, idx, val, b = oracle_py.synth_csc(n, m)
+    P = n * (n + 1) // 2
+
+    def unpack(col):
+        pk = np.zeros(P)
+        pk[idx[beg[col]:beg[col + 1]]] = val[beg[col]:beg[col + 1]]
+        A = np.zeros((n, n))
+        k = 0
+        for j in range(n):
+            for i in range(j, n):
+                A[i, j] = A[j, i] = pk[k]
+                k += 1
+        return A
+
+    y0, Cm = oracle_py.synth_objective(n, m, threads=3)
+    assert np.array_equal(Cm, unpack(0))
+    for c in (0, 7, m - 1):
+        A = oracle_py.synth_matrix(n, c)
+        assert np.array_equal(A, unpack(c + 1))
+        assert abs(np.trace(A) - b[c]) < 1e-13
+
+
+def test_full_size_golden_is_what_the_generator_and_fp64_blas_say():
+    """tests/golden/full2000.npz (n = m = 2000, made by oracle/full_size_golden.py) spot-checked on the CPU: the objective
+    is regenerated, S^-1 formed, and a handful of entries of M, ASinv and ASinvRdSinv recomputed from the definition
+    M_ij = tr(A_i S^-1 A_j S^-1) -- a different formula from the congruence + Gram form the fixture was built with"""
+    g = load_golden("full2000")
+    n, m = int(g["n"]), int(g["m"])
+    y0, Cm = oracle_py.synth_objective(n, m)
+    rows = [int(r) for r in g["bench_rows"]]
+    for st, pick in (("bench", (0, 5, 15)), ("hard", (3, 12))):
+        y, Rd = np.asarray(g[st + "_y"]), float(g[st + "_Rd"])
+        S = Cm - Rd * np.eye(n)
+        if np.any(y != 0.0):
+            for i in range(m):
+                S -= y[i] * oracle_py.synth_matrix(n, i)
+        Sinv = np.linalg.inv(S)
+        Sinv = 0.5 * (Sinv + Sinv.T)
+        for q in pick:
+            i = rows[q]
+            Ai = oracle_py.synth_matrix(n, i)
+            B = Sinv @ Ai @ Sinv
+            assert abs(np.sum(Ai * Sinv) - g[st + "_ASinv"][i]) <= 1e-9 * np.max(np.abs(g[st + "_ASinv"]))
+            assert abs(Rd * np.trace(B) - g[st + "_ASinvRdSinv"][i]) <= 1e-9 * np.max(np.abs(g[st + "_ASinvRdSinv"]))
+            for j in (0, 128, 1023, 1999):
+                ref = float(np.sum(oracle_py.synth_matrix(n, j) * B))
+                assert abs(ref - g[st + "_M_rows"][q, j]) <= 1e-9 * np.max(np.abs(g[st + "_diag_M"])), (st, i, j)
+            assert abs(g[st + "_M_rows"][q, i] - g[st + "_diag_M"][i]) == 0.0
