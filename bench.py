@@ -28,15 +28,29 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X vendor figure for dense fp64 matrix; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 
 
-# HBM bytes per launch of the hot kernels from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 for
-# the gfx950 wide-read correction + WRITE_SIZE, separate --pmc runs, n=m=2000): filled in by hand from the summaries,
-# bench.py cannot run the profiler on itself.  None = not measured for the current kernel generation.
-TRAFFIC_BYTES_PER_LAUNCH = {  # profiles/r01_h_summary_pmc_{FETCH,WRITE}_SIZE.txt (counters are in KiB; mean over the launches;
-                             # re-measured with the same values in r01_i and r01_j)
-    1: (2 * 7.525e7 + 1.566e7) * 1024,   # congruence step 1, 1000 constraints per launch: 170 GB
-    2: (2 * 1.418e8 + 1.575e7) * 1024,   # congruence step 2, 1000 constraints per launch: 307 GB
-    3: (2 * 1.824e8 + 1.641e7) * 1024,   # Gram, whole matrix, 1024 K splits:            390 GB
-}
+# HBM bytes per launch of the hot kernels come from the newest profiles/*_traffic.json (tools/gpu_profile.sh: separate
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, condensed by tools/prof_summary.py --traffic;
+# FETCH_SIZE x 2 for the gfx950 wide-read correction + WRITE_SIZE, KiB).  bench.py cannot run the profiler on itself, so
+# the file is matched on the kernel's NAME (role and variant are template arguments): a kernel that was renamed or
+# re-templated since the profile was taken yields `traffic: null` instead of a stale number.
+KERNEL_SYMBOL = {1: "hdm_gemm_kernel<false, true, 1, 64>", 2: "hdm_gemm_kernel<false, false, 2, 64>",
+                 3: "hdm_gemm_kernel<true, true, 3, 64>"}
+
+
+def traffic_bytes_per_launch(role):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files or os.environ.get("HDM_VAR"):
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            ks = json.load(f)["kernels"]
+    except Exception:
+        return None, None
+    hits = [v for k, v in ks.items() if KERNEL_SYMBOL[role].replace(" ", "") in k.replace(" ", "")]
+    if len(hits) != 1:
+        return None, os.path.basename(files[-1])
+    return hits[0]["bytes_per_launch"], os.path.basename(files[-1])
 
 
 def survey_flops(n, m):
@@ -212,7 +226,9 @@ def main():
     roofline = {
         "bound": "mfma", "kernel": names[dom],
         "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom) if (n, m, world) == (2000, 2000, 1) else None,
+        "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+        "traffic": traffic_bytes_per_launch(dom)[0] if (n, m, world) == (2000, 2000, 1) else None,
+        "traffic_source": traffic_bytes_per_launch(dom)[1] if (n, m, world) == (2000, 2000, 1) else None,
         "avg_launch_ms": round(float(dom_ms), 4), "launches": int(kln[dom]),
         "flops_per_launch": float(kfl[dom] / max(1, kln[dom])),
         # the same launch priced with SURVEY 8(d)'s per-unit figure (the reference's M3 count: 3 n^3 per constraint

@@ -36,6 +36,7 @@ EXPORTS = [
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
     "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
+    "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
     "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
@@ -152,6 +153,12 @@ def load_library():
         "HMiConeGetExchangeBuffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]),
         "HMiConeSetExchangeBuffers": (C.c_int, [vp, vp, vp]),
         "HMiKKTDeviceMatrix": (vp, [kp, C.POINTER(C.c_int64)]),
+        "HMiSetDevices": (C.c_int, [C.c_int, ip]),
+        "HMiGetDeviceGroup": (C.c_int, [ip, C.c_int, ip]),
+        "HMiSetShardMinDim": (None, [C.c_int]),
+        "HMiConeGetShardCount": (C.c_int, [vp]),
+        "HMiConeGetGroupTraffic": (None, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+        "HMiRcclSelfTest": (C.c_int, [C.c_int]),
         "HMiDeviceInit": (C.c_int, [C.c_int]),
         "HMiDeviceSynchronize": (C.c_int, []),
         "HMiStream": (vp, []),
@@ -177,6 +184,25 @@ def load_library():
         fn.restype, fn.argtypes = sig[name]
     _lib = lib
     return lib
+
+
+def set_devices(ids, shard_min_dim=None):
+    """single-process multi-device mode (include/hdsdp_mi355x.h: HMiSetDevices): cones created afterwards with rank 0 of
+    world 1 are sharded over `ids` (repeated ids = shards sharing a device, exchanged by device copies)"""
+    lib = load_library()
+    arr = (C.c_int * len(ids))(*ids)
+    if lib.HMiSetDevices(len(ids), arr) != 0:
+        raise HDSDPError("HMiSetDevices failed")
+    if shard_min_dim is not None:
+        lib.HMiSetShardMinDim(int(shard_min_dim))
+
+
+def device_group():
+    lib = load_library()
+    ids = (C.c_int * 16)()
+    tr = C.c_int(-1)
+    n = lib.HMiGetDeviceGroup(ids, 16, C.byref(tr))
+    return list(ids[:n]), tr.value
 
 
 def _check(rc, what):
@@ -355,6 +381,14 @@ class SDPCone:
         assert XSX.flags.c_contiguous and XSX.dtype == np.float64
         load_library().HMiConeBuildPrimalXSXDirection(self._h, _dptr(X), _dptr(XSX), 1 if dual_matrix else 0)
         return XSX
+
+    def shard_count(self):
+        return int(load_library().HMiConeGetShardCount(self._h))
+
+    def group_traffic(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        load_library().HMiConeGetGroupTraffic(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def exchange_stats(self):
         """(pieces of the last build's all-to-all, launches the staged second congruence step was cut into)"""

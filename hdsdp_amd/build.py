@@ -14,7 +14,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libhdsdp_mi355x.so")
 SOURCES = ["gemm_f64.hip", "chol.hip", "schur.hip", "lanczos.hip", "lu.hip", "engine.hip", "coeff.cpp", "sdpa.cpp"]
-HEADERS = ["hdm_common.h", "chol.h", "schur.h", "lanczos.h", "lu.h", "coeff.h", os.path.join(ROOT, "include", "hdsdp_mi355x.h")]
+HEADERS = ["hdm_common.h", "chol.h", "schur.h", "lanczos.h", "lu.h", "coeff.h", "group_impl.h", os.path.join(ROOT, "include", "hdsdp_mi355x.h")]
 
 
 def _stale(target, deps):
@@ -46,7 +46,9 @@ def build_library(force=False, verbose=True):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    # RCCL (the in-process device group's transport, csrc/group_impl.h) is linked, not dlopen'ed: the library's collectives
+    # are part of the product, and a missing librccl should fail at load time, not in the middle of a solve
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

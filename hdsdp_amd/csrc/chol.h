@@ -44,3 +44,6 @@ struct HdmChol {
     int solve_host(const double *rhs, double *sol, int nrhs, int which, hipStream_t s);
     int inverse_full(double *out_dev, long ldo, hipStream_t s);
 };
+
+// several engine shards share this device: the single-launch substitution (which needs co-resident workgroups) is off
+void hdm_flow_set_shared_device(int on);

@@ -13,6 +13,7 @@
 #include "hdm_common.h"
 #include "chol.h"
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 
 #define NB 128
@@ -639,11 +640,15 @@ int HdmChol::get_diag(double *diag_host, hipStream_t s) {
     return 0;
 }
 
-// HDM_TRSV_FLOW=0: always the per-block launches
+// HDM_TRSV_FLOW=0: always the per-block launches.  Also off while several engine shards share one device (a multi-shard
+// rehearsal on one GPU, group_impl.h): the single-launch substitution spins on flags and needs all its workgroups
+// co-resident, which nobody can promise when other streams of the same process compete for the CUs.
+static std::atomic<int> g_flow_shared_device{0};
+void hdm_flow_set_shared_device(int on) { g_flow_shared_device.store(on); }
 static bool hdm_flow_enabled() {
     static int on = -1;
     if (on < 0) { const char *e = getenv("HDM_TRSV_FLOW"); on = (e && atoi(e) == 0) ? 0 : 1; }
-    return on == 1;
+    return on == 1 && g_flow_shared_device.load() == 0;
 }
 
 int HdmChol::solve_device(double *b_dev, double *x_dev, int nrhs, long ldv, int which, hipStream_t s) {

@@ -20,9 +20,15 @@
 #include "lanczos.h"
 #include "lu.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
+#include <rccl/rccl.h>
 
 // kernels defined further down in this file (global scope)
 __global__ void mi_low_norms_kernel(const double *__restrict__ A, long astride, int n, long ld, int count, int a_l_form,
@@ -42,7 +48,25 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8];
     double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-} g;
+};
+// One context (device + stream + events) per host thread that drives a device: the caller's thread owns g_main; in the
+// single-process multi-device mode (group_impl.h) every shard has a worker thread whose t_ctx points at the shard's own
+// context, and all the code below reaches "its" stream through `g`.
+Ctx g_main;
+thread_local Ctx *t_ctx = nullptr;
+inline Ctx &cur_ctx() { return t_ctx ? *t_ctx : g_main; }
+#define g cur_ctx()
+
+int g_main_device_request = -1;   // HMiSetDevices / HDSDP_MI355X_GPUS: device of the caller's context (= shard 0's)
+
+int ctx_open(Ctx &c, int dev) {
+    HDM_HIP_CHECK(hipSetDevice(dev));
+    c.device = dev;
+    HDM_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i) HDM_HIP_CHECK(hipEventCreate(&c.ev[i]));
+    c.init = true;
+    return 0;
+}
 
 int ensure_ctx() {
     if (g.init) return 0;
@@ -54,12 +78,8 @@ int ensure_ctx() {
         return 1;
     }
     if (lr) dev = atoi(lr) % ndev;
-    HDM_HIP_CHECK(hipSetDevice(dev));
-    g.device = dev;
-    HDM_HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    for (int i = 0; i < 8; ++i) HDM_HIP_CHECK(hipEventCreate(&g.ev[i]));
-    g.init = true;
-    return 0;
+    if (g_main_device_request >= 0) dev = g_main_device_request % ndev;
+    return ctx_open(g, dev);
 }
 
 #define HIP_RC(expr)                                                                             \
@@ -319,6 +339,9 @@ struct MiCone {
     hmi_allreduce_fn allreduce = nullptr;
     void *xctx = nullptr;
     bool work_ready = false;
+    // single-process multi-device mode: the shards of one block share ONE Schur operator (the caller's); only shard 0
+    // writes into it, the others stop after the all-reduce
+    bool kkt_owner = true;
 };
 
 struct MiKKTPriv {
@@ -352,6 +375,14 @@ void priv_drop(hdsdp_kkt *k) {
             return;
         }
 }
+
+// single-process multi-device mode (group_impl.h): a group cone's slots fan out to one MiCone per device
+hdsdp_retcode gc_build_schur(void *cd, int iCone, void *kktv, int typeKKT);
+MiCone *cone_data(hdsdp_cone *cone);   // the block's device data; for a group cone that of shard 0
+int group_configure_from_env();
+bool group_wants_block(int nRow, int nCol, const int *beg, const int *idx, const double *val);
+hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *beg, const int *idx,
+                                const double *val, bool synthetic);
 
 int cone_alloc_common(MiCone *c) {
     c->n16 = (int) hdm_roundup(c->n, 16);
@@ -1150,7 +1181,8 @@ hdsdp_retcode corrector_components(MiCone *c, HdmChol &ch, MiKKTPriv *pv, int m)
                     c->corr + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));
     HIP_RC(hipStreamSynchronize(g.stream));
     if (!c->allreduce || c->allreduce(c->xctx, c->corr, (int64_t) 2 * m)) return HDSDP_RETCODE_FAILED;
-    RC(hdm_axpy_mat(pv->vecs, pv->vecs, c->corr, 1.0, 2L * m, g.stream));
+    if (c->kkt_owner) RC(hdm_axpy_mat(pv->vecs, pv->vecs, c->corr, 1.0, 2L * m, g.stream));
+    HIP_RC(hipStreamSynchronize(g.stream));
     return HDSDP_RETCODE_OK;
 }
 
@@ -1217,8 +1249,9 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     double *Mdev = kkt_Mdev(kkt, &ldm);
     const int hsd = (typeKKT == KKT_TYPE_HOMOGENEOUS);
     const long pI = (c->world == 1) ? c->mloc : (c->m + c->world - 1) / c->world;  // rows owned by rank 0 = position of the "I row"
-    RC(hdm_extract(c->Gm, c->R, c->R, pI, c->rows_seg, Mdev, ldm, pv->vecs, pv->vecs + m, pv->vecs + 2 * m,
-                   pv->vecs + 3 * m, c->Rd, hsd, g.stream));
+    if (c->kkt_owner)
+        RC(hdm_extract(c->Gm, c->R, c->R, pI, c->rows_seg, Mdev, ldm, pv->vecs, pv->vecs + m, pv->vecs + 2 * m,
+                       pv->vecs + 3 * m, c->Rd, hsd, g.stream));
     HIP_RC(hipEventRecord(g.ev[4], g.stream));
     HIP_RC(hipEventSynchronize(g.ev[4]));
     float ms = 0;
@@ -1772,7 +1805,7 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
     if (hipMalloc((void **) &pv->vecs, sizeof(double) * (3 * (size_t) nRow + 4)) != hipSuccess) return HDSDP_RETCODE_MEMORY;
     pv->n_engine = pv->n_foreign = 0;
     for (int i = 0; i < nCones; ++i) {
-        if (cones[i]->coneBuildSchur == cone_build_schur) pv->n_engine += 1;
+        if (cones[i]->coneBuildSchur == cone_build_schur || cones[i]->coneBuildSchur == gc_build_schur) pv->n_engine += 1;
         else pv->n_foreign += 1;
     }
     HKKT->dPrimalX = nullptr;
@@ -1972,30 +2005,30 @@ void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM) {
     pv->mirror = mirrorM;
 }
 void HMiConeSetExchangePieces(hdsdp_cone *cone, hmi_alltoall_piece_fn start, hmi_alltoall_wait_fn wait, int npieces) {
-    MiCone *c = (MiCone *) cone->coneData;
+    MiCone *c = cone_data(cone);
     c->a2a_start = start; c->a2a_wait = wait; c->a2a_pieces = std::max(1, npieces);
 }
 void HMiConeBuildPrimalXSXDirection(hdsdp_cone *cone, double *dPrimalScalMatrix, double *dPrimalXSXBuffer, int iDualMat) {
     cone->coneBuildPrimalDirection(cone->coneData, nullptr, dPrimalScalMatrix, dPrimalXSXBuffer, iDualMat);
 }
 void HMiConeGetExchangeStats(hdsdp_cone *cone, int *pieces, int *stagedLaunches) {
-    MiCone *c = (MiCone *) cone->coneData;
+    MiCone *c = cone_data(cone);
     if (pieces) *pieces = c->last_pieces;
     if (stagedLaunches) *stagedLaunches = c->last_staged;
 }
 void HMiConeSetExchange(hdsdp_cone *cone, hmi_alltoall_fn a2a, hmi_allreduce_fn ar, void *ctx) {
-    MiCone *c = (MiCone *) cone->coneData;
+    MiCone *c = cone_data(cone);
     c->alltoall = a2a; c->allreduce = ar; c->xctx = ctx;
 }
 hdsdp_retcode HMiConeGetExchangeBuffers(hdsdp_cone *cone, void **sendBuf, void **recvBuf, int64_t *chunkCount) {
-    MiCone *c = (MiCone *) cone->coneData;
+    MiCone *c = cone_data(cone);
     if (chunkCount) *chunkCount = (int64_t) c->npb_loc * c->Lr * 16;
     if (sendBuf) *sendBuf = c->AhatLoc;
     if (recvBuf) *recvBuf = c->AhatAll;
     return HDSDP_RETCODE_OK;
 }
 hdsdp_retcode HMiConeSetExchangeBuffers(hdsdp_cone *cone, void *sendBuf, void *recvBuf) {
-    MiCone *c = (MiCone *) cone->coneData;
+    MiCone *c = cone_data(cone);
     if (c->work_ready || !sendBuf || !recvBuf) return HDSDP_RETCODE_FAILED;
     c->AhatLoc = (double *) sendBuf;
     c->AhatAll = (c->world == 1) ? c->AhatLoc : (double *) recvBuf;
@@ -2012,6 +2045,25 @@ void *HMiKKTDeviceMatrix(hdsdp_kkt *HKKT, int64_t *ld) {
     return p;
 }
 
+}  // extern "C"
+
+// device group, copy transport: out[i] = sum over the shards (in shard order) of p[q][lo + i]
+struct MiGrpPtrs { const double *p[16]; };
+__global__ void mi_grp_sum_kernel(MiGrpPtrs pl, int W, long lo, long cnt, double *__restrict__ out) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    double s = 0.0;
+    for (int q = 0; q < W; ++q) s += pl.p[q][lo + i];
+    out[i] = s;
+}
+
+namespace {
+int grp_sum_launch(const double *const *ptrs, int W, long lo, long cnt, double *out, hipStream_t s) {
+    MiGrpPtrs pl = {};
+    for (int q = 0; q < W && q < 16; ++q) pl.p[q] = ptrs[q];
+    hipLaunchKernelGGL(mi_grp_sum_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, s, pl, W, lo, cnt, out);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 // ---------------------------------------------------------------- cone construction
 static int upload_dense_rows(MiCone *c) {
     // densify every owned constraint into a full symmetric n16 x n16 matrix (via packed staging)
@@ -2046,9 +2098,34 @@ static int upload_dense_rows(MiCone *c) {
     return 0;
 }
 
-hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *coneMatBeg,
-                               const int *coneMatIdx, const double *coneMatElem, int rank, int world) {
-    if (!pCone || nRow < 1 || nCol < 1 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
+// device path a block takes by itself: the rank-one fast path iff every non-zero constraint is rank one (the reference's
+// all-M2 plans), the sparse gather path iff all rows are short triplet lists, else congruence + Gram; sharded blocks
+// (world > 1) always take the latter
+static int natural_path(const MiBlockData &blk, int nRow, int nCol, int world) {
+    int nz = 0, r1 = 0;
+    for (int i = 0; i < nRow; ++i) {
+        int t = blk.rows[i].type;
+        if (t != MI_COEFF_ZERO) nz++;
+        if (t == MI_COEFF_SPR1 || t == MI_COEFF_DSR1) r1++;
+    }
+    int path = (nz > 0 && r1 == nz && world == 1) ? PATH_R1 : PATH_GEMM;
+    if (path == PATH_GEMM && world == 1 && nz > 0) {
+        // sparse gather path: only triplet-class rows, and the pair products are far cheaper than m congruences
+        bool all_sparse = true;
+        double tot = 0.0;
+        for (int i = 0; i < nRow; ++i) {
+            int t = blk.rows[i].type;
+            if (t == MI_COEFF_DENSE || t == MI_COEFF_DSR1) all_sparse = false;
+            tot += (double) blk.rows[i].idx.size();
+        }
+        if (all_sparse && tot * tot < 0.05 * (double) nRow * nCol * (double) nCol * nCol) path = PATH_SPARSE;
+    }
+    return path;
+}
+
+// the device data of one SDP block for rank `rank` of `world` on the calling thread's context
+static hdsdp_retcode make_sdp_cone(MiCone **out, int nRow, int nCol, const int *coneMatBeg, const int *coneMatIdx,
+                                   const double *coneMatElem, int rank, int world) {
     if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
     MiCone *c = new MiCone();
     c->n = nCol; c->m = nRow; c->rank = rank; c->world = world;
@@ -2063,25 +2140,7 @@ hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol
             if (j < nCol && d == co.idx[e]) c->trA[i] += co.val[e];
         }
     }
-    // device path: rank-one fast path iff every non-zero constraint is rank one (reference: all-M2 plans)
-    int nz = 0, r1 = 0;
-    for (int i = 0; i < nRow; ++i) {
-        int t = c->blk.rows[i].type;
-        if (t != MI_COEFF_ZERO) nz++;
-        if (t == MI_COEFF_SPR1 || t == MI_COEFF_DSR1) r1++;
-    }
-    c->path = (nz > 0 && r1 == nz && world == 1) ? PATH_R1 : PATH_GEMM;
-    if (c->path == PATH_GEMM && world == 1 && nz > 0) {
-        // sparse gather path: only triplet-class rows, and the pair products are far cheaper than m congruences
-        bool all_sparse = true;
-        double tot = 0.0;
-        for (int i = 0; i < nRow; ++i) {
-            int t = c->blk.rows[i].type;
-            if (t == MI_COEFF_DENSE || t == MI_COEFF_DSR1) all_sparse = false;
-            tot += (double) c->blk.rows[i].idx.size();
-        }
-        if (all_sparse && tot * tot < 0.05 * (double) nRow * nCol * (double) nCol * nCol) c->path = PATH_SPARSE;
-    }
+    c->path = natural_path(c->blk, nRow, nCol, world);
     const char *force = getenv("HDSDP_MI355X_FORCE_GEMM");
     if (force && atoi(force)) c->path = PATH_GEMM;
     const char *forcesp = getenv("HDSDP_MI355X_FORCE_PATH");
@@ -2138,12 +2197,11 @@ hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol
             return HDSDP_RETCODE_FAILED;
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    *pCone = new_cone_shell(c, iCone);
+    *out = c;
     return HDSDP_RETCODE_OK;
 }
 
-hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, int nRow, int rank, int world) {
-    if (!pCone || nRow < 1 || nCol < 1 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
+static hdsdp_retcode make_synth_cone(MiCone **out, int nCol, int nRow, int rank, int world) {
     if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
     MiCone *c = new MiCone();
     c->n = nCol; c->m = nRow; c->rank = rank; c->world = world; c->synthetic = true; c->path = PATH_GEMM;
@@ -2175,6 +2233,41 @@ hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, in
         c->trA[i] = tr;
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    *out = c;
+    return HDSDP_RETCODE_OK;
+}
+
+// single-process multi-device mode: device groups, worker threads, the two transports (device copies / RCCL) and the
+// group cone whose slots fan out to the shards
+#include "group_impl.h"
+
+}  // namespace
+
+extern "C" {
+
+hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *coneMatBeg,
+                               const int *coneMatIdx, const double *coneMatElem, int rank, int world) {
+    if (!pCone || nRow < 1 || nCol < 1 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
+    if (group_configure_from_env()) return HDSDP_RETCODE_FAILED;
+    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
+    if (rank == 0 && world == 1 && group_wants_block(nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem))
+        return group_create_cone(pCone, iCone, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem, false);
+    MiCone *c = nullptr;
+    hdsdp_retcode rc = make_sdp_cone(&c, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem, rank, world);
+    if (rc != HDSDP_RETCODE_OK) return rc;
+    *pCone = new_cone_shell(c, iCone);
+    return HDSDP_RETCODE_OK;
+}
+
+hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, int nRow, int rank, int world) {
+    if (!pCone || nRow < 1 || nCol < 1 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
+    if (group_configure_from_env()) return HDSDP_RETCODE_FAILED;
+    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
+    if (rank == 0 && world == 1 && group_wants_block(nRow, nCol, nullptr, nullptr, nullptr))
+        return group_create_cone(pCone, iCone, nRow, nCol, nullptr, nullptr, nullptr, true);
+    MiCone *c = nullptr;
+    hdsdp_retcode rc = make_synth_cone(&c, nCol, nRow, rank, world);
+    if (rc != HDSDP_RETCODE_OK) return rc;
     *pCone = new_cone_shell(c, iCone);
     return HDSDP_RETCODE_OK;
 }
@@ -2224,7 +2317,7 @@ void HMiConeGetPrimal(hdsdp_cone *cone, double dBarrierMu, double *dRowDual, dou
 }
 void HMiConeGetPresolve(hdsdp_cone *cone, int *coefType, int *coefRank, int *coefNnz, int *kktPerm, int *kktStrategy,
                         int *objType) {
-    MiCone *c = (MiCone *) cone->coneData;
+    MiCone *c = cone_data(cone);
     for (int i = 0; i < c->m && !c->synthetic; ++i) {
         if (coefType) coefType[i] = c->blk.rows[i].type;
         if (coefRank) coefRank[i] = c->blk.rows[i].rank;
@@ -2251,18 +2344,47 @@ hdsdp_retcode HMiPresolveCSC(int nRow, int nCol, const int *coneMatBeg, const in
     return HDSDP_RETCODE_OK;
 }
 hdsdp_retcode HMiConeGetDualMatrix(hdsdp_cone *cone, double *S) {
-    MiCone *c = (MiCone *) cone->coneData;
+    MiCone *c = cone_data(cone);
     if (hipMemcpy2DAsync(S, sizeof(double) * c->n, c->S, sizeof(double) * c->n16, sizeof(double) * c->n, c->n,
                          hipMemcpyDeviceToHost, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
     return hipStreamSynchronize(g.stream) == hipSuccess ? HDSDP_RETCODE_OK : HDSDP_RETCODE_FAILED;
 }
 hdsdp_retcode HMiConeGetTraces(hdsdp_cone *cone, double *trA) {
-    MiCone *c = (MiCone *) cone->coneData;
+    MiCone *c = cone_data(cone);
     if (!c->trA) return HDSDP_RETCODE_FAILED;
     memcpy(trA, c->trA, sizeof(double) * c->m);
     return HDSDP_RETCODE_OK;
 }
-int HMiConeGetPath(hdsdp_cone *cone) { return ((MiCone *) cone->coneData)->path; }
+int HMiConeGetPath(hdsdp_cone *cone) { return cone_data(cone)->path; }
+
+// ---------------------------------------------------------------- single-process multi-device mode (group_impl.h)
+int HMiSetDevices(int nDevices, const int *deviceIds) {
+    if (nDevices < 1 || !deviceIds) return 1;
+    g_group_env_done = true;     // an explicit call overrides HDSDP_MI355X_GPUS
+    int tr = -1;
+    if (const char *t = getenv("HDSDP_MI355X_TRANSPORT")) tr = (strcmp(t, "rccl") == 0) ? GRP_RCCL : GRP_COPIES;
+    return group_setup(nDevices, deviceIds, tr);
+}
+int HMiGetDeviceGroup(int *deviceIds, int maxIds, int *transport) {
+    if (!g_group) { if (transport) *transport = -1; if (deviceIds && maxIds > 0 && g_main.init) deviceIds[0] = g_main.device; return g_main.init ? 1 : 0; }
+    for (int r = 0; r < g_group->W && r < maxIds; ++r) if (deviceIds) deviceIds[r] = g_group->dev[r];
+    if (transport) *transport = g_group->transport;
+    return g_group->W;
+}
+void HMiSetShardMinDim(int nMin) { if (g_group) g_group->min_n = nMin; }
+int HMiConeGetShardCount(hdsdp_cone *cone) {
+    return (cone && cone->coneBuildSchur == gc_build_schur) ? ((MiConeGroup *) cone->coneData)->G->W : 1;
+}
+void HMiConeGetGroupTraffic(hdsdp_cone *cone, int64_t *bytesAllToAll, int64_t *bytesAllReduce) {
+    int64_t a = 0, b = 0;
+    if (cone && cone->coneBuildSchur == gc_build_schur) { MiConeGroup *cg = (MiConeGroup *) cone->coneData; a = cg->bytes_a2a; b = cg->bytes_ar; }
+    if (bytesAllToAll) *bytesAllToAll = a;
+    if (bytesAllReduce) *bytesAllReduce = b;
+}
+int HMiRcclSelfTest(int device) {
+    if (ensure_ctx()) return 1;
+    return rccl_self_test(device < 0 ? g_main.device : device);
+}
 
 // ---------------------------------------------------------------- raw kernels for tests
 int HMiGemmNT(const double *A, int64_t lda, int aKMajor, const double *B, int64_t ldb, int bKMajor, double *C,

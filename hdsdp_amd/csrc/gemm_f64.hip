@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
 namespace {
 struct TimedLaunch { hipEvent_t e0, e1; int role; double flops; };
 bool g_timing = false;
-bool g_capturing = false;
+thread_local bool g_capturing = false;   // per host thread: each shard of a device group captures its own chains
 std::vector<TimedLaunch> g_timed;
 unsigned long long *g_dbg = nullptr;
 int g_dbg_role = -1;

@@ -17,6 +17,7 @@
 // rounding (both are backward stable; tests pin it against the reference's own LDL^T solves); 2/3 m^3 flops instead
 // of 1/3 m^3, which is irrelevant: this path runs a handful of times at the very end of a hard solve, if ever.
 #include "lu.h"
+#include <mutex>
 
 #include <vector>
 
@@ -250,11 +251,19 @@ int HdmLu::init(int n_) {
     HDM_HIP_CHECK(hipMalloc((void **) &info_dev, sizeof(int)));
     HDM_HIP_CHECK(hdm_memset_sync(A, 0, mat + hdm_operand_pad(npad)));
     // the LDS limit of the solve kernel is a per-function attribute: only ever raise it
-    static int lds_limit = 48 * 1024;
+    static std::mutex lds_mu;
+    static int lds_limit[64];
     const int need = (int) (hdm_roundup(n, LNB) * sizeof(double));
-    if (need > lds_limit && need <= 156 * 1024) {
-        HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_lu_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need));
-        lds_limit = need;
+    int dev = 0;
+    HDM_HIP_CHECK(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(lds_mu);
+        int &lim = lds_limit[dev & 63];
+        if (lim == 0) lim = 48 * 1024;
+        if (need > lim && need <= 156 * 1024) {
+            HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_lu_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need));
+            lim = need;
+        }
     }
     return 0;
 }

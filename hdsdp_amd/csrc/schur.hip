@@ -495,8 +495,9 @@ int hdm_sym_dot2(const double *A, long astride, int n, long lda, int count, cons
     const int groups = (count + DOT2_G - 1) / DOT2_G;
     int nchunk = std::max(1, std::min(64, 4096 / std::max(1, groups)));
     nchunk = std::min(nchunk, std::max(1, n / 16));
-    static double *part = nullptr;
-    static size_t part_cap = 0;
+    // per host thread: a thread drives one device (the caller's, or one shard of a device group)
+    static thread_local double *part = nullptr;
+    static thread_local size_t part_cap = 0;
     const size_t need = sizeof(double) * 2 * (size_t) nchunk * count;
     if (need > part_cap) {
         if (part) (void) hipFree(part);

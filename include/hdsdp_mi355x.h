@@ -299,6 +299,29 @@ hdsdp_retcode HMiConeGetExchangeBuffers(hdsdp_cone *cone, void **sendBuf, void *
 hdsdp_retcode HMiConeSetExchangeBuffers(hdsdp_cone *cone, void *sendBuf, void *recvBuf);
 void *HMiKKTDeviceMatrix(hdsdp_kkt *HKKT, int64_t *ld);   /* device pointer of M (m x m, lower valid) */
 
+/* ======================  several GPUs behind the C ABI (one process, one caller thread)  ======================
+ * The reference's driver is a single-threaded process (tests/sdpasolve.c; interface/hdsdp_algo.c:1082-1101 calls
+ * HKKTBuildUp / Factorize / Solve in sequence), so for it the sharding has to happen below these calls.
+ * HMiSetDevices(n, ids), or HDSDP_MI355X_GPUS=n in the environment of an UNCHANGED driver (devices 0..n-1), configures a
+ * device group before the first cone is created.  From then on HMiConeCreateSDP / HMiConeCreateSynthetic (called with
+ * rank 0, world 1) return a GROUP CONE for every dense block of dimension >= HMiSetShardMinDim (default 512, env
+ * HDSDP_MI355X_SHARD_MIN_N) that takes the congruence + Gram path: its constraint rows are dealt cyclically over n shards,
+ * one per device, each with its own stream and host worker thread; every cone slot fans out to the shards, the all-to-all
+ * and the all-reduce of the sharded build run over RCCL inside the library (grouped ncclSend/ncclRecv per piece of the
+ * exchange, ncclAllReduce), and only shard 0 writes into the caller's Schur operator, which lives on ids[0].  Blocks on
+ * the rank-one / sparse paths and small blocks stay plain single-device cones on ids[0].
+ * Device ids may repeat (HDSDP_MI355X_LOOPBACK=1 with the environment form: shard r on device r mod visible): the
+ * shards then share a device and exchange by device-to-device copies -- a rehearsal of world = n on a 1-GPU box; the same
+ * copy transport can be forced between distinct, peer-accessible devices with HDSDP_MI355X_TRANSPORT=copy.
+ * The process-per-GPU mode above (HMiConeSetExchange*, torchrun) is unaffected.  All return 0 on success. */
+int HMiSetDevices(int nDevices, const int *deviceIds);
+int HMiGetDeviceGroup(int *deviceIds, int maxIds, int *transport);   /* returns the shard count (1 = no group); transport
+                                                                        0 = device copies, 1 = RCCL, -1 = none */
+void HMiSetShardMinDim(int nMin);
+int HMiConeGetShardCount(hdsdp_cone *cone);                          /* 1 for a plain cone */
+void HMiConeGetGroupTraffic(hdsdp_cone *cone, int64_t *bytesAllToAll, int64_t *bytesAllReduce);   /* sent by shard 0 so far */
+int HMiRcclSelfTest(int device);   /* one-rank communicator on `device` (-1: the engine's): all-reduce + grouped send/recv, checked */
+
 /* ================================  ingest (host only)  ================================
  * SDPA sparse format reader with the reference's semantics (interface/hdsdp_file_io.c:34-381): one CSC per
  * SDP block, shape n(n+1)/2 x (m+1), column 0 = C = -F0; rhs = the c vector.  Pointers stay valid until

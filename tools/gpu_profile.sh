@@ -2,7 +2,7 @@
 # run on the GPU box from the repo root: kernel-trace stats + PMC passes of bench.py (each in its own run)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_${1:-r01}
+OUT=$R/gpurun_out/prof_${1:-r02}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/stats_bench.json 2> $OUT/stats.err || echo "stats run failed"
@@ -11,8 +11,9 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$tag -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err || echo "pmc $tag failed"
   python3 $R/tools/prof_summary.py $OUT/pmc_$tag "pmc: $pass" > $OUT/summary_pmc_$tag.txt 2>&1
-  # keep only the summaries (raw CSVs can be hundreds of MB)
-  rm -rf $OUT/pmc_$tag
 done
+# HBM bytes per launch for bench.py's roofline.traffic (the two passes above), then drop the raw CSVs (hundreds of MB)
+python3 $R/tools/prof_summary.py --traffic $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/traffic.json 2> $OUT/traffic.err
+rm -rf $OUT/pmc_*/
 rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/stats/*/*agent* 2>/dev/null
 ls -la $OUT

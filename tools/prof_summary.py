@@ -15,7 +15,35 @@ def short(name):
     return name[:100]
 
 
+def traffic(dirs):
+    """--traffic <FETCH_SIZE run dir> <WRITE_SIZE run dir>: HBM bytes per launch of every kernel as JSON, the way
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (separate --pmc passes; the counters are in KiB;
+    FETCH_SIZE x 2 for the wide-read correction): {kernel name: {fetch_kib, write_kib, launches, bytes_per_launch}}.
+    bench.py reads the newest profiles/*_traffic.json and matches on the kernel name, so a renamed or re-templated
+    kernel shows up as `traffic: null` instead of a stale number."""
+    import json
+    agg = defaultdict(lambda: {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    a = agg[r["Kernel_Name"]][r["Counter_Name"]]
+                    a[0] += 1
+                    a[1] += float(r["Counter_Value"])
+    out = {}
+    for k, v in agg.items():
+        nf, nw = v["FETCH_SIZE"][0], v["WRITE_SIZE"][0]
+        if nf == 0 or nw == 0:
+            continue
+        fk, wk = v["FETCH_SIZE"][1] / nf, v["WRITE_SIZE"][1] / nw
+        out[k.replace("void ", "")] = {"fetch_kib": fk, "write_kib": wk, "launches": nf,
+                                       "bytes_per_launch": (2.0 * fk + wk) * 1024.0}
+    print(json.dumps({"unit": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024", "kernels": out}, indent=1))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
+        return traffic(sys.argv[2:])
     d = sys.argv[1]
     label = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(d.rstrip("/"))
     print(f"# rocprofv3 summary: {label}")
