@@ -54,7 +54,12 @@ def _phase_a(api, cone, kkt, Rd, y, hsd=True):
         out["hsd_scal"] = np.array([exh["CSinv"], exh["CSinvCSinv"], exh["CSinvRdSinv"], exh["TraceSinv"]])
     dy = 0.3 * np.cos(0.7 * np.arange(m) + 0.2)
     out["step"] = cone.ratio_test(0.0, dy, 0.0)
-    out["X"] = cone.get_primal(0.37, y, 0.01 * dy)
+    # primal recovery works on S = C - sum y_i A_i without the residual term: near the generator's strictly feasible y0
+    from test_gpu_parity import _splitmix_u
+    P = cone.n * (cone.n + 1) // 2
+    y0 = _splitmix_u(np.uint64(2 * m * P) + np.arange(m, dtype=np.uint64))
+    out["X"] = cone.get_primal(0.37, y0 + 1e-3 * np.sin(np.arange(m)), 0.01 * dy)
+    assert out["X"] is not None and np.isfinite(out["X"]).all()
     Xs = np.cos(0.01 * np.add.outer(np.arange(cone.n), np.arange(cone.n)))
     out["AX"] = cone.a_times_x(Xs)
     out["norms"] = np.array([cone.coeff_norm(1), cone.coeff_norm(2), cone.obj_norm(1), cone.obj_norm(2)])
