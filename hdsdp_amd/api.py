@@ -36,7 +36,7 @@ EXPORTS = [
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
     "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
-    "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest",
+    "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
     "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
@@ -159,6 +159,9 @@ def load_library():
         "HMiConeGetShardCount": (C.c_int, [vp]),
         "HMiConeGetGroupTraffic": (None, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "HMiRcclSelfTest": (C.c_int, [C.c_int]),
+        "HMiGetCallStats": (C.c_int, [dp, C.POINTER(C.c_int64), C.c_int]),
+        "HMiCallStatName": (C.c_char_p, [C.c_int]),
+        "HMiResetCallStats": (None, []),
         "HMiDeviceInit": (C.c_int, [C.c_int]),
         "HMiDeviceSynchronize": (C.c_int, []),
         "HMiStream": (vp, []),

@@ -21,6 +21,7 @@
 #include "lu.h"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
@@ -59,6 +60,8 @@ inline Ctx &cur_ctx() { return t_ctx ? *t_ctx : g_main; }
 
 int g_main_device_request = -1;   // HMiSetDevices / HDSDP_MI355X_GPUS: device of the caller's context (= shard 0's)
 
+void stats_print_at_exit();
+
 int ctx_open(Ctx &c, int dev) {
     HDM_HIP_CHECK(hipSetDevice(dev));
     c.device = dev;
@@ -79,7 +82,45 @@ int ensure_ctx() {
     }
     if (lr) dev = atoi(lr) % ndev;
     if (g_main_device_request >= 0) dev = g_main_device_request % ndev;
+    if (const char *e = getenv("HDSDP_MI355X_CALL_STATS")) if (atoi(e)) atexit(stats_print_at_exit);
     return ctx_open(g, dev);
+}
+
+
+// ---- where a caller's wall time goes inside the library (HMiGetCallStats; HDSDP_MI355X_CALL_STATS=1 prints the table at
+// exit): only the caller's thread counts, and only the outermost entry (HKKTBuildUp calls the cones' slots, the cones
+// call HFpLinsys*), so the categories add up to the time the driver spent below the C ABI
+enum { ST_BUILD_M = 0, ST_BUILD_CORR, ST_FACTORIZE, ST_SOLVE, ST_ASSEMBLE_FACTOR, ST_RATIO, ST_PRIMAL_UTIL, ST_LINSYS, ST_N };
+const char *g_stat_name[ST_N] = {"HKKTBuildUp (M-forming types)", "HKKTBuildUp (corrector)", "HKKTFactorize", "HKKTSolve",
+                                 "cone: S assembly + factor (update, interior checks, barrier, line search)",
+                                 "cone: ratio test", "cone: primal recovery + utilities", "HFpLinsys* called by CPU cones"};
+double g_stat_sec[ST_N];
+long g_stat_calls[ST_N];
+thread_local int t_stat_depth = 0;
+struct StatScope {
+    int k;
+    bool on = false;
+    std::chrono::steady_clock::time_point t0;
+    explicit StatScope(int k_) : k(k_) {
+        if (t_ctx) return;                       // worker threads of a device group run below an entry that is already timed
+        on = (t_stat_depth++ == 0);
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    ~StatScope() {
+        if (t_ctx) return;
+        --t_stat_depth;
+        if (on) {
+            g_stat_sec[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            g_stat_calls[k] += 1;
+        }
+    }
+};
+void stats_print_at_exit() {
+    double tot = 0.0;
+    for (int k = 0; k < ST_N; ++k) tot += g_stat_sec[k];
+    fprintf(stderr, "[hdsdp_mi355x] wall time below the C ABI: %.3f s\n", tot);
+    for (int k = 0; k < ST_N; ++k)
+        if (g_stat_calls[k]) fprintf(stderr, "[hdsdp_mi355x]   %-78s %8ld calls %10.3f s\n", g_stat_name[k], g_stat_calls[k], g_stat_sec[k]);
 }
 
 #define HIP_RC(expr)                                                                             \
@@ -533,7 +574,10 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
     return 0;
 }
 
-void cone_update(void *cd, double tau, double *y) { cone_assemble((MiCone *) cd, tau, y, ((MiCone *) cd)->S); }
+void cone_update(void *cd, double tau, double *y) {
+    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    cone_assemble((MiCone *) cd, tau, y, ((MiCone *) cd)->S);
+}
 
 hdsdp_retcode cone_factor_S(MiCone *c, int *isPsd) {
     MiLin *l = (MiLin *) c->dualFactor->chol;
@@ -569,6 +613,7 @@ hdsdp_retcode cone_factor_check(MiCone *c, int *isPsd) {
 // (+ the perturbation unless the target is the step buffer, :383-385) into the chosen buffer, then the PSD check
 hdsdp_retcode cone_interior_expert(void *cd, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef,
                                    int whichBuffer, int *isInterior) {
+    StatScope stat_(ST_ASSEMBLE_FACTOR);
     MiCone *c = (MiCone *) cd;
     std::vector<double> ys(std::max(1, c->m), 0.0);
     for (int i = 0; i < c->m; ++i) ys[i] = -dACoefScal * (dACoef ? dACoef[i] : 0.0);   // cone_assemble subtracts
@@ -582,6 +627,7 @@ hdsdp_retcode cone_interior_expert(void *cd, double dCCoef, double dACoefScal, d
 // sdpDenseConeAddStepToBufferAndCheck (hdsdp_conic_sdp.c:2333-2361): S + dStep*dS with the dS of the last ratio test;
 // BUFFER_DUALVAR updates S in place, BUFFER_DUALCHECK leaves S alone and factors the trial point in the checker
 hdsdp_retcode cone_axpy_check(void *cd, double dStep, int whichBuffer, int *isInterior) {
+    StatScope stat_(ST_ASSEMBLE_FACTOR);
     MiCone *c = (MiCone *) cd;
     if (!c->dS) return HDSDP_RETCODE_FAILED;
     const long cnt = (long) c->n16 * c->n16;
@@ -595,6 +641,7 @@ void cone_set_perturb(void *cd, double dDualPerturb) { ((MiCone *) cd)->perturb 
 
 // hdsdp_conic_sdp.c:2172-2180
 hdsdp_retcode cone_interior(void *cd, double tau, double *y, int *isInterior) {
+    StatScope stat_(ST_ASSEMBLE_FACTOR);
     MiCone *c = (MiCone *) cd;
     RC(cone_assemble(c, tau, y, c->S));
     return cone_factor_S(c, isInterior);
@@ -602,6 +649,7 @@ hdsdp_retcode cone_interior(void *cd, double tau, double *y, int *isInterior) {
 
 // hdsdp_conic_sdp.c:2252-2291
 hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, double *logdet) {
+    StatScope stat_(ST_ASSEMBLE_FACTOR);
     MiCone *c = (MiCone *) cd;
     if (y) {   // only with BUFFER_DUALVAR (the reference asserts it)
         int psd = 0;
@@ -624,6 +672,7 @@ hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, dou
 // largest alpha with S + alpha dS >= 0 by Lanczos on L^-1 (-dS) L^-T (lanczos.hip).  L is the factor of the chosen
 // buffer: the current S (BUFFER_DUALVAR) or the trial point factored last in the checker (BUFFER_DUALCHECK).
 hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAdaRatio, int whichBuffer, double *maxStep) {
+    StatScope stat_(ST_RATIO);
     MiCone *c = (MiCone *) cd;
     MiLin *l = (MiLin *) c->dualFactor->chol;
     HdmChol *fac = (whichBuffer == 0) ? &l->ch : c->checker;   // LTarget, :1661-1665
@@ -713,17 +762,20 @@ int cone_data_norms(MiCone *c, double *rows_abs, double *rows_fro, double *obj_a
     return cone_data_norms(c, rows_abs, rows_fro, obj_abs, obj_fro);
 }
 
-double cone_coeff_norm(void *cd, int whichNorm) {   // sdpDenseConeGetCoeffNorm, hdsdp_conic_sdp.c:1568-1586 (ABS_NORM 1, FRO_NORM 2)
+double cone_coeff_norm(void *cd, int whichNorm) {
+    StatScope stat_(ST_PRIMAL_UTIL);   // sdpDenseConeGetCoeffNorm, hdsdp_conic_sdp.c:1568-1586 (ABS_NORM 1, FRO_NORM 2)
     double v[4];
     if (cone_data_norms((MiCone *) cd, v, v + 1, v + 2, v + 3)) return NAN;
     return whichNorm == 1 ? v[0] : v[1];
 }
-double cone_obj_norm(void *cd, int whichNorm) {     // sdpDenseConeGetObjNorm, :1558-1561
+double cone_obj_norm(void *cd, int whichNorm) {
+    StatScope stat_(ST_PRIMAL_UTIL);     // sdpDenseConeGetObjNorm, :1558-1561
     double v[4];
     if (cone_data_norms((MiCone *) cd, v, v + 1, v + 2, v + 3)) return NAN;
     return whichNorm == 1 ? v[2] : v[3];
 }
-void cone_scal(void *cd, double dScal) {             // sdpDenseConeScal, :1604-1614: the objective is scaled, nothing else
+void cone_scal(void *cd, double dScal) {
+    StatScope stat_(ST_PRIMAL_UTIL);             // sdpDenseConeScal, :1604-1614: the objective is scaled, nothing else
     MiCone *c = (MiCone *) cd;
     const long cnt = (long) c->n16 * c->n16;
     hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, g.stream, c->Cfull, cnt, dScal);
@@ -751,6 +803,7 @@ static int cone_upload_X(MiCone *c, const double *X, long *ldx) {
 // n x n, host), D = the dual matrix (iDualMat != 0) or the dual step dS of the last ratio test, both resident.  Two
 // plain MFMA GEMMs on the device; only X goes up and the n x n product comes back.
 void cone_build_primal_dir(void *cd, void *kktv, double *X, double *XSX, int iDualMat) {
+    StatScope stat_(ST_PRIMAL_UTIL);
     (void) kktv;
     MiCone *c = (MiCone *) cd;
     const int n = c->n;
@@ -781,7 +834,8 @@ void cone_build_primal_dir(void *cd, void *kktv, double *X, double *XSX, int iDu
     for (size_t e = 0; e < h.size(); ++e) XSX[e] += h[e];
 }
 
-void cone_a_times_x(void *cd, double *X, double *ATimesX) {   // sdpDenseConeATimesX, :2470-2477: y_i += <A_i, X>
+void cone_a_times_x(void *cd, double *X, double *ATimesX) {
+    StatScope stat_(ST_PRIMAL_UTIL);   // sdpDenseConeATimesX, :2470-2477: y_i += <A_i, X>
     MiCone *c = (MiCone *) cd;
     long ldx = 0;
     double *out = nullptr;
@@ -813,15 +867,18 @@ static double cone_dot_with(MiCone *c, const double *dev, long ldd, int lower_va
     (void) hipFree(out);
     return h;
 }
-double cone_trace_cx(void *cd, double *X) {   // sdpDenseConeTraceCX, :2520-2523
+double cone_trace_cx(void *cd, double *X) {
+    StatScope stat_(ST_PRIMAL_UTIL);   // sdpDenseConeTraceCX, :2520-2523
     MiCone *c = (MiCone *) cd;
     return cone_dot_with(c, c->Cfull, c->n16, 0, X);
 }
-double cone_x_dot_s(void *cd, double *X) {    // sdpDenseConeXDotS, :2549-2560 (S is lower-valid: fds_dot_fds, dense_opts.c:134-156)
+double cone_x_dot_s(void *cd, double *X) {
+    StatScope stat_(ST_PRIMAL_UTIL);    // sdpDenseConeXDotS, :2549-2560 (S is lower-valid: fds_dot_fds, dense_opts.c:134-156)
     MiCone *c = (MiCone *) cd;
     return cone_dot_with(c, c->S, c->n16, 1, X);
 }
-void cone_get_dual(void *cd, double *dConeDual, double *dummy) {   // sdpDenseConeGetDual, :2494-2506: S, symmetrised
+void cone_get_dual(void *cd, double *dConeDual, double *dummy) {
+    StatScope stat_(ST_PRIMAL_UTIL);   // sdpDenseConeGetDual, :2494-2506: S, symmetrised
     (void) dummy;
     MiCone *c = (MiCone *) cd;
     const int n = c->n;
@@ -837,6 +894,7 @@ void cone_get_dual(void *cd, double *dConeDual, double *dummy) {   // sdpDenseCo
 // second resident factor object, inverted once, and the four products are plain MFMA GEMMs with the explicit Linv.
 // Like the reference, an S that is not positive definite prints a message and leaves the output untouched.
 void cone_precover(void *cd, double dBarrierMu, double *y, double *dy, double *X, double *aux) {
+    StatScope stat_(ST_PRIMAL_UTIL);
     (void) aux;
     MiCone *c = (MiCone *) cd;
     const double zero = 0.0;
@@ -1702,6 +1760,7 @@ hdsdp_retcode HFpLinsysSymbolic(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colM
     return HLin->cholSymbolic(HLin->chol, colMatBeg, colMatIdx);
 }
 hdsdp_retcode HFpLinsysNumeric(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx, double *colMatElem) {
+    StatScope stat_(ST_LINSYS);
     // hdsdp_linsolver.c:2029-2044: a failed factorisation of the Schur system switches to the indefinite solver
     HLin->nFactorizes += 1;
     hdsdp_retcode rc = HLin->cholNumeric(HLin->chol, colMatBeg, colMatIdx, colMatElem);
@@ -1713,18 +1772,22 @@ hdsdp_retcode HFpLinsysNumeric(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMa
 }
 hdsdp_retcode HFpLinsysSwitchToBackUp(hdsdp_linsys_fp *HLin) { (void) HLin; return HDSDP_RETCODE_OK; }
 hdsdp_retcode HFpLinsysPsdCheck(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx, double *colMatElem, int *isPsd) {
+    StatScope stat_(ST_LINSYS);
     HLin->nFactorizes += 1;
     return HLin->cholPsdCheck(HLin->chol, colMatBeg, colMatIdx, colMatElem, isPsd);
 }
 void HFpLinsysFSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec) {
+    StatScope stat_(ST_LINSYS);
     HLin->nSolves += 1;
     HLin->cholFSolve(HLin->chol, nRhs, rhsVec, solVec);
 }
 void HFpLinsysBSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec) {
+    StatScope stat_(ST_LINSYS);
     HLin->nSolves += 1;
     HLin->cholBSolve(HLin->chol, nRhs, rhsVec, solVec);
 }
 hdsdp_retcode HFpLinsysSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec) {
+    StatScope stat_(ST_LINSYS);
     // hdsdp_linsolver.c:2085-2110: NaN in the solution (or the right-hand side) counts as a failure, and a failed solve
     // of the Schur system switches to the indefinite solver and solves again
     hdsdp_retcode rc = HLin->cholSolve(HLin->chol, nRhs, rhsVec, solVec);
@@ -1740,6 +1803,7 @@ hdsdp_retcode HFpLinsysSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, do
 }
 hdsdp_retcode HFpLinsysGetDiag(hdsdp_linsys_fp *HLin, double *diagElem) { return HLin->cholGetDiag(HLin->chol, diagElem); }
 void HFpLinsysInvert(hdsdp_linsys_fp *HLin, double *dFullMatrix, double *dAuxiMatrix) {
+    StatScope stat_(ST_LINSYS);
     HLin->cholInvert(HLin->chol, dFullMatrix, dAuxiMatrix);
 }
 void HFpLinsysClear(hdsdp_linsys_fp *HLin) {
@@ -1876,6 +1940,7 @@ static hdsdp_retcode kkt_pull(hdsdp_kkt *HKKT, int typeKKT) {
 }
 
 hdsdp_retcode HKKTBuildUp(hdsdp_kkt *HKKT, int typeKKT) {
+    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M);
     hdsdp_retcode rc = kkt_clean(HKKT, typeKKT);
     if (rc != HDSDP_RETCODE_OK) return rc;
     for (int i = 0; i < HKKT->nCones; ++i) {
@@ -1887,11 +1952,13 @@ hdsdp_retcode HKKTBuildUp(hdsdp_kkt *HKKT, int typeKKT) {
 }
 
 hdsdp_retcode HKKTBuildUpExtraCone(hdsdp_kkt *HKKT, hdsdp_cone *cone, int typeKKT) {
+    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M);
     // CPU cones (bound / LP, hdsdp_conic_bound.c:201-249) write straight into the host fields
     return cone->coneBuildSchur(cone->coneData, cone->iCone, HKKT, typeKKT);
 }
 
 hdsdp_retcode HKKTBuildUpFixed(hdsdp_kkt *HKKT, int typeKKT, int kktStrategy) {
+    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M);
     hdsdp_retcode rc = kkt_clean(HKKT, typeKKT);
     if (rc != HDSDP_RETCODE_OK) return rc;
     for (int i = 0; i < HKKT->nCones; ++i) {
@@ -1915,6 +1982,7 @@ void HKKTExport(hdsdp_kkt *HKKT, double *dKKTASinvVec, double *dKKTASinvRdSinvVe
 }
 
 hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
+    StatScope stat_(ST_FACTORIZE);
     // hdsdp_schur.c:328-336.  With the host mirror on, the host matrix is authoritative (the driver and
     // the CPU cones may have touched it through kktDiag / kktMatElem); otherwise factor the device copy.
     MiKKTPriv *pv = priv_of(HKKT);
@@ -1944,6 +2012,7 @@ hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
 }
 
 hdsdp_retcode HKKTSolve(hdsdp_kkt *HKKT, double *dRhsVec, double *dLhsVec) {
+    StatScope stat_(ST_SOLVE);
     return HFpLinsysSolve(HKKT->kktM, 1, dRhsVec, dLhsVec);
 }
 
@@ -2381,6 +2450,12 @@ void HMiConeGetGroupTraffic(hdsdp_cone *cone, int64_t *bytesAllToAll, int64_t *b
     if (bytesAllToAll) *bytesAllToAll = a;
     if (bytesAllReduce) *bytesAllReduce = b;
 }
+int HMiGetCallStats(double *seconds, int64_t *calls, int n) {
+    for (int k = 0; k < n && k < ST_N; ++k) { if (seconds) seconds[k] = g_stat_sec[k]; if (calls) calls[k] = g_stat_calls[k]; }
+    return ST_N;
+}
+const char *HMiCallStatName(int k) { return (k >= 0 && k < ST_N) ? g_stat_name[k] : ""; }
+void HMiResetCallStats(void) { for (int k = 0; k < ST_N; ++k) { g_stat_sec[k] = 0.0; g_stat_calls[k] = 0; } }
 int HMiRcclSelfTest(int device) {
     if (ensure_ctx()) return 1;
     return rccl_self_test(device < 0 ? g_main.device : device);

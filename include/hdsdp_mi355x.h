@@ -320,6 +320,14 @@ int HMiGetDeviceGroup(int *deviceIds, int maxIds, int *transport);   /* returns 
 void HMiSetShardMinDim(int nMin);
 int HMiConeGetShardCount(hdsdp_cone *cone);                          /* 1 for a plain cone */
 void HMiConeGetGroupTraffic(hdsdp_cone *cone, int64_t *bytesAllToAll, int64_t *bytesAllReduce);   /* sent by shard 0 so far */
+/* wall time the caller's thread has spent below this C ABI, by category (outermost entry only, so the categories add up):
+ * [0] HKKTBuildUp of the M-forming types, [1] HKKTBuildUp(KKT_TYPE_CORRECTOR), [2] HKKTFactorize, [3] HKKTSolve,
+ * [4] cone slots that assemble and factor S (update, interior checks, barrier, line search), [5] ratio test, [6] primal
+ * recovery and the cone utilities, [7] HFpLinsys* called directly (the reference's CPU cones).  Returns the number of
+ * categories.  HDSDP_MI355X_CALL_STATS=1 in the environment prints the table on stderr when the process exits. */
+int HMiGetCallStats(double *seconds, int64_t *calls, int n);
+const char *HMiCallStatName(int k);
+void HMiResetCallStats(void);
 int HMiRcclSelfTest(int device);   /* one-rank communicator on `device` (-1: the engine's): all-reduce + grouped send/recv, checked */
 
 /* ================================  ingest (host only)  ================================
