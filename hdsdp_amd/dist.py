@@ -39,6 +39,53 @@ class ShardPlan:
         self.pI = maxloc                                        # augmented rows sit in segment 0
         self.chunk = self.npb_loc * self.Lr * 16                # doubles per all-to-all chunk
 
+    def hbm_bytes(self, rank=0, tcap_gib=32, slab_cap_gib=40):
+        """device memory one rank of the sharded GEMM path allocates, mirroring engine.hip (cone_alloc_common,
+        cone_alloc_gemm_work, make_synth_cone / upload_dense_rows) and chol.hip: constraint data, congruence
+        intermediates, both exchange buffers, Gram slabs, and the small replicated matrices.  Returns a dict of parts
+        plus "total"."""
+        n16, nn = self.n16, self.n16 * self.n16 * 8
+        npad = _roundup(self.n, 128)
+        mloc = len(self.owned(rank))
+        parts = {"A (A_L form, square)": mloc * nn}
+        bc = max(1, min(int(tcap_gib * (1 << 30) / nn), 1024))
+        launches = -(-max(1, mloc) // bc)
+        bc = -(-max(1, mloc) // launches)
+        parts["congruence intermediates T"] = bc * nn
+        ahat = self.world * self.npb_loc * self.Lr * 16 * 8
+        parts["exchange buffers (send + recv)"] = ahat * (1 if self.world == 1 else 2)
+        kblocks = self.npb_loc
+        RT = -(-self.R // 128)
+        tiles = RT * (RT + 1) // 2
+        slab_cap = max(1, int((4 << 30) / (8.0 * self.R * self.R)))
+        kcap = max(1, kblocks // 64)
+        ns, best = 1, -1.0
+        for cand in range(1, 65):
+            if cand > slab_cap or cand > kcap:
+                break
+            if cand > 8 and cand % 8:
+                continue
+            rounds = tiles * cand / 512.0
+            eff = rounds / np.ceil(rounds)
+            if rounds < 2.0:
+                eff *= 0.5 + 0.25 * rounds
+            if cand < 8 and kcap >= 8 and slab_cap >= 8:
+                eff *= 0.5
+            if eff > best + 1e-9:
+                best, ns = eff, cand
+        big_cap = int((slab_cap_gib << 30) / (8.0 * self.R * self.R))
+        byk = kblocks // 96
+        if byk >= 128:
+            big = min(1024, byk, big_cap) & ~7
+            ns = max(ns, big)
+        parts["Gram slabs (%d splits)" % ns] = ns * self.R * self.R * 8
+        parts["Gram matrix"] = self.R * self.R * 8
+        parts["S, checker, C, dS + Cholesky / inverse of S"] = 4 * nn + 4 * npad * npad * 8
+        mpad = _roundup(self.m, 128)
+        parts["Schur matrix M + its factor (replicated)"] = 3 * mpad * mpad * 8
+        parts["total"] = sum(parts.values())
+        return parts
+
     def owned(self, rank):
         return list(range(rank, self.m, self.world))
 

@@ -68,3 +68,17 @@ def test_shard_plan_invariants():
     # transpose volume: each rank sends (w-1)/w of its rows' data -- 1/w of an all-gather
     p = ShardPlan(2000, 2000, 8)
     assert p.chunk * 8 * 7 < 0.15 * (p.npb * 16 * 2000 * 8)
+
+
+def test_config5_fits_the_hbm_of_eight_mi355x():
+    """BASELINE configs[4] (n = 2000, m = 8000 over 8 GPUs): what one rank allocates, by the plan that mirrors the engine's
+    allocation rules, against 288 GB of HBM3E per MI355X -- half of it; two ranks could not hold the problem"""
+    from hdsdp_amd.dist import ShardPlan
+    HBM = 288e9
+    for rank in (0, 7):
+        parts = ShardPlan(2000, 8000, 8).hbm_bytes(rank)
+        assert parts["total"] < 0.6 * HBM, parts
+        assert parts["A (A_L form, square)"] == 1000 * 2000 * 2000 * 8
+    one = ShardPlan(2000, 2000, 1).hbm_bytes(0)
+    assert 120e9 < one["total"] < 200e9, one          # DESIGN.md section 3: about 170 GB for the 32 GB problem
+    assert ShardPlan(2000, 8000, 2).hbm_bytes(0)["total"] > HBM   # two ranks cannot hold it

@@ -235,6 +235,33 @@ def test_full_size_two_shards_against_host_fp64(group, monkeypatch):
         cone.destroy()
 
 
+def test_shard_plan_predicts_what_the_engine_allocates(group):
+    """hdsdp_amd.dist.ShardPlan.hbm_bytes -- the statement that BASELINE configs[4] fits 8 x 288 GB
+    (tests/test_dist_cpu.py) -- against the device memory the engine really takes, one device and two shards"""
+    import torch
+    from hdsdp_amd import api
+    from hdsdp_amd.dist import ShardPlan
+    n, m = 640, 900
+    for world in (1, 2):
+        if world > 1:
+            group(world)
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        cone = api.SDPCone.synthetic(n, m)
+        kkt = api.KKT(m, [cone])
+        cone.set_start(-10.0 * n)
+        assert cone.check_is_interior(1.0, np.zeros(m))
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        kkt.factorize()
+        free1, _ = torch.cuda.mem_get_info()
+        used = free0 - free1
+        plan = sum(ShardPlan(n, m, world).hbm_bytes(r)["total"] for r in range(world))
+        if world > 1:   # M and its factor exist once (the caller's operator), not per shard
+            plan -= (world - 1) * ShardPlan(n, m, world).hbm_bytes(0)["Schur matrix M + its factor (replicated)"]
+        kkt.destroy(); cone.destroy()
+        assert 0.8 * plan <= used <= 1.25 * plan + (256 << 20), (world, used / 1e9, plan / 1e9)
+
+
 def test_rccl_is_linked_and_works_in_process():
     """the library links librccl (the group's transport between distinct devices); one device cannot form a group, so
     the transport's three calls -- communicator, all-reduce, grouped send/receive -- run on a one-rank communicator and

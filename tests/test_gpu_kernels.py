@@ -246,9 +246,79 @@ def test_sparse_direct_linsys_takes_a_csc_and_behaves_like_the_cholesky_backend(
             assert np.array_equal(getattr(sp, f)(b), getattr(de, f)(b)), f
         assert np.array_equal(sp.invert(), de.invert())
         assert np.linalg.norm(S @ sp.solve(b) - b) <= 1e-12 * np.linalg.norm(b) * np.linalg.cond(S)
+        # ... and equals LAPACK on the dense matrix, observable by observable (not only the library's other object):
+        # sum log diag = half the log-determinant (all the reference uses GetDiag for), the solve, the inverse, and the
+        # forward / backward halves composing to the solve (L L^T = S, whatever the elimination order)
+        Lc = np.linalg.cholesky(S)
+        assert abs(2.0 * np.sum(np.log(sp.get_diag())) - np.linalg.slogdet(S)[1]) <= 1e-12 * abs(np.linalg.slogdet(S)[1])
+        assert np.linalg.norm(sp.solve(b) - np.linalg.solve(S, b)) <= 1e-13 * np.linalg.cond(S) * np.linalg.norm(b)
+        assert np.max(np.abs(sp.invert() - np.linalg.inv(S))) <= 1e-13 * np.linalg.cond(S) * np.max(np.abs(np.linalg.inv(S)))
+        assert np.linalg.norm(sp.bsolve(sp.fsolve(b)) - np.linalg.solve(S, b)) <= 1e-13 * np.linalg.cond(S) * np.linalg.norm(b)
+        assert np.linalg.norm(sp.fsolve(b) - np.linalg.solve(Lc, b)) <= 1e-13 * np.linalg.cond(S) * np.linalg.norm(b)
         bad = np.array(val)
         bad[beg[n // 2]] = -1.0                                    # a negative diagonal entry
         assert sp.psd_check_csc(bad) is False
     finally:
         sp.destroy()
         de.destroy()
+
+
+FALLBACK_SCRIPT = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from hdsdp_amd import api
+import ctypes as C
+lib = api.load_library()
+rng = np.random.default_rng(11)
+for n in (130, 300, 1000):
+    G = rng.uniform(-1, 1, (n, n))
+    S = G @ G.T / n + np.eye(n)
+    ls = api.LinSys(n, api.HDSDP_LINSYS_DENSE_DIRECT)
+    ls.numeric(np.triu(S))
+    Lc = np.linalg.cholesky(S)
+    for trial in range(3):
+        b = rng.uniform(-1, 1, n)
+        assert np.linalg.norm(ls.solve(b) - np.linalg.solve(S, b)) <= 1e-12 * np.linalg.cond(S) * np.linalg.norm(b), ("solve", n)
+        assert np.linalg.norm(ls.fsolve(b) - np.linalg.solve(Lc, b)) <= 1e-12 * np.linalg.cond(S) * np.linalg.norm(b), ("fsolve", n)
+        assert np.linalg.norm(ls.bsolve(b) - np.linalg.solve(Lc.T, b)) <= 1e-12 * np.linalg.cond(S) * np.linalg.norm(b), ("bsolve", n)
+        # in place, the way the reference's driver solves (solVec == NULL, hdsdp_algo.c:452-454)
+        x = b.copy()
+        assert lib.HFpLinsysSolve(ls._h, 1, x.ctypes.data_as(C.POINTER(C.c_double)), None) == 0
+        assert np.linalg.norm(x - np.linalg.solve(S, b)) <= 1e-12 * np.linalg.cond(S) * np.linalg.norm(b), ("in place", n)
+        B2 = rng.uniform(-1, 1, (3, n))
+        X2 = ls.solve(B2)
+        assert np.linalg.norm(X2 - np.linalg.solve(S, B2.T).T) <= 1e-12 * np.linalg.cond(S) * np.linalg.norm(B2), ("3 rhs", n)
+    ls.destroy()
+n = m = 300
+cone = api.SDPCone.synthetic(n, m)
+kkt = api.KKT(m, [cone])
+cone.set_start(-10.0 * n)
+assert cone.check_is_interior(1.0, np.zeros(m))
+kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+kkt.factorize()
+Mh = kkt.M
+A = np.triu(Mh) + np.triu(Mh, 1).T
+b = cone.traces()
+x = kkt.solve(b.copy(), inplace=True)
+assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(b)
+print("FALLBACK_OK")
+'''
+
+
+@pytest.mark.parametrize("env", [{"HDM_TRSV_FLOW": "0"}, {"HDM_GRAPHS": "0"}, {"HDM_GRAPHS": "2", "HDM_TRSV_FLOW": "0"},
+                                 {"HDM_TRSV_FLOW_FAIL_ONCE": "1"}],
+                         ids=["per-block-substitution", "no-graphs", "graph-replayed-substitution", "flow-gives-up-once"])
+def test_fallback_chains_of_the_factor_and_solve_kernels(env):
+    """the paths behind the defaults stay covered: the per-block substitution launches (HDM_TRSV_FLOW=0, also what a
+    timed-out single-launch substitution falls back to), eager instead of graph-replayed factorisation chains
+    (HDM_GRAPHS=0), graph-replayed substitutions (HDM_GRAPHS=2), and the give-up path itself (HDM_TRSV_FLOW_FAIL_ONCE=1
+    throws the first single-launch result away): in-place solves included -- a retry must start from the caller's
+    untouched right-hand side -- all against LAPACK.  Child process: the switches are read once per process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", FALLBACK_SCRIPT % root], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **env))
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    if "HDM_TRSV_FLOW_FAIL_ONCE" in env:
+        assert "single-launch substitution timed out" in r.stderr
