@@ -487,14 +487,37 @@ class KKT:
                 "CSinvRdSinv": s[2].value, "TraceSinv": s[3].value}
 
     @property
+    def is_sparse(self):
+        """isKKTSparse: the host Schur matrix is the aggregated-pattern CSC of interface/hdsdp_schur.c:46-139"""
+        return bool(self._k.contents.isKKTSparse)
+
+    def csc(self):
+        """(kktMatBeg, kktMatIdx, kktMatElem) of a sparse operator as numpy views: lower triangle, column by column"""
+        k = self._k.contents
+        beg = np.ctypeslib.as_array(k.kktMatBeg, shape=(self.m + 1,))
+        nnz = int(beg[self.m])
+        return beg, np.ctypeslib.as_array(k.kktMatIdx, shape=(nnz,)), np.ctypeslib.as_array(k.kktMatElem, shape=(nnz,))
+
+    @property
     def M(self):
         """kktMatElem as the reference leaves it: m x m column-major, lower triangle valid.
-        Returned in numpy C-order, i.e. M[j, i] is element (row i, col j): valid where i >= j."""
+        Returned in numpy C-order, i.e. M[j, i] is element (row i, col j): valid where i >= j.
+        For a sparse operator the CSC is expanded into such an array (a copy, not a view)."""
         k = self._k.contents
+        if k.isKKTSparse:
+            beg, idx, val = self.csc()
+            D = np.zeros((self.m, self.m))
+            for j in range(self.m):
+                D[j, idx[beg[j]:beg[j + 1]]] = val[beg[j]:beg[j + 1]]
+            return D
         return np.ctypeslib.as_array(k.kktMatElem, shape=(self.m, self.m))
 
     def add_to_diag(self, v):
         """what the y-box cone does through kktDiag[] (interface/hdsdp_conic_bound.c:201-229)"""
+        if self.is_sparse:
+            beg, idx, val = self.csc()
+            val[beg[:-1]] += v
+            return
         M = self.M
         idx = np.arange(self.m)
         M[idx, idx] += v

@@ -40,6 +40,10 @@ __global__ void mi_lower_dot_kernel(const double *__restrict__ S, long lds_, con
                                     double *__restrict__ out);
 __global__ void mi_mat_dot_kernel(const double *__restrict__ X, long ldx, const double *__restrict__ Y, long ldy, int n,
                                   int diag_only, double scale, double *__restrict__ out);
+__global__ void mi_csc_gather_kernel(const double *__restrict__ M, long ld, const int *__restrict__ rows,
+                                     const int *__restrict__ cols, long nnz, double *__restrict__ vals);
+__global__ void mi_csc_scatter_kernel(double *__restrict__ M, long ld, const int *__restrict__ rows,
+                                      const int *__restrict__ cols, long nnz, const double *__restrict__ vals);
 
 namespace {
 
@@ -383,6 +387,7 @@ struct MiCone {
     // single-process multi-device mode: the shards of one block share ONE Schur operator (the caller's); only shard 0
     // writes into it, the others stop after the all-reduce
     bool kkt_owner = true;
+    int kkt_counted = 0;       // progress of the aggregated-pattern queries (cone_add_sym_nz)
 };
 
 struct MiKKTPriv {
@@ -394,6 +399,11 @@ struct MiKKTPriv {
     // reference's CPU cones: they accumulate into the host fields, hdsdp_conic_*.c)
     int n_engine = 0, n_foreign = 0;
     double *Mtmp = nullptr;   // pinned m x m staging buffer for the mixed case (device part added to the host part)
+    // sparse Schur operator (isKKTSparse, hdsdp_schur.c:46-139): the host matrix is the aggregated CSC pattern; its
+    // entries as (row, column) pairs on the device, plus a staging vector of nnz values
+    long nnz = 0;
+    int *sp_rows = nullptr, *sp_cols = nullptr;
+    double *sp_vals = nullptr;
 };
 
 // the kkt private state hangs off kktM->chol's MiLin (Mdev) plus a side struct keyed by the kkt pointer
@@ -411,6 +421,9 @@ void priv_drop(hdsdp_kkt *k) {
             if (g_priv[i].second->vecs) (void) hipFree(g_priv[i].second->vecs);
             if (g_priv[i].second->rhs) (void) hipFree(g_priv[i].second->rhs);
             if (g_priv[i].second->Mtmp) (void) hipHostFree(g_priv[i].second->Mtmp);
+            if (g_priv[i].second->sp_rows) (void) hipFree(g_priv[i].second->sp_rows);
+            if (g_priv[i].second->sp_cols) (void) hipFree(g_priv[i].second->sp_cols);
+            if (g_priv[i].second->sp_vals) (void) hipFree(g_priv[i].second->sp_vals);
             delete g_priv[i].second;
             g_priv.erase(g_priv.begin() + i);
             return;
@@ -551,7 +564,29 @@ int cone_alloc_gemm_work(MiCone *c) {
 // --- vtable slots ---------------------------------------------------------------------------
 void cone_setstart(void *cd, double rResi) { ((MiCone *) cd)->Rd = rResi; }  // hdsdp_conic_sdp.c:1546-1550
 int cone_getdim(void *cd) { return ((MiCone *) cd)->n; }
-int64_t cone_getsymnnz(void *cd) { MiCone *c = (MiCone *) cd; return (int64_t) c->m * c->m; }  // :1404-1405
+// rows of M this block contributes to: all m for a dense block (:1404-1405), the k rows on which the block has data for
+// a block most constraints are zero on (the reference's sparse SDP cone, :1479-1480) -- what HKKTInit weighs against
+// 0.3 m^2 when it chooses between the dense Schur matrix and the aggregated-pattern CSC
+int cone_kkt_rows(const MiCone *c) {
+    const bool compact = (c->world == 1 && !c->synthetic && (int) c->blk.rows.size() == c->m);
+    return compact ? c->mloc : c->m;
+}
+int64_t cone_getsymnnz(void *cd) { MiCone *c = (MiCone *) cd; const int64_t k = cone_kkt_rows(c); return k * k; }
+// the two pattern queries of HKKTAllocSparseKKT (hdsdp_schur.c:46-139), with the protocol of the reference's sparse SDP
+// cone (sdpSparseConeAddSymNnzImpl / sdpSparseConeGetSymMapping, hdsdp_conic_sdp.c:2086-2170): columns are visited in
+// order; in the column of its next row the block marks that row and all its later ones.  The positions handed back in
+// the second call are not kept: the engine's builders write a dense device matrix at global (row, column) indices and
+// the operator gathers the pattern's entries from it.
+void cone_add_sym_nz(void *cd, int iCol, int *schurMatCol) {
+    MiCone *c = (MiCone *) cd;
+    if (c->kkt_counted >= c->mloc || c->own[c->kkt_counted] != iCol) return;
+    for (int e = c->kkt_counted; e < c->mloc; ++e) schurMatCol[c->own[e]] = 1;
+}
+void cone_get_kkt_map(void *cd, int iCol, int *schurMatCol) {
+    (void) schurMatCol;
+    MiCone *c = (MiCone *) cd;
+    if (c->kkt_counted < c->mloc && c->own[c->kkt_counted] == iCol) c->kkt_counted += 1;
+}
 
 // S <- tau*C - sum y_i A_i - Rd*I (+ perturb)   hdsdp_conic_sdp.c:343-402, :1616-1633
 // Sharded: every rank sums its own rows (rank 0 also adds tau*C and the identity term), then all-reduce.
@@ -1657,6 +1692,8 @@ hdsdp_cone *new_cone_shell(MiCone *c, int iCone) {
     h->coneSetStart = cone_setstart;
     h->coneUpdate = cone_update;
     h->coneGetSymNnz = cone_getsymnnz;
+    h->coneAddSymNz = cone_add_sym_nz;
+    h->coneGetKKTMap = cone_get_kkt_map;
     h->coneGetDim = cone_getdim;
     h->coneBuildSchur = cone_build_schur;
     h->coneBuildSchurFixed = cone_build_schur_fixed;
@@ -1846,21 +1883,83 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
     if (!HKKT->invBuffer || !HKKT->kktBuffer || !HKKT->kktBuffer2 || !HKKT->dASinvVec || !HKKT->dASinvCSinvVec ||
         !HKKT->dASinvRdSinvVec || !HKKT->kktDiag)
         return HDSDP_RETCODE_MEMORY;
-    // The accelerated operator always carries a dense Schur matrix (hdsdp_schur.c:11-44); the sparse
-    // aggregated-pattern variant (:46-139) stays with the CPU reference.
-    HKKT->isKKTSparse = 0;
-    // pinned so the D2H/H2D of M after BuildUp / before Factorize runs at PCIe rate
-    if (hipHostMalloc((void **) &HKKT->kktMatElem, sizeof(double) * (size_t) nRow * nRow, hipHostMallocDefault) != hipSuccess)
-        return HDSDP_RETCODE_MEMORY;
-    memset(HKKT->kktMatElem, 0, sizeof(double) * (size_t) nRow * nRow);
-    hdsdp_retcode rc = HFpLinsysCreate(&HKKT->kktM, nRow, HDSDP_LINSYS_DENSE_ITERATIVE);
-    if (rc != HDSDP_RETCODE_OK) return rc;
-    double acc = 1e-12;  // KKT_ACCURACY (hdsdp.h:27); loosened for big systems exactly as hdsdp_schur.c:21-35
-    int iters = -1;
-    if (nRow > 20000) { acc *= 100.0; iters = 500; } else if (nRow > 15000) { acc *= 50.0; iters = 450; }
-    else if (nRow > 5000) { acc *= 5.0; iters = 120; }
-    HFpLinsysSetParam(HKKT->kktM, 5.0 * acc, acc, -1, iters, -1);
-    for (int i = 0; i < nRow; ++i) HKKT->kktDiag[i] = &HKKT->kktMatElem[i + (size_t) i * nRow];
+    // Dense Schur matrix (hdsdp_schur.c:11-44) or the aggregated-pattern CSC (:46-139): the reference's own rule.  A cone
+    // whose share of M reaches 0.3 m^2 entries makes it dense at once (:229-238); otherwise the columns' patterns are
+    // collected from the cones (coneAddSymNz / coneGetKKTMap) and the CSC is kept unless it grows to 0.3 m^2 (:104-108).
+    // HDSDP_MI355X_SPARSE_KKT=0 forces the dense matrix.
+    MiKKTPriv *pv0 = priv_of(HKKT);
+    HKKT->isKKTSparse = 1;
+    const int64_t nDense = (int64_t) (0.3 * (double) nRow * (double) nRow);     // HDSDP_SPARSE_SCHUR_THRESHOLD, hdsdp.h:29
+    if (const char *e = getenv("HDSDP_MI355X_SPARSE_KKT")) if (atoi(e) == 0) HKKT->isKKTSparse = 0;
+    for (int i = 0; i < nCones && HKKT->isKKTSparse; ++i) {
+        if (!cones[i]->coneGetSymNnz || !cones[i]->coneAddSymNz || !cones[i]->coneGetKKTMap ||
+            cones[i]->coneGetSymNnz(cones[i]->coneData) >= nDense) HKKT->isKKTSparse = 0;
+    }
+    if (HKKT->isKKTSparse) {
+        for (int i = 0; i < nCones; ++i)      // an engine cone may serve a second operator: its pattern walk starts over
+            if (cones[i]->coneBuildSchur == cone_build_schur) ((MiCone *) cones[i]->coneData)->kkt_counted = 0;
+        std::vector<int> beg((size_t) nRow + 1, 0), idx, col((size_t) nRow);
+        for (int iCol = 0; iCol < nRow && HKKT->isKKTSparse; ++iCol) {
+            std::fill(col.begin(), col.end(), 0);
+            for (int i = 0; i < nCones; ++i) cones[i]->coneAddSymNz(cones[i]->coneData, iCol, col.data());
+            for (int iRow = iCol; iRow < nRow; ++iRow)
+                if (col[iRow]) { col[iRow] = (int) idx.size(); idx.push_back(iRow); }
+            for (int i = 0; i < nCones; ++i) cones[i]->coneGetKKTMap(cones[i]->coneData, iCol, col.data());
+            beg[iCol + 1] = (int) idx.size();
+            if ((int64_t) idx.size() >= nDense) HKKT->isKKTSparse = 0;      // aggregation made it dense after all
+        }
+        if (HKKT->isKKTSparse) {
+            const size_t nnz = idx.size();
+            for (int iCol = 0; iCol < nRow; ++iCol)
+                if (beg[iCol] == beg[iCol + 1] || idx[beg[iCol]] != iCol) {
+                    printf("KKT solver detects an empty column.\n");     // :116-121
+                    return HDSDP_RETCODE_FAILED;
+                }
+            HKKT->kktMatBeg = (int *) malloc(sizeof(int) * ((size_t) nRow + 1));
+            HKKT->kktMatIdx = (int *) malloc(sizeof(int) * std::max<size_t>(1, nnz));
+            if (!HKKT->kktMatBeg || !HKKT->kktMatIdx) return HDSDP_RETCODE_MEMORY;
+            memcpy(HKKT->kktMatBeg, beg.data(), sizeof(int) * ((size_t) nRow + 1));
+            memcpy(HKKT->kktMatIdx, idx.data(), sizeof(int) * nnz);
+            if (hipHostMalloc((void **) &HKKT->kktMatElem, sizeof(double) * std::max<size_t>(1, nnz), hipHostMallocDefault) != hipSuccess)
+                return HDSDP_RETCODE_MEMORY;
+            memset(HKKT->kktMatElem, 0, sizeof(double) * nnz);
+            for (int iCol = 0; iCol < nRow; ++iCol) HKKT->kktDiag[iCol] = &HKKT->kktMatElem[beg[iCol]];
+            hdsdp_retcode rcs = HFpLinsysCreate(&HKKT->kktM, nRow, HDSDP_LINSYS_SPARSE_DIRECT);
+            if (rcs != HDSDP_RETCODE_OK) return rcs;
+            rcs = HFpLinsysSymbolic(HKKT->kktM, HKKT->kktMatBeg, HKKT->kktMatIdx);
+            if (rcs != HDSDP_RETCODE_OK) return rcs;
+            // the pattern as (row, column) pairs on the device
+            std::vector<int> cols(nnz);
+            for (int iCol = 0; iCol < nRow; ++iCol)
+                for (int q = beg[iCol]; q < beg[iCol + 1]; ++q) cols[q] = iCol;
+            pv0->nnz = (long) nnz;
+            if (hipMalloc((void **) &pv0->sp_rows, sizeof(int) * std::max<size_t>(1, nnz)) != hipSuccess ||
+                hipMalloc((void **) &pv0->sp_cols, sizeof(int) * std::max<size_t>(1, nnz)) != hipSuccess ||
+                hipMalloc((void **) &pv0->sp_vals, sizeof(double) * std::max<size_t>(1, nnz)) != hipSuccess)
+                return HDSDP_RETCODE_MEMORY;
+            if (hdm_memcpy_h2d_sync(pv0->sp_rows, idx.data(), sizeof(int) * nnz) != hipSuccess ||
+                hdm_memcpy_h2d_sync(pv0->sp_cols, cols.data(), sizeof(int) * nnz) != hipSuccess)
+                return HDSDP_RETCODE_FAILED;
+            printf("    Using sparse Schur complement (%d nnzs)\n", HKKT->kktMatBeg[nRow]);
+        }
+    }
+    if (!HKKT->isKKTSparse) {
+        // pinned so the D2H/H2D of M after BuildUp / before Factorize runs at PCIe rate
+        if (hipHostMalloc((void **) &HKKT->kktMatElem, sizeof(double) * (size_t) nRow * nRow, hipHostMallocDefault) != hipSuccess)
+            return HDSDP_RETCODE_MEMORY;
+        memset(HKKT->kktMatElem, 0, sizeof(double) * (size_t) nRow * nRow);
+        hdsdp_retcode rc = HFpLinsysCreate(&HKKT->kktM, nRow, HDSDP_LINSYS_DENSE_ITERATIVE);
+        if (rc != HDSDP_RETCODE_OK) return rc;
+        double acc = 1e-12;  // KKT_ACCURACY (hdsdp.h:27); loosened for big systems exactly as hdsdp_schur.c:21-35
+        int iters = -1;
+        if (nRow > 20000) { acc *= 100.0; iters = 500; } else if (nRow > 15000) { acc *= 50.0; iters = 450; }
+        else if (nRow > 5000) { acc *= 5.0; iters = 120; }
+        HFpLinsysSetParam(HKKT->kktM, 5.0 * acc, acc, -1, iters, -1);
+        for (int i = 0; i < nRow; ++i) HKKT->kktDiag[i] = &HKKT->kktMatElem[i + (size_t) i * nRow];
+    }
+    // On the device M stays a dense m x m matrix in either case: the cones' builders write it at global (row, column)
+    // indices, the blocked Cholesky factors it densely.  What the sparse form changes is the host side -- the matrix the
+    // driver, the CPU cones (through kktMapping / kktDiag) and HKKTRegularize see is the nnz-long CSC, not m^2 doubles.
     MiLin *l = (MiLin *) HKKT->kktM->chol;
     const size_t mm = sizeof(double) * (size_t) l->ch.npad * l->ch.npad;
     if (hipMalloc((void **) &l->Mdev, mm) != hipSuccess) return HDSDP_RETCODE_MEMORY;
@@ -1891,7 +1990,8 @@ static hdsdp_retcode kkt_clean(hdsdp_kkt *HKKT, int typeKKT) {  // hdsdp_schur.c
         MiLin *l = (MiLin *) HKKT->kktM->chol;
         if (hipMemsetAsync(l->Mdev, 0, sizeof(double) * (size_t) l->ch.npad * l->ch.npad, g.stream) != hipSuccess)
             return HDSDP_RETCODE_FAILED;
-        if (pv->mirror) memset(HKKT->kktMatElem, 0, sizeof(double) * (size_t) m * m);
+        if (HKKT->isKKTSparse) memset(HKKT->kktMatElem, 0, sizeof(double) * (size_t) HKKT->kktMatBeg[m]);   // (CPU cones add into it)
+        else if (pv->mirror) memset(HKKT->kktMatElem, 0, sizeof(double) * (size_t) m * m);
     }
     return HDSDP_RETCODE_OK;
 }
@@ -1907,23 +2007,36 @@ static hdsdp_retcode kkt_pull(hdsdp_kkt *HKKT, int typeKKT) {
     // straight into kktMatElem: with only engine cones the device matrix simply replaces the (zeroed) host one, with
     // only foreign cones there is nothing to bring back, and in the mixed case the device part is added to the host part.
     bool add_M = false;
+    size_t mcount = 0;     // entries of the host matrix that came back through Mtmp
     if (typeKKT != KKT_TYPE_CORRECTOR && pv->mirror && pv->n_engine > 0) {
         long ld = 0;
         double *Mdev = kkt_Mdev(HKKT, &ld);
         double *dst = HKKT->kktMatElem;
+        mcount = HKKT->isKKTSparse ? (size_t) pv->nnz : (size_t) m * m;
         if (pv->n_foreign > 0) {
-            if (!pv->Mtmp && hipHostMalloc((void **) &pv->Mtmp, sizeof(double) * (size_t) m * m) != hipSuccess) return HDSDP_RETCODE_MEMORY;
+            if (!pv->Mtmp && hipHostMalloc((void **) &pv->Mtmp, sizeof(double) * std::max<size_t>(1, mcount)) != hipSuccess) return HDSDP_RETCODE_MEMORY;
             dst = pv->Mtmp;
             add_M = true;
         }
-        if (hipMemcpy2DAsync(dst, sizeof(double) * m, Mdev, sizeof(double) * ld, sizeof(double) * m, m,
-                             hipMemcpyDeviceToHost, g.stream) != hipSuccess)
+        if (HKKT->isKKTSparse) {
+            // the pattern's entries of the dense device matrix (an engine cone only writes inside the pattern it declared)
+            if (pv->nnz > 0) {
+                hipLaunchKernelGGL(mi_csc_gather_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, Mdev, ld,
+                                   pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
+                if (hipMemcpyAsync(dst, pv->sp_vals, sizeof(double) * (size_t) pv->nnz, hipMemcpyDeviceToHost, g.stream) != hipSuccess)
+                    return HDSDP_RETCODE_FAILED;
+            }
+        } else if (hipMemcpy2DAsync(dst, sizeof(double) * m, Mdev, sizeof(double) * ld, sizeof(double) * m, m,
+                                    hipMemcpyDeviceToHost, g.stream) != hipSuccess)
             return HDSDP_RETCODE_FAILED;
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    if (add_M)
-        for (int j = 0; j < m; ++j)                    // lower triangle, column-major
-            for (int i = j; i < m; ++i) HKKT->kktMatElem[i + (size_t) j * m] += pv->Mtmp[i + (size_t) j * m];
+    if (add_M) {
+        if (HKKT->isKKTSparse) for (size_t q = 0; q < mcount; ++q) HKKT->kktMatElem[q] += pv->Mtmp[q];
+        else
+            for (int j = 0; j < m; ++j)                    // lower triangle, column-major
+                for (int i = j; i < m; ++i) HKKT->kktMatElem[i + (size_t) j * m] += pv->Mtmp[i + (size_t) j * m];
+    }
     for (int i = 0; i < m; ++i) {
         HKKT->dASinvVec[i] += h[i];
         HKKT->dASinvRdSinvVec[i] += h[m + i];
@@ -1989,14 +2102,26 @@ hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
     MiLin *l = (MiLin *) HKKT->kktM->chol;
     HKKT->kktM->nFactorizes += 1;
     int info = 0;
-    if (pv->mirror) {
+    if (pv->mirror && HKKT->isKKTSparse) {
+        // the host CSC is authoritative: its values go up (nnz doubles) and are scattered over the zeroed dense device
+        // matrix, which is then factored like the dense operator's
+        if (hipMemsetAsync(l->Mdev, 0, sizeof(double) * (size_t) l->ch.npad * l->ch.npad, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
+        if (pv->nnz > 0) {
+            if (hipMemcpyAsync(pv->sp_vals, HKKT->kktMatElem, sizeof(double) * (size_t) pv->nnz, hipMemcpyHostToDevice, g.stream) != hipSuccess)
+                return HDSDP_RETCODE_FAILED;
+            hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->Mdev,
+                               (long) l->ch.npad, pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
+        }
+        pv->Mdev_valid = true;
+        l->srcHost = nullptr; l->srcDev = l->Mdev; l->srcLd = l->ch.npad;
+    } else if (pv->mirror) {
         l->srcHost = HKKT->kktMatElem; l->srcDev = nullptr; l->srcLd = HKKT->nRow;
     } else {
         if (!pv->Mdev_valid) return HDSDP_RETCODE_FAILED;
         l->srcHost = nullptr; l->srcDev = l->Mdev; l->srcLd = l->ch.npad;
     }
     if (l->indef) return lin_factor_indef(l);     // switched earlier: stays switched (hdsdp_linsolver.c:1838)
-    if (pv->mirror) {
+    if (pv->mirror && !HKKT->isKKTSparse) {
         if (l->ch.load_host(HKKT->kktMatElem, HKKT->nRow, g.stream)) return HDSDP_RETCODE_FAILED;
     } else {
         if (l->ch.load_device(l->Mdev, l->ch.npad, g.stream)) return HDSDP_RETCODE_FAILED;
@@ -2115,6 +2240,18 @@ void *HMiKKTDeviceMatrix(hdsdp_kkt *HKKT, int64_t *ld) {
 }
 
 }  // extern "C"
+
+// sparse Schur operator: entry p of the aggregated CSC pattern <-> element (rows[p], cols[p]) of the dense device matrix
+__global__ void mi_csc_gather_kernel(const double *__restrict__ M, long ld, const int *__restrict__ rows,
+                                     const int *__restrict__ cols, long nnz, double *__restrict__ vals) {
+    const long p = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nnz) vals[p] = M[rows[p] + (long) cols[p] * ld];
+}
+__global__ void mi_csc_scatter_kernel(double *__restrict__ M, long ld, const int *__restrict__ rows,
+                                      const int *__restrict__ cols, long nnz, const double *__restrict__ vals) {
+    const long p = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nnz) M[rows[p] + (long) cols[p] * ld] = vals[p];
+}
 
 // device group, copy transport: out[i] = sum over the shards (in shard order) of p[q][lo + i]
 struct MiGrpPtrs { const double *p[16]; };

@@ -258,14 +258,20 @@ int main(int argc, char **argv) {
         hdsdp_kkt *kk = NULL;
         HDSDP_CALL(HKKTCreate(&kk));
         HDSDP_CALL(HKKTInit(kk, mm, nBlks, cones));
-        if (kk->isKKTSparse) { fprintf(stderr, "sparse Schur: harness dumps dense M only\n"); return 4; }
+        /* a sparse Schur operator (isKKTSparse, hdsdp_schur.c:46-139: every block touches few constraints) is dumped as
+           what it is: the aggregated lower-triangular CSC pattern and its nnz values */
+        { int sp = kk->isKKTSparse; dump_i("kkt_sparse", &sp, 1); }
+        const int knz = kk->isKKTSparse ? kk->kktMatBeg[mm] : 0;
+        if (kk->isKKTSparse) { dump_i("kkt_beg", kk->kktMatBeg, mm + 1); dump_i("kkt_idx", kk->kktMatIdx, knz); }
         HDSDP_CALL(HKKTBuildUp(kk, KKT_TYPE_HOMOGENEOUS));
-        dump_d2("M_hsd", kk->kktMatElem, mm, mm);
+        if (kk->isKKTSparse) dump_d("M_hsd", kk->kktMatElem, knz); else dump_d2("M_hsd", kk->kktMatElem, mm, mm);
         dump_d("ASinv_hsd", kk->dASinvVec, mm); dump_d("ASinvRdSinv_hsd", kk->dASinvRdSinvVec, mm);
         dump_d("ASinvCSinv_hsd", kk->dASinvCSinvVec, mm);
         { double sc[4] = { kk->dCSinv, kk->dCSinvCSinv, kk->dCSinvRdSinv, kk->dTraceSinv }; dump_d("hsd_scalars", sc, 4); }
+        HDSDP_CALL(HKKTBuildUp(kk, KKT_TYPE_CORRECTOR));
+        dump_d("ASinv_cor", kk->dASinvVec, mm); dump_d("ASinvRdSinv_cor", kk->dASinvRdSinvVec, mm);
         HDSDP_CALL(HKKTBuildUp(kk, KKT_TYPE_INFEASIBLE));
-        dump_d2("M_inf", kk->kktMatElem, mm, mm);
+        if (kk->isKKTSparse) dump_d("M_inf", kk->kktMatElem, knz); else dump_d2("M_inf", kk->kktMatElem, mm, mm);
         dump_d("ASinv_inf", kk->dASinvVec, mm); dump_d("ASinvRdSinv_inf", kk->dASinvRdSinvVec, mm);
         double *so = calloc(mm, sizeof(double));
         HDSDP_CALL(HKKTFactorize(kk));

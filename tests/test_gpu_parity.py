@@ -5,7 +5,7 @@ ASinvCSinv; 1e-8 relative 2-norm for the Schur solves; 1e-12 relative for logdet
 import numpy as np
 import pytest
 
-from util import primal_X, KKT_TOL, RATIO_TOL, check_close, kkt_err, load_golden, lower_mask, y_of
+from util import golden_schur_dense, primal_X, KKT_TOL, RATIO_TOL, check_close, kkt_err, load_golden, lower_mask, y_of
 
 pytestmark = pytest.mark.gpu
 
@@ -673,7 +673,7 @@ def test_regularize_follows_the_reference_rule():
         cone.destroy()
 
 
-@pytest.mark.parametrize("name,fname", [("truss1_A", "truss1.dat-s"), ("blocks3_A", "blocks3.dat-s")])
+@pytest.mark.parametrize("name,fname", [("truss1_A", "truss1.dat-s"), ("blocks3_A", "blocks3.dat-s"), ("chain16_A", "chain16.dat-s")])
 def test_multi_block_instance_against_reference(name, fname):
     """multi-block instances through the engine's own SDPA reader, all cones in one KKT object, against the reference's
     numbers for the same file (the reference run with one dense-SDP cone per block): truss1 (2 x 2 blocks and a 1 x 1),
@@ -704,18 +704,48 @@ def test_multi_block_instance_against_reference(name, fname):
         assert abs(ld - float(g["logdet"][0])) <= 1e-12 * abs(float(g["logdet"][0]))
         kkt = api.KKT(m, cones)
         msk = lower_mask(m)
+        # chain16: sixteen blocks of five constraints each -- the operator must come up SPARSE like the reference's
+        # (aggregated CSC pattern, hdsdp_schur.c:46-139), with the reference's pattern, entry for entry
+        assert kkt.is_sparse == bool(int(g["kkt_sparse"][0]))
+        if kkt.is_sparse:
+            beg, idx, val = kkt.csc()
+            assert np.array_equal(beg, g["kkt_beg"]) and np.array_equal(idx, g["kkt_idx"])
         kkt.build_up(api.KKT_TYPE_HOMOGENEOUS)
         ex = kkt.export()
-        check_close(kkt.M[msk], g["M_hsd"][msk], name + " M_hsd")
+        if kkt.is_sparse:
+            check_close(kkt.csc()[2], g["M_hsd"], name + " M_hsd (CSC values)")
+        check_close(kkt.M[msk], golden_schur_dense(g, "M_hsd")[msk], name + " M_hsd")
         check_close(ex["ASinv"], g["ASinv_hsd"], "truss1 ASinv")
         check_close(ex["ASinvRdSinv"], g["ASinvRdSinv_hsd"], "truss1 ASinvRdSinv")
         check_close(ex["ASinvCSinv"], g["ASinvCSinv_hsd"], "truss1 ASinvCSinv")
         check_close([ex["CSinv"], ex["CSinvCSinv"], ex["CSinvRdSinv"], ex["TraceSinv"]], g["hsd_scalars"], "truss1 scalars")
+        kkt.build_up(api.KKT_TYPE_CORRECTOR)
+        exc = kkt.export()
+        check_close(exc["ASinv"], g["ASinv_cor"], name + " ASinv_cor")
+        check_close(exc["ASinvRdSinv"], g["ASinvRdSinv_cor"], name + " ASinvRdSinv_cor")
         kkt.build_up(api.KKT_TYPE_INFEASIBLE)
-        check_close(kkt.M[msk], g["M_inf"][msk], "truss1 M_inf")
+        check_close(kkt.M[msk], golden_schur_dense(g, "M_inf")[msk], name + " M_inf")
         kkt.factorize()
         x = kkt.solve(g["b"])
         assert np.linalg.norm(x - g["sol_b"]) <= 1e-8 * np.linalg.norm(g["sol_b"])
+        if kkt.is_sparse:
+            # what a CPU cone / the driver does to a sparse operator: through kktDiag into the CSC, then factor again
+            kkt.add_to_diag(0.25)
+            kkt.factorize()
+            A = np.triu(kkt.M) + np.triu(kkt.M, 1).T
+            x2 = kkt.solve(g["b"])
+            assert np.linalg.norm(A @ x2 - g["b"]) <= 1e-11 * np.linalg.norm(g["b"])
+            assert np.linalg.norm(x2 - x) > 1e-6 * np.linalg.norm(x)
+            d0 = kkt.csc()[2][kkt.csc()[0][:-1]].copy()
+            kkt.regularize(1e3)                                   # HKKTRegularize goes through kktDiag as well
+            assert np.array_equal(kkt.csc()[2][kkt.csc()[0][:-1]], d0 + min(1e3 * d0.min(), 1e-5))
+            # the device-resident flavour of the same operator (no host round trip of M)
+            kdev = api.KKT(m, cones, host_mirror=False)
+            assert kdev.is_sparse
+            kdev.build_up(api.KKT_TYPE_INFEASIBLE)
+            kdev.factorize()
+            assert np.linalg.norm(kdev.solve(g["b"]) - g["sol_b"]) <= 1e-8 * np.linalg.norm(g["sol_b"])
+            kdev.destroy()
         kkt.destroy()
     finally:
         for c in cones:

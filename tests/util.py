@@ -62,3 +62,17 @@ def primal_X(n):
     X = 0.5 / n * np.cos(0.37 * (I + J) + 0.11 * I * J)
     X[np.arange(n), np.arange(n)] = 2.0 + 0.01 * (np.arange(n) % 7)
     return np.ascontiguousarray(X)
+
+
+def golden_schur_dense(g, key):
+    """the Schur matrix of a multi-block golden as the dense m x m array the tests compare (C-order view of the
+    column-major matrix, lower triangle at [col, row]); a golden dumped from the reference's SPARSE operator
+    (kkt_sparse = 1: aggregated CSC pattern kkt_beg / kkt_idx + nnz values) is expanded"""
+    if "kkt_sparse" not in g or int(g["kkt_sparse"][0]) == 0:
+        return g[key]
+    m = int(g["mb_dims"][1])
+    beg, idx, val = g["kkt_beg"], g["kkt_idx"], g[key]
+    D = np.zeros((m, m))
+    for j in range(m):
+        D[j, idx[beg[j]:beg[j + 1]]] = val[beg[j]:beg[j + 1]]
+    return D
