@@ -569,7 +569,9 @@ int cone_getdim(void *cd) { return ((MiCone *) cd)->n; }
 // 0.3 m^2 when it chooses between the dense Schur matrix and the aggregated-pattern CSC
 int cone_kkt_rows(const MiCone *c) {
     const bool compact = (c->world == 1 && !c->synthetic && (int) c->blk.rows.size() == c->m);
-    return compact ? c->mloc : c->m;
+    // the reference makes a block a sparse SDP cone iff at most 0.3 m of the constraints have data on it
+    // (HUserDataChooseCone, hdsdp_user_data.c:82-86; HDSDP_SPARSE_CONE_THRESHOLD); its dense cone claims all of M
+    return (compact && (double) c->mloc <= 0.3 * (double) c->m) ? c->mloc : c->m;
 }
 int64_t cone_getsymnnz(void *cd) { MiCone *c = (MiCone *) cd; const int64_t k = cone_kkt_rows(c); return k * k; }
 // the two pattern queries of HKKTAllocSparseKKT (hdsdp_schur.c:46-139), with the protocol of the reference's sparse SDP

@@ -2,6 +2,8 @@
 from the compiled reference (oracle/gen_golden.py).  Tolerance = the reference's own HUtilKKTCheck
 bar (|a-b|/(|a|+1e-4) < 1e-8, interface/hdsdp_utils.c:621-641) for M / ASinv / ASinvRdSinv /
 ASinvCSinv; 1e-8 relative 2-norm for the Schur solves; 1e-12 relative for logdet(S)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -746,6 +748,74 @@ def test_multi_block_instance_against_reference(name, fname):
             kdev.factorize()
             assert np.linalg.norm(kdev.solve(g["b"]) - g["sol_b"]) <= 1e-8 * np.linalg.norm(g["sol_b"])
             kdev.destroy()
+        kkt.destroy()
+    finally:
+        for c in cones:
+            c.destroy()
+
+
+def _block_with_rows(n, m, keep):
+    """a block of the synthetic family on which only the constraints in `keep` have data (CSC, column 0 = C)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    beg0, idx0, val0, _ = oracle_py.synth_csc(n, m)
+    beg, idx, val = [0], [], []
+    for col in range(m + 1):
+        lo, hi = int(beg0[col]), int(beg0[col + 1])
+        if col == 0 or (col - 1) in keep:
+            idx += [int(v) for v in idx0[lo:hi]]; val += [float(v) for v in val0[lo:hi]]
+        beg.append(len(idx))
+    return np.array(beg, dtype=np.int32), np.array(idx, dtype=np.int32), np.array(val)
+
+
+@pytest.mark.parametrize("nblocks,per,expect_sparse", [(12, 7, False), (12, 3, True)])
+def test_sparse_operator_decision_and_its_dense_way_back(nblocks, per, expect_sparse):
+    """HKKTInit's two-stage rule (interface/hdsdp_schur.c:229-238, :104-108) on blocks that are each sparse candidates
+    (at most 0.3 m constraints with data): twelve blocks of three scattered constraints aggregate to a sparse pattern;
+    twelve blocks of seven scattered constraints aggregate past 0.3 m^2, so the operator must fall back to the dense matrix
+    in the middle of the pattern walk -- and be right either way: M, the vectors and a solve against the oracle's
+    block-by-block sum"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    from hdsdp_amd import api
+    m = 24
+    rng = np.random.default_rng(100 + nblocks)
+    dims = [12 + 3 * (b % 4) for b in range(nblocks)]
+    # block b: constraints 2b, 2b+1 (so every constraint has data somewhere) and per-2 scattered ones
+    keeps = []
+    for b in range(nblocks):
+        base = {(2 * b) % m, (2 * b + 1) % m}
+        rest = [int(v) for v in rng.permutation(m) if int(v) not in base][:per - 2]
+        keeps.append(sorted(base | set(rest)))
+    Rd, tau = -40.0, 1.0
+    y = 0.05 * np.cos(np.arange(m) + 0.3)
+    cones, Mref, aref = [], np.zeros((m, m)), np.zeros(m)
+    try:
+        for b, (n, keep) in enumerate(zip(dims, keeps)):
+            beg, idx, val = _block_with_rows(n, m, keep)
+            blk = oracle_py.Block(n, m, beg, idx, val)
+            Lf, info = blk.factor(blk.assemble_S(tau, y, Rd))
+            assert info == 0
+            ref = blk.kkt_build(blk.inverse(Lf), Rd, 0)
+            Mref += ref["M"]; aref += ref["ASinv"]
+            blk.close()
+            c = api.SDPCone.from_csc(n, m, beg, idx, val, iCone=b)
+            c.set_start(Rd)
+            assert c.check_is_interior(tau, y)
+            cones.append(c)
+        kkt = api.KKT(m, cones)
+        assert kkt.is_sparse == expect_sparse
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        msk = lower_mask(m)
+        check_close(kkt.M[msk], Mref[msk], "M")
+        check_close(kkt.export()["ASinv"], aref, "ASinv")
+        kkt.factorize()
+        rhs = np.sin(np.arange(m) + 1.0)
+        A = np.triu(Mref) + np.triu(Mref, 1).T
+        x = kkt.solve(rhs)
+        assert np.linalg.norm(A @ x - rhs) <= 1e-10 * np.linalg.norm(rhs)
         kkt.destroy()
     finally:
         for c in cones:

@@ -45,7 +45,12 @@ CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None), "mcp100": (-226.15735
          # reference's own final solution check overrunning a 2-element eigenvalue array (interface/hdsdp.c:811 ->
          # dsyevr); the harness now hands that call an array of the size LAPACK documents (oracle/syev_guard.c, which
          # also reports on stderr whenever dsyevr writes past the reference's two entries), so nothing is skipped.
-         "blocks": (9.4410357041, None), "blockslp": (10.616269973, None)}
+         "blocks": (9.4410357041, None), "blockslp": (10.616269973, None),
+         # tests/golden/chain16.dat-s (oracle/make_chain_sdpa.py): sixteen small blocks of five constraints each -- the
+         # driver's HKKTInit comes up with the SPARSE Schur operator (aggregated CSC pattern, 192 entries, as in the pure
+         # reference), every block is one of the reference's sparse SDP cones (they stay CPU cones in both modes and write
+         # through kktMapping into the engine's CSC), and the engine factors and solves what they assembled
+         "chain16": (74.932288321, 42)}
 
 
 @pytest.mark.parametrize("attach", ["0", "1"], ids=["cpu-cones+engine-operator", "engine-cones"])
@@ -87,6 +92,8 @@ def test_reference_driver_runs_on_the_engine(inst, attach, tmp_path):
         assert "Switch to the pivoted" not in out
     else:
         assert "Primal refinement starts" in out
+    if inst == "chain16":
+        assert "Using sparse Schur complement (192 nnzs)" in out
     if ref_iters is not None:
         its = [int(m.group(1)) for m in re.finditer(r"^\s+(\d+)\s+[-+]\d\.\d+e[-+]\d+\s+[-+]\d\.\d+e[-+]\d+", out, re.M)]
         assert its and abs(max(its) - ref_iters) <= 2, (max(its) if its else None, ref_iters)
