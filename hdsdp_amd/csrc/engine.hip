@@ -101,11 +101,13 @@ const char *g_stat_name[ST_N] = {"HKKTBuildUp (M-forming types)", "HKKTBuildUp (
 double g_stat_sec[ST_N];
 long g_stat_calls[ST_N];
 thread_local int t_stat_depth = 0;
+static bool stat_trace() { static int t = -1; if (t < 0) { const char *e = getenv("HDSDP_MI355X_TRACE"); t = (e && atoi(e)) ? 1 : 0; } return t == 1; }
 struct StatScope {
     int k;
     bool on = false;
     std::chrono::steady_clock::time_point t0;
-    explicit StatScope(int k_) : k(k_) {
+    const char *name;
+    StatScope(int k_, const char *name_) : k(k_), name(name_) {
         if (t_ctx) return;                       // worker threads of a device group run below an entry that is already timed
         on = (t_stat_depth++ == 0);
         if (on) t0 = std::chrono::steady_clock::now();
@@ -113,6 +115,10 @@ struct StatScope {
     ~StatScope() {
         if (t_ctx) return;
         --t_stat_depth;
+        if (on && stat_trace()) {                // HDSDP_MI355X_TRACE=1: drain the device after every entry and say which
+            const hipError_t e = hipDeviceSynchronize();
+            fprintf(stderr, "[hdsdp_mi355x trace] %s -> %s\n", name, e == hipSuccess ? "ok" : hipGetErrorName(e));
+        }
         if (on) {
             g_stat_sec[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             g_stat_calls[k] += 1;
@@ -612,7 +618,7 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
 }
 
 void cone_update(void *cd, double tau, double *y) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     cone_assemble((MiCone *) cd, tau, y, ((MiCone *) cd)->S);
 }
 
@@ -650,7 +656,7 @@ hdsdp_retcode cone_factor_check(MiCone *c, int *isPsd) {
 // (+ the perturbation unless the target is the step buffer, :383-385) into the chosen buffer, then the PSD check
 hdsdp_retcode cone_interior_expert(void *cd, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef,
                                    int whichBuffer, int *isInterior) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     MiCone *c = (MiCone *) cd;
     std::vector<double> ys(std::max(1, c->m), 0.0);
     for (int i = 0; i < c->m; ++i) ys[i] = -dACoefScal * (dACoef ? dACoef[i] : 0.0);   // cone_assemble subtracts
@@ -664,7 +670,7 @@ hdsdp_retcode cone_interior_expert(void *cd, double dCCoef, double dACoefScal, d
 // sdpDenseConeAddStepToBufferAndCheck (hdsdp_conic_sdp.c:2333-2361): S + dStep*dS with the dS of the last ratio test;
 // BUFFER_DUALVAR updates S in place, BUFFER_DUALCHECK leaves S alone and factors the trial point in the checker
 hdsdp_retcode cone_axpy_check(void *cd, double dStep, int whichBuffer, int *isInterior) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     MiCone *c = (MiCone *) cd;
     if (!c->dS) return HDSDP_RETCODE_FAILED;
     const long cnt = (long) c->n16 * c->n16;
@@ -678,7 +684,7 @@ void cone_set_perturb(void *cd, double dDualPerturb) { ((MiCone *) cd)->perturb 
 
 // hdsdp_conic_sdp.c:2172-2180
 hdsdp_retcode cone_interior(void *cd, double tau, double *y, int *isInterior) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     MiCone *c = (MiCone *) cd;
     RC(cone_assemble(c, tau, y, c->S));
     return cone_factor_S(c, isInterior);
@@ -686,7 +692,7 @@ hdsdp_retcode cone_interior(void *cd, double tau, double *y, int *isInterior) {
 
 // hdsdp_conic_sdp.c:2252-2291
 hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, double *logdet) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     MiCone *c = (MiCone *) cd;
     if (y) {   // only with BUFFER_DUALVAR (the reference asserts it)
         int psd = 0;
@@ -709,7 +715,7 @@ hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, dou
 // largest alpha with S + alpha dS >= 0 by Lanczos on L^-1 (-dS) L^-T (lanczos.hip).  L is the factor of the chosen
 // buffer: the current S (BUFFER_DUALVAR) or the trial point factored last in the checker (BUFFER_DUALCHECK).
 hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAdaRatio, int whichBuffer, double *maxStep) {
-    StatScope stat_(ST_RATIO);
+    StatScope stat_(ST_RATIO, __func__);
     MiCone *c = (MiCone *) cd;
     MiLin *l = (MiLin *) c->dualFactor->chol;
     HdmChol *fac = (whichBuffer == 0) ? &l->ch : c->checker;   // LTarget, :1661-1665
@@ -800,19 +806,19 @@ int cone_data_norms(MiCone *c, double *rows_abs, double *rows_fro, double *obj_a
 }
 
 double cone_coeff_norm(void *cd, int whichNorm) {
-    StatScope stat_(ST_PRIMAL_UTIL);   // sdpDenseConeGetCoeffNorm, hdsdp_conic_sdp.c:1568-1586 (ABS_NORM 1, FRO_NORM 2)
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeGetCoeffNorm, hdsdp_conic_sdp.c:1568-1586 (ABS_NORM 1, FRO_NORM 2)
     double v[4];
     if (cone_data_norms((MiCone *) cd, v, v + 1, v + 2, v + 3)) return NAN;
     return whichNorm == 1 ? v[0] : v[1];
 }
 double cone_obj_norm(void *cd, int whichNorm) {
-    StatScope stat_(ST_PRIMAL_UTIL);     // sdpDenseConeGetObjNorm, :1558-1561
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);     // sdpDenseConeGetObjNorm, :1558-1561
     double v[4];
     if (cone_data_norms((MiCone *) cd, v, v + 1, v + 2, v + 3)) return NAN;
     return whichNorm == 1 ? v[2] : v[3];
 }
 void cone_scal(void *cd, double dScal) {
-    StatScope stat_(ST_PRIMAL_UTIL);             // sdpDenseConeScal, :1604-1614: the objective is scaled, nothing else
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);             // sdpDenseConeScal, :1604-1614: the objective is scaled, nothing else
     MiCone *c = (MiCone *) cd;
     const long cnt = (long) c->n16 * c->n16;
     hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, g.stream, c->Cfull, cnt, dScal);
@@ -840,7 +846,7 @@ static int cone_upload_X(MiCone *c, const double *X, long *ldx) {
 // n x n, host), D = the dual matrix (iDualMat != 0) or the dual step dS of the last ratio test, both resident.  Two
 // plain MFMA GEMMs on the device; only X goes up and the n x n product comes back.
 void cone_build_primal_dir(void *cd, void *kktv, double *X, double *XSX, int iDualMat) {
-    StatScope stat_(ST_PRIMAL_UTIL);
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
     (void) kktv;
     MiCone *c = (MiCone *) cd;
     const int n = c->n;
@@ -872,7 +878,7 @@ void cone_build_primal_dir(void *cd, void *kktv, double *X, double *XSX, int iDu
 }
 
 void cone_a_times_x(void *cd, double *X, double *ATimesX) {
-    StatScope stat_(ST_PRIMAL_UTIL);   // sdpDenseConeATimesX, :2470-2477: y_i += <A_i, X>
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeATimesX, :2470-2477: y_i += <A_i, X>
     MiCone *c = (MiCone *) cd;
     long ldx = 0;
     double *out = nullptr;
@@ -905,17 +911,17 @@ static double cone_dot_with(MiCone *c, const double *dev, long ldd, int lower_va
     return h;
 }
 double cone_trace_cx(void *cd, double *X) {
-    StatScope stat_(ST_PRIMAL_UTIL);   // sdpDenseConeTraceCX, :2520-2523
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeTraceCX, :2520-2523
     MiCone *c = (MiCone *) cd;
     return cone_dot_with(c, c->Cfull, c->n16, 0, X);
 }
 double cone_x_dot_s(void *cd, double *X) {
-    StatScope stat_(ST_PRIMAL_UTIL);    // sdpDenseConeXDotS, :2549-2560 (S is lower-valid: fds_dot_fds, dense_opts.c:134-156)
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);    // sdpDenseConeXDotS, :2549-2560 (S is lower-valid: fds_dot_fds, dense_opts.c:134-156)
     MiCone *c = (MiCone *) cd;
     return cone_dot_with(c, c->S, c->n16, 1, X);
 }
 void cone_get_dual(void *cd, double *dConeDual, double *dummy) {
-    StatScope stat_(ST_PRIMAL_UTIL);   // sdpDenseConeGetDual, :2494-2506: S, symmetrised
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeGetDual, :2494-2506: S, symmetrised
     (void) dummy;
     MiCone *c = (MiCone *) cd;
     const int n = c->n;
@@ -931,7 +937,7 @@ void cone_get_dual(void *cd, double *dConeDual, double *dummy) {
 // second resident factor object, inverted once, and the four products are plain MFMA GEMMs with the explicit Linv.
 // Like the reference, an S that is not positive definite prints a message and leaves the output untouched.
 void cone_precover(void *cd, double dBarrierMu, double *y, double *dy, double *X, double *aux) {
-    StatScope stat_(ST_PRIMAL_UTIL);
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
     (void) aux;
     MiCone *c = (MiCone *) cd;
     const double zero = 0.0;
@@ -994,8 +1000,10 @@ double cong2_mask_share(int NT, unsigned long long mask) {
 // phase 0: both steps; 1: step 1 only; 2: step 2 only (count <= Bc, T still holds step 1's output), optionally only the
 // output tiles of the tile columns in `colmask` -- the multi-GPU build runs step 2 by packed-index range so that the
 // finished ranges can leave for the other ranks while the rest is still being computed
-int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, int count, long row0, int phase = 0,
-                    unsigned long long colmask = 0) {
+// `asrc_span`: elements readable from Asrc (the buffer's operand slack included), for the launcher's check of the
+// unmasked tile loads
+int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, long asrc_span, int count, long row0,
+                    int phase = 0, unsigned long long colmask = 0) {
     // rows row0 .. row0+count-1 of AhatLoc  <-  blocked( Linv * A * Linv^T ),  A = A_L + A_L^T given in A_L form:
     //   step 1  U  = Linv * A_L                 (lower x lower = lower triangular: k in [col tile, row tile], n^3/3)
     //   step 2  At = U * Linv^T + Linv * U^T    (SYR2K form, lower tiles, k <= col tile, 2n^3/3)
@@ -1011,6 +1019,9 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, in
         k1.M = c->n16; k1.N = c->n16; k1.K = c->n16; k1.batch = nb; k1.alpha = 1.0;
         k1.klimit = HDM_KLIM_BAND; k1.lower_only = 1; k1.epilogue = HDM_EPI_STORE; k1.role = HDM_ROLE_CONG1;
         k1.flops = (double) nb * n3 / 3.0;
+        const long linv_span = (long) ch.npad * ch.npad;
+        const long t_span = nn * c->Bc + (long) (hdm_operand_pad(c->n16) / sizeof(double));
+        k1.spanA = linv_span; k1.spanB = asrc_span - (long) b0 * astride;
         if (phase != 2 && hdm_launch_gemm(k1, g.stream)) return 1;
         if (phase == 1) continue;
         HdmGemmArgs k2 = {};
@@ -1022,6 +1033,7 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, in
         k2.klimit = HDM_KLIM_BY_N; k2.lower_only = 1; k2.epilogue = HDM_EPI_BLOCKED;
         k2.blk_row_stride = c->Lr; k2.blk_row0 = row0 + b0; k2.nblk = c->nblk; k2.role = HDM_ROLE_CONG2;
         k2.tile_col_mask = colmask;
+        k2.spanA = t_span; k2.spanB = linv_span; k2.spanA2 = linv_span; k2.spanB2 = t_span;
         k2.flops = (double) nb * n3 * 2.0 / 3.0 * cong2_mask_share((c->n16 + HDM_TILE - 1) / HDM_TILE, colmask);
         if (hdm_launch_gemm(k2, g.stream)) return 1;
     }
@@ -1039,6 +1051,7 @@ int gram_splits(MiCone *c, int z0, int nz) {
     const long chunk = (c->npb_loc + c->nsplit - 1) / c->nsplit;
     gq.k_chunk = chunk * 16; gq.slab_stride = c->R * c->R; gq.alpha = 1.0; gq.role = HDM_ROLE_GRAM;
     gq.k_base = (long) z0 * gq.k_chunk;
+    gq.spanA = gq.spanB = (long) c->world * c->npb_loc * c->Lr * 16 + HDM_OPERAND_PAD_DOUBLES;
     gq.C = c->slabs + (long) z0 * gq.slab_stride;
     {   // (m+3)(m+4)/2 inner products of length n(n+1)/2 (this rank's share), 2 flops each
         const double rows = (double) c->m + 3.0;
@@ -1294,6 +1307,8 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     RC(ch.invert_factor(g.stream));
     HIP_RC(hipEventRecord(g.ev[1], g.stream));
     const long nn = (long) c->n16 * c->n16;
+    const long opad = (long) (hdm_operand_pad(c->n16) / sizeof(double));       // slack behind Afull / CL / T (allocation sites)
+    const long afull_span = nn * std::max(1, c->mloc) + opad;
     // Multi-GPU: run step 2 of the owned rows by packed-index range, in the order of the exchange pieces, so that a piece
     // crosses the links while the later ranges are still being computed (at two ranks the all-to-all moves 8 GB per
     // rank over a single link, more than the Gram product alone can hide).  Needs the piecewise exchange hooks, all
@@ -1303,7 +1318,7 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     bool staged = c->world > 1 && P > 1 && P <= 64 && c->mloc <= c->Bc && NT <= 64;
     if (const char *e = getenv("HDSDP_MI355X_STAGED_A2A")) staged = staged && atoi(e) != 0;
     c->last_pieces = P; c->last_staged = 0;
-    if (!staged) RC(congruence_rows(c, ch, c->Afull, nn, c->mloc, 0));
+    if (!staged) RC(congruence_rows(c, ch, c->Afull, nn, afull_span, c->mloc, 0));
     if (c->rank == 0) {
         // "I row": A = I => T = Linv, At = Linv Linv^T.  Reuse step 2 with T := Linv.
         HdmGemmArgs k2 = {};
@@ -1317,16 +1332,16 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
                 HIP_RC(hipMalloc((void **) &c->CL, sizeof(double) * (size_t) nn + hdm_operand_pad(c->n16)));
                 RC(hdm_lower_half(c->Cfull, c->CL, c->n, c->n16, g.stream));
             }
-            RC(congruence_rows(c, ch, c->CL, nn, 1, c->mloc + 2));
+            RC(congruence_rows(c, ch, c->CL, nn, nn + opad, 1, c->mloc + 2));
         }
     }
     if (staged) {
-        RC(congruence_rows(c, ch, c->Afull, nn, c->mloc, 0, 1));
+        RC(congruence_rows(c, ch, c->Afull, nn, afull_span, c->mloc, 0, 1));
         const unsigned long long all = (NT >= 64) ? ~0ULL : ((1ULL << NT) - 1);
         unsigned long long done = 0;
         for (int k = 0; k < P; ++k) {
             unsigned long long mk = (k == P - 1 ? all : piece_tile_cols(c, k, P)) & all & ~done;
-            if (mk) { RC(congruence_rows(c, ch, c->Afull, nn, c->mloc, 0, 2, mk)); c->last_staged += 1; }
+            if (mk) { RC(congruence_rows(c, ch, c->Afull, nn, afull_span, c->mloc, 0, 2, mk)); c->last_staged += 1; }
             done |= mk;
             if (!c->piece_ev[k]) HIP_RC(hipEventCreateWithFlags(&c->piece_ev[k], hipEventDisableTiming));
             HIP_RC(hipEventRecord(c->piece_ev[k], g.stream));
@@ -1536,6 +1551,14 @@ __global__ __launch_bounds__(256, LB) void mi_mfma_probe3_kernel(double *out, in
 
 namespace {
 
+#define TRACE_STEP(msg)                                                                                          \
+    do {                                                                                                         \
+        if (stat_trace()) {                                                                                      \
+            const hipError_t e_ = hipDeviceSynchronize();                                                        \
+            fprintf(stderr, "[hdsdp_mi355x trace]     %s (n %d, rows %d, m %d) -> %s\n", msg, c->n, c->mloc, m, \
+                    e_ == hipSuccess ? "ok" : hipGetErrorName(e_));                                              \
+        }                                                                                                        \
+    } while (0)
 hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT) {
     // all (non-zero) constraints are rank one: A_i = s_i a_i a_i'  (reference strategy M2)
     MiLin *l = (MiLin *) c->dualFactor->chol;
@@ -1543,20 +1566,24 @@ hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKK
     const int m = kkt->nRow;
     const int n16 = c->n16, m16 = c->mloc16;
     RC(ch.invert_factor(g.stream));
+    TRACE_STEP("r1 step 1");
     HdmGemmArgs u = {};  // U = Linv * Avec
     u.A = ch.Linv; u.lda = ch.npad; u.B = c->Avec; u.ldb = n16; u.b_kmajor = 1; u.C = c->U; u.ldc = n16;
     u.M = n16; u.N = m16; u.K = n16; u.batch = 1; u.alpha = 1.0; u.klimit = HDM_KLIM_BY_M; u.epilogue = HDM_EPI_STORE;
     RC(hdm_launch_gemm(u, g.stream));
+    TRACE_STEP("r1 step 2");
     HdmGemmArgs v = {};  // V = Linv^T * U = S^-1 * Avec
     v.A = ch.Linv; v.lda = ch.npad; v.a_kmajor = 1; v.B = c->U; v.ldb = n16; v.b_kmajor = 1; v.C = c->V; v.ldc = n16;
     v.M = n16; v.N = m16; v.K = n16; v.batch = 1; v.alpha = 1.0; v.epilogue = HDM_EPI_STORE;
     RC(hdm_launch_gemm(v, g.stream));
+    TRACE_STEP("r1 step 3");
     long ldm = 0;
     double *Mdev = kkt_Mdev(kkt, &ldm);
     if (typeKKT == KKT_TYPE_CORRECTOR) {
         // ASinv_i = s_i a_i' S^-1 a_i = s_i <u_i,u_i>; ASinvRdSinv_i = Rd s_i |v_i|^2
         hipLaunchKernelGGL(mi_col_dot_kernel, dim3((c->mloc + 3) / 4), dim3(256), 0, g.stream, c->U, c->U, (long) n16,
                            n16, c->sgn, c->rows_own, c->mloc, pv->vecs);
+    TRACE_STEP("r1 step 4");
         if (c->Rd != 0.0) RC(hdm_r1_colnorm(c->V, n16, n16, c->sgn, c->rows_own, c->mloc, c->Rd, pv->vecs + m, g.stream));
         return HDSDP_RETCODE_OK;
     }
@@ -1564,12 +1591,16 @@ hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKK
     gq.A = c->U; gq.lda = n16; gq.a_kmajor = 1; gq.B = c->U; gq.ldb = n16; gq.b_kmajor = 1; gq.C = c->Gr1; gq.ldc = m16;
     gq.M = m16; gq.N = m16; gq.K = n16; gq.batch = 1; gq.alpha = 1.0; gq.lower_only = 1; gq.epilogue = HDM_EPI_STORE;
     RC(hdm_launch_gemm(gq, g.stream));
+    TRACE_STEP("r1 step 5");
     RC(hdm_r1_hadamard(c->Gr1, m16, c->sgn, c->rows_own, c->mloc, Mdev, ldm, pv->vecs, g.stream));
+    TRACE_STEP("r1 step 6");
     if (c->Rd != 0.0) {
         RC(hdm_r1_colnorm(c->V, n16, n16, c->sgn, c->rows_own, c->mloc, c->Rd, pv->vecs + m, g.stream));
+    TRACE_STEP("r1 step 7");
         // TraceSinv = |Linv|_F^2
         hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, ch.Linv, (long) ch.npad, ch.Linv,
                            (long) ch.npad, c->n, 0, 1.0, pv->vecs + 3 * m);
+    TRACE_STEP("r1 step 8");
     }
     if (typeKKT == KKT_TYPE_HOMOGENEOUS && c->rank == 0) {
         // Ct = Linv C Linv^T (full);  ASinvCSinv_i = s_i u_i' Ct u_i;  CSinv = tr Ct; CSinvCSinv = |Ct|_F^2;
@@ -1578,27 +1609,35 @@ hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKK
         k1.A = ch.Linv; k1.lda = ch.npad; k1.B = c->Cfull; k1.ldb = n16; k1.C = c->W; k1.ldc = n16;
         k1.M = n16; k1.N = n16; k1.K = n16; k1.batch = 1; k1.alpha = 1.0; k1.klimit = HDM_KLIM_BY_M;
         RC(hdm_launch_gemm(k1, g.stream));
+    TRACE_STEP("r1 step 9");
         HdmGemmArgs k2 = {};
         k2.A = c->W; k2.lda = n16; k2.B = ch.Linv; k2.ldb = ch.npad; k2.C = c->Ct; k2.ldc = n16;
         k2.M = n16; k2.N = n16; k2.K = n16; k2.batch = 1; k2.alpha = 1.0; k2.klimit = HDM_KLIM_BY_N;
         RC(hdm_launch_gemm(k2, g.stream));
+    TRACE_STEP("r1 step 10");
         HdmGemmArgs w = {};  // W = Ct * U
         w.A = c->Ct; w.lda = n16; w.B = c->U; w.ldb = n16; w.b_kmajor = 1; w.C = c->W; w.ldc = n16;
         w.M = n16; w.N = m16; w.K = n16; w.batch = 1; w.alpha = 1.0;
         RC(hdm_launch_gemm(w, g.stream));
+    TRACE_STEP("r1 step 11");
         hipLaunchKernelGGL(mi_col_dot_kernel, dim3((c->mloc + 3) / 4), dim3(256), 0, g.stream, c->U, c->W, (long) n16,
                            n16, c->sgn, c->rows_own, c->mloc, pv->vecs + 2 * m);
+    TRACE_STEP("r1 step 12");
         hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Ct, (long) n16, nullptr, 0L, c->n, 1,
                            1.0, pv->vecs + 3 * m + 1);
+    TRACE_STEP("r1 step 13");
         hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Ct, (long) n16, c->Ct, (long) n16,
                            c->n, 0, 1.0, pv->vecs + 3 * m + 2);
+    TRACE_STEP("r1 step 14");
         if (c->Rd != 0.0) {
             HdmGemmArgs q = {};  // Xinv := Linv Linv^T
             q.A = ch.Linv; q.lda = ch.npad; q.B = ch.Linv; q.ldb = ch.npad; q.C = c->Xinv; q.ldc = n16;
             q.M = n16; q.N = n16; q.K = n16; q.batch = 1; q.alpha = 1.0;
             RC(hdm_launch_gemm(q, g.stream));
+    TRACE_STEP("r1 step 15");
             hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Ct, (long) n16, c->Xinv,
                                (long) n16, c->n, 0, c->Rd, pv->vecs + 3 * m + 3);
+    TRACE_STEP("r1 step 16");
         }
     }
     HIP_RC(hipGetLastError());
@@ -1799,7 +1838,7 @@ hdsdp_retcode HFpLinsysSymbolic(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colM
     return HLin->cholSymbolic(HLin->chol, colMatBeg, colMatIdx);
 }
 hdsdp_retcode HFpLinsysNumeric(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx, double *colMatElem) {
-    StatScope stat_(ST_LINSYS);
+    StatScope stat_(ST_LINSYS, __func__);
     // hdsdp_linsolver.c:2029-2044: a failed factorisation of the Schur system switches to the indefinite solver
     HLin->nFactorizes += 1;
     hdsdp_retcode rc = HLin->cholNumeric(HLin->chol, colMatBeg, colMatIdx, colMatElem);
@@ -1811,22 +1850,22 @@ hdsdp_retcode HFpLinsysNumeric(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMa
 }
 hdsdp_retcode HFpLinsysSwitchToBackUp(hdsdp_linsys_fp *HLin) { (void) HLin; return HDSDP_RETCODE_OK; }
 hdsdp_retcode HFpLinsysPsdCheck(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx, double *colMatElem, int *isPsd) {
-    StatScope stat_(ST_LINSYS);
+    StatScope stat_(ST_LINSYS, __func__);
     HLin->nFactorizes += 1;
     return HLin->cholPsdCheck(HLin->chol, colMatBeg, colMatIdx, colMatElem, isPsd);
 }
 void HFpLinsysFSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec) {
-    StatScope stat_(ST_LINSYS);
+    StatScope stat_(ST_LINSYS, __func__);
     HLin->nSolves += 1;
     HLin->cholFSolve(HLin->chol, nRhs, rhsVec, solVec);
 }
 void HFpLinsysBSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec) {
-    StatScope stat_(ST_LINSYS);
+    StatScope stat_(ST_LINSYS, __func__);
     HLin->nSolves += 1;
     HLin->cholBSolve(HLin->chol, nRhs, rhsVec, solVec);
 }
 hdsdp_retcode HFpLinsysSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec) {
-    StatScope stat_(ST_LINSYS);
+    StatScope stat_(ST_LINSYS, __func__);
     // hdsdp_linsolver.c:2085-2110: NaN in the solution (or the right-hand side) counts as a failure, and a failed solve
     // of the Schur system switches to the indefinite solver and solves again
     hdsdp_retcode rc = HLin->cholSolve(HLin->chol, nRhs, rhsVec, solVec);
@@ -1842,7 +1881,7 @@ hdsdp_retcode HFpLinsysSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, do
 }
 hdsdp_retcode HFpLinsysGetDiag(hdsdp_linsys_fp *HLin, double *diagElem) { return HLin->cholGetDiag(HLin->chol, diagElem); }
 void HFpLinsysInvert(hdsdp_linsys_fp *HLin, double *dFullMatrix, double *dAuxiMatrix) {
-    StatScope stat_(ST_LINSYS);
+    StatScope stat_(ST_LINSYS, __func__);
     HLin->cholInvert(HLin->chol, dFullMatrix, dAuxiMatrix);
 }
 void HFpLinsysClear(hdsdp_linsys_fp *HLin) {
@@ -2055,25 +2094,30 @@ static hdsdp_retcode kkt_pull(hdsdp_kkt *HKKT, int typeKKT) {
 }
 
 hdsdp_retcode HKKTBuildUp(hdsdp_kkt *HKKT, int typeKKT) {
-    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M);
+    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M, __func__);
     hdsdp_retcode rc = kkt_clean(HKKT, typeKKT);
     if (rc != HDSDP_RETCODE_OK) return rc;
     for (int i = 0; i < HKKT->nCones; ++i) {
         hdsdp_cone *c = HKKT->cones[i];
         rc = c->coneBuildSchur(c->coneData, c->iCone, HKKT, typeKKT);  // == HConeBuildSchurComplement
+        if (stat_trace()) {
+            const hipError_t e = hipDeviceSynchronize();
+            fprintf(stderr, "[hdsdp_mi355x trace]   build type %d, cone %d of %d -> rc %d, %s\n", typeKKT, i, HKKT->nCones, (int) rc,
+                    e == hipSuccess ? "ok" : hipGetErrorName(e));
+        }
         if (rc != HDSDP_RETCODE_OK) return rc;
     }
     return kkt_pull(HKKT, typeKKT);
 }
 
 hdsdp_retcode HKKTBuildUpExtraCone(hdsdp_kkt *HKKT, hdsdp_cone *cone, int typeKKT) {
-    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M);
+    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M, __func__);
     // CPU cones (bound / LP, hdsdp_conic_bound.c:201-249) write straight into the host fields
     return cone->coneBuildSchur(cone->coneData, cone->iCone, HKKT, typeKKT);
 }
 
 hdsdp_retcode HKKTBuildUpFixed(hdsdp_kkt *HKKT, int typeKKT, int kktStrategy) {
-    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M);
+    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M, __func__);
     hdsdp_retcode rc = kkt_clean(HKKT, typeKKT);
     if (rc != HDSDP_RETCODE_OK) return rc;
     for (int i = 0; i < HKKT->nCones; ++i) {
@@ -2097,7 +2141,7 @@ void HKKTExport(hdsdp_kkt *HKKT, double *dKKTASinvVec, double *dKKTASinvRdSinvVe
 }
 
 hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
-    StatScope stat_(ST_FACTORIZE);
+    StatScope stat_(ST_FACTORIZE, __func__);
     // hdsdp_schur.c:328-336.  With the host mirror on, the host matrix is authoritative (the driver and
     // the CPU cones may have touched it through kktDiag / kktMatElem); otherwise factor the device copy.
     MiKKTPriv *pv = priv_of(HKKT);
@@ -2139,7 +2183,7 @@ hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
 }
 
 hdsdp_retcode HKKTSolve(hdsdp_kkt *HKKT, double *dRhsVec, double *dLhsVec) {
-    StatScope stat_(ST_SOLVE);
+    StatScope stat_(ST_SOLVE, __func__);
     return HFpLinsysSolve(HKKT->kktM, 1, dRhsVec, dLhsVec);
 }
 

@@ -398,7 +398,11 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         stA.chain(a.A2 + (long) z * a.strideA2, a.lda2, m0, kt0, tid, kt1 - kt0);
         stB.chain(a.B2 + (long) z * a.strideB2, a.ldb2, n0, kt0, tid, kt1 - kt0);
     }
-    if (a.lower_only && tm == tn) {   // workgroup-uniform: diagonal tile, 36-cell scheme
+    // (roles 1-3 only: the cell paths stage with UNMASKED loads, which needs the slack the engine gives those operand
+    // buffers and the launcher verifies (hdm_launch_gemm: operand spans); a generic launch -- Cholesky updates, the small
+    // products of the rank-one path on buffers of a few KB -- takes the masked loop below, whose epilogue knows about
+    // diagonal tiles.  A generic diagonal tile on this path once read 16 KB past a 2 KB operand: a device fault.)
+    if (ROLE != HDM_ROLE_GENERIC && a.lower_only && tm == tn) {   // workgroup-uniform: diagonal tile, 36-cell scheme
         const int nst = (kt1 - kt0) * npass;
         switch (wave) {
             case 0: cell_tile<DiagCells<0>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
@@ -755,6 +759,43 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
         return 1;
     }
     const int MT = (args.M + HDM_TILE - 1) / HDM_TILE, NT = (args.N + HDM_TILE - 1) / HDM_TILE;
+    if (args.role != HDM_ROLE_GENERIC) {
+        // Roles 1-3 stage whole 128-row tiles WITHOUT a row mask (Stager::load_nomask): rows past the matrix edge are
+        // read and thrown away.  Every such launch therefore states how many elements are readable from each operand
+        // pointer, and the launch is refused unless the farthest element an unmasked load can touch lies inside.
+        auto farthest = [&](bool kmajor, long ld, long kblk, long stride, int rows, bool seg) {
+            const long maxrow = (long) ((rows + HDM_TILE - 1) / HDM_TILE) * HDM_TILE - 1;
+            long kfirst = 0, klast = args.K - 1;
+            if (args.epilogue == HDM_EPI_SLAB) {
+                kfirst = args.k_base;
+                klast = std::min<long>(args.K, args.k_base + (long) args.batch * args.k_chunk) - 1;
+            }
+            (void) kfirst;
+            const long nb = (args.epilogue == HDM_EPI_SLAB) ? 1 : args.batch;
+            long off = (nb - 1) * stride;
+            if (kmajor) {
+                off += (klast / HDM_BK) * (kblk ? kblk : HDM_BK) + maxrow * ld + (HDM_BK - 1);
+                if (seg && args.seg_rows) off += (maxrow / args.seg_rows) * args.seg_extra;
+            } else {
+                off += klast * ld + maxrow;
+            }
+            return off + 1;
+        };
+        struct { const double *p; long span; bool km; long ld, kblk, stride; int rows; const char *nm; } ops[4] = {
+            {args.A, args.spanA, args.a_kmajor != 0, args.lda, args.a_kblk, args.strideA, args.M, "A"},
+            {args.B, args.spanB, args.b_kmajor != 0, args.ldb, args.b_kblk, args.strideB, args.N, "B"},
+            {args.A2, args.spanA2, args.a_kmajor != 0, args.lda2, (long) HDM_BK, args.strideA2, args.M, "A2"},
+            {args.B2, args.spanB2, args.b_kmajor != 0, args.ldb2, (long) HDM_BK, args.strideB2, args.N, "B2"}};
+        for (auto &o : ops) {
+            if (!o.p) continue;
+            const long need = farthest(o.km, o.ld, o.kblk, o.stride, o.rows, true);
+            if (o.span < need) {
+                fprintf(stderr, "[hdsdp_mi355x] gemm role %d: operand %s needs %ld readable elements for its unmasked tile "
+                                "loads, the caller vouches for %ld: launch refused\n", args.role, o.nm, need, o.span);
+                return 1;
+            }
+        }
+    }
     TileList tl;
     if (get_tiles(MT, NT, args.klimit, args.lower_only, args.tile_col_mask, tl)) return 1;
     if (tl.n == 0) return 0;

@@ -338,11 +338,11 @@ int gc_getdim(void *cd) { return ((MiConeGroup *) cd)->n; }
 int64_t gc_getsymnnz(void *cd) { MiConeGroup *cg = (MiConeGroup *) cd; return (int64_t) cg->m * cg->m; }
 
 void gc_update(void *cd, double tau, double *y) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     (void) grun((MiConeGroup *) cd, [&](int, MiCone *c) { cone_update(c, tau, y); return 0; });
 }
 hdsdp_retcode gc_interior(void *cd, double tau, double *y, int *isInterior) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     MiConeGroup *cg = (MiConeGroup *) cd;
     std::vector<int> res(cg->G->W, 0);
     hdsdp_retcode rc = grun(cg, [&](int r, MiCone *c) { return cone_interior(c, tau, y, &res[r]); });
@@ -351,7 +351,7 @@ hdsdp_retcode gc_interior(void *cd, double tau, double *y, int *isInterior) {
 }
 hdsdp_retcode gc_interior_expert(void *cd, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef, int whichBuffer,
                                  int *isInterior) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     MiConeGroup *cg = (MiConeGroup *) cd;
     std::vector<int> res(cg->G->W, 0);
     hdsdp_retcode rc = grun(cg, [&](int r, MiCone *c) {
@@ -360,7 +360,7 @@ hdsdp_retcode gc_interior_expert(void *cd, double dCCoef, double dACoefScal, dou
     return rc;
 }
 hdsdp_retcode gc_axpy_check(void *cd, double dStep, int whichBuffer, int *isInterior) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     MiConeGroup *cg = (MiConeGroup *) cd;
     std::vector<int> res(cg->G->W, 0);
     hdsdp_retcode rc = grun(cg, [&](int r, MiCone *c) { return cone_axpy_check(c, dStep, whichBuffer, &res[r]); });
@@ -368,7 +368,7 @@ hdsdp_retcode gc_axpy_check(void *cd, double dStep, int whichBuffer, int *isInte
     return rc;
 }
 hdsdp_retcode gc_barrier(void *cd, double tau, double *y, int whichBuffer, double *logdet) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR);
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     MiConeGroup *cg = (MiConeGroup *) cd;
     std::vector<double> res(cg->G->W, 0.0);
     hdsdp_retcode rc = grun(cg, [&](int r, MiCone *c) { return cone_barrier(c, tau, y, whichBuffer, &res[r]); });
@@ -376,7 +376,7 @@ hdsdp_retcode gc_barrier(void *cd, double tau, double *y, int whichBuffer, doubl
     return rc;
 }
 hdsdp_retcode gc_ratio_test(void *cd, double dTauStep, double *dy, double dAdaRatio, int whichBuffer, double *maxStep) {
-    StatScope stat_(ST_RATIO);
+    StatScope stat_(ST_RATIO, __func__);
     MiConeGroup *cg = (MiConeGroup *) cd;
     std::vector<double> res(cg->G->W, 0.0);
     hdsdp_retcode rc = grun(cg, [&](int r, MiCone *c) { return cone_ratio_test(c, dTauStep, dy, dAdaRatio, whichBuffer, &res[r]); });
@@ -395,28 +395,28 @@ hdsdp_retcode gc_build_schur_fixed(void *cd, int iCone, void *kktv, int typeKKT,
 }
 // the slots below change no replicated state and have no collective inside: shard 0 alone answers
 void gc_build_primal_dir(void *cd, void *kktv, double *X, double *XSX, int iDualMat) {
-    StatScope stat_(ST_PRIMAL_UTIL);
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
     (void) grun((MiConeGroup *) cd, [&](int r, MiCone *c) { if (r == 0) cone_build_primal_dir(c, kktv, X, XSX, iDualMat); return 0; });
 }
 double gc_trace_cx(void *cd, double *X) {
-    StatScope stat_(ST_PRIMAL_UTIL);
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
     double v = NAN;
     (void) grun((MiConeGroup *) cd, [&](int r, MiCone *c) { if (r == 0) v = cone_trace_cx(c, X); return 0; });
     return v;
 }
 double gc_x_dot_s(void *cd, double *X) {
-    StatScope stat_(ST_PRIMAL_UTIL);
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
     double v = NAN;
     (void) grun((MiConeGroup *) cd, [&](int r, MiCone *c) { if (r == 0) v = cone_x_dot_s(c, X); return 0; });
     return v;
 }
 void gc_get_dual(void *cd, double *S, double *aux) {
-    StatScope stat_(ST_PRIMAL_UTIL);
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
     (void) grun((MiConeGroup *) cd, [&](int r, MiCone *c) { if (r == 0) cone_get_dual(c, S, aux); return 0; });
 }
 // these have a collective inside (rows are sharded) or move replicated state: every shard runs them, shard 0's output counts
 void gc_a_times_x(void *cd, double *X, double *ATimesX) {
-    StatScope stat_(ST_PRIMAL_UTIL);
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
     MiConeGroup *cg = (MiConeGroup *) cd;
     (void) grun(cg, [&](int r, MiCone *c) {
         if (r == 0) { cone_a_times_x(c, X, ATimesX); return 0; }
@@ -425,7 +425,7 @@ void gc_a_times_x(void *cd, double *X, double *ATimesX) {
         return 0; });
 }
 void gc_precover(void *cd, double mu, double *y, double *dy, double *X, double *aux) {
-    StatScope stat_(ST_PRIMAL_UTIL);
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
     MiConeGroup *cg = (MiConeGroup *) cd;
     (void) grun(cg, [&](int r, MiCone *c) {
         if (r == 0) { cone_precover(c, mu, y, dy, X, aux); return 0; }
@@ -434,20 +434,20 @@ void gc_precover(void *cd, double mu, double *y, double *dy, double *X, double *
         return 0; });
 }
 double gc_coeff_norm(void *cd, int whichNorm) {
-    StatScope stat_(ST_PRIMAL_UTIL);
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
     MiConeGroup *cg = (MiConeGroup *) cd;
     std::vector<double> res(cg->G->W, NAN);
     (void) grun(cg, [&](int r, MiCone *c) { res[r] = cone_coeff_norm(c, whichNorm); return 0; });
     return res[0];
 }
 double gc_obj_norm(void *cd, int whichNorm) {
-    StatScope stat_(ST_PRIMAL_UTIL);
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
     MiConeGroup *cg = (MiConeGroup *) cd;
     std::vector<double> res(cg->G->W, NAN);
     (void) grun(cg, [&](int r, MiCone *c) { res[r] = cone_obj_norm(c, whichNorm); return 0; });
     return res[0];
 }
-void gc_scal(void *cd, double dScal) { StatScope stat_(ST_PRIMAL_UTIL); (void) grun((MiConeGroup *) cd, [&](int, MiCone *c) { cone_scal(c, dScal); return 0; }); }
+void gc_scal(void *cd, double dScal) { StatScope stat_(ST_PRIMAL_UTIL, __func__); (void) grun((MiConeGroup *) cd, [&](int, MiCone *c) { cone_scal(c, dScal); return 0; }); }
 
 void gc_destroy_data(void **pcd) {
     if (!pcd || !*pcd) return;

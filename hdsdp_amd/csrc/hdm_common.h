@@ -70,6 +70,8 @@ struct HdmGemmArgs {
     // same shapes, storage classes and K range as the first pair; A2 == nullptr: single product
     const double *A2, *B2;
     long lda2, ldb2, strideA2, strideB2;
+    // roles 1-3 (unmasked tile loads): elements readable from each operand pointer, slack included; checked at launch
+    long spanA, spanB, spanA2, spanB2;
     long lda, ldb, ldc;
     long strideA, strideB, strideC;  // batch strides (elements) along blockIdx.z (batch) -- 0 = shared
     int M, N, K;

@@ -62,7 +62,10 @@ hdsdp_retcode HConePresolveData(hdsdp_cone *HCone) {
     hdsdp_retcode rc = real(HCone);
     if (rc != HDSDP_RETCODE_OK) return rc;
     const char *sw = getenv("HDSDP_DROP_ATTACH");
-    if ((sw && atoi(sw) == 0) || HCone->cone != HDSDP_CONETYPE_DENSE_SDP || g_ntab >= MAX_ATTACHED) return rc;
+    /* dense SDP cones, and the reference's sparse SDP cones (blocks on which most constraints are zero,
+       hdsdp_conic_sdp.c:1814-1886): the engine keeps only the constraints that have data on a block */
+    if ((sw && atoi(sw) == 0) || (HCone->cone != HDSDP_CONETYPE_DENSE_SDP && HCone->cone != HDSDP_CONETYPE_SPARSE_SDP) ||
+        g_ntab >= MAX_ATTACHED) return rc;
     user_data *u = (user_data *) HCone->usrData;
     hdsdp_cone *g = NULL;
     rc = HMiConeCreateSDP(&g, HCone->iCone, u->nConicRow, u->nConicCol, u->coneMatBeg, u->coneMatIdx, u->coneMatElem, 0, 1);
@@ -76,6 +79,7 @@ hdsdp_retcode HConePresolveData(hdsdp_cone *HCone) {
     HCone->coneSetStart = g->coneSetStart;                     HCone->coneUpdate = g->coneUpdate;
     HCone->coneRatioTest = g->coneRatioTest;
     HCone->coneGetSymNnz = g->coneGetSymNnz;                   HCone->coneGetDim = g->coneGetDim;
+    HCone->coneAddSymNz = g->coneAddSymNz;                     HCone->coneGetKKTMap = g->coneGetKKTMap;   /* sparse Schur pattern */
     HCone->coneBuildSchur = g->coneBuildSchur;                 HCone->coneBuildSchurFixed = g->coneBuildSchurFixed;
     HCone->coneBuildPrimalDirection = g->coneBuildPrimalDirection;
     HCone->coneInteriorCheck = g->coneInteriorCheck;           HCone->coneInteriorCheckExpert = g->coneInteriorCheckExpert;
