@@ -1949,13 +1949,13 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
             beg[iCol + 1] = (int) idx.size();
             if ((int64_t) idx.size() >= nDense) HKKT->isKKTSparse = 0;      // aggregation made it dense after all
         }
+        // a constraint no cone has data for leaves an empty column: the reference stops there ("KKT solver detects an
+        // empty column", :116-121); the engine keeps such an operator usable on the dense matrix, where the row simply
+        // stays zero until a CPU cone (the bound cone's diagonal) or the regularisation fills it
+        for (int iCol = 0; iCol < nRow && HKKT->isKKTSparse; ++iCol)
+            if (beg[iCol] == beg[iCol + 1] || idx[beg[iCol]] != iCol) HKKT->isKKTSparse = 0;
         if (HKKT->isKKTSparse) {
             const size_t nnz = idx.size();
-            for (int iCol = 0; iCol < nRow; ++iCol)
-                if (beg[iCol] == beg[iCol + 1] || idx[beg[iCol]] != iCol) {
-                    printf("KKT solver detects an empty column.\n");     // :116-121
-                    return HDSDP_RETCODE_FAILED;
-                }
             HKKT->kktMatBeg = (int *) malloc(sizeof(int) * ((size_t) nRow + 1));
             HKKT->kktMatIdx = (int *) malloc(sizeof(int) * std::max<size_t>(1, nnz));
             if (!HKKT->kktMatBeg || !HKKT->kktMatIdx) return HDSDP_RETCODE_MEMORY;
