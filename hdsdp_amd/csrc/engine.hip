@@ -390,6 +390,7 @@ struct MiCone {
     hmi_allreduce_fn allreduce = nullptr;
     void *xctx = nullptr;
     bool work_ready = false;
+    bool shared_ts = false;    // T and the Gram slabs are one buffer (one GPU): T's diagonal-tile uppers are re-zeroed per batch
     // single-process multi-device mode: the shards of one block share ONE Schur operator (the caller's); only shard 0
     // writes into it, the others stop after the all-reduce
     bool kkt_owner = true;
@@ -550,8 +551,32 @@ int cone_alloc_gemm_work(MiCone *c) {
         }
     }
     if (const char *e = getenv("HDM_NSPLIT")) ns = std::max(1L, std::min(atol(e), kblocks / 16));   // A/B knob
+    // One GPU: the congruence intermediates T are dead by the time the Gram product writes its split-K slabs, so the two
+    // share ONE buffer (the larger of the two sizes: 33 GB instead of 32 + 33 GB at n = m = 2000).  The only thing step 2
+    // reads of T that step 1 does not write is the strict upper triangle of T's diagonal tiles: with the buffer shared
+    // it is re-zeroed before every batch (hdm_zero_diag_upper, 1 GB of stores per 1000 matrices) instead of once at
+    // allocation.  Sharded builds keep them apart: there the Gram splits of the early exchange pieces run while step 2
+    // still reads T for the later ones.  HDM_SHARE_T_SLABS=0 keeps two buffers (A/B runs).
+    bool share = (c->world == 1);
+    if (const char *e = getenv("HDM_SHARE_T_SLABS")) share = share && atoi(e) != 0;
+    if (share) {
+        const size_t tbytes = nn * (size_t) c->Bc + hdm_operand_pad(c->n16);
+        for (;;) {
+            c->nsplit = (int) ns;
+            const size_t sbytes = sizeof(double) * (size_t) c->R * c->R * c->nsplit;
+            if (sbytes <= tbytes) { c->slabs = c->T; c->shared_ts = true; break; }
+            // the slabs are the bigger of the two: one buffer of their size serves both
+            (void) hipFree(c->T);
+            c->T = nullptr;
+            if (hipMalloc((void **) &c->T, sbytes + hdm_operand_pad(c->n16)) == hipSuccess) { c->slabs = c->T; c->shared_ts = true; break; }
+            (void) hipGetLastError();
+            if (hipMalloc((void **) &c->T, tbytes) != hipSuccess) { (void) hipGetLastError(); c->T = nullptr; return 1; }
+            if (ns <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the Gram slabs\n"); return 1; }
+            ns = std::max(8L, (ns / 2) & ~7L);
+        }
+    }
     // the slabs are the one allocation here that is a tuning choice: halve the split count until it fits
-    for (;;) {
+    for (; !c->shared_ts;) {
         c->nsplit = (int) ns;
         if (hipMalloc((void **) &c->slabs, sizeof(double) * (size_t) c->R * c->R * c->nsplit) == hipSuccess) break;
         (void) hipGetLastError();
@@ -1022,6 +1047,7 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, lo
         const long linv_span = (long) ch.npad * ch.npad;
         const long t_span = nn * c->Bc + (long) (hdm_operand_pad(c->n16) / sizeof(double));
         k1.spanA = linv_span; k1.spanB = asrc_span - (long) b0 * astride;
+        if (phase != 2 && c->shared_ts && hdm_zero_diag_upper(c->T, nn, c->n16, nb, g.stream)) return 1;
         if (phase != 2 && hdm_launch_gemm(k1, g.stream)) return 1;
         if (phase == 1) continue;
         HdmGemmArgs k2 = {};
@@ -1694,6 +1720,7 @@ hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int ty
 void cone_destroy_data(void **pcd) {
     if (!pcd || !*pcd) return;
     MiCone *c = (MiCone *) *pcd;
+    if (c->shared_ts) c->slabs = nullptr;      // one buffer, freed as T
     double *bufs[] = {c->Afull, c->Cfull, c->CL, c->Avec, c->sgn, c->S, c->Scheck, c->ydev, c->T, c->slabs, c->Gm,
                       c->U, c->V, c->Gr1, c->Ct, c->W, c->Xinv, c->Yinv};
     for (double *b : bufs)

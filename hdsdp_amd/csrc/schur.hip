@@ -530,3 +530,22 @@ int hdm_sparse_dot(const int *rp, const int *ti, const int *tj, const double *tv
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// The congruence's first step writes the lower triangle of its output's diagonal tiles only, the second step reads those
+// tiles whole (gemm_f64.hip): the strict upper part has to read as zero.  One workgroup per (matrix, diagonal tile);
+// thread t owns column pair (2t, 2t+1) of the tile... kept simple: 256 threads sweep the 128 columns, 128 rows each.
+__global__ void hdm_zero_diag_upper_kernel(double *__restrict__ T, long tstride, int n) {
+    const int tile = blockIdx.x, z = blockIdx.y;
+    const int base = tile * 128;
+    double *M = T + (long) z * tstride;
+    for (int e = threadIdx.x; e < 128 * 128; e += 256) {
+        const int i = base + (e & 127), j = base + (e >> 7);
+        if (i < j && j < n) M[i + (long) j * n] = 0.0;
+    }
+}
+int hdm_zero_diag_upper(double *T, long tstride, int n, int batch, hipStream_t s) {
+    if (batch <= 0) return 0;
+    hipLaunchKernelGGL(hdm_zero_diag_upper_kernel, dim3((n + 127) / 128, batch), dim3(256), 0, s, T, tstride, n);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -78,7 +78,13 @@ class ShardPlan:
         if byk >= 128:
             big = min(1024, byk, big_cap) & ~7
             ns = max(ns, big)
-        parts["Gram slabs (%d splits)" % ns] = ns * self.R * self.R * 8
+        slab = ns * self.R * self.R * 8
+        if self.world == 1:
+            # one GPU: T is dead when the Gram product starts, the two share one buffer of the larger size
+            tb = parts.pop("congruence intermediates T")
+            parts["congruence intermediates T / Gram slabs (%d splits), one shared buffer" % ns] = max(tb, slab)
+        else:
+            parts["Gram slabs (%d splits)" % ns] = slab
         parts["Gram matrix"] = self.R * self.R * 8
         parts["S, checker, C, dS + Cholesky / inverse of S"] = 4 * nn + 4 * npad * npad * 8
         mpad = _roundup(self.m, 128)

@@ -80,5 +80,5 @@ def test_config5_fits_the_hbm_of_eight_mi355x():
         assert parts["total"] < 0.6 * HBM, parts
         assert parts["A (A_L form, square)"] == 1000 * 2000 * 2000 * 8
     one = ShardPlan(2000, 2000, 1).hbm_bytes(0)
-    assert 120e9 < one["total"] < 200e9, one          # about 170 GB for the 32 GB problem
+    assert 110e9 < one["total"] < 140e9, one          # about 130 GB for the 32 GB problem
     assert ShardPlan(2000, 8000, 2).hbm_bytes(0)["total"] > HBM   # two ranks cannot hold it
