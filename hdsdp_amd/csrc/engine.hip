@@ -349,6 +349,7 @@ struct MiCone {
     double *Avec = nullptr;    // n16 x mloc16 rank-one factors (R1 path)
     double *sgn = nullptr;     // mloc signs (R1 path)
     int mloc16 = 0;
+    long astride = 0;          // elements per constraint matrix in Afull (skyline storage of the A_L form, hdm_common.h)
     int *sp_rp = nullptr, *sp_ti = nullptr, *sp_tj = nullptr;  // sparse path: triplets of the owned rows
     double *sp_tv = nullptr;
     int *rows_seg = nullptr;   // world*Lr: segment-ordered Gram row -> global constraint (-1 pad, -2.. aug)
@@ -447,6 +448,7 @@ hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCo
 
 int cone_alloc_common(MiCone *c) {
     c->n16 = (int) hdm_roundup(c->n, 16);
+    c->astride = hdm_sky_size(c->n16);
     c->nblk = c->n16 / 16;
     c->npb = (long) c->nblk * (c->nblk + 1) / 2 * 16;
     c->npb_loc = (c->npb + c->world - 1) / c->world;
@@ -633,7 +635,7 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
     for (int q = 0; q < c->mloc; ++q) { yo[q] = y_host ? y_host[c->own[q]] : 0.0; any |= (yo[q] != 0.0); }
     HDM_HIP_CHECK(hipMemcpyAsync(c->ydev, yo, sizeof(double) * c->mloc, hipMemcpyHostToDevice, g.stream));
     const double lead = (c->rank == 0) ? 1.0 : 0.0;
-    if (hdm_sym_combine(c->Afull, (long) c->n16 * c->n16, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
+    if (hdm_sym_combine(c->Afull, c->astride, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
                         lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)), target, c->n, c->n16, c->n16, g.stream)) return 1;
     if (c->world > 1) {
         HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
@@ -806,7 +808,7 @@ int cone_data_norms(MiCone *c, double *rows_abs, double *rows_fro, double *obj_a
         HDM_HIP_CHECK(hipMalloc((void **) &tmp, sizeof(double) * 4));
         HDM_HIP_CHECK(hipMemsetAsync(tmp, 0, sizeof(double) * 4, g.stream));
         if (c->mloc > 0)
-            hipLaunchKernelGGL(mi_low_norms_kernel, dim3(c->mloc), dim3(256), 0, g.stream, c->Afull, (long) c->n16 * c->n16,
+            hipLaunchKernelGGL(mi_low_norms_kernel, dim3(c->mloc), dim3(256), 0, g.stream, c->Afull, c->astride,
                                c->n, (long) c->n16, c->mloc, 1, tmp);
         hipLaunchKernelGGL(mi_low_norms_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, 0L, c->n, (long) c->n16, 1, 0, tmp + 2);
         double h[4];
@@ -847,7 +849,7 @@ void cone_scal(void *cd, double dScal) {
     MiCone *c = (MiCone *) cd;
     const long cnt = (long) c->n16 * c->n16;
     hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, g.stream, c->Cfull, cnt, dScal);
-    if (c->CL) hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, g.stream, c->CL, cnt, dScal);
+    if (c->CL) hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((c->astride + 255) / 256)), dim3(256), 0, g.stream, c->CL, c->astride, dScal);
     c->objScal *= dScal;
     c->norms_ready = false;
     (void) hipStreamSynchronize(g.stream);
@@ -911,7 +913,7 @@ void cone_a_times_x(void *cd, double *X, double *ATimesX) {
     if (hipMalloc((void **) &out, sizeof(double) * 2 * (size_t) c->m) != hipSuccess) return;
     (void) hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t) c->m, g.stream);
     // A is stored in A_L form: <A, X> = 2 <A_L, X> for symmetric X
-    if (hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Xup, nullptr, ldx, out, out + c->m,
+    if (hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xup, nullptr, ldx, out, out + c->m,
                      c->rows_own, 2.0, 0.0, g.stream) == 0) {
         if (c->world > 1 && c->allreduce) { (void) hipStreamSynchronize(g.stream); (void) c->allreduce(c->xctx, out, c->m); }
         std::vector<double> h(c->m);
@@ -1039,7 +1041,7 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, lo
         const int nb = std::min(c->Bc, count - b0);
         HdmGemmArgs k1 = {};
         k1.A = ch.Linv; k1.lda = ch.npad; k1.strideA = 0;
-        k1.B = Asrc + (long) b0 * astride; k1.ldb = c->n16; k1.strideB = astride; k1.b_kmajor = 1;
+        k1.B = Asrc + (long) b0 * astride; k1.ldb = c->n16; k1.strideB = astride; k1.b_kmajor = 1; k1.b_sky = 1;
         k1.C = c->T; k1.ldc = c->n16; k1.strideC = nn;
         k1.M = c->n16; k1.N = c->n16; k1.K = c->n16; k1.batch = nb; k1.alpha = 1.0;
         k1.klimit = HDM_KLIM_BAND; k1.lower_only = 1; k1.epilogue = HDM_EPI_STORE; k1.role = HDM_ROLE_CONG1;
@@ -1201,19 +1203,23 @@ hdsdp_retcode build_primal_general(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, con
     const size_t np2 = sizeof(double) * (size_t) ldx * ldx;
     if (!c->Pr1) HIP_RC(hipMalloc((void **) &c->Pr1, np2));
     if (!c->Pr2) HIP_RC(hipMalloc((void **) &c->Pr2, np2));
-    double *Mdev = kkt_Mdev(kkt, &ldm), *row = nullptr;
+    double *Mdev = kkt_Mdev(kkt, &ldm), *row = nullptr, *ALsq = nullptr;
     HIP_RC(hipMalloc((void **) &row, sizeof(double) * (size_t) m));
+    HIP_RC(hipMalloc((void **) &ALsq, sizeof(double) * (size_t) c->n16 * c->n16 + hdm_operand_pad(c->n16)));
     HdmGemmArgs q = {};
     q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE; q.ldc = ldx;
     // vectors: ASinv_i = <A_i, X>, ASinvRdSinv_i = Rd <A_i, X^2>   (Pr2 <- X X^T)
     q.A = c->Xup; q.lda = ldx; q.B = c->Xup; q.ldb = ldx; q.C = c->Pr2;
     hdsdp_retcode rc = HDSDP_RETCODE_OK;
     if (hdm_launch_gemm(q, g.stream) ||
-        hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Xup, c->Pr2, ldx, pv->vecs, pv->vecs + m,
+        hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xup, c->Pr2, ldx, pv->vecs, pv->vecs + m,
                      c->rows_own, 2.0, 2.0 * c->Rd, g.stream))
         rc = HDSDP_RETCODE_FAILED;
     for (int qi = 0; qi < c->mloc && rc == HDSDP_RETCODE_OK; ++qi) {
-        const double *AL = c->Afull + (long) qi * c->n16 * c->n16;
+        // this fallback multiplies with A_L as a generic operand in both orientations: unpack the row's skyline storage
+        // into a square scratch matrix first
+        if (hdm_sky_to_square(c->Afull + (long) qi * c->astride, ALsq, c->n16, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
+        const double *AL = ALsq;
         // Pr1 = X A_L            (B operand element (j, k) = A_L(k, j): K-major)
         q.A = c->Xup; q.lda = ldx; q.a_kmajor = 0; q.B = AL; q.ldb = c->n16; q.b_kmajor = 1; q.C = c->Pr1; q.beta = 0.0;
         if (hdm_launch_gemm(q, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
@@ -1224,12 +1230,13 @@ hdsdp_retcode build_primal_general(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, con
         q.A = c->Pr1; q.lda = ldx; q.B = c->Xup; q.ldb = ldx; q.b_kmajor = 1; q.C = c->Pr2; q.beta = 0.0;
         if (hdm_launch_gemm(q, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
         if (hipMemsetAsync(row, 0, sizeof(double) * (size_t) m, g.stream) != hipSuccess ||
-            hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Pr2, nullptr, ldx, row, row,
+            hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Pr2, nullptr, ldx, row, row,
                          c->rows_own, 2.0, 0.0, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
         hipLaunchKernelGGL(mi_put_row_kernel, dim3((m + 255) / 256), dim3(256), 0, g.stream, Mdev, ldm, c->own[qi], row, m);
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) rc = HDSDP_RETCODE_FAILED;
     (void) hipFree(row);
+    (void) hipFree(ALsq);
     if (rc != HDSDP_RETCODE_OK) return rc;
     if (c->Rd != 0.0) {                      // dTraceSinv += tr X (hdsdp_conic_sdp.c:1767-1769)
         double tr = 0.0;
@@ -1302,7 +1309,7 @@ hdsdp_retcode corrector_components(MiCone *c, HdmChol &ch, MiKKTPriv *pv, int m)
     }
     // A is stored in A_L form: <A, X> = 2 <A_L, X>
     if (c->world == 1) {
-        RC(hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, pv->vecs,
+        RC(hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, pv->vecs,
                         pv->vecs + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));
         return HDSDP_RETCODE_OK;
     }
@@ -1311,7 +1318,7 @@ hdsdp_retcode corrector_components(MiCone *c, HdmChol &ch, MiKKTPriv *pv, int m)
     // multiply what the cones before this one have put there by the number of ranks.
     if (!c->corr) HIP_RC(hipMalloc((void **) &c->corr, sizeof(double) * 2 * (size_t) m));
     HIP_RC(hipMemsetAsync(c->corr, 0, sizeof(double) * 2 * (size_t) m, g.stream));
-    RC(hdm_sym_dot2(c->Afull, (long) c->n16 * c->n16, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, c->corr,
+    RC(hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, c->corr,
                     c->corr + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));
     HIP_RC(hipStreamSynchronize(g.stream));
     if (!c->allreduce || c->allreduce(c->xctx, c->corr, (int64_t) 2 * m)) return HDSDP_RETCODE_FAILED;
@@ -1334,7 +1341,7 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     HIP_RC(hipEventRecord(g.ev[1], g.stream));
     const long nn = (long) c->n16 * c->n16;
     const long opad = (long) (hdm_operand_pad(c->n16) / sizeof(double));       // slack behind Afull / CL / T (allocation sites)
-    const long afull_span = nn * std::max(1, c->mloc) + opad;
+    const long afull_span = c->astride * std::max(1, c->mloc) + opad;
     // Multi-GPU: run step 2 of the owned rows by packed-index range, in the order of the exchange pieces, so that a piece
     // crosses the links while the later ranges are still being computed (at two ranks the all-to-all moves 8 GB per
     // rank over a single link, more than the Gram product alone can hide).  Needs the piecewise exchange hooks, all
@@ -1344,7 +1351,7 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     bool staged = c->world > 1 && P > 1 && P <= 64 && c->mloc <= c->Bc && NT <= 64;
     if (const char *e = getenv("HDSDP_MI355X_STAGED_A2A")) staged = staged && atoi(e) != 0;
     c->last_pieces = P; c->last_staged = 0;
-    if (!staged) RC(congruence_rows(c, ch, c->Afull, nn, afull_span, c->mloc, 0));
+    if (!staged) RC(congruence_rows(c, ch, c->Afull, c->astride, afull_span, c->mloc, 0));
     if (c->rank == 0) {
         // "I row": A = I => T = Linv, At = Linv Linv^T.  Reuse step 2 with T := Linv.
         HdmGemmArgs k2 = {};
@@ -1355,19 +1362,20 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
         RC(hdm_launch_gemm(k2, g.stream));
         if (typeKKT == KKT_TYPE_HOMOGENEOUS) {
             if (!c->CL) {
-                HIP_RC(hipMalloc((void **) &c->CL, sizeof(double) * (size_t) nn + hdm_operand_pad(c->n16)));
+                HIP_RC(hipMalloc((void **) &c->CL, sizeof(double) * (size_t) c->astride + hdm_operand_pad(c->n16)));
+                HIP_RC(hipMemsetAsync(c->CL, 0, sizeof(double) * (size_t) c->astride, g.stream));
                 RC(hdm_lower_half(c->Cfull, c->CL, c->n, c->n16, g.stream));
             }
-            RC(congruence_rows(c, ch, c->CL, nn, nn + opad, 1, c->mloc + 2));
+            RC(congruence_rows(c, ch, c->CL, c->astride, c->astride + opad, 1, c->mloc + 2));
         }
     }
     if (staged) {
-        RC(congruence_rows(c, ch, c->Afull, nn, afull_span, c->mloc, 0, 1));
+        RC(congruence_rows(c, ch, c->Afull, c->astride, afull_span, c->mloc, 0, 1));
         const unsigned long long all = (NT >= 64) ? ~0ULL : ((1ULL << NT) - 1);
         unsigned long long done = 0;
         for (int k = 0; k < P; ++k) {
             unsigned long long mk = (k == P - 1 ? all : piece_tile_cols(c, k, P)) & all & ~done;
-            if (mk) { RC(congruence_rows(c, ch, c->Afull, nn, afull_span, c->mloc, 0, 2, mk)); c->last_staged += 1; }
+            if (mk) { RC(congruence_rows(c, ch, c->Afull, c->astride, afull_span, c->mloc, 0, 2, mk)); c->last_staged += 1; }
             done |= mk;
             if (!c->piece_ev[k]) HIP_RC(hipEventCreateWithFlags(&c->piece_ev[k], hipEventDisableTiming));
             HIP_RC(hipEventRecord(c->piece_ev[k], g.stream));
@@ -1448,7 +1456,8 @@ __global__ void mi_low_norms_kernel(const double *__restrict__ A, long astride, 
     for (long e = threadIdx.x; e < (long) n * n; e += 256) {
         const int i = (int) (e % n), j = (int) (e / n);
         if (i < j) continue;
-        double v = M[i + (long) j * ld];
+        // A_L form lives in skyline storage (hdm_common.h), a full symmetric matrix in a plain square
+        double v = a_l_form ? M[hdm_sky_off(i, j, (int) ld)] : M[i + (long) j * ld];
         if (i == j) { if (a_l_form) v *= 2.0; sa += fabs(v); sf += v * v; }
         else { sa += 2.0 * fabs(v); sf += 2.0 * v * v; }
     }
@@ -2348,8 +2357,8 @@ static int upload_dense_rows(MiCone *c) {
     // densify every owned constraint into a full symmetric n16 x n16 matrix (via packed staging)
     const long P = (long) c->n * (c->n + 1) / 2;
     const long nn = (long) c->n16 * c->n16;
-    HDM_HIP_CHECK(hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) nn * std::max(1, c->mloc) + hdm_operand_pad(c->n16)));
-    HDM_HIP_CHECK(hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) nn * std::max(1, c->mloc)));
+    HDM_HIP_CHECK(hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc) + hdm_operand_pad(c->n16)));
+    HDM_HIP_CHECK(hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc)));
     const int chunk = (int) std::max(1L, std::min<long>(64, (256L << 20) / (P * 8)));
     double *stage_dev = nullptr, *stage_host = nullptr;
     HDM_HIP_CHECK(hipMalloc((void **) &stage_dev, sizeof(double) * (size_t) P * chunk));
@@ -2362,7 +2371,7 @@ static int upload_dense_rows(MiCone *c) {
             for (size_t e = 0; e < co.idx.size(); ++e) stage_host[(size_t) q * P + co.idx[e]] = co.val[e];
         }
         HDM_HIP_CHECK(hipMemcpyAsync(stage_dev, stage_host, sizeof(double) * (size_t) P * nc, hipMemcpyHostToDevice, g.stream));
-        if (hdm_unpack_low(stage_dev, P, c->Afull + (long) r0 * nn, nn, c->n, c->n16, nc, g.stream)) return 1;
+        if (hdm_unpack_low(stage_dev, P, c->Afull + (long) r0 * c->astride, c->astride, c->n, c->n16, nc, g.stream)) return 1;
         HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
     }
     {   // objective
@@ -2486,14 +2495,14 @@ static hdsdp_retcode make_synth_cone(MiCone **out, int nCol, int nRow, int rank,
     c->n = nCol; c->m = nRow; c->rank = rank; c->world = world; c->synthetic = true; c->path = PATH_GEMM;
     if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
     const long nn = (long) c->n16 * c->n16;
-    if (hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) nn * std::max(1, c->mloc) + hdm_operand_pad(c->n16)) != hipSuccess) {
+    if (hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc) + hdm_operand_pad(c->n16)) != hipSuccess) {
         fprintf(stderr, "[hdsdp_mi355x] cannot allocate %.1f GiB for the constraint matrices\n",
-                (double) nn * c->mloc * 8 / (1 << 30));
+                (double) c->astride * c->mloc * 8 / (1 << 30));
         return HDSDP_RETCODE_MEMORY;
     }
-    if (hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) nn * std::max(1, c->mloc)) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    if (hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc)) != hipSuccess) return HDSDP_RETCODE_FAILED;
     for (int q = 0; q < c->mloc; ++q)  // owned rows are strided in the global numbering
-        if (hdm_synth_fill_low(c->Afull + (long) q * nn, nn, c->n, c->n16, c->own[q], 1, g.stream)) return HDSDP_RETCODE_FAILED;
+        if (hdm_synth_fill_low(c->Afull + (long) q * c->astride, c->astride, c->n, c->n16, c->own[q], 1, g.stream)) return HDSDP_RETCODE_FAILED;
     if (hdm_synth_obj(c->Cfull, c->n, c->n16, c->m, g.stream)) return HDSDP_RETCODE_FAILED;
     // b_i = tr(A_i): diagonal draws only (host, m*n splitmix evaluations)
     c->trA = (double *) calloc(nRow, sizeof(double));

@@ -391,8 +391,16 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     Stager<AKM> stA;
     Stager<BKM> stB;
     // VAR & 128: timing-only ablation (wrong results): every tile stages rows 0..127, so all operand traffic hits in L2
+    long ldb = a.ldb;
+    if (ROLE == HDM_ROLE_CONG1 && a.b_sky) {
+        // A_L in skyline storage (hdm_common.h): tile column tn reads panel tn, a plain K-major matrix of leading dimension
+        // N - 128 tn whose element (row 128 tn, k 128 tn) sits at the panel's start -- the pointer is moved back so that
+        // the stager's absolute (row, k) arithmetic lands there
+        ldb = a.N - 128L * tn;
+        B += hdm_sky_panel(tn, a.N) - 128L * tn * (ldb + 1);
+    }
     stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, (VAR & 128) ? 0 : m0, kt0, tid);
-    stB.init(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, (VAR & 128) ? 0 : n0, kt0, tid);
+    stB.init(B, ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, (VAR & 128) ? 0 : n0, kt0, tid);
     const int npass = a.A2 ? 2 : 1;
     if (a.A2) {
         stA.chain(a.A2 + (long) z * a.strideA2, a.lda2, m0, kt0, tid, kt1 - kt0);
@@ -788,7 +796,14 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
             {args.B2, args.spanB2, args.b_kmajor != 0, args.ldb2, (long) HDM_BK, args.strideB2, args.N, "B2"}};
         for (auto &o : ops) {
             if (!o.p) continue;
-            const long need = farthest(o.km, o.ld, o.kblk, o.stride, o.rows, true);
+            long need = farthest(o.km, o.ld, o.kblk, o.stride, o.rows, true);
+            if (o.p == args.B && args.b_sky) {
+                // skyline operand: the last panel (width w < 128 columns, height w) is read as 128 "rows" of its leading
+                // dimension, i.e. up to (128 - w) columns' worth past the matrix
+                const int t = (args.N + HDM_TILE - 1) / HDM_TILE - 1;
+                const long h = args.N - 128L * t;
+                need = (long) (args.batch - 1) * args.strideB + hdm_sky_panel(t, args.N) + 127 * h + h;
+            }
             if (o.span < need) {
                 fprintf(stderr, "[hdsdp_mi355x] gemm role %d: operand %s needs %ld readable elements for its unmasked tile "
                                 "loads, the caller vouches for %ld: launch refused\n", args.role, o.nm, need, o.span);

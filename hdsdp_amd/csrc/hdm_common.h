@@ -19,6 +19,25 @@ static inline size_t hdm_operand_pad(long ld) { return (size_t) 128 * (size_t) (
 
 typedef double hdm_d4 __attribute__((ext_vector_type(4)));
 
+// "Skyline" storage of a matrix in A_L form (strict lower triangle + half the diagonal; the constraint matrices and the
+// objective as the congruence reads them): only the 128-column panels from their diagonal block downwards are stored --
+// panel t holds rows 128 t .. n-1 of columns 128 t .. 128 t + 127 as a plain column-major (n - 128 t) x 128 matrix, the
+// panels follow each other.  53 % of the square at n = 2000 (34 GB instead of 64 GB for 2000 matrices); inside a panel
+// every column is contiguous and 128-byte aligned (n is a multiple of 16), so tile loads stay full lines, and the one
+// GEMM operand that reads A_L (congruence step 1, B side: rows = columns of panel tn, k = rows from the panel's top)
+// sees panel tn as an ordinary K-major matrix with leading dimension n - 128 tn.  The strict upper triangle of each
+// panel's top block is stored and stays zero.
+__host__ __device__ inline long hdm_sky_panel(int t, int n) { return 128L * ((long) t * n - 64L * t * (t - 1)); }   // start of panel t
+__host__ __device__ inline long hdm_sky_off(int i, int j, int n) {   // element (i, j), i >= 128 * (j / 128)
+    const int t = j >> 7;
+    return hdm_sky_panel(t, n) + (long) (j & 127) * (n - 128 * t) + (i - 128 * t);
+}
+__host__ __device__ inline long hdm_sky_size(int n) {                // elements of one matrix
+    const int t = (n + 127) / 128 - 1;
+    const long w = n - 128L * t;
+    return hdm_sky_panel(t, n) + w * w;
+}
+
 #define HDM_HIP_CHECK(expr)                                                                     \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \
@@ -70,6 +89,7 @@ struct HdmGemmArgs {
     // same shapes, storage classes and K range as the first pair; A2 == nullptr: single product
     const double *A2, *B2;
     long lda2, ldb2, strideA2, strideB2;
+    int b_sky;        // congruence step 1: the B operand is a batch of skyline-stored A_L matrices (N = their dimension)
     // roles 1-3 (unmasked tile loads): elements readable from each operand pointer, slack included; checked at launch
     long spanA, spanB, spanA2, spanB2;
     long lda, ldb, ldc;

@@ -26,3 +26,5 @@ int hdm_synth_fill_low(double *full, long fstride, int n, int ld, int c0, int ba
 int hdm_lower_half(const double *full, double *low, int n, long ld, hipStream_t s);
 // strict upper triangle of the 128 x 128 diagonal tiles of `batch` column-major n x n matrices (ld = n) <- 0
 int hdm_zero_diag_upper(double *T, long tstride, int n, int batch, hipStream_t s);
+// one skyline-stored A_L matrix (hdm_common.h) -> square column-major n x n
+int hdm_sky_to_square(const double *sky, double *sq, int n, hipStream_t s);

@@ -74,10 +74,10 @@ __device__ __forceinline__ void write_low_tile(const Src &src, double *__restric
     const int tx = threadIdx.x, ty = threadIdx.y;
     for (int jj = ty; jj < 32; jj += 8) {
         const int i = ti * 32 + tx, j = tj * 32 + jj;
-        if (i < ld && j < ld) {
+        if (i < ld && j < ld && i >= (j & ~127)) {      // skyline storage (hdm_common.h): nothing above a panel's top block
             double v = 0.0;
             if (i < n && j < n && i >= j) v = (i == j) ? 0.5 * src(i, j) : src(i, j);
-            dst[i + (long) j * ld] = v;
+            dst[hdm_sky_off(i, j, (int) ld)] = v;
         }
     }
 }
@@ -100,14 +100,15 @@ __global__ __launch_bounds__(256) void hdm_synth_low_kernel(double *__restrict__
     write_low_tile(s, full + (long) blockIdx.y * fstride, (long) ld, n, tj + t, tj);
 }
 
-// full symmetric -> A_L form (objective matrix)
+// full symmetric -> A_L form in skyline storage (objective matrix)
 __global__ void hdm_lower_half_kernel(const double *__restrict__ full, double *__restrict__ low, int n, long ld) {
     long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long) ld * ld) return;
     int i = (int) (e % ld), j = (int) (e / ld);
+    if (i < (j & ~127)) return;
     double v = 0.0;
     if (i < n && j < n && i >= j) v = (i == j) ? 0.5 * full[e] : full[e];
-    low[e] = v;
+    low[hdm_sky_off(i, j, (int) ld)] = v;
 }
 
 __global__ __launch_bounds__(256) void hdm_unpack_sym_kernel(const double *__restrict__ packed, long pstride,
@@ -232,11 +233,11 @@ __global__ void hdm_sym_combine_kernel(const double *__restrict__ A, long astrid
     if (e >= (long) n * n) return;
     int i = (int) (e % n), j = (int) (e / n);
     if (i < j) return;
-    long off = i + (long) j * lda;
+    const long off = hdm_sky_off(i, j, (int) lda);   // the constraint matrices: A_L form (half diagonal), skyline storage of dimension lda
     double acc = 0.0;
     for (int c = 0; c < m; ++c) acc -= y[c] * A[(long) c * astride + off];
-    if (i == j) acc *= 2.0;  // the constraint matrices are stored in A_L form (half diagonal)
-    acc += tau * C[off];
+    if (i == j) acc *= 2.0;
+    acc += tau * C[i + (long) j * lda];
     if (i == j) acc += eye;
     S[i + (long) j * lds_] = acc;
 }
@@ -294,11 +295,12 @@ __global__ __launch_bounds__(256) void hdm_sym_dot2_kernel(const double *__restr
     for (int q = 0; q < DOT2_G; ++q) { ax[q] = 0.0; ay[q] = 0.0; }
     for (int j = j0; j < j1; ++j) {
         const double *xc = X + (long) j * ldx, *yc = Y ? Y + (long) j * ldx : nullptr;
+        const long cj = hdm_sky_off(0, j, (int) lda);      // column j of a skyline-stored A_L matrix (element (i, j) at cj + i)
         for (int i = j + threadIdx.x; i < n; i += 256) {
             const double x = xc[i], y = yc ? yc[i] : 0.0;
 #pragma unroll
             for (int q = 0; q < DOT2_G; ++q) {
-                const double a = Aq[q][i + (long) j * lda];
+                const double a = Aq[q][cj + i];
                 ax[q] += a * x;
                 ay[q] += a * y;
             }
@@ -546,6 +548,20 @@ __global__ void hdm_zero_diag_upper_kernel(double *__restrict__ T, long tstride,
 int hdm_zero_diag_upper(double *T, long tstride, int n, int batch, hipStream_t s) {
     if (batch <= 0) return 0;
     hipLaunchKernelGGL(hdm_zero_diag_upper_kernel, dim3((n + 127) / 128, batch), dim3(256), 0, s, T, tstride, n);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// skyline-stored A_L matrix -> square column-major n x n (ld = n), zeros above the diagonal blocks' lower part
+__global__ void hdm_sky_to_square_kernel(const double *__restrict__ sky, double *__restrict__ sq, int n) {
+    const long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long) n * n) return;
+    const int i = (int) (e % n), j = (int) (e / n);
+    sq[e] = (i >= (j & ~127)) ? sky[hdm_sky_off(i, j, n)] : 0.0;
+}
+int hdm_sky_to_square(const double *sky, double *sq, int n, hipStream_t s) {
+    const long tot = (long) n * n;
+    hipLaunchKernelGGL(hdm_sky_to_square_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, sky, sq, n);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -47,7 +47,10 @@ class ShardPlan:
         n16, nn = self.n16, self.n16 * self.n16 * 8
         npad = _roundup(self.n, 128)
         mloc = len(self.owned(rank))
-        parts = {"A (A_L form, square)": mloc * nn}
+        # constraint matrices: A_L form in skyline storage (csrc/hdm_common.h): 128-column panels from the diagonal down
+        t = (n16 + 127) // 128 - 1
+        sky = 128 * (t * n16 - 64 * t * (t - 1)) + (n16 - 128 * t) ** 2
+        parts = {"A (A_L form, skyline)": mloc * sky * 8}
         bc = max(1, min(int(tcap_gib * (1 << 30) / nn), 1024))
         launches = -(-max(1, mloc) // bc)
         bc = -(-max(1, mloc) // launches)

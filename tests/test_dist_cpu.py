@@ -78,7 +78,7 @@ def test_config5_fits_the_hbm_of_eight_mi355x():
     for rank in (0, 7):
         parts = ShardPlan(2000, 8000, 8).hbm_bytes(rank)
         assert parts["total"] < 0.6 * HBM, parts
-        assert parts["A (A_L form, square)"] == 1000 * 2000 * 2000 * 8
+        assert 0.52 * 1000 * 2000 * 2000 * 8 < parts["A (A_L form, skyline)"] < 0.55 * 1000 * 2000 * 2000 * 8
     one = ShardPlan(2000, 2000, 1).hbm_bytes(0)
-    assert 110e9 < one["total"] < 140e9, one          # about 130 GB for the 32 GB problem
-    assert ShardPlan(2000, 8000, 2).hbm_bytes(0)["total"] > HBM   # two ranks cannot hold it
+    assert 90e9 < one["total"] < 110e9, one           # about 100 GB for the 32 GB problem
+    assert ShardPlan(2000, 8000, 2).hbm_bytes(0)["total"] < HBM < ShardPlan(2000, 8000, 1).hbm_bytes(0)["total"] * 2
