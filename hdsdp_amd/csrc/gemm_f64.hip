@@ -330,6 +330,111 @@ __device__ __forceinline__ void cell_tile(const HdmGemmArgs &a, Stager<AKM> &stA
     cell_epilogue<T>(a, z, m0, n0, l15, lq, rv, tri, acc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Congruence step 2's main tiles without LDS and without barriers ("direct" body).
+//
+// Both operands of step 2 (U = the step-1 output T, and W = Linv) are M-major: the 16 rows of an MFMA sub-tile are 128
+// consecutive bytes, so the fragment the MFMA wants from lane l -- element (row l & 15, k + (l >> 4)) -- is ONE
+// global_load_dwordx2 per lane whose 64 lanes cover four full 128-byte lines.  The f64 MFMA is slow enough (16 x 16 x 4 in
+// 64 cycles) that a wave needs only 8 such loads per 16 MFMAs, which L1/L2 deliver with room to spare; so each wave
+// streams its own fragments straight into registers, two k-steps (32 MFMAs, > 2000 cycles) ahead, and never meets its
+// siblings: no LDS image, no __syncthreads.  In the LDS kernel a wave parks at one barrier per 64 MFMAs waiting for the
+// slowest of its three siblings, each of which shares its SIMD with a wave of the co-resident workgroup; whenever both
+// waves of a SIMD are parked the matrix pipe idles (MFMA busy 87 % in profiles/r02_a).  Here the only thing a wave ever
+// waits for is its own loads.  The price is L1/L2 request traffic: a row panel is fetched by the two waves that own
+// its sub-tiles instead of once per workgroup.
+// Tiles: tm > tn, all 128 rows valid; the diagonal and bottom-edge tiles of the same launch keep the cell-dealt LDS
+// paths (hdm_gemm_kernel calls this body where its LDS main loop used to be, VAR & 256).  K loop: both products over k < (tn + 1) * 128 in macro-steps of 8 k; the sixteen macro-steps
+// of the last K block (the B-side operand's diagonal block) run only the live column sub-tiles, as in the LDS kernel.
+// ---------------------------------------------------------------------------------------------
+template <int JLO>
+__device__ __forceinline__ void cd_mma(hdm_d4 (&acc)[4][4], const double (&fa)[4], const double (&fb)[4]) {
+#pragma unroll
+    for (int j = JLO; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
+}
+
+__device__ __forceinline__ void cong2_direct_body(const HdmGemmArgs &a, int z, int tm, int tn, int wm, int wn, int l15, int lq) {
+    const int m0 = tm * HDM_TILE, n0 = tn * HDM_TILE;
+    hdm_d4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
+
+    // product 1: rows of U (tile tm) x rows of W (tile tn); product 2: rows of W (tile tm) x rows of U (tile tn)
+    const double *U = a.A + (long) z * a.strideA;      // T_z, M-major, ld = lda
+    const double *W = a.B;                             // Linv, M-major, ld = ldb (shared by the batch)
+    const long ldu = a.lda, ldw = a.ldb;
+    const int nms_full = tn * 16;                      // macro-steps (8 k each) before the last K block, per product
+
+    double fa0[4], fb0[4], fa1[4], fb1[4], fa2[4], fb2[4], fa3[4], fb3[4];   // set A = (0,1): k-steps 0,1 of a macro-step; set B = (2,3)
+#define CD_LOAD(FA, FB, pr, pc)                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) FB[i] = (pr)[32 * i];                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) FA[j] = (pc)[32 * j];
+    for (int prod = 0; prod < 2; ++prod) {
+        const double *R = prod == 0 ? U : W, *C = prod == 0 ? W : U;
+        const long ldr = prod == 0 ? ldu : ldw, ldc = prod == 0 ? ldw : ldu;
+        // this lane's element of row sub-tile (2i + wm) / column sub-tile (2j + wn) at k = lq: + 32 * i doubles per sub-tile
+        const double *pr = R + (m0 + wm * 16 + l15) + (long) lq * ldr;
+        const double *pc = C + (n0 + wn * 16 + l15) + (long) lq * ldc;
+        const long r4 = 4 * ldr, c4 = 4 * ldc;
+        // macro-step 0 into set A
+        CD_LOAD(fa0, fb0, pr, pc) CD_LOAD(fa1, fb1, pr + r4, pc + c4)
+        pr += 2 * r4; pc += 2 * c4;
+        // full macro-steps come in pairs (A then B); nms_full is even
+        for (int ms = 0; ms < nms_full; ms += 2) {
+            CD_LOAD(fa2, fb2, pr, pc) CD_LOAD(fa3, fb3, pr + r4, pc + c4)
+            pr += 2 * r4; pc += 2 * c4;
+            __builtin_amdgcn_sched_barrier(0);
+            cd_mma<0>(acc, fa0, fb0); cd_mma<0>(acc, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            CD_LOAD(fa0, fb0, pr, pc) CD_LOAD(fa1, fb1, pr + r4, pc + c4)
+            pr += 2 * r4; pc += 2 * c4;
+            __builtin_amdgcn_sched_barrier(0);
+            cd_mma<0>(acc, fa2, fb2); cd_mma<0>(acc, fa3, fb3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // last K block: 16 macro-steps h = 0..15 (k = n0 + 8h ..): column sub-tiles below h / 4 (in the wave's own
+        // numbering: 2j + wn < h / 2) are structurally zero rows of the triangular operand
+#define CD_PAIR(JA, JB, LAST)                                                             \
+        CD_LOAD(fa2, fb2, pr, pc) CD_LOAD(fa3, fb3, pr + r4, pc + c4)                     \
+        pr += 2 * r4; pc += 2 * c4;                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        cd_mma<JA>(acc, fa0, fb0); cd_mma<JA>(acc, fa1, fb1);                             \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (!(LAST)) { CD_LOAD(fa0, fb0, pr, pc) CD_LOAD(fa1, fb1, pr + r4, pc + c4) pr += 2 * r4; pc += 2 * c4; } \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        cd_mma<JB>(acc, fa2, fb2); cd_mma<JB>(acc, fa3, fb3);                             \
+        __builtin_amdgcn_sched_barrier(0);
+        // macro-steps (0,1) (2,3) ... (14,15): stage s = h / 2 of the LDS kernel keeps column sub-tiles j >= s / 2
+        CD_PAIR(0, 0, false) CD_PAIR(0, 0, false) CD_PAIR(1, 1, false) CD_PAIR(1, 1, false)
+        CD_PAIR(2, 2, false) CD_PAIR(2, 2, false) CD_PAIR(3, 3, false) CD_PAIR(3, 3, true)
+#undef CD_PAIR
+    }
+#undef CD_LOAD
+    // epilogue: the 16x16-blocked, sqrt(2)-weighted layout of the congruence output (same as the LDS kernel's)
+    const long rs16 = a.blk_row_stride * 16;
+    double *lane_base = a.C + (a.blk_row0 + z) * 16 + l15 + (long) lq * rs16;
+    const double rt2 = 1.4142135623730951;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bi = (m0 >> 4) + 2 * i + wm;
+            const int bj = (n0 >> 4) + 2 * j + wn;
+            if (bi < bj || bi >= a.nblk) continue;
+            const double sc = (bi == bj) ? 1.0 : rt2;
+            const long sub = (long) bj * a.nblk - (long) bj * (bj - 1) / 2 + (bi - bj);
+            double *q = lane_base + sub * 16 * rs16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[(long) (4 * r) * rs16] = sc * acc[j][i][r];
+        }
+    }
+}
+
+
 template <bool AKM, bool BKM, int ROLE, int VAR>
 __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     __shared__ __attribute__((aligned(16))) double smem[4 * STAGE_DOUBLES];
@@ -436,6 +541,12 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         return;
     }
 
+    if constexpr (ROLE == HDM_ROLE_CONG2 && (VAR & 256) != 0) {
+        // main tile of congruence step 2 (tm > tn, 128 valid rows; the two cell paths above took the others): fragments
+        // straight from global memory, no LDS image, no barrier
+        cong2_direct_body(a, z, tm, tn, wm, wn, l15, lq);
+        return;
+    }
     auto compute = [&](const double *cA, const double *cB) {
 
 #pragma unroll
@@ -703,6 +814,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     stamp_end();
 }
 
+
 // ---------------------------------------------------------------------------------------------
 // host side: tile lists (heaviest first) cached in device memory
 // ---------------------------------------------------------------------------------------------
@@ -720,12 +832,14 @@ struct TileList {
 std::mutex g_tl_mutex;
 std::map<std::tuple<int, int, int, int, int, unsigned long long>, TileList> g_tl_cache;
 
-int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long colmask, TileList &out) {
+// subset: 0 = all tiles; 1 = main tiles only (below the diagonal, all 128 rows valid: rows = the M dimension);
+// 2 = the others (diagonal and bottom-edge tiles)
+int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long colmask, TileList &out, int subset = 0, int rows = 0) {
     int dev = 0;
     HDM_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_tl_mutex);
     if (NT > 64) colmask = 0;
-    auto key = std::make_tuple(dev, MT, NT, klimit, lower_only, colmask);
+    auto key = std::make_tuple(dev, MT, NT, klimit + 16 * subset + 64 * (subset ? rows : 0), lower_only, colmask);
     auto it = g_tl_cache.find(key);
     if (it != g_tl_cache.end()) {
         out = it->second;
@@ -736,6 +850,10 @@ int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long col
         for (int tn = 0; tn < NT; ++tn) {
             if (lower_only && tm < tn) continue;
             if (colmask && !((colmask >> tn) & 1ULL)) continue;
+            if (subset) {
+                const bool main_tile = (tm > tn) && ((tm + 1) * HDM_TILE <= rows);
+                if ((subset == 1) != main_tile) continue;
+            }
             long w = 1;
             if (klimit == HDM_KLIM_BY_M) w = tm + 1;
             if (klimit == HDM_KLIM_BY_N) w = tn + 1;
@@ -849,7 +967,23 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     const int g_var = g_env_var >= 0 ? g_env_var : 64;   // default: the rotated, explicitly interleaved loop
     switch (args.role) {
         case HDM_ROLE_CONG1: HDM_LAUNCH_V(false, true, HDM_ROLE_CONG1); break;   // U = Linv * A_L (A_L k-contiguous)
-        case HDM_ROLE_CONG2: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG2); break;  // At = U Linv^T + Linv U^T
+        case HDM_ROLE_CONG2: {
+            // HDM_CONG2_DIRECT=1: the main tiles of step 2 take the LDS-free, barrier-free body (cong2_direct_body,
+            // VAR 64 + 256) instead of the LDS loop.  Measured on one box, same build (profiles/r02_b_direct_ab.txt): alone
+            // on the chip the body keeps the matrix pipe 91 % busy against the LDS kernel's 88 %, but the chip answers with
+            // a lower clock (2.33 vs 2.37 GHz) and the step time is the same to 0.3 % (165.5 vs 165.1 ms for step 2) --
+            // barriers and LDS are NOT what holds this kernel at 0.82 of the fp64 peak.  Bit-identical results, all
+            // parity tests green with it; kept as an A/B switch, off by default.  The body assumes the SYR2K form the
+            // engine launches: U x W^T + W x U^T, both M-major, blocked epilogue, K limit by column tile.
+            static int g_direct = -1;
+            if (g_direct < 0) { const char *e = getenv("HDM_CONG2_DIRECT"); g_direct = e ? atoi(e) : 0; }
+            const bool direct = g_direct && g_var == 64 && args.A2 && !args.a_kmajor && !args.b_kmajor &&
+                                args.epilogue == HDM_EPI_BLOCKED && args.lower_only && args.klimit == HDM_KLIM_BY_N &&
+                                args.A2 == args.B && args.B2 == args.A;
+            if (direct) HDM_LAUNCH(false, false, HDM_ROLE_CONG2, 320);
+            else HDM_LAUNCH_V(false, false, HDM_ROLE_CONG2);
+            break;
+        }
         case HDM_ROLE_GRAM: HDM_LAUNCH_V(true, true, HDM_ROLE_GRAM); break;      // M = Ahat Ahat^T
         default:
             if (lay == 3) HDM_LAUNCH(true, true, HDM_ROLE_GENERIC, 0);
