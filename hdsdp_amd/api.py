@@ -36,7 +36,7 @@ EXPORTS = [
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
     "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
-    "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats",
+    "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
     "HMiMfmaPeakProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
@@ -162,6 +162,8 @@ def load_library():
         "HMiGetCallStats": (C.c_int, [dp, C.POINTER(C.c_int64), C.c_int]),
         "HMiCallStatName": (C.c_char_p, [C.c_int]),
         "HMiResetCallStats": (None, []),
+        "HMiKKTPhaseAEligible": (C.c_int, [kp]),
+        "HMiKKTPhaseA": (C.c_int, [kp, C.c_double, dp, dp, dp, dp, dp, ip, dp]),
         "HMiDeviceInit": (C.c_int, [C.c_int]),
         "HMiDeviceSynchronize": (C.c_int, []),
         "HMiStream": (vp, []),
@@ -467,6 +469,20 @@ class KKT:
         sol = np.zeros_like(rhs)
         _check(load_library().HKKTSolve(self._k, _dptr(rhs), _dptr(sol)), "HKKTSolve")
         return sol
+
+    def phase_a_eligible(self):
+        return bool(load_library().HMiKKTPhaseAEligible(self._k))
+
+    def phase_a(self, tau, y, rhs):
+        """HMiKKTPhaseA: interior check + INFEASIBLE build + factorisation + the three solves in ONE launch (small rank-one
+        blocks).  Returns (is_interior, logdet S, d1, d2, d3); the operator's host fields are filled as after build_up."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        d1, d2, d3 = (np.zeros(self.m) for _ in range(3))
+        ok, ld = C.c_int(0), C.c_double(0.0)
+        _check(load_library().HMiKKTPhaseA(self._k, float(tau), _dptr(y), _dptr(rhs), _dptr(d1), _dptr(d2), _dptr(d3),
+                                           C.byref(ok), C.byref(ld)), "HMiKKTPhaseA")
+        return bool(ok.value), ld.value, d1, d2, d3
 
     def regularize(self, reg):
         load_library().HKKTRegularize(self._k, float(reg))

@@ -13,8 +13,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libhdsdp_mi355x.so")
-SOURCES = ["gemm_f64.hip", "chol.hip", "schur.hip", "lanczos.hip", "lu.hip", "engine.hip", "coeff.cpp", "sdpa.cpp"]
-HEADERS = ["hdm_common.h", "chol.h", "schur.h", "lanczos.h", "lu.h", "coeff.h", "group_impl.h", os.path.join(ROOT, "include", "hdsdp_mi355x.h")]
+SOURCES = ["gemm_f64.hip", "chol.hip", "schur.hip", "lanczos.hip", "lu.hip", "small.hip", "engine.hip", "coeff.cpp", "sdpa.cpp"]
+HEADERS = ["hdm_common.h", "chol.h", "schur.h", "lanczos.h", "lu.h", "coeff.h", "group_impl.h", "small.h", os.path.join(ROOT, "include", "hdsdp_mi355x.h")]
 
 
 def _stale(target, deps):

@@ -19,6 +19,7 @@
 #include "schur.h"
 #include "lanczos.h"
 #include "lu.h"
+#include "small.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -396,6 +397,14 @@ struct MiCone {
     // writes into it, the others stop after the all-reduce
     bool kkt_owner = true;
     int kkt_counted = 0;       // progress of the aggregated-pattern queries (cone_add_sym_nz)
+    // fused single-launch Phase-A pass of a small rank-one block (small.hip): factors as a CSR, built on first use
+    struct SmallPlan {
+        int state = 0;         // 0 = not looked at, 1 = ready, -1 = not eligible
+        int *fp = nullptr, *fi = nullptr, *dense_of = nullptr, *dense_rows = nullptr;
+        double *fv = nullptr, *sgn = nullptr;
+        int ndense = 0;
+        double *io_host = nullptr, *io_dev = nullptr;   // mapped pinned block: y[m], b[m] in; 4 + 5 m doubles out
+    } small;
 };
 
 struct MiKKTPriv {
@@ -1746,6 +1755,10 @@ void cone_destroy_data(void **pcd) {
     if (c->rows_own) (void) hipFree(c->rows_own);
     if (c->trA) free(c->trA);
     if (c->yhost) (void) hipHostFree(c->yhost);
+    { int *ip[] = {c->small.fp, c->small.fi, c->small.dense_of, c->small.dense_rows}; for (int *q : ip) if (q) (void) hipFree(q); }
+    if (c->small.fv) (void) hipFree(c->small.fv);
+    if (c->small.sgn) (void) hipFree(c->small.sgn);
+    if (c->small.io_host) (void) hipHostFree(c->small.io_host);
     if (c->corr) (void) hipFree(c->corr);
     HFpLinsysDestroy(&c->dualFactor);
     if (c->primal) { c->primal->destroy(); delete c->primal; }
@@ -2669,6 +2682,118 @@ void HMiConeGetGroupTraffic(hdsdp_cone *cone, int64_t *bytesAllToAll, int64_t *b
     if (bytesAllToAll) *bytesAllToAll = a;
     if (bytesAllReduce) *bytesAllReduce = b;
 }
+// ---------------------------------------------------------------- fused small-block Phase-A pass (small.hip)
+static int small_plan(MiCone *c) {
+    MiCone::SmallPlan &sp = c->small;
+    if (sp.state) return sp.state;
+    sp.state = -1;
+    if (c->path != PATH_R1 || c->world != 1 || c->synthetic || c->n > SMALL_P || c->mloc != c->m || c->m > SMALL_P) return -1;
+    const int n = c->n, m = c->m;
+    std::vector<int> fp(m + 1, 0), fi, dense_of(m, -1), dense_rows;
+    std::vector<double> fv, sg(m, 0.0);
+    for (int q = 0; q < m; ++q) {
+        const MiCoeff &co = c->blk.rows[c->own[q]];
+        if (co.type != MI_COEFF_SPR1 && co.type != MI_COEFF_DSR1) return -1;
+        int nz = 0;
+        for (int r = 0; r < n; ++r) nz += (co.factor[r] != 0.0);
+        sg[q] = co.sign;
+        if (nz > SMALL_SPMAX) {                       // dense factor: all n entries, in order
+            if ((int) dense_rows.size() >= SMALL_NDENSE) return -1;
+            dense_of[q] = (int) dense_rows.size();
+            dense_rows.push_back(q);
+            for (int r = 0; r < n; ++r) { fi.push_back(r); fv.push_back(co.factor[r]); }
+        } else {
+            for (int r = 0; r < n; ++r) if (co.factor[r] != 0.0) { fi.push_back(r); fv.push_back(co.factor[r]); }
+        }
+        fp[q + 1] = (int) fi.size();
+    }
+    dense_rows.resize(SMALL_NDENSE, 0);
+    const size_t nf = std::max<size_t>(1, fi.size());
+    if (hipMalloc((void **) &sp.fp, sizeof(int) * (m + 1)) != hipSuccess || hipMalloc((void **) &sp.fi, sizeof(int) * nf) != hipSuccess ||
+        hipMalloc((void **) &sp.fv, sizeof(double) * nf) != hipSuccess || hipMalloc((void **) &sp.sgn, sizeof(double) * m) != hipSuccess ||
+        hipMalloc((void **) &sp.dense_of, sizeof(int) * m) != hipSuccess ||
+        hipMalloc((void **) &sp.dense_rows, sizeof(int) * SMALL_NDENSE) != hipSuccess ||
+        hipHostMalloc((void **) &sp.io_host, sizeof(double) * (7 * (size_t) m + 8), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **) &sp.io_dev, sp.io_host, 0) != hipSuccess)
+        return -1;
+    if (hdm_memcpy_h2d_sync(sp.fp, fp.data(), sizeof(int) * (m + 1)) != hipSuccess ||
+        (fi.size() && (hdm_memcpy_h2d_sync(sp.fi, fi.data(), sizeof(int) * fi.size()) != hipSuccess ||
+                       hdm_memcpy_h2d_sync(sp.fv, fv.data(), sizeof(double) * fv.size()) != hipSuccess)) ||
+        hdm_memcpy_h2d_sync(sp.sgn, sg.data(), sizeof(double) * m) != hipSuccess ||
+        hdm_memcpy_h2d_sync(sp.dense_of, dense_of.data(), sizeof(int) * m) != hipSuccess ||
+        hdm_memcpy_h2d_sync(sp.dense_rows, dense_rows.data(), sizeof(int) * SMALL_NDENSE) != hipSuccess)
+        return -1;
+    sp.ndense = 0;
+    for (int q = 0; q < m; ++q) sp.ndense += (dense_of[q] >= 0);
+    sp.state = 1;
+    return 1;
+}
+
+int HMiKKTPhaseAEligible(hdsdp_kkt *HKKT) {
+    if (!HKKT || HKKT->nCones != 1 || HKKT->isKKTSparse) return 0;
+    hdsdp_cone *hc = HKKT->cones[0];
+    if (hc->coneBuildSchur != cone_build_schur) return 0;
+    MiCone *c = (MiCone *) hc->coneData;
+    return (c->m == HKKT->nRow && small_plan(c) == 1) ? 1 : 0;
+}
+
+hdsdp_retcode HMiKKTPhaseA(hdsdp_kkt *HKKT, double barHsdTau, double *rowDual, double *rhs, double *d1, double *d2, double *d3,
+                           int *isInterior, double *logdet) {
+    StatScope stat_(ST_BUILD_M, __func__);
+    if (!HMiKKTPhaseAEligible(HKKT)) return HDSDP_RETCODE_FAILED;
+    MiCone *c = (MiCone *) HKKT->cones[0]->coneData;
+    MiCone::SmallPlan &sp = c->small;
+    MiKKTPriv *pv = priv_of(HKKT);
+    MiLin *ls = (MiLin *) c->dualFactor->chol, *lm = (MiLin *) HKKT->kktM->chol;
+    const int m = c->m, n = c->n;
+    HIP_RC(hipStreamSynchronize(g.stream));            // the mapped block is about to be rewritten
+    double *yin = sp.io_host, *bin = sp.io_host + m, *out = sp.io_host + 2 * (size_t) m;
+    for (int i = 0; i < m; ++i) { yin[i] = rowDual ? rowDual[i] : 0.0; bin[i] = rhs ? rhs[i] : 0.0; }
+    out[0] = -1.0;
+    HdmSmallArgs a = {};
+    a.n = n; a.m = m; a.C = c->Cfull; a.ldc = c->n16;
+    a.fp = sp.fp; a.fi = sp.fi; a.fv = sp.fv; a.sgn = sp.sgn; a.dense_of = sp.dense_of; a.ndense = sp.ndense; a.dense_rows = sp.dense_rows;
+    a.y = sp.io_dev; a.b = sp.io_dev + m; a.out = sp.io_dev + 2 * (size_t) m;
+    a.tau = barHsdTau; a.eye = -c->Rd + c->perturb; a.Rd = c->Rd;
+    a.Sout = c->S; a.lds = c->n16;
+    a.LS = ls->ch.L; a.WS = ls->ch.Dinv; a.M = lm->Mdev; a.ldm = lm->ch.npad; a.LM = lm->ch.L; a.WM = lm->ch.Dinv;
+    if (ls->ch.npad != SMALL_P || lm->ch.npad != SMALL_P) return HDSDP_RETCODE_FAILED;
+    // the operator's accumulators as HKKTBuildUp(KKT_TYPE_INFEASIBLE) leaves them (hdsdp_schur.c:141-165, :256-268)
+    HIP_RC(hipMemsetAsync(lm->Mdev, 0, sizeof(double) * (size_t) SMALL_P * SMALL_P, g.stream));
+    RC(hdm_small_phase_a(a, g.stream));
+    if (pv->mirror)
+        HIP_RC(hipMemcpy2DAsync(HKKT->kktMatElem, sizeof(double) * m, lm->Mdev, sizeof(double) * SMALL_P, sizeof(double) * m, m,
+                                hipMemcpyDeviceToHost, g.stream));
+    HIP_RC(hipStreamSynchronize(g.stream));
+    const int infoS = (int) out[0], infoM = (int) out[1];
+    ls->ch.factored = (infoS == 0); ls->ch.have_inv = false;
+    c->dualFactor->nFactorizes += 1;
+    if (isInterior) *isInterior = (infoS == 0);
+    if (infoS != 0) return HDSDP_RETCODE_OK;           // "not positive definite" is a value, not an error
+    if (logdet) *logdet = out[2];
+    memset(HKKT->dASinvVec, 0, sizeof(double) * m); memset(HKKT->dASinvRdSinvVec, 0, sizeof(double) * m);
+    for (int i = 0; i < m; ++i) { HKKT->dASinvVec[i] = out[4 + i]; HKKT->dASinvRdSinvVec[i] = out[4 + m + i]; }
+    HKKT->dTraceSinv = (c->Rd != 0.0) ? out[3] : 0.0;
+    pv->Mdev_valid = true;
+    lm->ch.factored = (infoM == 0); lm->ch.have_inv = false;
+    lm->srcHost = nullptr; lm->srcDev = lm->Mdev; lm->srcLd = SMALL_P;
+    HKKT->kktM->nFactorizes += 1;
+    if (infoM != 0) {
+        // the Schur matrix is not numerically positive definite: the multi-launch path's way out (pivoted solver) takes over
+        fprintf(stderr, "[hdsdp_mi355x] HMiKKTPhaseA: Schur matrix is not positive definite (pivot %d); solving through HKKTFactorize\n", infoM);
+        if (HKKTFactorize(HKKT) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+        if (d1 && HKKTSolve(HKKT, rhs, d1) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+        if (d2 && HKKTSolve(HKKT, HKKT->dASinvVec, d2) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+        if (d3 && HKKTSolve(HKKT, HKKT->dASinvRdSinvVec, d3) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+        return HDSDP_RETCODE_OK;
+    }
+    HKKT->kktM->nSolves += 3;
+    if (d1) memcpy(d1, out + 4 + 2 * (size_t) m, sizeof(double) * m);
+    if (d2) memcpy(d2, out + 4 + 3 * (size_t) m, sizeof(double) * m);
+    if (d3) memcpy(d3, out + 4 + 4 * (size_t) m, sizeof(double) * m);
+    return HDSDP_RETCODE_OK;
+}
+
 int HMiGetCallStats(double *seconds, int64_t *calls, int n) {
     for (int k = 0; k < n && k < ST_N; ++k) { if (seconds) seconds[k] = g_stat_sec[k]; if (calls) calls[k] = g_stat_calls[k]; }
     return ST_N;

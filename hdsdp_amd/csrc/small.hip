@@ -1,0 +1,365 @@
+// small.hip -- one launch for a whole Phase-A pass on a small rank-one block (BASELINE configs 2-3: mcp100, gpp100).
+//
+// Reference path being replaced (one pass = interface/hdsdp_algo.c:1082-1101 on a block whose constraints are all
+// A_i = s_i a_i a_i', the reference's all-M2 plans, hdsdp_conic_sdp.c:687-778):
+//     S = tau C - sum y_i A_i - Rd I -> Cholesky (PSD check, log det) -> S^-1 -> M_ij = s_i s_j (a_i' S^-1 a_j)^2,
+//     ASinv_i = s_i a_i' S^-1 a_i,  ASinvRdSinv_i = Rd s_i |S^-1 a_i|^2,  tr S^-1 -> Cholesky of M -> three solves.
+// On the multi-launch path that is about forty launches and six host synchronisations for 0.2 MB of operands: 0.6 ms,
+// twice what one host core needs.  Here it is ONE workgroup of 512 threads and one synchronisation.
+//
+// Layout.  n, m <= 128.  A 128 x 128 matrix lives in REGISTERS, dealt cyclically over a 16 x 32 thread grid: thread
+// (ty, tx) holds rows ty + 16 r (r < 8) of columns tx + 32 c (c < 4), 32 doubles per matrix.  The cyclic deal keeps
+// every thread busy through a triangular sweep.
+//
+// The sweep (sm_sweep) is a right-looking Cholesky in which step k also finishes row k of W = L^-1 (forward substitution
+// on the identity, carried along as a second register matrix): the column of A and the row of R that step k needs are put
+// into LDS by their owners, one barrier, and every thread updates its own elements; rows / columns that a step cannot
+// touch are skipped with wave-uniform bounds.  One pass over k = 0 .. n-1 with ONE barrier per step (the two LDS lines are
+// double-buffered) yields L, L^-1 and log det S.  S^-1 = W'W follows in n / 4 independent rounds (sm_wtw).  (Carrying X
+// along in the same sweep as a third register matrix spilled 118 VGPRs at two waves per SIMD.)
+//
+// The factors are left where the multi-launch path keeps them (HdmChol::L and ::Dinv of the dual matrix and of the Schur
+// system -- for one 128-block, Dinv IS the triangular inverse), so every later call on the same state (HKKTSolve, log
+// barrier, ratio test) finds what it expects.
+#include "small.h"
+#include <algorithm>
+#include <cmath>
+
+#define SM_T 512
+#define SM_NR 8
+#define SM_NC 4
+
+// one sweep over k < n: a (full symmetric in) -> lower part = L;  rr -> W = L^-1 (lower).
+// colb / rowb: 2 x 128 doubles of LDS each.  Returns 0, or k + 1 for the first non-positive pivot (all threads alike).
+__device__ __forceinline__ int sm_sweep(int n, double (&a)[SM_NR][SM_NC], double (&rr)[SM_NR][SM_NC],
+                                        double *colb, double *rowb, int ty, int tx, double *logdet) {
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r)
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) rr[r][c] = (ty + 16 * r == tx + 32 * c) ? 1.0 : 0.0;
+    double ld = 0.0;
+    int info = 0;
+    for (int k = 0; k < n; ++k) {
+        double *cb = colb + (k & 1) * SMALL_P, *rb = rowb + (k & 1) * SMALL_P;
+        const int kc = k >> 5, kr = k >> 4;     // wave-uniform: local column / row index of global index k
+        if (tx == (k & 31)) {                    // owners of column k publish it (rows ty + 16 r)
+#pragma unroll
+            for (int r = 0; r < SM_NR; ++r) {
+                double v = a[r][0];
+#pragma unroll
+                for (int c = 1; c < SM_NC; ++c) v = (c == kc) ? a[r][c] : v;
+                cb[ty + 16 * r] = v;
+            }
+        }
+        if (ty == (k & 15)) {                    // owners of row k of R publish it (columns tx + 32 c)
+#pragma unroll
+            for (int c = 0; c < SM_NC; ++c) {
+                double v = rr[0][c];
+#pragma unroll
+                for (int r = 1; r < SM_NR; ++r) v = (r == kr) ? rr[r][c] : v;
+                rb[tx + 32 * c] = v;
+            }
+        }
+        __syncthreads();
+        const double p = cb[k];
+        if (!(p > 0.0)) { info = k + 1; break; }
+        const double rs = 1.0 / sqrt(p);
+        ld += log(p);
+        double li[SM_NR], lj[SM_NC], wj[SM_NC];
+#pragma unroll
+        for (int r = 0; r < SM_NR; ++r) {
+            const int i = ty + 16 * r;
+            li[r] = (i > k) ? cb[i] * rs : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) {
+            const int j = tx + 32 * c;
+            lj[c] = (j > k) ? cb[j] * rs : 0.0;
+            wj[c] = (j <= k) ? rb[j] * rs : 0.0;
+        }
+        if (tx == (k & 31)) {                    // column k of L is final: L[i, k] = A[i, k] / sqrt(p), i >= k
+#pragma unroll
+            for (int r = 0; r < SM_NR; ++r) {
+                const int i = ty + 16 * r;
+                const double v = cb[i] * rs;
+#pragma unroll
+                for (int c = 0; c < SM_NC; ++c) a[r][c] = (c == kc && i >= k) ? v : a[r][c];
+            }
+        }
+        if (ty == (k & 15)) {                    // row k of W is final
+#pragma unroll
+            for (int c = 0; c < SM_NC; ++c) {
+#pragma unroll
+                for (int r = 0; r < SM_NR; ++r) rr[r][c] = (r == kr) ? wj[c] : rr[r][c];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < SM_NR; ++r) {
+            if (r >= kr) {                       // rows that can lie below k
+#pragma unroll
+                for (int c = 0; c < SM_NC; ++c) {
+                    if (c >= kc) a[r][c] -= li[r] * lj[c];      // trailing update (columns right of k)
+                    if (c <= kc) rr[r][c] -= li[r] * wj[c];     // forward substitution on the identity (columns up to k)
+                }
+            }
+        }
+    }
+    *logdet = ld;
+    return info;
+}
+
+// x = W'W for the lower-triangular W in registers (x_ij = sum_k W_ki W_kj): the rows of W are published four at a time
+// (buf: 4 x 128 doubles of LDS), so n / 4 rounds of two barriers; no step depends on the one before
+__device__ __forceinline__ void sm_wtw(int n, const double (&w)[SM_NR][SM_NC], double (&x)[SM_NR][SM_NC], double *buf, int ty, int tx) {
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r)
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) x[r][c] = 0.0;
+    for (int k0 = 0; k0 < n; k0 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + q, kr = k >> 4;
+            if (ty == (k & 15)) {
+#pragma unroll
+                for (int c = 0; c < SM_NC; ++c) {
+                    double v = w[0][c];
+#pragma unroll
+                    for (int r = 1; r < SM_NR; ++r) v = (r == kr) ? w[r][c] : v;
+                    buf[q * SMALL_P + tx + 32 * c] = (k < n) ? v : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        const int krm = (k0 + 3) >> 4, kcm = (k0 + 3) >> 5;   // row k of W is zero right of column k
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int r = 0; r < SM_NR; ++r) {
+                if (r <= krm) {
+                    const double wi = buf[q * SMALL_P + ty + 16 * r];
+#pragma unroll
+                    for (int c = 0; c < SM_NC; ++c)
+                        if (c <= kcm) x[r][c] += wi * buf[q * SMALL_P + tx + 32 * c];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// L (lower, identity padded, ld = 128) and W = L^-1 (lower, zeros above, identity padded) to global memory
+__device__ __forceinline__ void sm_store_factor(int n, const double (&a)[SM_NR][SM_NC], const double (&rr)[SM_NR][SM_NC],
+                                                double *L, double *W, int ty, int tx) {
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r)
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) {
+            const int i = ty + 16 * r, j = tx + 32 * c;
+            const bool in = (i < n && j < n);
+            const double pad = (i == j) ? 1.0 : 0.0;
+            L[i + (long) j * SMALL_P] = in ? ((i >= j) ? a[r][c] : 0.0) : pad;
+            W[i + (long) j * SMALL_P] = in ? ((i >= j) ? rr[r][c] : 0.0) : pad;
+        }
+}
+
+// x = W' (W b) for the lower-triangular W held in registers; b, t: LDS vectors; part: 16 x 128 LDS doubles; out: m results
+__device__ __forceinline__ void sm_solve(int m, const double (&w)[SM_NR][SM_NC], const double *b, double *t, double *part,
+                                         double *out, int ty, int tx, int tid) {
+    double s[SM_NR];
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) acc += w[r][c] * b[tx + 32 * c];
+        for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 32);     // over the 32 threads of one ty
+        s[r] = acc;
+    }
+    if (tx == 0) {
+#pragma unroll
+        for (int r = 0; r < SM_NR; ++r) t[ty + 16 * r] = s[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < SM_NC; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < SM_NR; ++r) acc += w[r][c] * t[ty + 16 * r];
+        part[ty * SMALL_P + tx + 32 * c] = acc;
+    }
+    __syncthreads();
+    if (tid < m) {
+        double acc = 0.0;
+        for (int q = 0; q < 16; ++q) acc += part[q * SMALL_P + tid];
+        out[tid] = acc;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = p.n, m = p.m;
+    const int ld = SMALL_P + 1;
+    double *Xl = sm;                                   // S, later X = S^-1, later solve scratch: 128 x 129
+    double *colb = sm + (long) SMALL_P * ld;           // 2 x 128
+    double *rowb = colb + 2 * SMALL_P;                 // 2 x 128
+    double *vden = rowb + 2 * SMALL_P;                 // SMALL_NDENSE x 128: X a_d of the dense factors
+    double *asinv = vden + SMALL_NDENSE * SMALL_P;     // 128
+    double *asinvrd = asinv + SMALL_P;                 // 128
+    double *tvec = asinvrd + SMALL_P;                  // 128
+    double *bvec = tvec + SMALL_P;                     // 128
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+
+    // ---- S = tau C - sum y_i s_i a_i a_i' + eye I, assembled in LDS (full symmetric)
+    for (int e = tid; e < n * n; e += SM_T) {
+        const int i = e % n, j = e / n;
+        Xl[i + j * ld] = p.tau * p.C[i + (long) j * p.ldc] + ((i == j) ? p.eye : 0.0);
+    }
+    if (tid < m) bvec[tid] = p.b[tid];
+    __syncthreads();
+    for (int q = tid; q < m; q += SM_T) {              // sparse factors: a handful of entries each
+        const int f0 = p.fp[q], f1 = p.fp[q + 1];
+        if (f1 - f0 > SMALL_SPMAX) continue;
+        const double coef = -p.y[q] * p.sgn[q];
+        if (coef == 0.0) continue;
+        for (int u = f0; u < f1; ++u)
+            for (int v = f0; v < f1; ++v) atomicAdd(&Xl[p.fi[u] + p.fi[v] * ld], coef * p.fv[u] * p.fv[v]);
+    }
+    __syncthreads();
+    for (int d = 0; d < p.ndense; ++d) {               // dense factors: the whole workgroup per row
+        const int q = p.dense_rows[d];
+        const double coef = -p.y[q] * p.sgn[q];
+        const double *av = p.fv + p.fp[q];             // all n entries are listed
+        if (coef != 0.0)
+            for (int e = tid; e < n * n; e += SM_T) {
+                const int i = e % n, j = e / n;
+                Xl[i + j * ld] += coef * av[i] * av[j];
+            }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += SM_T) {          // the dual matrix itself stays resident for the other cone slots
+        const int i = e % n, j = e / n;
+        if (i >= j) p.Sout[i + (long) j * p.lds] = Xl[i + j * ld];
+    }
+    double a[SM_NR][SM_NC], rr[SM_NR][SM_NC];
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r)
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) {
+            const int i = ty + 16 * r, j = tx + 32 * c;
+            a[r][c] = (i < n && j < n) ? Xl[i + j * ld] : ((i == j) ? 1.0 : 0.0);
+        }
+    __syncthreads();
+
+    // ---- factor S, invert the factor, form S^-1: one sweep
+    double logdet = 0.0;
+    const int infoS = sm_sweep(n, a, rr, colb, rowb, ty, tx, &logdet);
+    if (infoS) {
+        if (tid == 0) { p.out[0] = (double) infoS; p.out[1] = 0.0; p.out[2] = 0.0; p.out[3] = 0.0; }
+        return;
+    }
+    sm_store_factor(n, a, rr, p.LS, p.WS, ty, tx);
+    __syncthreads();
+    sm_wtw(n, rr, a, colb, ty, tx);                    // (colb and rowb are contiguous: 4 x 128 doubles; `a` is free now)
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r)
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) {
+            const int i = ty + 16 * r, j = tx + 32 * c;
+            if (i < n && j < n) Xl[i + j * ld] = a[r][c];
+        }
+    __syncthreads();
+
+    // ---- the rank-one Schur build on X = S^-1
+    for (int d = 0; d < p.ndense; ++d) {               // v_d = X a_d
+        const double *av = p.fv + p.fp[p.dense_rows[d]];
+        for (int r = tid; r < n; r += SM_T) {
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc += av[k] * Xl[r + k * ld];
+            vden[d * SMALL_P + r] = acc;
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < m; q += SM_T) {              // Gamma_qq and |X a_q|^2
+        const int f0 = p.fp[q], f1 = p.fp[q + 1], dq = p.dense_of[q];
+        double gii = 0.0, nrm = 0.0;
+        if (dq >= 0) {
+            const double *v = vden + dq * SMALL_P;
+            for (int k = 0; k < n; ++k) { gii += p.fv[f0 + k] * v[k]; nrm += v[k] * v[k]; }
+        } else {
+            for (int u = f0; u < f1; ++u)
+                for (int v = f0; v < f1; ++v) gii += p.fv[u] * p.fv[v] * Xl[p.fi[u] + p.fi[v] * ld];
+            for (int r = 0; r < n; ++r) {
+                double t = 0.0;
+                for (int u = f0; u < f1; ++u) t += p.fv[u] * Xl[r + p.fi[u] * ld];
+                nrm += t * t;
+            }
+        }
+        asinv[q] = p.sgn[q] * gii;
+        asinvrd[q] = p.Rd * p.sgn[q] * nrm;
+    }
+    const int npairs = m * (m + 1) / 2;
+    for (int e = tid; e < npairs; e += SM_T) {         // M_ij = s_i s_j (a_i' X a_j)^2, i >= j
+        int i = (int) ((sqrt(8.0 * (double) e + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= e) ++i;
+        while (i * (i + 1) / 2 > e) --i;
+        const int j = e - i * (i + 1) / 2;
+        const int i0 = p.fp[i], i1 = p.fp[i + 1], j0 = p.fp[j], j1 = p.fp[j + 1];
+        const int di = p.dense_of[i], dj = p.dense_of[j];
+        double gam = 0.0;
+        if (dj >= 0) {
+            const double *v = vden + dj * SMALL_P;
+            for (int u = i0; u < i1; ++u) gam += p.fv[u] * v[p.fi[u]];
+        } else if (di >= 0) {
+            const double *v = vden + di * SMALL_P;
+            for (int u = j0; u < j1; ++u) gam += p.fv[u] * v[p.fi[u]];
+        } else {
+            for (int u = i0; u < i1; ++u)
+                for (int v = j0; v < j1; ++v) gam += p.fv[u] * p.fv[v] * Xl[p.fi[u] + p.fi[v] * ld];
+        }
+        p.M[i + (long) j * p.ldm] = p.sgn[i] * p.sgn[j] * gam * gam;
+    }
+    double trs = 0.0;
+    if (tid == 0) for (int k = 0; k < n; ++k) trs += Xl[k + k * ld];
+    __threadfence();
+    __syncthreads();
+    if (tid < m) { p.out[4 + tid] = asinv[tid]; p.out[4 + m + tid] = asinvrd[tid]; }
+
+    // ---- factor M, invert the factor, three solves
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r)
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) {
+            const int i = ty + 16 * r, j = tx + 32 * c;
+            const int hi = max(i, j), lo = min(i, j);
+            a[r][c] = (i < m && j < m) ? p.M[hi + (long) lo * p.ldm] : ((i == j) ? 1.0 : 0.0);
+        }
+    double logdetM = 0.0;
+    const int infoM = sm_sweep(m, a, rr, colb, rowb, ty, tx, &logdetM);
+    if (tid == 0) { p.out[0] = 0.0; p.out[1] = (double) infoM; p.out[2] = logdet; p.out[3] = trs; }
+    if (infoM) return;
+    sm_store_factor(m, a, rr, p.LM, p.WM, ty, tx);
+    __syncthreads();
+    double *part = Xl;                                 // X is no longer needed: 16 x 128 partial sums
+    sm_solve(m, rr, bvec, tvec, part, p.out + 4 + 2 * m, ty, tx, tid);
+    sm_solve(m, rr, asinv, tvec, part, p.out + 4 + 3 * m, ty, tx, tid);
+    sm_solve(m, rr, asinvrd, tvec, part, p.out + 4 + 4 * m, ty, tx, tid);
+}
+
+size_t hdm_small_lds_bytes() {
+    return sizeof(double) * ((size_t) SMALL_P * (SMALL_P + 1) + 4 * SMALL_P + SMALL_NDENSE * SMALL_P + 4 * SMALL_P);
+}
+
+int hdm_small_phase_a(const HdmSmallArgs &args, hipStream_t s) {
+    if (args.n < 1 || args.n > SMALL_P || args.m < 1 || args.m > SMALL_P || args.ndense > SMALL_NDENSE) return 1;
+    static thread_local int configured_dev = -1;
+    int dev = 0;
+    HDM_HIP_CHECK(hipGetDevice(&dev));
+    if (configured_dev != dev) {
+        HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_small_phase_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int) hdm_small_lds_bytes()));
+        configured_dev = dev;
+    }
+    hipLaunchKernelGGL(hdm_small_phase_a_kernel, dim3(1), dim3(SM_T), hdm_small_lds_bytes(), s, args);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -320,6 +320,20 @@ int HMiGetDeviceGroup(int *deviceIds, int maxIds, int *transport);   /* returns 
 void HMiSetShardMinDim(int nMin);
 int HMiConeGetShardCount(hdsdp_cone *cone);                          /* 1 for a plain cone */
 void HMiConeGetGroupTraffic(hdsdp_cone *cone, int64_t *bytesAllToAll, int64_t *bytesAllReduce);   /* sent by shard 0 so far */
+/* One launch for a whole Phase-A pass of a SMALL rank-one block (BASELINE configs 2-3; csrc/small.hip).  The sequence
+ *     HConeCheckIsInterior(tau, y) -> HKKTBuildUp(KKT_TYPE_INFEASIBLE) -> HKKTFactorize -> HKKTSolve x 3
+ * (interface/hdsdp_algo.c:1082-1101: right-hand sides rhs, ASinv, ASinvRdSinv) is forty launches and six host
+ * synchronisations on the call-by-call path, which is what a 100 x 100 block costs there, not its arithmetic.  For an
+ * operator with ONE engine cone whose constraints are all rank one (n, m <= 128, at most 4 dense factors) this entry does
+ * the whole sequence in one single-workgroup kernel and one synchronisation, with the same results: *isInterior and the
+ * log-determinant of S, the operator's dASinvVec / dASinvRdSinvVec / dTraceSinv (and kktMatElem with the host mirror on),
+ * the three solutions; the Cholesky factors of S and M are left in the objects HFpLinsys* / HKKTSolve use, so any later call
+ * on the same state works as after the separate calls.  HMiKKTPhaseAEligible says whether the operator qualifies; the call
+ * itself returns HDSDP_RETCODE_FAILED if not (nothing has been touched then).  The reference's call sites stay as they are:
+ * this is an additional entry for drivers that want the latency, used by bench.py's small-config lines. */
+int HMiKKTPhaseAEligible(hdsdp_kkt *HKKT);
+hdsdp_retcode HMiKKTPhaseA(hdsdp_kkt *HKKT, double barHsdTau, double *rowDual, double *rhs, double *d1, double *d2, double *d3,
+                           int *isInterior, double *logdet);
 /* wall time the caller's thread has spent below this C ABI, by category (outermost entry only, so the categories add up):
  * [0] HKKTBuildUp of the M-forming types, [1] HKKTBuildUp(KKT_TYPE_CORRECTOR), [2] HKKTFactorize, [3] HKKTSolve,
  * [4] cone slots that assemble and factor S (update, interior checks, barrier, line search), [5] ratio test, [6] primal

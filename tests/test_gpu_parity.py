@@ -754,6 +754,75 @@ def test_multi_block_instance_against_reference(name, fname):
             c.destroy()
 
 
+@pytest.mark.parametrize("name", ["mcp100_A", "mcp100_B", "gpp100_A", "gpp100_B"])
+def test_fused_phase_a_pass_of_small_rank_one_blocks(name):
+    """HMiKKTPhaseA (csrc/small.hip): BASELINE configs 2-3 in ONE launch -- S assembly, Cholesky + triangular inverse + S^-1
+    in registers, the rank-one Schur build, Cholesky of M, three solves -- against the compiled reference's goldens for the
+    same state (M, both vectors, log det S, tr S^-1), against LAPACK for the three solutions, and against the call-by-call
+    path of the same library; afterwards the factor objects must serve later calls (HKKTSolve, the barrier, a ratio test)
+    exactly as after the separate calls"""
+    from hdsdp_amd import api
+    g = load_golden(name)
+    cone, n, m = _make_cone(name, g)
+    Rd, tau, y = float(g["Rd"][0]), float(g["tau"][0]), y_of(g)
+    try:
+        assert cone.path == 1
+        kkt = api.KKT(m, [cone])
+        assert kkt.phase_a_eligible()
+        cone.set_start(Rd)
+        b = np.asarray(g["b"], dtype=np.float64)
+        ok, logdet, d1, d2, d3 = kkt.phase_a(tau, y, b)
+        assert ok
+        assert abs(logdet - float(g["logdet"][0])) <= 1e-12 * abs(float(g["logdet"][0]))
+        msk = lower_mask(m)
+        ex = kkt.export()
+        check_close(kkt.M[msk], g["M_inf"][msk], name + " M")
+        check_close(ex["ASinv"], g["ASinv_inf"], name + " ASinv")
+        check_close(ex["ASinvRdSinv"], g["ASinvRdSinv_inf"], name + " ASinvRdSinv")
+        check_close([ex["TraceSinv"]], g["TraceSinv_inf"], name + " TraceSinv")
+        Mg = g["M_inf"]
+        A = np.triu(Mg) + np.triu(Mg, 1).T
+        for x, rhs in ((d1, b), (d2, g["ASinv_inf"]), (d3, g["ASinvRdSinv_inf"])):
+            ref = np.linalg.solve(A, np.asarray(rhs, dtype=np.float64))
+            assert np.linalg.norm(x - ref) <= 1e-8 * np.linalg.norm(ref)
+        # the objects behind the fused call are in the state the separate calls leave them in
+        x4 = kkt.solve(b)
+        assert np.linalg.norm(x4 - d1) <= 1e-13 * np.linalg.norm(d1)
+        assert abs(cone.log_barrier_of(api.BUFFER_DUALVAR) - logdet) <= 1e-13 * abs(logdet)
+        if "rt_step1" in g:
+            par = g["rt_par1"]
+            step = cone.ratio_test(float(par[0]), g["rt_dy1"], float(par[1]))
+            assert abs(step - float(g["rt_step1"][0])) <= RATIO_TOL * abs(float(g["rt_step1"][0]))
+        # ... and the call-by-call path gives the same numbers
+        assert cone.check_is_interior(tau, y)
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        ex2 = kkt.export()
+        assert np.max(np.abs(ex2["ASinv"] - ex["ASinv"])) <= 1e-12 * np.max(np.abs(ex["ASinv"]))
+        kkt.factorize()
+        y2 = kkt.solve(ex2["ASinv"])
+        assert np.linalg.norm(y2 - d2) <= 1e-10 * np.linalg.norm(d2)
+        # a state outside the cone is a value, not an error
+        cone.set_start(1e6)
+        ok, _, _, _, _ = kkt.phase_a(tau, y, b)
+        assert ok is False
+        kkt.destroy()
+    finally:
+        cone.destroy()
+
+
+def test_fused_phase_a_refuses_what_it_cannot_do():
+    from hdsdp_amd import api
+    cone = api.SDPCone.synthetic(64, 40)          # dense block: congruence path
+    try:
+        kkt = api.KKT(40, [cone])
+        assert not kkt.phase_a_eligible()
+        with pytest.raises(api.HDSDPError):
+            kkt.phase_a(1.0, np.zeros(40), np.ones(40))
+        kkt.destroy()
+    finally:
+        cone.destroy()
+
+
 def _block_with_rows(n, m, keep):
     """a block of the synthetic family on which only the constraints in `keep` have data (CSC, column 0 = C)"""
     import sys
