@@ -2713,7 +2713,7 @@ static int small_plan(MiCone *c) {
         hipMalloc((void **) &sp.fv, sizeof(double) * nf) != hipSuccess || hipMalloc((void **) &sp.sgn, sizeof(double) * m) != hipSuccess ||
         hipMalloc((void **) &sp.dense_of, sizeof(int) * m) != hipSuccess ||
         hipMalloc((void **) &sp.dense_rows, sizeof(int) * SMALL_NDENSE) != hipSuccess ||
-        hipHostMalloc((void **) &sp.io_host, sizeof(double) * (7 * (size_t) m + 8), hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **) &sp.io_host, sizeof(double) * (7 * (size_t) m + 16), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **) &sp.io_dev, sp.io_host, 0) != hipSuccess)
         return -1;
     if (hdm_memcpy_h2d_sync(sp.fp, fp.data(), sizeof(int) * (m + 1)) != hipSuccess ||
@@ -2791,6 +2791,7 @@ hdsdp_retcode HMiKKTPhaseA(hdsdp_kkt *HKKT, double barHsdTau, double *rowDual, d
     if (d1) memcpy(d1, out + 4 + 2 * (size_t) m, sizeof(double) * m);
     if (d2) memcpy(d2, out + 4 + 3 * (size_t) m, sizeof(double) * m);
     if (d3) memcpy(d3, out + 4 + 4 * (size_t) m, sizeof(double) * m);
+    for (int i = 0; i < 7; ++i) g.stage_ms[i] = (i < 6) ? (out[4 + 5 * (size_t) m + i + 1] - out[4 + 5 * (size_t) m + i]) * 1e-5 : 0.0;   // HMiGetStageTimes: 100 MHz ticks -> ms
     return HDSDP_RETCODE_OK;
 }
 

@@ -21,7 +21,8 @@ struct HdmSmallArgs {
     double *LS, *WS;                    // 128 x 128: Cholesky factor of S and its inverse (HdmChol::L, ::Dinv)
     double *M; long ldm;                // Schur matrix, lower triangle (device)
     double *LM, *WM;                    // 128 x 128: factor of M and its inverse
-    double *out;                        // [0] info S, [1] info M, [2] logdet S, [3] tr S^-1, then ASinv, ASinvRdSinv, d1, d2, d3 (m each)
+    double *out;                        // [0] info S, [1] info M, [2] logdet S, [3] tr S^-1, then ASinv, ASinvRdSinv, d1, d2, d3 (m each),
+                                        // then 8 phase stamps (s_memrealtime, 100 MHz)
 };
 
 size_t hdm_small_lds_bytes();

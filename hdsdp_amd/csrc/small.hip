@@ -29,81 +29,127 @@
 #define SM_NR 8
 #define SM_NC 4
 
+// Register matrices are indexed with compile-time constants only.  Where the wanted local row / column is a run-time but
+// wave-uniform number, a switch over the constants selects it: a select chain over the whole array (v = c == kc ? a[r][c] : v)
+// makes the compiler keep the array in scratch memory (606 scratch instructions, 1.8 ms per pass instead of 0.1).
+#define SM_SWITCH4(kc, BODY)   \
+    switch (kc) {              \
+        case 0: { constexpr int C_ = 0; BODY } break;  \
+        case 1: { constexpr int C_ = 1; BODY } break;  \
+        case 2: { constexpr int C_ = 2; BODY } break;  \
+        default: { constexpr int C_ = 3; BODY } break; \
+    }
+#define SM_SWITCH8(kr, BODY)   \
+    switch (kr) {              \
+        case 0: { constexpr int R_ = 0; BODY } break;  \
+        case 1: { constexpr int R_ = 1; BODY } break;  \
+        case 2: { constexpr int R_ = 2; BODY } break;  \
+        case 3: { constexpr int R_ = 3; BODY } break;  \
+        case 4: { constexpr int R_ = 4; BODY } break;  \
+        case 5: { constexpr int R_ = 5; BODY } break;  \
+        case 6: { constexpr int R_ = 6; BODY } break;  \
+        default: { constexpr int R_ = 7; BODY } break; \
+    }
+
 // one sweep over k < n: a (full symmetric in) -> lower part = L;  rr -> W = L^-1 (lower).
-// colb / rowb: 2 x 128 doubles of LDS each.  Returns 0, or k + 1 for the first non-positive pivot (all threads alike).
+// colb / rowb: 2 x 128 doubles of LDS each, rsv: 128.  Returns 0, or k + 1 for the first non-positive pivot (all threads alike).
+//
+// Column k of the trailing matrix and row k of R are never touched again after step k, and what is final about them is
+// only a scale factor 1 / sqrt(pivot_k) away: L[i, k] = A_k[i, k] rs_k, W[k, j] = R_k[k, j] rs_k.  So the loop never writes
+// a "final" column or row back into the register matrices (an insert at a run-time position costs a phi of the whole
+// array per step); the factors rs_k are kept in LDS and applied once at the end.  All LDS reads of a step are issued
+// together and unconditionally -- under per-element conditions the compiler put every ds_read behind its own branch and
+// its own wait, 49 serialised LDS round trips per step (2.1 us per step instead of 0.3).
+// sixteen steps k = 16 KR .. 16 KR + 15 of the sweep.  The local row index of the published row (KR) and the local column
+// index of the published column (KR / 2) are template constants: the register matrices are indexed with constants only,
+// the bounds of the update loops fold, and a step is one straight-line block between two barriers.
+template <int KR>
+__device__ __forceinline__ int sm_sweep_chunk(int n, double (&a)[SM_NR][SM_NC], double (&rr)[SM_NR][SM_NC],
+                                              double *colb, double *rowb, double *rsv, int ty, int tx) {
+    constexpr int KC = KR / 2;
+    const int kend = min(n, 16 * KR + 16);
+    for (int k = 16 * KR; k < kend; ++k) {
+        double *cb = colb + (k & 1) * SMALL_P, *rb = rowb + (k & 1) * SMALL_P;
+        if (tx == (k & 31)) {                    // owners of column k publish it (rows ty + 16 r)
+#pragma unroll
+            for (int r = 0; r < SM_NR; ++r) cb[ty + 16 * r] = a[r][KC];
+        }
+        if (ty == (k & 15)) {                    // owners of row k of R publish it (columns tx + 32 c)
+#pragma unroll
+            for (int c = 0; c < SM_NC; ++c) rb[tx + 32 * c] = rr[KR][c];
+        }
+        __syncthreads();
+        const double p = cb[k];
+        double cbi[SM_NR], cbj[SM_NC], rbj[SM_NC];
+#pragma unroll
+        for (int r = KR; r < SM_NR; ++r) cbi[r] = cb[ty + 16 * r];
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) { cbj[c] = (c >= KC) ? cb[tx + 32 * c] : 0.0; rbj[c] = (c <= KC) ? rb[tx + 32 * c] : 0.0; }
+        if (!(p > 0.0)) return k + 1;
+        // 1 / sqrt(p): the hardware estimate (v_rsq_f64, about 2^-26) and two Newton steps
+        double rs = __builtin_amdgcn_rsq(p);
+        rs = rs * (1.5 - 0.5 * p * rs * rs);
+        rs = rs * (1.5 - 0.5 * p * rs * rs);
+        if (ty == 0 && tx == 0) rsv[k] = rs;
+        double li[SM_NR], lj[SM_NC], wj[SM_NC];
+#pragma unroll
+        for (int r = KR; r < SM_NR; ++r) li[r] = cbi[r] * ((ty + 16 * r > k) ? rs : 0.0);
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) {
+            lj[c] = cbj[c] * ((tx + 32 * c > k) ? rs : 0.0);
+            wj[c] = rbj[c] * ((tx + 32 * c <= k) ? rs : 0.0);
+        }
+#pragma unroll
+        for (int r = KR; r < SM_NR; ++r) {       // rows that can lie below k
+#pragma unroll
+            for (int c = 0; c < SM_NC; ++c) {
+                if (c >= KC) a[r][c] -= li[r] * lj[c];      // trailing update (columns right of k)
+                if (c <= KC) rr[r][c] -= li[r] * wj[c];     // forward substitution on the identity (columns up to k)
+            }
+        }
+    }
+    return 0;
+}
+
 __device__ __forceinline__ int sm_sweep(int n, double (&a)[SM_NR][SM_NC], double (&rr)[SM_NR][SM_NC],
-                                        double *colb, double *rowb, int ty, int tx, double *logdet) {
+                                        double *colb, double *rowb, double *rsv, int ty, int tx, double *logdet) {
 #pragma unroll
     for (int r = 0; r < SM_NR; ++r)
 #pragma unroll
         for (int c = 0; c < SM_NC; ++c) rr[r][c] = (ty + 16 * r == tx + 32 * c) ? 1.0 : 0.0;
-    double ld = 0.0;
     int info = 0;
-    for (int k = 0; k < n; ++k) {
-        double *cb = colb + (k & 1) * SMALL_P, *rb = rowb + (k & 1) * SMALL_P;
-        const int kc = k >> 5, kr = k >> 4;     // wave-uniform: local column / row index of global index k
-        if (tx == (k & 31)) {                    // owners of column k publish it (rows ty + 16 r)
-#pragma unroll
-            for (int r = 0; r < SM_NR; ++r) {
-                double v = a[r][0];
-#pragma unroll
-                for (int c = 1; c < SM_NC; ++c) v = (c == kc) ? a[r][c] : v;
-                cb[ty + 16 * r] = v;
-            }
-        }
-        if (ty == (k & 15)) {                    // owners of row k of R publish it (columns tx + 32 c)
-#pragma unroll
-            for (int c = 0; c < SM_NC; ++c) {
-                double v = rr[0][c];
-#pragma unroll
-                for (int r = 1; r < SM_NR; ++r) v = (r == kr) ? rr[r][c] : v;
-                rb[tx + 32 * c] = v;
-            }
-        }
-        __syncthreads();
-        const double p = cb[k];
-        if (!(p > 0.0)) { info = k + 1; break; }
-        const double rs = 1.0 / sqrt(p);
-        ld += log(p);
-        double li[SM_NR], lj[SM_NC], wj[SM_NC];
-#pragma unroll
-        for (int r = 0; r < SM_NR; ++r) {
-            const int i = ty + 16 * r;
-            li[r] = (i > k) ? cb[i] * rs : 0.0;
-        }
+    if (!info && n > 0) info = sm_sweep_chunk<0>(n, a, rr, colb, rowb, rsv, ty, tx);
+    if (!info && n > 16) info = sm_sweep_chunk<1>(n, a, rr, colb, rowb, rsv, ty, tx);
+    if (!info && n > 32) info = sm_sweep_chunk<2>(n, a, rr, colb, rowb, rsv, ty, tx);
+    if (!info && n > 48) info = sm_sweep_chunk<3>(n, a, rr, colb, rowb, rsv, ty, tx);
+    if (!info && n > 64) info = sm_sweep_chunk<4>(n, a, rr, colb, rowb, rsv, ty, tx);
+    if (!info && n > 80) info = sm_sweep_chunk<5>(n, a, rr, colb, rowb, rsv, ty, tx);
+    if (!info && n > 96) info = sm_sweep_chunk<6>(n, a, rr, colb, rowb, rsv, ty, tx);
+    if (!info && n > 112) info = sm_sweep_chunk<7>(n, a, rr, colb, rowb, rsv, ty, tx);
+    __syncthreads();
+    double ld = 0.0;
+    if (!info) {
+        // apply the deferred scale factors: column j of L and row i of W; log det = 2 sum log L_kk from the owners of the
+        // diagonal (the sum is finished by the caller)
 #pragma unroll
         for (int c = 0; c < SM_NC; ++c) {
             const int j = tx + 32 * c;
-            lj[c] = (j > k) ? cb[j] * rs : 0.0;
-            wj[c] = (j <= k) ? rb[j] * rs : 0.0;
-        }
-        if (tx == (k & 31)) {                    // column k of L is final: L[i, k] = A[i, k] / sqrt(p), i >= k
+            const double sj = (j < n) ? rsv[j] : 1.0;
 #pragma unroll
-            for (int r = 0; r < SM_NR; ++r) {
-                const int i = ty + 16 * r;
-                const double v = cb[i] * rs;
-#pragma unroll
-                for (int c = 0; c < SM_NC; ++c) a[r][c] = (c == kc && i >= k) ? v : a[r][c];
-            }
-        }
-        if (ty == (k & 15)) {                    // row k of W is final
-#pragma unroll
-            for (int c = 0; c < SM_NC; ++c) {
-#pragma unroll
-                for (int r = 0; r < SM_NR; ++r) rr[r][c] = (r == kr) ? wj[c] : rr[r][c];
-            }
+            for (int r = 0; r < SM_NR; ++r) a[r][c] *= sj;
         }
 #pragma unroll
         for (int r = 0; r < SM_NR; ++r) {
-            if (r >= kr) {                       // rows that can lie below k
+            const int i = ty + 16 * r;
+            const double si = (i < n) ? rsv[i] : 1.0;
 #pragma unroll
-                for (int c = 0; c < SM_NC; ++c) {
-                    if (c >= kc) a[r][c] -= li[r] * lj[c];      // trailing update (columns right of k)
-                    if (c <= kc) rr[r][c] -= li[r] * wj[c];     // forward substitution on the identity (columns up to k)
-                }
+            for (int c = 0; c < SM_NC; ++c) {
+                rr[r][c] *= si;
+                if (i == tx + 32 * c && i < n) ld += 2.0 * log(a[r][c]);
             }
         }
     }
+    __syncthreads();
     *logdet = ld;
     return info;
 }
@@ -120,13 +166,7 @@ __device__ __forceinline__ void sm_wtw(int n, const double (&w)[SM_NR][SM_NC], d
         for (int q = 0; q < 4; ++q) {
             const int k = k0 + q, kr = k >> 4;
             if (ty == (k & 15)) {
-#pragma unroll
-                for (int c = 0; c < SM_NC; ++c) {
-                    double v = w[0][c];
-#pragma unroll
-                    for (int r = 1; r < SM_NR; ++r) v = (r == kr) ? w[r][c] : v;
-                    buf[q * SMALL_P + tx + 32 * c] = (k < n) ? v : 0.0;
-                }
+                SM_SWITCH8(kr, _Pragma("unroll") for (int c = 0; c < SM_NC; ++c) buf[q * SMALL_P + tx + 32 * c] = (k < n) ? w[R_][c] : 0.0;)
             }
         }
         __syncthreads();
@@ -206,8 +246,13 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
     double *asinv = vden + SMALL_NDENSE * SMALL_P;     // 128
     double *asinvrd = asinv + SMALL_P;                 // 128
     double *tvec = asinvrd + SMALL_P;                  // 128
-    double *bvec = tvec + SMALL_P;                     // 128
+    double *bvec = tvec + SMALL_P;                     // 128 (+ 128 behind it: the sweep's deferred scale factors)
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    // phase stamps (100 MHz wall clock) behind the results: [0] start, [1] S assembled, [2] factor + inverse of S,
+    // [3] S^-1, [4] Schur build, [5] factor + inverse of M, [6] solves
+    double *stamp = p.out + 4 + 5 * m;
+#define SM_STAMP(i) if (tid == 0) stamp[i] = (double) __builtin_amdgcn_s_memrealtime();
+    SM_STAMP(0)
 
     // ---- S = tau C - sum y_i s_i a_i a_i' + eye I, assembled in LDS (full symmetric)
     for (int e = tid; e < n * n; e += SM_T) {
@@ -249,16 +294,24 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
             a[r][c] = (i < n && j < n) ? Xl[i + j * ld] : ((i == j) ? 1.0 : 0.0);
         }
     __syncthreads();
+    SM_STAMP(1)
 
     // ---- factor S, invert the factor, form S^-1: one sweep
     double logdet = 0.0;
-    const int infoS = sm_sweep(n, a, rr, colb, rowb, ty, tx, &logdet);
+    const int infoS = sm_sweep(n, a, rr, colb, rowb, bvec + SMALL_P, ty, tx, &logdet);
+    if (tid == 0) tvec[0] = 0.0;
+    __syncthreads();
+    if (logdet != 0.0) atomicAdd(&tvec[0], logdet);
+    __syncthreads();
+    logdet = tvec[0];
+    __syncthreads();
     if (infoS) {
         if (tid == 0) { p.out[0] = (double) infoS; p.out[1] = 0.0; p.out[2] = 0.0; p.out[3] = 0.0; }
         return;
     }
     sm_store_factor(n, a, rr, p.LS, p.WS, ty, tx);
     __syncthreads();
+    SM_STAMP(2)
     sm_wtw(n, rr, a, colb, ty, tx);                    // (colb and rowb are contiguous: 4 x 128 doubles; `a` is free now)
 #pragma unroll
     for (int r = 0; r < SM_NR; ++r)
@@ -269,6 +322,7 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
         }
     __syncthreads();
 
+    SM_STAMP(3)
     // ---- the rank-one Schur build on X = S^-1
     for (int d = 0; d < p.ndense; ++d) {               // v_d = X a_d
         const double *av = p.fv + p.fp[p.dense_rows[d]];
@@ -324,6 +378,7 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
     __syncthreads();
     if (tid < m) { p.out[4 + tid] = asinv[tid]; p.out[4 + m + tid] = asinvrd[tid]; }
 
+    SM_STAMP(4)
     // ---- factor M, invert the factor, three solves
 #pragma unroll
     for (int r = 0; r < SM_NR; ++r)
@@ -334,19 +389,22 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
             a[r][c] = (i < m && j < m) ? p.M[hi + (long) lo * p.ldm] : ((i == j) ? 1.0 : 0.0);
         }
     double logdetM = 0.0;
-    const int infoM = sm_sweep(m, a, rr, colb, rowb, ty, tx, &logdetM);
+    const int infoM = sm_sweep(m, a, rr, colb, rowb, bvec + SMALL_P, ty, tx, &logdetM);
     if (tid == 0) { p.out[0] = 0.0; p.out[1] = (double) infoM; p.out[2] = logdet; p.out[3] = trs; }
     if (infoM) return;
     sm_store_factor(m, a, rr, p.LM, p.WM, ty, tx);
     __syncthreads();
+    SM_STAMP(5)
     double *part = Xl;                                 // X is no longer needed: 16 x 128 partial sums
     sm_solve(m, rr, bvec, tvec, part, p.out + 4 + 2 * m, ty, tx, tid);
     sm_solve(m, rr, asinv, tvec, part, p.out + 4 + 3 * m, ty, tx, tid);
     sm_solve(m, rr, asinvrd, tvec, part, p.out + 4 + 4 * m, ty, tx, tid);
+    SM_STAMP(6)
+#undef SM_STAMP
 }
 
 size_t hdm_small_lds_bytes() {
-    return sizeof(double) * ((size_t) SMALL_P * (SMALL_P + 1) + 4 * SMALL_P + SMALL_NDENSE * SMALL_P + 4 * SMALL_P);
+    return sizeof(double) * ((size_t) SMALL_P * (SMALL_P + 1) + 4 * SMALL_P + SMALL_NDENSE * SMALL_P + 5 * SMALL_P);
 }
 
 int hdm_small_phase_a(const HdmSmallArgs &args, hipStream_t s) {
