@@ -257,6 +257,18 @@ def main():
     if ex is not None:
         out["config"]["exchange_bytes_per_step"] = {"all_to_all": ex.bytes_a2a // (args.steps + args.warmup),
                                                     "all_reduce": ex.bytes_ar // (args.steps + args.warmup)}
+    if world == 1 and (n, m) == (2000, 2000):
+        # BASELINE configs 2-3 (mcp100, gpp100 "on 1 MI355X"): parity cases, not the headline -- one timed line each so that
+        # the driver-run record carries them: a Phase-A pass call by call through the reference's operator surface, the same
+        # pass as ONE fused launch (csrc/small.hip, HMiKKTPhaseA), achieved GB/s against the ~0.2 MB of algorithmic bytes,
+        # and the plain-C oracle port on one host core (tools/small_configs.py)
+        try:
+            kkt.destroy(); cone.destroy()          # give the 100 GB back before the small cones are made
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import small_configs
+            out["small_configs"] = [small_configs.measure(nm, reps=30, cpu=not args.no_cpu) for nm in ("mcp100_A", "gpp100_A")]
+        except Exception as e:  # never lose the headline line over the extras
+            out["small_configs"] = {"error": str(e)}
     if not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(n, m)
         out["cpu_baseline_blas3"] = cpu_baseline_blas3(n, m)

@@ -154,37 +154,45 @@ __device__ __forceinline__ int sm_sweep(int n, double (&a)[SM_NR][SM_NC], double
     return info;
 }
 
-// x = W'W for the lower-triangular W in registers (x_ij = sum_k W_ki W_kj): the rows of W are published four at a time
-// (buf: 4 x 128 doubles of LDS), so n / 4 rounds of two barriers; no step depends on the one before
+// x = W'W for the lower-triangular W in registers (x_ij = sum_k W_ki W_kj).  Every thread owns exactly one row of each
+// block of sixteen rows (row 16 KR + ty, its local row KR), so a block is published by ALL threads at once -- no owner
+// test, constant register indices -- and consumed as sixteen outer products: eight rounds of two barriers for the whole
+// product.  buf: 16 x 128 doubles of LDS.  Row k of W is zero right of column k: rows / columns beyond the block's last row
+// are skipped.
+template <int KR>
+__device__ __forceinline__ void sm_wtw_block(int n, const double (&w)[SM_NR][SM_NC], double (&x)[SM_NR][SM_NC], double *buf, int ty, int tx) {
+    constexpr int KC = KR / 2;
+#pragma unroll
+    for (int c = 0; c < SM_NC; ++c) buf[ty * SMALL_P + tx + 32 * c] = (16 * KR + ty < n) ? w[KR][c] : 0.0;
+    __syncthreads();
+    const int qend = min(16, n - 16 * KR);
+    for (int q = 0; q < qend; ++q) {
+        const double *row = buf + q * SMALL_P;
+        double wi[SM_NR], wj[SM_NC];
+#pragma unroll
+        for (int r = 0; r <= KR; ++r) wi[r] = row[ty + 16 * r];
+#pragma unroll
+        for (int c = 0; c <= KC; ++c) wj[c] = row[tx + 32 * c];
+#pragma unroll
+        for (int r = 0; r <= KR; ++r)
+#pragma unroll
+            for (int c = 0; c <= KC; ++c) x[r][c] += wi[r] * wj[c];
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ void sm_wtw(int n, const double (&w)[SM_NR][SM_NC], double (&x)[SM_NR][SM_NC], double *buf, int ty, int tx) {
 #pragma unroll
     for (int r = 0; r < SM_NR; ++r)
 #pragma unroll
         for (int c = 0; c < SM_NC; ++c) x[r][c] = 0.0;
-    for (int k0 = 0; k0 < n; k0 += 4) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + q, kr = k >> 4;
-            if (ty == (k & 15)) {
-                SM_SWITCH8(kr, _Pragma("unroll") for (int c = 0; c < SM_NC; ++c) buf[q * SMALL_P + tx + 32 * c] = (k < n) ? w[R_][c] : 0.0;)
-            }
-        }
-        __syncthreads();
-        const int krm = (k0 + 3) >> 4, kcm = (k0 + 3) >> 5;   // row k of W is zero right of column k
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int r = 0; r < SM_NR; ++r) {
-                if (r <= krm) {
-                    const double wi = buf[q * SMALL_P + ty + 16 * r];
-#pragma unroll
-                    for (int c = 0; c < SM_NC; ++c)
-                        if (c <= kcm) x[r][c] += wi * buf[q * SMALL_P + tx + 32 * c];
-                }
-            }
-        }
-        __syncthreads();
-    }
+    if (n > 0) sm_wtw_block<0>(n, w, x, buf, ty, tx);
+    if (n > 16) sm_wtw_block<1>(n, w, x, buf, ty, tx);
+    if (n > 32) sm_wtw_block<2>(n, w, x, buf, ty, tx);
+    if (n > 48) sm_wtw_block<3>(n, w, x, buf, ty, tx);
+    if (n > 64) sm_wtw_block<4>(n, w, x, buf, ty, tx);
+    if (n > 80) sm_wtw_block<5>(n, w, x, buf, ty, tx);
+    if (n > 96) sm_wtw_block<6>(n, w, x, buf, ty, tx);
+    if (n > 112) sm_wtw_block<7>(n, w, x, buf, ty, tx);
 }
 
 // L (lower, identity padded, ld = 128) and W = L^-1 (lower, zeros above, identity padded) to global memory
@@ -247,6 +255,14 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
     double *asinvrd = asinv + SMALL_P;                 // 128
     double *tvec = asinvrd + SMALL_P;                  // 128
     double *bvec = tvec + SMALL_P;                     // 128 (+ 128 behind it: the sweep's deferred scale factors)
+    // the rank-one factors' CSR, staged once: every later use is a handful of dependent reads per pair of constraints,
+    // which from global memory cost an L2 round trip each (the build took 25-45 us that way)
+    double *fvl = bvec + 2 * SMALL_P;                  // SMALL_P * SMALL_SPMAX values of the sparse factors
+    double *sgl = fvl + SMALL_P * SMALL_SPMAX;         // 128 signs
+    int *fil = (int *) (sgl + SMALL_P);                // SMALL_P * SMALL_SPMAX indices
+    int *fpl = fil + SMALL_P * SMALL_SPMAX;            // 129 row starts INTO fvl / fil (dense rows: empty)
+    int *fnl = fpl + SMALL_P + 4;                      // 128: entries per row (a dense row: n, its values stay in global memory)
+    int *dol = fnl + SMALL_P;                          // 128: dense_of
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
     // phase stamps (100 MHz wall clock) behind the results: [0] start, [1] S assembled, [2] factor + inverse of S,
     // [3] S^-1, [4] Schur build, [5] factor + inverse of M, [6] solves
@@ -260,14 +276,30 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
         Xl[i + j * ld] = p.tau * p.C[i + (long) j * p.ldc] + ((i == j) ? p.eye : 0.0);
     }
     if (tid < m) bvec[tid] = p.b[tid];
+    if (tid == 0) {                                    // row starts of the staged (sparse-only) CSR: a serial scan of <= 128 rows
+        int pos = 0;
+        for (int q = 0; q < m; ++q) {
+            const int cnt = p.fp[q + 1] - p.fp[q];
+            fpl[q] = pos; fnl[q] = cnt;
+            if (cnt <= SMALL_SPMAX) pos += cnt;
+        }
+        fpl[m] = pos;
+    }
+    if (tid < m) { sgl[tid] = p.sgn[tid]; dol[tid] = p.dense_of[tid]; }
+    __syncthreads();
+    for (int q = tid; q < m; q += SM_T) {
+        const int f0 = p.fp[q], cnt = fnl[q];
+        if (cnt <= SMALL_SPMAX)
+            for (int u = 0; u < cnt; ++u) { fvl[fpl[q] + u] = p.fv[f0 + u]; fil[fpl[q] + u] = p.fi[f0 + u]; }
+    }
     __syncthreads();
     for (int q = tid; q < m; q += SM_T) {              // sparse factors: a handful of entries each
-        const int f0 = p.fp[q], f1 = p.fp[q + 1];
-        if (f1 - f0 > SMALL_SPMAX) continue;
-        const double coef = -p.y[q] * p.sgn[q];
+        if (fnl[q] > SMALL_SPMAX) continue;
+        const int f0 = fpl[q], f1 = f0 + fnl[q];
+        const double coef = -p.y[q] * sgl[q];
         if (coef == 0.0) continue;
         for (int u = f0; u < f1; ++u)
-            for (int v = f0; v < f1; ++v) atomicAdd(&Xl[p.fi[u] + p.fi[v] * ld], coef * p.fv[u] * p.fv[v]);
+            for (int v = f0; v < f1; ++v) atomicAdd(&Xl[fil[u] + fil[v] * ld], coef * fvl[u] * fvl[v]);
     }
     __syncthreads();
     for (int d = 0; d < p.ndense; ++d) {               // dense factors: the whole workgroup per row
@@ -312,7 +344,7 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
     sm_store_factor(n, a, rr, p.LS, p.WS, ty, tx);
     __syncthreads();
     SM_STAMP(2)
-    sm_wtw(n, rr, a, colb, ty, tx);                    // (colb and rowb are contiguous: 4 x 128 doubles; `a` is free now)
+    sm_wtw(n, rr, a, Xl, ty, tx);                      // (the S image in LDS is free: 16 x 128 doubles of it serve as the row buffer; `a` is free too)
 #pragma unroll
     for (int r = 0; r < SM_NR; ++r)
 #pragma unroll
@@ -334,46 +366,66 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
     }
     __syncthreads();
     for (int q = tid; q < m; q += SM_T) {              // Gamma_qq and |X a_q|^2
-        const int f0 = p.fp[q], f1 = p.fp[q + 1], dq = p.dense_of[q];
+        const int dq = dol[q];
         double gii = 0.0, nrm = 0.0;
         if (dq >= 0) {
-            const double *v = vden + dq * SMALL_P;
-            for (int k = 0; k < n; ++k) { gii += p.fv[f0 + k] * v[k]; nrm += v[k] * v[k]; }
+            const double *v = vden + dq * SMALL_P, *av = p.fv + p.fp[q];
+            for (int k = 0; k < n; ++k) { gii += av[k] * v[k]; nrm += v[k] * v[k]; }
         } else {
+            const int f0 = fpl[q], f1 = f0 + fnl[q];
             for (int u = f0; u < f1; ++u)
-                for (int v = f0; v < f1; ++v) gii += p.fv[u] * p.fv[v] * Xl[p.fi[u] + p.fi[v] * ld];
+                for (int v = f0; v < f1; ++v) gii += fvl[u] * fvl[v] * Xl[fil[u] + fil[v] * ld];
             for (int r = 0; r < n; ++r) {
                 double t = 0.0;
-                for (int u = f0; u < f1; ++u) t += p.fv[u] * Xl[r + p.fi[u] * ld];
+                for (int u = f0; u < f1; ++u) t += fvl[u] * Xl[r + fil[u] * ld];
                 nrm += t * t;
             }
         }
-        asinv[q] = p.sgn[q] * gii;
-        asinvrd[q] = p.Rd * p.sgn[q] * nrm;
+        asinv[q] = sgl[q] * gii;
+        asinvrd[q] = p.Rd * sgl[q] * nrm;
     }
-    const int npairs = m * (m + 1) / 2;
-    for (int e = tid; e < npairs; e += SM_T) {         // M_ij = s_i s_j (a_i' X a_j)^2, i >= j
-        int i = (int) ((sqrt(8.0 * (double) e + 1.0) - 1.0) * 0.5);
-        while ((i + 1) * (i + 2) / 2 <= e) ++i;
-        while (i * (i + 1) / 2 > e) --i;
-        const int j = e - i * (i + 1) / 2;
-        const int i0 = p.fp[i], i1 = p.fp[i + 1], j0 = p.fp[j], j1 = p.fp[j + 1];
-        const int di = p.dense_of[i], dj = p.dense_of[j];
-        double gam = 0.0;
-        if (dj >= 0) {
-            const double *v = vden + dj * SMALL_P;
-            for (int u = i0; u < i1; ++u) gam += p.fv[u] * v[p.fi[u]];
-        } else if (di >= 0) {
-            const double *v = vden + di * SMALL_P;
-            for (int u = j0; u < j1; ++u) gam += p.fv[u] * v[p.fi[u]];
-        } else {
-            for (int u = i0; u < i1; ++u)
-                for (int v = j0; v < j1; ++v) gam += p.fv[u] * p.fv[v] * Xl[p.fi[u] + p.fi[v] * ld];
+    {   // M_ij = s_i s_j (a_i' X a_j)^2 for i >= j: thread t keeps column j = t mod 128 (its factor in registers) and walks
+        // the rows i = t / 128, +4, ...; the row's data are the same address for a whole wave (LDS broadcasts)
+        const int j = tid & (SMALL_P - 1);
+        if (j < m) {
+            const int dj = dol[j], j0 = fpl[j], jn = (dj >= 0) ? 0 : fnl[j];
+            const double aj0 = (jn > 0) ? fvl[j0] : 0.0;               // the common case: one entry per factor
+            const int ij0 = (jn > 0) ? fil[j0] : 0;
+            const double sj = sgl[j];
+            const int istart = j + ((((tid >> 7) - j) % 4 + 4) % 4);      // first row >= j of this thread's residue class
+            for (int i = istart; i < m; i += 4) {
+                const int di = dol[i];
+                double gam = 0.0;
+                if (di >= 0 && dj >= 0) {                  // both dense (a handful of pairs at most): a_i from global memory
+                    const double *v = vden + dj * SMALL_P, *av = p.fv + p.fp[i];
+                    for (int k = 0; k < n; ++k) gam += av[k] * v[k];
+                } else if (dj >= 0) {
+                    const double *v = vden + dj * SMALL_P;
+                    for (int u = fpl[i]; u < fpl[i] + fnl[i]; ++u) gam += fvl[u] * v[fil[u]];
+                } else if (di >= 0) {
+                    const double *v = vden + di * SMALL_P;
+                    for (int u = j0; u < j0 + jn; ++u) gam += fvl[u] * v[fil[u]];
+                } else {
+                    const int i0 = fpl[i], in_ = fnl[i];
+                    if (in_ == 1 && jn == 1) gam = fvl[i0] * aj0 * Xl[fil[i0] + ij0 * ld];
+                    else
+                        for (int u = 0; u < in_; ++u) {
+                            const double *xc = Xl + fil[i0 + u];       // row index of X from a_i, column from a_j
+                            double t = 0.0;
+                            for (int v = j0; v < j0 + jn; ++v) t += fvl[v] * xc[fil[v] * ld];
+                            gam += fvl[i0 + u] * t;
+                        }
+                }
+                p.M[i + (long) j * p.ldm] = sgl[i] * sj * gam * gam;
+            }
         }
-        p.M[i + (long) j * p.ldm] = p.sgn[i] * p.sgn[j] * gam * gam;
     }
     double trs = 0.0;
-    if (tid == 0) for (int k = 0; k < n; ++k) trs += Xl[k + k * ld];
+    if (tid < 64) {                                    // tr S^-1: one wave, two entries per lane, shuffles
+        double t = ((tid < n) ? Xl[tid + tid * ld] : 0.0) + ((tid + 64 < n) ? Xl[(tid + 64) + (tid + 64) * ld] : 0.0);
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        trs = t;
+    }
     __threadfence();
     __syncthreads();
     if (tid < m) { p.out[4 + tid] = asinv[tid]; p.out[4 + m + tid] = asinvrd[tid]; }
@@ -404,7 +456,8 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
 }
 
 size_t hdm_small_lds_bytes() {
-    return sizeof(double) * ((size_t) SMALL_P * (SMALL_P + 1) + 4 * SMALL_P + SMALL_NDENSE * SMALL_P + 5 * SMALL_P);
+    return sizeof(double) * ((size_t) SMALL_P * (SMALL_P + 1) + 4 * SMALL_P + SMALL_NDENSE * SMALL_P + 5 * SMALL_P + SMALL_P * SMALL_SPMAX + SMALL_P) +
+           sizeof(int) * ((size_t) SMALL_P * SMALL_SPMAX + (SMALL_P + 4) + 2 * SMALL_P);
 }
 
 int hdm_small_phase_a(const HdmSmallArgs &args, hipStream_t s) {
