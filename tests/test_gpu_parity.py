@@ -810,6 +810,80 @@ def test_fused_phase_a_pass_of_small_rank_one_blocks(name):
         cone.destroy()
 
 
+def _rank_one_block(n, m, rng, ndense=1, nnz=(1, 2, 3)):
+    """CSC (column 0 = C) of a block whose constraints are all sigma a a' -- sparse factors with a few entries, `ndense` dense"""
+    P = n * (n + 1) // 2
+
+    def pk(i, j):
+        return (2 * n - j - 1) * j // 2 + i
+
+    cols = []
+    Cm = np.diag(3.0 + rng.uniform(0, 1, n))
+    Cm += 0.05 * np.tril(rng.uniform(-1, 1, (n, n)), -1)
+    cols.append({pk(i, j): Cm[i, j] for j in range(n) for i in range(j, n) if Cm[i, j] != 0.0})
+    for q in range(m):
+        a = np.zeros(n)
+        if q < ndense:
+            a[:] = rng.uniform(-1, 1, n)
+        else:
+            k = int(rng.choice(nnz))
+            idx = rng.choice(n, min(k, n), replace=False)
+            a[idx] = rng.uniform(0.3, 1.0, len(idx)) * rng.choice([-1.0, 1.0], len(idx))
+        sig = float(rng.choice([-1.0, 1.0])) * rng.uniform(0.5, 1.5)
+        nz = np.nonzero(a)[0]
+        cols.append({pk(max(i, j), min(i, j)): sig * a[i] * a[j] for i in nz for j in nz if i >= j})
+    beg, idx, val = [0], [], []
+    for c in cols:
+        for k in sorted(c):
+            idx.append(k); val.append(c[k])
+        beg.append(len(idx))
+    return np.array(beg, dtype=np.int32), np.array(idx, dtype=np.int32), np.array(val)
+
+
+@pytest.mark.parametrize("n,m,ndense", [(128, 128, 4), (100, 128, 0), (37, 5, 1), (2, 3, 0), (1, 1, 0), (64, 90, 2)])
+def test_fused_phase_a_on_generated_rank_one_blocks(n, m, ndense):
+    """the fused pass at its limits (n = m = 128, four dense factors), on ragged and tiny shapes, signs of both kinds, factors
+    with one to three entries: against the plain-C oracle's column-by-column build (the reference's M2 formulas) and LAPACK"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    from hdsdp_amd import api
+    rng = np.random.default_rng(1000 * n + m)
+    beg, idx, val = _rank_one_block(n, m, rng, ndense=ndense)
+    cone = api.SDPCone.from_csc(n, m, beg, idx, val)
+    blk = oracle_py.Block(n, m, beg, idx, val)
+    try:
+        if cone.path != 1:
+            pytest.skip("not classified rank one")
+        kkt = api.KKT(m, [cone])
+        assert kkt.phase_a_eligible()
+        Rd, tau = -2.0, 0.9
+        y = 0.05 * np.cos(np.arange(m) + 0.3)
+        cone.set_start(Rd)
+        b = np.sin(np.arange(m) + 1.0)
+        ok, logdet, d1, d2, d3 = kkt.phase_a(tau, y, b)
+        S = blk.assemble_S(tau, y, Rd)
+        Lf, info = blk.factor(S)
+        assert ok == (info == 0) and ok
+        assert abs(logdet - blk.logdet(Lf)) <= 1e-12 * max(1.0, abs(blk.logdet(Lf)))
+        ref = blk.kkt_build(blk.inverse(Lf), Rd, 0)
+        msk = lower_mask(m)
+        ex = kkt.export()
+        check_close(kkt.M[msk], ref["M"][msk], "M")
+        check_close(ex["ASinv"], ref["ASinv"], "ASinv")
+        check_close(ex["ASinvRdSinv"], ref["ASinvRdSinv"], "ASinvRdSinv")
+        check_close([ex["TraceSinv"]], [ref["TraceSinv"]], "TraceSinv")
+        A = np.triu(ref["M"]) + np.triu(ref["M"], 1).T
+        if np.linalg.cond(A) < 1e10:
+            for x, rhs in ((d1, b), (d2, ref["ASinv"]), (d3, ref["ASinvRdSinv"])):
+                xr = np.linalg.solve(A, rhs)
+                assert np.linalg.norm(x - xr) <= 1e-8 * max(np.linalg.norm(xr), 1e-300) * max(1.0, np.linalg.cond(A) * 1e-6)
+        kkt.destroy()
+    finally:
+        cone.destroy()
+        blk.close()
+
+
 def test_fused_phase_a_refuses_what_it_cannot_do():
     from hdsdp_amd import api
     cone = api.SDPCone.synthetic(64, 40)          # dense block: congruence path
