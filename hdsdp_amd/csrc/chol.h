@@ -47,3 +47,4 @@ struct HdmChol {
 
 // several engine shards share this device: the single-launch substitution (which needs co-resident workgroups) is off
 void hdm_flow_set_shared_device(int on);
+double hdm_diag_block_probe(int variant, int reps, hipStream_t s);   // diagnostic: us per diagonal-block kernel (0: LDS panels, 1: register sweep)

@@ -12,6 +12,7 @@
 // triangular inverse Linv (needed by the congruence kernels) is assembled from them by GEMMs.
 #include "hdm_common.h"
 #include "chol.h"
+#include "sweep128.h"
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -190,6 +191,36 @@ __global__ __launch_bounds__(256) void hdm_potrf_diag_kernel(double *__restrict_
         }
     }
     for (int e = tid; e < NB * NB; e += 256) Dinv[e] = a[e];
+}
+
+// The same contract on the register sweep of sweep128.h (round 2): the block lives in the registers of 512 threads, four
+// pivots per barrier, the triangular inverse is carried along in the same pass.  113 -> about 55 us per block; the old
+// kernel stays for A/B runs (HDM_DIAG_SWEEP=0).  A non-positive pivot is not patched here: everything after it turns into
+// NaNs (the caller reads `info` and discards the factor).
+#define DIAG_SWEEP_LDS_DOUBLES (SMALL_P * (SMALL_P + 1) + 2 * SMALL_P)
+__global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_kernel(double *__restrict__ A, long ld, double *__restrict__ Dinv,
+                                                                    int *__restrict__ info, int col0) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *img = sm;                                  // 128 x 129 staging image; its head doubles as the sweep's block images
+    double *rsv = sm + SMALL_P * (SMALL_P + 1);
+    constexpr int ldi = SMALL_P + 1;
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const int ei = tid & (SMALL_P - 1), ej0 = tid >> 7;
+#pragma unroll 8
+    for (int j = ej0; j < SMALL_P; j += SM_T / SMALL_P) img[ei + j * ldi] = (ei >= j) ? A[ei + (long) j * ld] : 0.0;
+    __syncthreads();
+    double a[SM_NR][SM_NC], rr[SM_NR][SM_NC];
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r)
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) a[r][c] = img[(ty + 16 * r) + (tx + 32 * c) * ldi];
+    __syncthreads();
+    double unused;
+    const int bad = sm_sweep<false>(SMALL_P, a, rr, img, rsv, ty, tx, &unused);
+    if (bad && tid == 0) atomicCAS(info, 0, col0 + bad);
+    __syncthreads();
+    sm_store_one<true>(SMALL_P, a, img, A, ld, ty, tx, tid);
+    sm_store_one<false>(SMALL_P, rr, img, Dinv, SMALL_P, ty, tx, tid);
 }
 
 // pad region of an (npad x npad) matrix whose valid part is n x n: identity on the diagonal
@@ -433,6 +464,39 @@ __global__ __launch_bounds__(256) void hdm_trsv_flow_kernel(const double *__rest
     if (tid == 0) __hip_atomic_store(fb + i, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// diagnostic: average duration (us, HIP events) of `reps` launches of one diagonal-block kernel on a 128 x 128 SPD block
+__global__ void hdm_probe_spd_block_kernel(double *A, long ld) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = e & (NB - 1), j = e >> 7;
+    if (j < NB) A[i + (long) j * ld] = (i == j) ? 4.0 + 0.01 * i : 1.0 / (1.0 + abs(i - j));
+}
+double hdm_diag_block_probe(int variant, int reps, hipStream_t s) {
+    double *A = nullptr, *D = nullptr;
+    int *info = nullptr;
+    hipEvent_t e0, e1;
+    if (hipMalloc((void **) &A, sizeof(double) * NB * NB) != hipSuccess || hipMalloc((void **) &D, sizeof(double) * NB * NB) != hipSuccess ||
+        hipMalloc((void **) &info, sizeof(int)) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return -1.0;
+    (void) hipFuncSetAttribute((const void *) hdm_potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + LDW * PB) * (int) sizeof(double));
+    (void) hipFuncSetAttribute((const void *) hdm_potrf_diag_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_SWEEP_LDS_DOUBLES * (int) sizeof(double));
+    (void) hipMemsetAsync(info, 0, sizeof(int), s);
+    float ms = 0.f, total = 0.f;
+    for (int r = -2; r < reps; ++r) {
+        hipLaunchKernelGGL(hdm_probe_spd_block_kernel, dim3(NB * NB / 256), dim3(256), 0, s, A, (long) NB);
+        (void) hipEventRecord(e0, s);
+        if (variant)
+            hipLaunchKernelGGL(hdm_potrf_diag_sweep_kernel, dim3(1), dim3(SM_T), DIAG_SWEEP_LDS_DOUBLES * sizeof(double), s, A, (long) NB, D, info, 0);
+        else
+            hipLaunchKernelGGL(hdm_potrf_diag_kernel, dim3(1), dim3(256), (NB * NB + LDW * PB) * sizeof(double), s, A, (long) NB, D, info, 0);
+        (void) hipEventRecord(e1, s);
+        (void) hipEventSynchronize(e1);
+        (void) hipEventElapsedTime(&ms, e0, e1);
+        if (r >= 0) total += ms;
+    }
+    (void) hipFree(A); (void) hipFree(D); (void) hipFree(info); (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    return total / reps * 1e3;
+}
+
 // ------------------------------------------------------------------------------------------
 // host drivers
 // ------------------------------------------------------------------------------------------
@@ -448,6 +512,8 @@ int HdmChol::init(int n_) {
     HDM_HIP_CHECK(hdm_memset_sync(L, 0, mat));
     HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (NB * NB + LDW * PB) * (int) sizeof(double)));
+    HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_potrf_diag_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      DIAG_SWEEP_LDS_DOUBLES * (int) sizeof(double)));
     return 0;
 }
 
@@ -551,10 +617,15 @@ int HdmChol::enqueue_factor(hipStream_t s) {
     HDM_HIP_CHECK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
     const long ld = npad;
     const size_t shm = (NB * NB + LDW * PB) * sizeof(double);
+    static const bool diag_sweep = [] { const char *e = getenv("HDM_DIAG_SWEEP"); return !(e && atoi(e) == 0); }();
     for (int k = 0; k < nblk; ++k) {
         double *Akk = L + (long) k * NB * (ld + 1);
-        hipLaunchKernelGGL(hdm_potrf_diag_kernel, dim3(1), dim3(256), shm, s, Akk, ld, Dinv + (long) k * NB * NB,
-                           info_dev, k * NB);
+        if (diag_sweep)
+            hipLaunchKernelGGL(hdm_potrf_diag_sweep_kernel, dim3(1), dim3(SM_T), DIAG_SWEEP_LDS_DOUBLES * sizeof(double), s, Akk, ld,
+                               Dinv + (long) k * NB * NB, info_dev, k * NB);
+        else
+            hipLaunchKernelGGL(hdm_potrf_diag_kernel, dim3(1), dim3(256), shm, s, Akk, ld, Dinv + (long) k * NB * NB,
+                               info_dev, k * NB);
         HDM_HIP_CHECK(hipGetLastError());
         const int rows = npad - (k + 1) * NB;
         if (rows <= 0) break;

@@ -2758,8 +2758,8 @@ hdsdp_retcode HMiKKTPhaseA(hdsdp_kkt *HKKT, double barHsdTau, double *rowDual, d
     a.Sout = c->S; a.lds = c->n16;
     a.LS = ls->ch.L; a.WS = ls->ch.Dinv; a.M = lm->Mdev; a.ldm = lm->ch.npad; a.LM = lm->ch.L; a.WM = lm->ch.Dinv;
     if (ls->ch.npad != SMALL_P || lm->ch.npad != SMALL_P) return HDSDP_RETCODE_FAILED;
-    // the operator's accumulators as HKKTBuildUp(KKT_TYPE_INFEASIBLE) leaves them (hdsdp_schur.c:141-165, :256-268)
-    HIP_RC(hipMemsetAsync(lm->Mdev, 0, sizeof(double) * (size_t) SMALL_P * SMALL_P, g.stream));
+    // (the operator's accumulators as HKKTBuildUp(KKT_TYPE_INFEASIBLE) leaves them, hdsdp_schur.c:141-165, :256-268: the
+    // kernel itself zeroes what it does not fill of the 128 x 128 device matrix)
     RC(hdm_small_phase_a(a, g.stream));
     if (pv->mirror)
         HIP_RC(hipMemcpy2DAsync(HKKT->kktMatElem, sizeof(double) * m, lm->Mdev, sizeof(double) * SMALL_P, sizeof(double) * m, m,
@@ -2791,7 +2791,9 @@ hdsdp_retcode HMiKKTPhaseA(hdsdp_kkt *HKKT, double barHsdTau, double *rowDual, d
     if (d1) memcpy(d1, out + 4 + 2 * (size_t) m, sizeof(double) * m);
     if (d2) memcpy(d2, out + 4 + 3 * (size_t) m, sizeof(double) * m);
     if (d3) memcpy(d3, out + 4 + 4 * (size_t) m, sizeof(double) * m);
-    for (int i = 0; i < 7; ++i) g.stage_ms[i] = (i < 6) ? (out[4 + 5 * (size_t) m + i + 1] - out[4 + 5 * (size_t) m + i]) * 1e-5 : 0.0;   // HMiGetStageTimes: 100 MHz ticks -> ms
+    const double *stamp = out + 4 + 5 * (size_t) m;
+    for (int i = 0; i < 6; ++i) g.stage_ms[i] = (stamp[i + 1] - stamp[i]) * 1e-5;   // HMiGetStageTimes: 100 MHz ticks -> ms
+    g.stage_ms[6] = (stamp[6] > stamp[0]) ? stamp[7] / ((stamp[6] - stamp[0]) * 10.0) : 0.0;   // shader clock during the pass, GHz
     return HDSDP_RETCODE_OK;
 }
 
@@ -2830,6 +2832,11 @@ int HMiPotrf(double *A_dev, int n, int64_t lda, int *info) {
     HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
     ch.destroy();
     return 0;
+}
+
+double HMiDiagBlockProbe(int variant, int reps) {
+    if (ensure_ctx()) return -1.0;
+    return hdm_diag_block_probe(variant, reps, g.stream);
 }
 
 double HMiMfmaPeakProbe(int iters) {

@@ -25,134 +25,7 @@
 #include <algorithm>
 #include <cmath>
 
-#define SM_T 512
-#define SM_NR 8
-#define SM_NC 4
-
-// Register matrices are indexed with compile-time constants only.  Where the wanted local row / column is a run-time but
-// wave-uniform number, a switch over the constants selects it: a select chain over the whole array (v = c == kc ? a[r][c] : v)
-// makes the compiler keep the array in scratch memory (606 scratch instructions, 1.8 ms per pass instead of 0.1).
-#define SM_SWITCH4(kc, BODY)   \
-    switch (kc) {              \
-        case 0: { constexpr int C_ = 0; BODY } break;  \
-        case 1: { constexpr int C_ = 1; BODY } break;  \
-        case 2: { constexpr int C_ = 2; BODY } break;  \
-        default: { constexpr int C_ = 3; BODY } break; \
-    }
-#define SM_SWITCH8(kr, BODY)   \
-    switch (kr) {              \
-        case 0: { constexpr int R_ = 0; BODY } break;  \
-        case 1: { constexpr int R_ = 1; BODY } break;  \
-        case 2: { constexpr int R_ = 2; BODY } break;  \
-        case 3: { constexpr int R_ = 3; BODY } break;  \
-        case 4: { constexpr int R_ = 4; BODY } break;  \
-        case 5: { constexpr int R_ = 5; BODY } break;  \
-        case 6: { constexpr int R_ = 6; BODY } break;  \
-        default: { constexpr int R_ = 7; BODY } break; \
-    }
-
-// one sweep over k < n: a (full symmetric in) -> lower part = L;  rr -> W = L^-1 (lower).
-// colb / rowb: 2 x 128 doubles of LDS each, rsv: 128.  Returns 0, or k + 1 for the first non-positive pivot (all threads alike).
-//
-// Column k of the trailing matrix and row k of R are never touched again after step k, and what is final about them is
-// only a scale factor 1 / sqrt(pivot_k) away: L[i, k] = A_k[i, k] rs_k, W[k, j] = R_k[k, j] rs_k.  So the loop never writes
-// a "final" column or row back into the register matrices (an insert at a run-time position costs a phi of the whole
-// array per step); the factors rs_k are kept in LDS and applied once at the end.  All LDS reads of a step are issued
-// together and unconditionally -- under per-element conditions the compiler put every ds_read behind its own branch and
-// its own wait, 49 serialised LDS round trips per step (2.1 us per step instead of 0.3).
-// sixteen steps k = 16 KR .. 16 KR + 15 of the sweep.  The local row index of the published row (KR) and the local column
-// index of the published column (KR / 2) are template constants: the register matrices are indexed with constants only,
-// the bounds of the update loops fold, and a step is one straight-line block between two barriers.
-template <int KR>
-__device__ __forceinline__ int sm_sweep_chunk(int n, double (&a)[SM_NR][SM_NC], double (&rr)[SM_NR][SM_NC],
-                                              double *colb, double *rowb, double *rsv, int ty, int tx) {
-    constexpr int KC = KR / 2;
-    const int kend = min(n, 16 * KR + 16);
-    for (int k = 16 * KR; k < kend; ++k) {
-        double *cb = colb + (k & 1) * SMALL_P, *rb = rowb + (k & 1) * SMALL_P;
-        if (tx == (k & 31)) {                    // owners of column k publish it (rows ty + 16 r)
-#pragma unroll
-            for (int r = 0; r < SM_NR; ++r) cb[ty + 16 * r] = a[r][KC];
-        }
-        if (ty == (k & 15)) {                    // owners of row k of R publish it (columns tx + 32 c)
-#pragma unroll
-            for (int c = 0; c < SM_NC; ++c) rb[tx + 32 * c] = rr[KR][c];
-        }
-        __syncthreads();
-        const double p = cb[k];
-        double cbi[SM_NR], cbj[SM_NC], rbj[SM_NC];
-#pragma unroll
-        for (int r = KR; r < SM_NR; ++r) cbi[r] = cb[ty + 16 * r];
-#pragma unroll
-        for (int c = 0; c < SM_NC; ++c) { cbj[c] = (c >= KC) ? cb[tx + 32 * c] : 0.0; rbj[c] = (c <= KC) ? rb[tx + 32 * c] : 0.0; }
-        if (!(p > 0.0)) return k + 1;
-        // 1 / sqrt(p): the hardware estimate (v_rsq_f64, about 2^-26) and two Newton steps
-        double rs = __builtin_amdgcn_rsq(p);
-        rs = rs * (1.5 - 0.5 * p * rs * rs);
-        rs = rs * (1.5 - 0.5 * p * rs * rs);
-        if (ty == 0 && tx == 0) rsv[k] = rs;
-        double li[SM_NR], lj[SM_NC], wj[SM_NC];
-#pragma unroll
-        for (int r = KR; r < SM_NR; ++r) li[r] = cbi[r] * ((ty + 16 * r > k) ? rs : 0.0);
-#pragma unroll
-        for (int c = 0; c < SM_NC; ++c) {
-            lj[c] = cbj[c] * ((tx + 32 * c > k) ? rs : 0.0);
-            wj[c] = rbj[c] * ((tx + 32 * c <= k) ? rs : 0.0);
-        }
-#pragma unroll
-        for (int r = KR; r < SM_NR; ++r) {       // rows that can lie below k
-#pragma unroll
-            for (int c = 0; c < SM_NC; ++c) {
-                if (c >= KC) a[r][c] -= li[r] * lj[c];      // trailing update (columns right of k)
-                if (c <= KC) rr[r][c] -= li[r] * wj[c];     // forward substitution on the identity (columns up to k)
-            }
-        }
-    }
-    return 0;
-}
-
-__device__ __forceinline__ int sm_sweep(int n, double (&a)[SM_NR][SM_NC], double (&rr)[SM_NR][SM_NC],
-                                        double *colb, double *rowb, double *rsv, int ty, int tx, double *logdet) {
-#pragma unroll
-    for (int r = 0; r < SM_NR; ++r)
-#pragma unroll
-        for (int c = 0; c < SM_NC; ++c) rr[r][c] = (ty + 16 * r == tx + 32 * c) ? 1.0 : 0.0;
-    int info = 0;
-    if (!info && n > 0) info = sm_sweep_chunk<0>(n, a, rr, colb, rowb, rsv, ty, tx);
-    if (!info && n > 16) info = sm_sweep_chunk<1>(n, a, rr, colb, rowb, rsv, ty, tx);
-    if (!info && n > 32) info = sm_sweep_chunk<2>(n, a, rr, colb, rowb, rsv, ty, tx);
-    if (!info && n > 48) info = sm_sweep_chunk<3>(n, a, rr, colb, rowb, rsv, ty, tx);
-    if (!info && n > 64) info = sm_sweep_chunk<4>(n, a, rr, colb, rowb, rsv, ty, tx);
-    if (!info && n > 80) info = sm_sweep_chunk<5>(n, a, rr, colb, rowb, rsv, ty, tx);
-    if (!info && n > 96) info = sm_sweep_chunk<6>(n, a, rr, colb, rowb, rsv, ty, tx);
-    if (!info && n > 112) info = sm_sweep_chunk<7>(n, a, rr, colb, rowb, rsv, ty, tx);
-    __syncthreads();
-    double ld = 0.0;
-    if (!info) {
-        // apply the deferred scale factors: column j of L and row i of W; log det = 2 sum log L_kk from the owners of the
-        // diagonal (the sum is finished by the caller)
-#pragma unroll
-        for (int c = 0; c < SM_NC; ++c) {
-            const int j = tx + 32 * c;
-            const double sj = (j < n) ? rsv[j] : 1.0;
-#pragma unroll
-            for (int r = 0; r < SM_NR; ++r) a[r][c] *= sj;
-        }
-#pragma unroll
-        for (int r = 0; r < SM_NR; ++r) {
-            const int i = ty + 16 * r;
-            const double si = (i < n) ? rsv[i] : 1.0;
-#pragma unroll
-            for (int c = 0; c < SM_NC; ++c) {
-                rr[r][c] *= si;
-                if (i == tx + 32 * c && i < n) ld += 2.0 * log(a[r][c]);
-            }
-        }
-    }
-    __syncthreads();
-    *logdet = ld;
-    return info;
-}
+#include "sweep128.h"
 
 // x = W'W for the lower-triangular W in registers (x_ij = sum_k W_ki W_kj).  Every thread owns exactly one row of each
 // block of sixteen rows (row 16 KR + ty, its local row KR), so a block is published by ALL threads at once -- no owner
@@ -195,21 +68,6 @@ __device__ __forceinline__ void sm_wtw(int n, const double (&w)[SM_NR][SM_NC], d
     if (n > 112) sm_wtw_block<7>(n, w, x, buf, ty, tx);
 }
 
-// L (lower, identity padded, ld = 128) and W = L^-1 (lower, zeros above, identity padded) to global memory
-__device__ __forceinline__ void sm_store_factor(int n, const double (&a)[SM_NR][SM_NC], const double (&rr)[SM_NR][SM_NC],
-                                                double *L, double *W, int ty, int tx) {
-#pragma unroll
-    for (int r = 0; r < SM_NR; ++r)
-#pragma unroll
-        for (int c = 0; c < SM_NC; ++c) {
-            const int i = ty + 16 * r, j = tx + 32 * c;
-            const bool in = (i < n && j < n);
-            const double pad = (i == j) ? 1.0 : 0.0;
-            L[i + (long) j * SMALL_P] = in ? ((i >= j) ? a[r][c] : 0.0) : pad;
-            W[i + (long) j * SMALL_P] = in ? ((i >= j) ? rr[r][c] : 0.0) : pad;
-        }
-}
-
 // x = W' (W b) for the lower-triangular W held in registers; b, t: LDS vectors; part: 16 x 128 LDS doubles; out: m results
 __device__ __forceinline__ void sm_solve(int m, const double (&w)[SM_NR][SM_NC], const double *b, double *t, double *part,
                                          double *out, int ty, int tx, int tid) {
@@ -247,10 +105,8 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = p.n, m = p.m;
     const int ld = SMALL_P + 1;
-    double *Xl = sm;                                   // S, later X = S^-1, later solve scratch: 128 x 129
-    double *colb = sm + (long) SMALL_P * ld;           // 2 x 128
-    double *rowb = colb + 2 * SMALL_P;                 // 2 x 128
-    double *vden = rowb + 2 * SMALL_P;                 // SMALL_NDENSE x 128: X a_d of the dense factors
+    double *Xl = sm;                                   // S, later X = S^-1, later solve scratch: 128 x 129 (its first 2 x 1024 doubles: the sweeps' block images)
+    double *vden = sm + (long) SMALL_P * ld;           // SMALL_NDENSE x 128: X a_d of the dense factors
     double *asinv = vden + SMALL_NDENSE * SMALL_P;     // 128
     double *asinvrd = asinv + SMALL_P;                 // 128
     double *tvec = asinvrd + SMALL_P;                  // 128
@@ -269,13 +125,21 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
     double *stamp = p.out + 4 + 5 * m;
 #define SM_STAMP(i) if (tid == 0) stamp[i] = (double) __builtin_amdgcn_s_memrealtime();
     SM_STAMP(0)
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
 
     // ---- S = tau C - sum y_i s_i a_i a_i' + eye I, assembled in LDS (full symmetric)
-    for (int e = tid; e < n * n; e += SM_T) {
-        const int i = e % n, j = e / n;
-        Xl[i + j * ld] = p.tau * p.C[i + (long) j * p.ldc] + ((i == j) ? p.eye : 0.0);
+    // (thread = row tid mod 128 of the columns tid / 128, + 4, ...: no integer division, and the loads of an unrolled
+    // group are in flight together -- one load per trip of a divided index ran at a memory round trip per element)
+    const int ei = tid & (SMALL_P - 1), ej0 = tid >> 7;
+    if (ei < n) {
+#pragma unroll 8
+        for (int j = ej0; j < n; j += SM_T / SMALL_P)
+            Xl[ei + j * ld] = p.tau * p.C[ei + (long) j * p.ldc] + ((ei == j) ? p.eye : 0.0);
     }
-    if (tid < m) bvec[tid] = p.b[tid];
+    if (tid < SMALL_P) {                               // (entries past m meet zeros of the padded factor in the solves: they must be numbers)
+        bvec[tid] = (tid < m) ? p.b[tid] : 0.0;
+        asinv[tid] = 0.0; asinvrd[tid] = 0.0; tvec[tid] = 0.0;
+    }
     if (tid == 0) {                                    // row starts of the staged (sparse-only) CSR: a serial scan of <= 128 rows
         int pos = 0;
         for (int q = 0; q < m; ++q) {
@@ -307,15 +171,15 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
         const double coef = -p.y[q] * p.sgn[q];
         const double *av = p.fv + p.fp[q];             // all n entries are listed
         if (coef != 0.0)
-            for (int e = tid; e < n * n; e += SM_T) {
-                const int i = e % n, j = e / n;
-                Xl[i + j * ld] += coef * av[i] * av[j];
+            if (ei < n) {
+                const double ai = coef * av[ei];
+                for (int j = ej0; j < n; j += SM_T / SMALL_P) Xl[ei + j * ld] += ai * av[j];
             }
         __syncthreads();
     }
-    for (int e = tid; e < n * n; e += SM_T) {          // the dual matrix itself stays resident for the other cone slots
-        const int i = e % n, j = e / n;
-        if (i >= j) p.Sout[i + (long) j * p.lds] = Xl[i + j * ld];
+    if (ei < n) {                                      // the dual matrix itself stays resident for the other cone slots
+#pragma unroll 8
+        for (int j = ej0; j <= ei; j += SM_T / SMALL_P) p.Sout[ei + (long) j * p.lds] = Xl[ei + j * ld];
     }
     double a[SM_NR][SM_NC], rr[SM_NR][SM_NC];
 #pragma unroll
@@ -330,20 +194,14 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
 
     // ---- factor S, invert the factor, form S^-1: one sweep
     double logdet = 0.0;
-    const int infoS = sm_sweep(n, a, rr, colb, rowb, bvec + SMALL_P, ty, tx, &logdet);
-    if (tid == 0) tvec[0] = 0.0;
-    __syncthreads();
-    if (logdet != 0.0) atomicAdd(&tvec[0], logdet);
-    __syncthreads();
-    logdet = tvec[0];
-    __syncthreads();
+    const int infoS = sm_sweep(n, a, rr, Xl, bvec + SMALL_P, ty, tx, &logdet);
+    SM_STAMP(2)
     if (infoS) {
         if (tid == 0) { p.out[0] = (double) infoS; p.out[1] = 0.0; p.out[2] = 0.0; p.out[3] = 0.0; }
         return;
     }
-    sm_store_factor(n, a, rr, p.LS, p.WS, ty, tx);
+    sm_store_factor(n, a, rr, Xl, p.LS, p.WS, ty, tx, tid);
     __syncthreads();
-    SM_STAMP(2)
     sm_wtw(n, rr, a, Xl, ty, tx);                      // (the S image in LDS is free: 16 x 128 doubles of it serve as the row buffer; `a` is free too)
 #pragma unroll
     for (int r = 0; r < SM_NR; ++r)
@@ -384,16 +242,16 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
         asinv[q] = sgl[q] * gii;
         asinvrd[q] = p.Rd * sgl[q] * nrm;
     }
-    {   // M_ij = s_i s_j (a_i' X a_j)^2 for i >= j: thread t keeps column j = t mod 128 (its factor in registers) and walks
-        // the rows i = t / 128, +4, ...; the row's data are the same address for a whole wave (LDS broadcasts)
+    {   // M_ji = s_i s_j (a_i' X a_j)^2 for j >= i: thread t keeps ROW j = t mod 128 (its factor in registers) and walks
+        // the columns i = t / 128, +4, ... <= j; the column's data are the same address for a whole wave (LDS broadcasts),
+        // and the 64 stores of a wave are consecutive rows of one column (full lines)
         const int j = tid & (SMALL_P - 1);
         if (j < m) {
             const int dj = dol[j], j0 = fpl[j], jn = (dj >= 0) ? 0 : fnl[j];
             const double aj0 = (jn > 0) ? fvl[j0] : 0.0;               // the common case: one entry per factor
             const int ij0 = (jn > 0) ? fil[j0] : 0;
             const double sj = sgl[j];
-            const int istart = j + ((((tid >> 7) - j) % 4 + 4) % 4);      // first row >= j of this thread's residue class
-            for (int i = istart; i < m; i += 4) {
+            for (int i = tid >> 7; i <= j; i += 4) {
                 const int di = dol[i];
                 double gam = 0.0;
                 if (di >= 0 && dj >= 0) {                  // both dense (a handful of pairs at most): a_i from global memory
@@ -416,7 +274,7 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
                             gam += fvl[i0 + u] * t;
                         }
                 }
-                p.M[i + (long) j * p.ldm] = sgl[i] * sj * gam * gam;
+                p.M[j + (long) i * p.ldm] = sgl[i] * sj * gam * gam;
             }
         }
     }
@@ -432,19 +290,33 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
 
     SM_STAMP(4)
     // ---- factor M, invert the factor, three solves
+    // M comes back through the LDS image (X is dead): full-line loads of the lower triangle, and the rest of the 128 x 128
+    // device matrix is zeroed on the way -- the state HKKTBuildUp leaves (hdsdp_schur.c:141-165), without a memset launch
+    if (ei < SMALL_P) {
+#pragma unroll 8
+        for (int j = ej0; j < SMALL_P; j += SM_T / SMALL_P) {
+            const bool low = (ei < m && j <= ei);
+            double v = 0.0;
+            if (low) v = p.M[ei + (long) j * p.ldm];
+            else p.M[ei + (long) j * p.ldm] = 0.0;
+            Xl[ei + j * ld] = v;
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < SM_NR; ++r)
 #pragma unroll
         for (int c = 0; c < SM_NC; ++c) {
             const int i = ty + 16 * r, j = tx + 32 * c;
             const int hi = max(i, j), lo = min(i, j);
-            a[r][c] = (i < m && j < m) ? p.M[hi + (long) lo * p.ldm] : ((i == j) ? 1.0 : 0.0);
+            a[r][c] = (i < m && j < m) ? Xl[hi + lo * ld] : ((i == j) ? 1.0 : 0.0);
         }
+    __syncthreads();
     double logdetM = 0.0;
-    const int infoM = sm_sweep(m, a, rr, colb, rowb, bvec + SMALL_P, ty, tx, &logdetM);
+    const int infoM = sm_sweep(m, a, rr, Xl, bvec + SMALL_P, ty, tx, &logdetM);
     if (tid == 0) { p.out[0] = 0.0; p.out[1] = (double) infoM; p.out[2] = logdet; p.out[3] = trs; }
     if (infoM) return;
-    sm_store_factor(m, a, rr, p.LM, p.WM, ty, tx);
+    sm_store_factor(m, a, rr, Xl, p.LM, p.WM, ty, tx, tid);
     __syncthreads();
     SM_STAMP(5)
     double *part = Xl;                                 // X is no longer needed: 16 x 128 partial sums
@@ -452,11 +324,12 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
     sm_solve(m, rr, asinv, tvec, part, p.out + 4 + 3 * m, ty, tx, tid);
     sm_solve(m, rr, asinvrd, tvec, part, p.out + 4 + 4 * m, ty, tx, tid);
     SM_STAMP(6)
+    if (tid == 0) stamp[7] = (double) (__builtin_amdgcn_s_memtime() - clk0);      // shader-clock cycles of the whole pass
 #undef SM_STAMP
 }
 
 size_t hdm_small_lds_bytes() {
-    return sizeof(double) * ((size_t) SMALL_P * (SMALL_P + 1) + 4 * SMALL_P + SMALL_NDENSE * SMALL_P + 5 * SMALL_P + SMALL_P * SMALL_SPMAX + SMALL_P) +
+    return sizeof(double) * ((size_t) SMALL_P * (SMALL_P + 1) + SMALL_NDENSE * SMALL_P + 5 * SMALL_P + SMALL_P * SMALL_SPMAX + SMALL_P) +
            sizeof(int) * ((size_t) SMALL_P * SMALL_SPMAX + (SMALL_P + 4) + 2 * SMALL_P);
 }
 

@@ -378,6 +378,7 @@ void HMiSetDebugBuffer(void *dev, int role);
 int HMiGemmNT(const double *A, int64_t lda, int aKMajor, const double *B, int64_t ldb, int bKMajor, double *C,
               int64_t ldc, int M, int N, int K, double alpha, double beta, int kLimit, int lowerOnly);
 int HMiPotrf(double *A_dev, int n, int64_t lda, int *info);  /* in place, lower */
+double HMiDiagBlockProbe(int variant, int reps);   /* us per 128 x 128 diagonal-block kernel of the Cholesky (0: LDS panels, 1: register sweep) */
 double HMiMfmaPeakProbe(int iters);    /* measured fp64 MFMA TFLOP/s of a register-only loop */
 /* GEMM-shaped issue probe: mode 0 = 16 accumulators x (4+4) operand registers, 1 = one operand pair */
 double HMiMfmaIssueProbe(int mode, int wgPerCu, int iters);

@@ -48,6 +48,7 @@ def measure(name, reps=50, cpu=True):
         fused_ms = (time.perf_counter() - t0) / (reps * 4) * 1e3
         out["fused_kernel_phases_us"] = dict(zip(("assemble_S", "factor_and_invert_S", "Sinv", "schur_build", "factor_and_invert_M", "solves"),
                                                   [round(float(v) * 1e3, 1) for v in kkt.stage_times_ms()[:6]]))
+        out["fused_kernel_shader_clock_GHz"] = round(float(kkt.stage_times_ms()[6]), 3)
         out.update({"fused_ms_per_pass": round(fused_ms, 4), "fused_launches_per_pass": 1, "fused_host_syncs_per_pass": 1,
                     "fused_achieved_GBps": round(data_bytes / fused_ms / 1e6, 3)})
     if cpu:
