@@ -435,33 +435,15 @@ __device__ __forceinline__ void cong2_direct_body(const HdmGemmArgs &a, int z, i
 }
 
 
+// one tile (batch entry z, entry t of the tile list) by one workgroup; sidx: this tile's slot in the diagnostic stamp buffer
 template <bool AKM, bool BKM, int ROLE, int VAR>
-__global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
+__device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, const int t, const long sidx) {
+    // (declared here, not handed in as a pointer: through a pointer parameter the LDS addresses became 64-bit run-time
+    // values instead of instruction immediates, and step 2's kernel spilled 113 VGPRs)
     __shared__ __attribute__((aligned(16))) double smem[4 * STAGE_DOUBLES];
     double *sA = smem;                      // [2][STAGE]
     double *sB = smem + 2 * STAGE_DOUBLES;  // [2][STAGE]
-
     const HdmGemmArgs &a = p.a;
-    // XCD-aware decode: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so the
-    // batch index (one constraint matrix / one K split) is the fast index: with batch % 8 == 0 the
-    // workgroups of one XCD keep to their own batch entries and share operand panels in that L2;
-    // tiles are walked heaviest-first (host-sorted list).
-    const int nb = a.batch;
-    const int wg = blockIdx.x;
-    int z, t;
-    if (nb >= 8) {
-        // workgroup ids are dealt round-robin over the 8 XCDs: XCD x walks batch entries x, x+8, ... one after the
-        // other and, inside an entry, the tile list in order -- so the ~64 workgroups an XCD runs at any time work
-        // on ONE operand set and on neighbouring tiles, and share their row/column panels in that XCD's L2.  The
-        // grid is sized for the batch rounded up to a multiple of 8; the surplus workgroups leave at once.
-        const int idx = wg >> 3;
-        z = (wg & 7) + 8 * (idx / p.ntiles);
-        t = idx % p.ntiles;
-    } else {
-        z = wg % nb;
-        t = wg / nb;
-    }
-    if (t >= p.ntiles || z >= nb) return;
     const int tm = p.tiles[t].x, tn = p.tiles[t].y;
 
     const int tid = threadIdx.x;
@@ -511,6 +493,17 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
         stA.chain(a.A2 + (long) z * a.strideA2, a.lda2, m0, kt0, tid, kt1 - kt0);
         stB.chain(a.B2 + (long) z * a.strideB2, a.ldb2, n0, kt0, tid, kt1 - kt0);
     }
+    // diagnostic builds: the cell-dealt tiles leave a stamp too (start, end, where; d[6] = -kind), so that a timeline sees
+    // every workgroup of a launch
+#define HDM_CELL_STAMP(KIND)                                                                        \
+    if ((VAR & 32) && p.dbg && tid == 0) {                                                          \
+        unsigned long long *d = p.dbg + (size_t) sidx * 8;                                    \
+        d[0] = t_start; d[1] = t_start; d[2] = t_start; d[3] = __builtin_amdgcn_s_memtime();        \
+        d[4] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);                                \
+        d[5] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);                                \
+        d[6] = (unsigned long long) (long long) -(KIND);                                            \
+        d[7] = __builtin_amdgcn_s_memrealtime();                                                    \
+    }
     // (roles 1-3 only: the cell paths stage with UNMASKED loads, which needs the slack the engine gives those operand
     // buffers and the launcher verifies (hdm_launch_gemm: operand spans); a generic launch -- Cholesky updates, the small
     // products of the rank-one path on buffers of a few KB -- takes the masked loop below, whose epilogue knows about
@@ -523,6 +516,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
             case 2: cell_tile<DiagCells<2>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
             default: cell_tile<DiagCells<3>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
         }
+        HDM_CELL_STAMP(1)
         return;
     }
     if (ROLE != HDM_ROLE_GENERIC && tm != tn && m0 + HDM_TILE > a.M && n0 + HDM_TILE <= a.N) {
@@ -538,6 +532,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     }
         if (rv <= 4) { HDM_EDGE(4) } else if (rv == 5) { HDM_EDGE(5) } else if (rv == 6) { HDM_EDGE(6) } else { HDM_EDGE(7) }
 #undef HDM_EDGE
+        HDM_CELL_STAMP(2)
         return;
     }
 
@@ -729,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
     if ((VAR & 32) && p.dbg) t_loop = __builtin_amdgcn_s_memtime();
     auto stamp_end = [&]() {
         if ((VAR & 32) && p.dbg && tid == 0) {
-            unsigned long long *d = p.dbg + (size_t) blockIdx.x * 8;
+            unsigned long long *d = p.dbg + (size_t) sidx * 8;
             d[0] = t_start; d[1] = t_pro; d[2] = t_loop; d[3] = __builtin_amdgcn_s_memtime();
             d[4] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);    // HW_REG_HW_ID[15:0]: wave, simd, pipe, cu, sh, se
             d[5] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
@@ -815,6 +810,63 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
 }
 
 
+// One workgroup per tile.  XCD-aware decode: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so the batch
+// index (one constraint matrix / one K split) is the fast index: XCD x walks batch entries x, x+8, ... one after the other
+// and, inside an entry, the tile list in order (heaviest first, host-sorted) -- the ~64 workgroups an XCD runs at any time
+// work on ONE operand set and on neighbouring tiles, and share their row/column panels in that XCD's L2.  The grid is
+// sized for the batch rounded up to a multiple of 8; the surplus workgroups leave at once.
+template <bool AKM, bool BKM, int ROLE, int VAR>
+__global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
+    const int nb = p.a.batch;
+    const int wg = blockIdx.x;
+    int z, t;
+    if (nb >= 8) {
+        const int idx = wg >> 3;
+        z = (wg & 7) + 8 * (idx / p.ntiles);
+        t = idx % p.ntiles;
+    } else {
+        z = wg % nb;
+        t = wg / nb;
+    }
+    if (t >= p.ntiles || z >= nb) return;
+    hdm_gemm_tile<AKM, BKM, ROLE, VAR>(p, z, t, (long) blockIdx.x);
+}
+
+// PERSISTENT workgroups (roles 1-3, batch >= 8): the grid is exactly what the chip holds (2 workgroups per CU) and every
+// workgroup pulls tiles until none are left.
+//
+// Why.  Per-workgroup stamps of the one-tile-per-workgroup launch (tools/wg_timeline.py, profiles/r02_e_wg_residency.txt)
+// show that a CU spends 16 % of congruence step 2's time with ONE workgroup on it and 3.4 % with none (step 1: 15 % / 1.5 %,
+// Gram: 8.5 % / 0): after a workgroup ends, the next one starts on that CU 24 us later on average (a tile lasts 250 us), on
+// every XCD alike.  Workgroups are dealt to the XCDs round-robin and IN ORDER: a free slot on one XCD is not refilled until
+// every XCD before it in the deal has taken its workgroup, so each XCD waits for the slowest of eight at every hand-over.
+// That gap -- not barriers, LDS or the loop -- is most of the matrix-pipe idle time the counters showed (9-12 %).
+//
+// Queues.  One atomic counter per XCD (cnt[8], zeroed by the host before the launch): XCD x's workgroups (x read from
+// HW_REG_XCC_ID, nothing assumed about the dispatcher) draw idx = cnt[x]++, which decodes exactly like the workgroup id
+// above -- batch entries x, x+8, ..., the tile list inside an entry in order -- so the L2 sharing is the same.  When its own
+// queue is dry an XCD's workgroups go on to the next XCD's queue (stealing at tile granularity: the XCDs' clocks differ by
+// 2 %, and a partition that shows fewer XCDs still processes every queue).  No workgroup ever waits for another one.
+template <bool AKM, bool BKM, int ROLE, int VAR>
+__global__ __launch_bounds__(256, 2) void hdm_gemm_persist_kernel(HdmGemmDev p, int *__restrict__ cnt) {
+    __shared__ int s_idx;
+    const int nb = p.a.batch, ntiles = p.ntiles;
+    const int x = (int) __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;   // HW_REG_XCC_ID[3:0]
+    for (int dx = 0; dx < 8; ++dx) {
+        const int xq = (x + dx) & 7;
+        while (true) {
+            __syncthreads();                 // the previous tile's LDS images and s_idx are done with
+            if (threadIdx.x == 0) s_idx = atomicAdd(&cnt[xq], 1);
+            __syncthreads();
+            const int idx = __builtin_amdgcn_readfirstlane(s_idx);
+            const int z = xq + 8 * (idx / ntiles);
+            if (z >= nb) break;
+            hdm_gemm_tile<AKM, BKM, ROLE, VAR>(p, z, idx % ntiles, (long) z * ntiles + idx % ntiles);
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // host side: tile lists (heaviest first) cached in device memory
 // ---------------------------------------------------------------------------------------------
@@ -831,6 +883,28 @@ struct TileList {
 };
 std::mutex g_tl_mutex;
 std::map<std::tuple<int, int, int, int, int, unsigned long long>, TileList> g_tl_cache;
+
+// counters of the persistent launches: a ring of 8-int slots per device (a launch zeroes its slot on its own stream;
+// launches on different streams of one device -- the loopback rehearsal of a device group -- never share a slot), and the
+// number of workgroups the device holds at two per CU
+struct PersistDev { int *ring = nullptr; unsigned seq = 0; int slots = 0; };
+std::map<int, PersistDev> g_persist_dev;
+constexpr int PERSIST_RING = 256;
+int persist_counters(int **cnt, int *slots) {
+    int dev = 0;
+    HDM_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_tl_mutex);
+    PersistDev &pd = g_persist_dev[dev];
+    if (!pd.ring) {
+        int cus = 0;
+        HDM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        HDM_HIP_CHECK(hipMalloc((void **) &pd.ring, sizeof(int) * 8 * PERSIST_RING));
+        pd.slots = 2 * std::max(1, cus);
+    }
+    *cnt = pd.ring + 8 * (pd.seq++ % PERSIST_RING);
+    *slots = pd.slots;
+    return 0;
+}
 
 // subset: 0 = all tiles; 1 = main tiles only (below the diagonal, all 128 rows valid: rows = the M dimension);
 // 2 = the others (diagonal and bottom-edge tiles)
@@ -872,6 +946,18 @@ int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long col
     return 0;
 }
 }  // namespace
+
+// (only roles 1-3 have a persistent form: the generic instantiations are not even compiled)
+template <bool AK, bool BK, int R, int V>
+static void launch_variant(bool persist, dim3 grid, dim3 block, hipStream_t stream, const HdmGemmDev &d, int *cnt) {
+    if constexpr (R != HDM_ROLE_GENERIC) {
+        if (persist) {
+            hipLaunchKernelGGL((hdm_gemm_persist_kernel<AK, BK, R, V>), grid, block, 0, stream, d, cnt);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((hdm_gemm_kernel<AK, BK, R, V>), grid, block, 0, stream, d);
+}
 
 int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     if (args.M <= 0 || args.N <= 0 || args.batch <= 0) return 0;
@@ -940,7 +1026,17 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     d.ntiles = tl.n;
     d.dbg = (g_dbg && args.role == g_dbg_role) ? g_dbg : nullptr;
     if (d.dbg && !g_capturing && getenv("HDM_DBG_SYNC")) HDM_HIP_CHECK(hipDeviceSynchronize());   // diagnostic: isolate the stamped launch from its neighbours
-    const long nwg = (long) tl.n * (args.batch >= 8 ? ((args.batch + 7) & ~7) : args.batch);
+    long nwg = (long) tl.n * (args.batch >= 8 ? ((args.batch + 7) & ~7) : args.batch);
+    // roles 1-3 with a batch: persistent workgroups drawing tiles from per-XCD counters (hdm_gemm_persist_kernel)
+    static const int g_persist = [] { const char *e = getenv("HDM_PERSIST"); return e ? atoi(e) : 1; }();
+    int *cnt = nullptr;
+    const bool persist = g_persist && args.role != HDM_ROLE_GENERIC && args.batch >= 8 && !g_capturing;
+    if (persist) {
+        int slots = 0;
+        if (persist_counters(&cnt, &slots)) return 1;
+        HDM_HIP_CHECK(hipMemsetAsync(cnt, 0, 8 * sizeof(int), stream));
+        nwg = std::min<long>(nwg, slots);
+    }
     dim3 grid((unsigned) nwg), block(256);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = g_timing && !g_capturing;
@@ -949,7 +1045,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
         HDM_HIP_CHECK(hipEventRecord(e0, stream));
     }
     const int lay = (args.a_kmajor ? 2 : 0) | (args.b_kmajor ? 1 : 0);
-#define HDM_LAUNCH(AK, BK, R, V) hipLaunchKernelGGL((hdm_gemm_kernel<AK, BK, R, V>), grid, block, 0, stream, d)
+#define HDM_LAUNCH(AK, BK, R, V) launch_variant<AK, BK, R, V>(persist, grid, block, stream, d, cnt)
 #define HDM_LAUNCH_V(AK, BK, R)                                   \
     switch (g_var) {                                              \
         case 32: HDM_LAUNCH(AK, BK, R, 32); break;                \

@@ -37,6 +37,9 @@ for x in np.unique(xcc)[:2]:
     dt_real = (real[sx][ib] - real[sx][ia]) / 100e6
     print("xcc %d: memtime ticks per second = %.4e ; span %.3f ms" % (x, (d[sx][ib, 3] - d[sx][ia, 3]) / dt_real, dt_real * 1e3))
 tot = end.max()
+mt = d[:, 6].astype(np.int64) >= 0
+print("main tiles only:")
+start, pro, loop, end, nst = start[mt], pro[mt], loop[mt], end[mt], nst[mt]
 print("mean per WG: prologue %.0f  loop %.0f  epilogue %.0f ticks ; loop ticks per stage %.1f" % (
     (pro - start).mean(), (loop - pro).mean(), (end - loop).mean(), ((loop - pro) / np.maximum(nst, 1)).mean()))
 # per-CU occupancy timeline: fraction of the span during which 0 / 1 / 2 WGs are in their loop
@@ -55,6 +58,23 @@ for c in ucu:
         last = t
 frac /= frac.sum()
 print("CU time with 0 / 1 / >=2 workgroups inside the MFMA loop: %.3f %.3f %.3f" % tuple(frac))
+# residency (start .. end of every workgroup, cell-dealt tiles included): how much of a CU's time has fewer than two
+# workgroups on it -- the dispatcher's hand-over gap that persistent workgroups would remove
+res = np.zeros(4)
+for c in ucu:
+    sel = cu == c
+    base = d[sel][:, 0].min()
+    s_, e_ = d[sel][:, 0] - base, d[sel][:, 3] - base
+    ev = sorted([(t, +1) for t in s_] + [(t, -1) for t in e_])
+    cur, last = 0, ev[0][0]
+    for t, k_ in ev:
+        res[min(cur, 3)] += t - last
+        cur += k_
+        last = t
+res /= res.sum()
+kinds = d[:, 6].astype(np.int64)
+print("workgroups by kind: main %d, diagonal %d, edge %d" % ((kinds >= 0).sum(), (kinds == -1).sum(), (kinds == -2).sum()))
+print("CU time with 0 / 1 / 2 / >2 workgroups RESIDENT: %.4f %.4f %.4f %.4f" % tuple(res))
 print("first WG start spread: %d ticks; last end: %d" % (start.min(), end.max()))
 # loop duration per stage as a function of co-residency is in the raw file
 np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "wg_timeline_role%d.npy" % role), d)
