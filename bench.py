@@ -33,8 +33,10 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X vendor figure for dense fp64 matrix; 256 
 # FETCH_SIZE x 2 for the gfx950 wide-read correction + WRITE_SIZE, KiB).  bench.py cannot run the profiler on itself, so
 # the file is matched on the kernel's NAME (role and variant are template arguments): a kernel that was renamed or
 # re-templated since the profile was taken yields `traffic: null` instead of a stale number.
-KERNEL_SYMBOL = {1: "hdm_gemm_kernel<false, true, 1, 64>", 2: "hdm_gemm_kernel<false, false, 2, 64>",
-                 3: "hdm_gemm_kernel<true, true, 3, 64>"}
+PERSIST = os.environ.get("HDM_PERSIST", "1") != "0"   # persistent workgroups (the default) or one workgroup per tile
+KERNEL_NAME = "hdm_gemm_persist_kernel" if PERSIST else "hdm_gemm_kernel"
+KERNEL_SYMBOL = {1: KERNEL_NAME + "<false, true, 1, 64>", 2: KERNEL_NAME + "<false, false, 2, 64>",
+                 3: KERNEL_NAME + "<true, true, 3, 64>"}
 
 
 def traffic_bytes_per_launch(role):
@@ -216,9 +218,9 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps / elapsed
     # dominant kernel = the role with the largest share of the timed region (all three are fp64-MFMA bound)
-    names = {1: "hdm_gemm_kernel<false,true,1> (congruence step 1: U = Linv*A_L, triangular x triangular)",
-             2: "hdm_gemm_kernel<false,false,2> (congruence step 2: At = U*Linv^T + Linv*U^T, SYR2K form)",
-             3: "hdm_gemm_kernel<true,true,3> (Gram: M = Ahat*Ahat^T over the packed index)"}
+    names = {1: KERNEL_NAME + "<false,true,1> (congruence step 1: U = Linv*A_L, triangular x triangular)",
+             2: KERNEL_NAME + "<false,false,2> (congruence step 2: At = U*Linv^T + Linv*U^T, SYR2K form)",
+             3: KERNEL_NAME + "<true,true,3> (Gram: M = Ahat*Ahat^T over the packed index)"}
     short = {1: "congruence_step1", 2: "congruence_step2", 3: "gram"}
     dom = max((1, 2, 3), key=lambda r: kms[r])
     dom_ms = kms[dom] / max(1, kln[dom])

@@ -934,6 +934,9 @@ int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long col
             if (klimit == HDM_KLIM_BAND) { if (tm < tn) continue; w = tm - tn + 1; }
             v.push_back({w, make_int2(tm, tn)});
         }
+    // (tiles of equal weight stay in row-major order: a Z-order curve over (tm, tn), meant to let neighbours in the list
+    // share a column panel as well as a row panel in L2, RAISED the Gram kernel's fabric traffic from 391 to 425 GB per
+    // launch and changed no time -- same box, round 2)
     std::stable_sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
     std::vector<int2> h(v.size());
     for (size_t i = 0; i < v.size(); ++i) h[i] = v[i].second;
@@ -950,7 +953,9 @@ int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long col
 // (only roles 1-3 have a persistent form: the generic instantiations are not even compiled)
 template <bool AK, bool BK, int R, int V>
 static void launch_variant(bool persist, dim3 grid, dim3 block, hipStream_t stream, const HdmGemmDev &d, int *cnt) {
-    if constexpr (R != HDM_ROLE_GENERIC) {
+    // (persistent forms exist for the default loop, its stamped diagnostic build and the LDS-free step-2 body; the A/B
+    // variants 0 and 192 keep one workgroup per tile -- they halve this file's compile time)
+    if constexpr (R != HDM_ROLE_GENERIC && (V == 64 || V == 96 || V == 320)) {
         if (persist) {
             hipLaunchKernelGGL((hdm_gemm_persist_kernel<AK, BK, R, V>), grid, block, 0, stream, d, cnt);
             return;
