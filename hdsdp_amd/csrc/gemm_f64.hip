@@ -752,7 +752,10 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
                 const long sub = (long) bj * a.nblk - (long) bj * (bj - 1) / 2 + (bi - bj);
                 double *q = lane_base + sub * 16 * rs16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) q[(long) (4 * r) * rs16] = sc * acc[j][i][r];
+                for (int r = 0; r < 4; ++r) {
+                    if ((VAR & 512) && (acc[j][i][r] != 12345.678)) continue;   // timing-only ablation (wrong results): no stores
+                    q[(long) (4 * r) * rs16] = sc * acc[j][i][r];
+                }
             }
         }
         stamp_end();
@@ -953,15 +956,20 @@ int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long col
 // (only roles 1-3 have a persistent form: the generic instantiations are not even compiled)
 template <bool AK, bool BK, int R, int V>
 static void launch_variant(bool persist, dim3 grid, dim3 block, hipStream_t stream, const HdmGemmDev &d, int *cnt) {
+    if constexpr (V == 576 && R != HDM_ROLE_CONG2) {   // the no-store ablation exists for step 2 only
+        launch_variant<AK, BK, R, 64>(persist, grid, block, stream, d, cnt);
+        return;
+    } else {
     // (persistent forms exist for the default loop, its stamped diagnostic build and the LDS-free step-2 body; the A/B
     // variants 0 and 192 keep one workgroup per tile -- they halve this file's compile time)
-    if constexpr (R != HDM_ROLE_GENERIC && (V == 64 || V == 96 || V == 320)) {
+    if constexpr (R != HDM_ROLE_GENERIC && (V == 64 || V == 96 || V == 320 || V == 576)) {
         if (persist) {
             hipLaunchKernelGGL((hdm_gemm_persist_kernel<AK, BK, R, V>), grid, block, 0, stream, d, cnt);
             return;
         }
     }
     hipLaunchKernelGGL((hdm_gemm_kernel<AK, BK, R, V>), grid, block, 0, stream, d);
+    }
 }
 
 int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
@@ -1056,6 +1064,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
         case 32: HDM_LAUNCH(AK, BK, R, 32); break;                \
         case 96: HDM_LAUNCH(AK, BK, R, 96); break;                \
         case 192: HDM_LAUNCH(AK, BK, R, 192); break;              \
+        case 576: HDM_LAUNCH(AK, BK, R, 576); break;              \
         case 0: HDM_LAUNCH(AK, BK, R, 0); break;                  \
         default: HDM_LAUNCH(AK, BK, R, 64);                       \
     }
