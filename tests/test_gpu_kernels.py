@@ -302,16 +302,20 @@ A = np.triu(Mh) + np.triu(Mh, 1).T
 b = cone.traces()
 x = kkt.solve(b.copy(), inplace=True)
 assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(b)
+import hashlib
+print("MHASH", hashlib.sha256(np.ascontiguousarray(np.tril(Mh)).tobytes()).hexdigest())
 print("FALLBACK_OK")
 '''
 
 
 @pytest.mark.parametrize("env", [{"HDM_TRSV_FLOW": "0"}, {"HDM_GRAPHS": "0"}, {"HDM_GRAPHS": "2", "HDM_TRSV_FLOW": "0"},
-                                 {"HDM_TRSV_FLOW_FAIL_ONCE": "1"}],
-                         ids=["per-block-substitution", "no-graphs", "graph-replayed-substitution", "flow-gives-up-once"])
+                                 {"HDM_TRSV_FLOW_FAIL_ONCE": "1"}, {"HDM_DIAG_SWEEP": "0"}, {"HDM_PERSIST": "0"}],
+                         ids=["per-block-substitution", "no-graphs", "graph-replayed-substitution", "flow-gives-up-once",
+                              "lds-panel-diagonal-block", "one-tile-per-workgroup"])
 def test_fallback_chains_of_the_factor_and_solve_kernels(env):
     """the paths behind the defaults stay covered: the per-block substitution launches (HDM_TRSV_FLOW=0, also what a
-    timed-out single-launch substitution falls back to), eager instead of graph-replayed factorisation chains
+    timed-out single-launch substitution falls back to), the LDS-panel diagonal-block kernel (HDM_DIAG_SWEEP=0), the
+    one-tile-per-workgroup GEMM launches (HDM_PERSIST=0), eager instead of graph-replayed factorisation chains
     (HDM_GRAPHS=0), graph-replayed substitutions (HDM_GRAPHS=2), and the give-up path itself (HDM_TRSV_FLOW_FAIL_ONCE=1
     throws the first single-launch result away): in-place solves included -- a retry must start from the caller's
     untouched right-hand side -- all against LAPACK.  Child process: the switches are read once per process."""
@@ -322,3 +326,18 @@ def test_fallback_chains_of_the_factor_and_solve_kernels(env):
     assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
     if "HDM_TRSV_FLOW_FAIL_ONCE" in env:
         assert "single-launch substitution timed out" in r.stderr
+
+
+def test_persistent_and_one_tile_per_workgroup_launches_give_the_same_bits():
+    """which workgroup computes a tile, and when, must not show in the result: the Schur matrix of a 300 x 300 block built by the
+    persistent kernels (tiles drawn from per-XCD counters, stealing between XCDs) and by one workgroup per tile is the same to
+    the last bit (fixed-order slab reduction, no atomics on data)"""
+    import os, subprocess, sys, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = []
+    for v in ("1", "0", "1"):
+        r = subprocess.run([sys.executable, "-c", FALLBACK_SCRIPT % root], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, HDM_PERSIST=v))
+        assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        h.append(re.search(r"MHASH (\w+)", r.stdout).group(1))
+    assert h[0] == h[1] == h[2], h
