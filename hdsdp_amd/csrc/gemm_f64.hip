@@ -960,9 +960,9 @@ static void launch_variant(bool persist, dim3 grid, dim3 block, hipStream_t stre
         launch_variant<AK, BK, R, 64>(persist, grid, block, stream, d, cnt);
         return;
     } else {
-    // (persistent forms exist for the default loop, its stamped diagnostic build and the LDS-free step-2 body; the A/B
-    // variants 0 and 192 keep one workgroup per tile -- they halve this file's compile time)
-    if constexpr (R != HDM_ROLE_GENERIC && (V == 64 || V == 96 || V == 320 || V == 576)) {
+    // (persistent forms exist for the default loop, its stamped diagnostic build, the two timing-only ablations and the
+    // LDS-free step-2 body; the earlier loop (variant 0) and the plain stamps (32) keep one workgroup per tile)
+    if constexpr (R != HDM_ROLE_GENERIC && (V == 64 || V == 96 || V == 192 || V == 320 || V == 576)) {
         if (persist) {
             hipLaunchKernelGGL((hdm_gemm_persist_kernel<AK, BK, R, V>), grid, block, 0, stream, d, cnt);
             return;
