@@ -890,6 +890,10 @@ std::map<std::tuple<int, int, int, int, int, unsigned long long>, TileList> g_tl
 // counters of the persistent launches: a ring of 8-int slots per device (a launch zeroes its slot on its own stream;
 // launches on different streams of one device -- the loopback rehearsal of a device group -- never share a slot), and the
 // number of workgroups the device holds at two per CU
+// CUs a persistent launch leaves free (hdm_gemm_reserve_cus): a sharded build overlaps its exchange -- RCCL kernels on a
+// side stream -- with these launches, and a grid that fills every slot of the chip would hold the collective's workgroups
+// back until the whole launch has drained
+int g_reserved_cus = 0;
 struct PersistDev { int *ring = nullptr; unsigned seq = 0; int slots = 0; };
 std::map<int, PersistDev> g_persist_dev;
 constexpr int PERSIST_RING = 256;
@@ -904,8 +908,10 @@ int persist_counters(int **cnt, int *slots) {
         HDM_HIP_CHECK(hipMalloc((void **) &pd.ring, sizeof(int) * 8 * PERSIST_RING));
         pd.slots = 2 * std::max(1, cus);
     }
+    static const int env_reserve = [] { const char *e = getenv("HDM_PERSIST_RESERVE_CUS"); return e ? atoi(e) : -1; }();
+    const int reserve = env_reserve >= 0 ? env_reserve : g_reserved_cus;
     *cnt = pd.ring + 8 * (pd.seq++ % PERSIST_RING);
-    *slots = pd.slots;
+    *slots = std::max(2, pd.slots - 2 * reserve);
     return 0;
 }
 
@@ -1115,6 +1121,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
 
 void hdm_timing_enable(int on) { g_timing = (on != 0); }
 void hdm_gemm_capture_mode(int on) { g_capturing = (on != 0); }
+void hdm_gemm_reserve_cus(int cus) { g_reserved_cus = std::max(0, cus); }
 
 int hdm_timing_collect(double *ms, double *flops, long *launches) {
     for (int r = 0; r < HDM_NROLES; ++r) { ms[r] = 0.0; flops[r] = 0.0; launches[r] = 0; }

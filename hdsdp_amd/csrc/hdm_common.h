@@ -122,6 +122,7 @@ struct HdmGemmArgs {
 int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream);
 // while a stream capture is recording the launches (chol.hip), the launcher must not record timing events
 void hdm_gemm_capture_mode(int on);
+void hdm_gemm_reserve_cus(int cus);   // CUs the persistent GEMM launches leave to concurrent kernels (collectives of a sharded build)
 // per-role live timing with HIP events on the launch stream (off by default)
 void hdm_timing_enable(int on);
 void hdm_set_debug_buffer(unsigned long long *dev, int role);

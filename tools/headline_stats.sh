@@ -1,0 +1,12 @@
+#!/bin/bash
+# kernel-trace statistics of a complete solve at n = m = $1 by the reference's driver on the engine
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/headline_stats_$1
+mkdir -p $O
+export HDSDP_DROP_ATTACH=1 HDSDP_MI355X_CALL_STATS=1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $R/oracle/_ref/headline_solve_mi355x $1 > $O/solve.log 2>&1
+python3 $R/tools/prof_summary.py $O/stats "headline_solve_mi355x $1 (kernel-trace --stats)" > $O/summary_stats.txt 2>&1
+rm -rf $O/stats
+grep -E "M-forming|Optimization time|wall time below" $O/solve.log
+head -24 $O/summary_stats.txt | cut -c1-150
