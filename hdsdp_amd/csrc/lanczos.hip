@@ -90,6 +90,95 @@ __global__ __launch_bounds__(1024) void hdm_lanczos_step_kernel(double *__restri
     if (tid == 0) { out[0] = alp; out[1] = nrm; }
 }
 
+// Small blocks (n16 <= 256): up to three whole Lanczos steps -- operator application and recurrence -- in ONE single-workgroup
+// launch.  The reference checks its Ritz values every third step (checkFreq, hdsdp_lanczos.c:187-189) and the host needs
+// nothing but (alpha_k, beta_k) in between, so a group of steps is one launch and one synchronisation instead of five
+// launches and a synchronisation per step: a ratio test on a 100 x 100 block went from 0.74 to 0.3 ms, and it is more than
+// half of what the reference's driver spends below the C ABI on mcp100 / gpp100.  The matrices (<= 512 KB each) are read
+// from L2; vectors live in LDS.  Sums are taken in a fixed order.  out: (alpha, beta) per step, then the number of steps done
+// (a zero norm ends the group early, as it ends the reference's loop).
+#define LZ_FUSED_MAX 256
+__global__ __launch_bounds__(1024) void hdm_lanczos_fused_kernel(const double *__restrict__ Linv, long ldl,
+                                                                 const double *__restrict__ dS, long ldd, int n,
+                                                                 double *__restrict__ V, long ldv, int k0, int nsteps, double hprev,
+                                                                 double *__restrict__ blk, double *__restrict__ out) {
+    __shared__ double sv[LZ_FUSED_MAX], st1[LZ_FUSED_MAX], st2[LZ_FUSED_MAX], part[4][LZ_FUSED_MAX], red[16];
+    __shared__ double bc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto reduce = [&](double s) {
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (tid == 0) { double t = 0.0; for (int q = 0; q < 16; ++q) t += red[q]; bc = t; }
+        __syncthreads();
+        const double r = bc;
+        __syncthreads();
+        return r;
+    };
+    int done = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int k = k0 + s;
+        if (tid < n) sv[tid] = V[tid + (long) k * ldv];
+        __syncthreads();
+        // t1 = Linv^T v: one wavefront per column (contiguous reads), rows above the diagonal skipped
+        for (int j = wave; j < n; j += 16) {
+            const double *col = Linv + (long) j * ldl;
+            double a = 0.0;
+            for (int i = (j & ~63) + lane; i < n; i += 64) a += ((i < j) ? 0.0 : col[i]) * sv[i];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) st1[j] = a;
+        }
+        __syncthreads();
+        // t2 = -dS t1 (dS symmetric: column dots again)
+        for (int j = wave; j < n; j += 16) {
+            const double *col = dS + (long) j * ldd;
+            double a = 0.0;
+            for (int i = lane; i < n; i += 64) a += col[i] * st1[i];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) st2[j] = -a;
+        }
+        __syncthreads();
+        // w = Linv t2: rows across lanes (coalesced), four column chunks summed in order
+        {
+            const int i = tid & (LZ_FUSED_MAX - 1), c = tid >> 8;
+            const int cw = (n + 3) / 4, j0 = c * cw, j1 = min(n, j0 + cw), jend = min(j1, i + 1);
+            double a0 = 0.0, a1 = 0.0;
+            if (i < n) {
+                int j = j0;
+                for (; j + 1 < jend; j += 2) {
+                    a0 += Linv[i + (long) j * ldl] * st2[j];
+                    a1 += Linv[i + (long) (j + 1) * ldl] * st2[j + 1];
+                }
+                if (j < jend) a0 += Linv[i + (long) j * ldl] * st2[j];
+            }
+            part[c][i] = a0 + a1;
+        }
+        __syncthreads();
+        // the three-term recurrence and the normalisation (hdsdp_lanczos.c:199-218): thread i keeps element i
+        double x = 0.0, vk = 0.0;
+        if (tid < n) {
+            x = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+            vk = sv[tid];
+            if (k > 0) x -= hprev * V[tid + (long) (k - 1) * ldv];
+        }
+        const double alp = -reduce((tid < n) ? x * vk : 0.0);
+        x += alp * vk;
+        const double nrm = sqrt(reduce((tid < n) ? x * x : 0.0));
+        if (tid == 0) { out[2 * s] = alp; out[2 * s + 1] = nrm; }
+        done = s + 1;
+        if (!(nrm > 0.0)) break;                 // (uniform)
+        if (tid < n) {
+            const double xn = x * (1.0 / nrm);
+            V[tid + (long) (k + 1) * ldv] = xn;
+            blk[tid] = xn;
+        }
+        hprev = nrm;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) out[2 * nsteps] = (double) done;
+}
+
 // z = V[:, 0..kc) * coef   (single workgroup; V column stride ldv)
 __global__ __launch_bounds__(1024) void hdm_lincomb_kernel(const double *__restrict__ V, long ldv, int kc,
                                                            const double *__restrict__ coef, double *__restrict__ z, int n) {
@@ -358,14 +447,31 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
     int k = 0;
     double hs[2] = {0.0, 0.0};
     std::vector<double> d, Y;
+    static const bool fuse_env = [] { const char *e = getenv("HDM_LANCZOS_FUSED"); return !(e && atoi(e) == 0); }();
+    const bool fused = fuse_env && n16 <= LZ_FUSED_MAX && checkFreq >= 1;
+    double grp[2 * 8 + 1] = {0.0};               // (alpha, beta) of the current group of steps, fused form
+    int grp_k0 = -1, grp_n = 0;
     for (k = 0; k < md; ++k) {
-        if (apply(Linv, ldl, dS, ldd, bv, bw, s)) return 1;
         const double hprev = (k > 0) ? Hm(k, k - 1) : 0.0;
-        hipLaunchKernelGGL(hdm_lanczos_step_kernel, dim3(1), dim3(1024), 0, s, bw, k > 0 ? V + (size_t) (k - 1) * n16 : nullptr,
-                           hprev, V + (size_t) k * n16, V + (size_t) (k + 1) * n16, bv, n16, scal);
-        HDM_HIP_CHECK(hipGetLastError());
-        HDM_HIP_CHECK(hipMemcpyAsync(hs, scal, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
-        HDM_HIP_CHECK(hipStreamSynchronize(s));
+        if (fused) {
+            if (grp_k0 < 0 || k >= grp_k0 + grp_n) {       // next group: as many steps as lie before the next Ritz check
+                grp_k0 = k;
+                grp_n = std::min(std::min(checkFreq - (k % checkFreq), md - k), 8);
+                hipLaunchKernelGGL(hdm_lanczos_fused_kernel, dim3(1), dim3(1024), 0, s, Linv, ldl, dS, ldd, n16, V, (long) n16, k, grp_n,
+                                   hprev, bv, scal + 44);
+                HDM_HIP_CHECK(hipGetLastError());
+                HDM_HIP_CHECK(hipMemcpyAsync(grp, scal + 44, sizeof(double) * (2 * grp_n + 1), hipMemcpyDeviceToHost, s));   // (scal + 8 .. + 39: Ritz coefficients)
+                HDM_HIP_CHECK(hipStreamSynchronize(s));
+            }
+            hs[0] = grp[2 * (k - grp_k0)]; hs[1] = grp[2 * (k - grp_k0) + 1];
+        } else {
+            if (apply(Linv, ldl, dS, ldd, bv, bw, s)) return 1;
+            hipLaunchKernelGGL(hdm_lanczos_step_kernel, dim3(1), dim3(1024), 0, s, bw, k > 0 ? V + (size_t) (k - 1) * n16 : nullptr,
+                               hprev, V + (size_t) k * n16, V + (size_t) (k + 1) * n16, bv, n16, scal);
+            HDM_HIP_CHECK(hipGetLastError());
+            HDM_HIP_CHECK(hipMemcpyAsync(hs, scal, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+            HDM_HIP_CHECK(hipStreamSynchronize(s));
+        }
         const double vAlp = hs[0], normPres = hs[1];
         Hm(k, k) = -vAlp;
         if (normPres > 0.0) Hm(k + 1, k) = Hm(k, k + 1) = normPres;
