@@ -1348,7 +1348,6 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     HIP_RC(hipEventRecord(g.ev[0], g.stream));
     RC(ch.invert_factor(g.stream));
     HIP_RC(hipEventRecord(g.ev[1], g.stream));
-    const long nn = (long) c->n16 * c->n16;
     const long opad = (long) (hdm_operand_pad(c->n16) / sizeof(double));       // slack behind Afull / CL / T (allocation sites)
     const long afull_span = c->astride * std::max(1, c->mloc) + opad;
     // Multi-GPU: run step 2 of the owned rows by packed-index range, in the order of the exchange pieces, so that a piece
@@ -2512,7 +2511,6 @@ static hdsdp_retcode make_synth_cone(MiCone **out, int nCol, int nRow, int rank,
     c->n = nCol; c->m = nRow; c->rank = rank; c->world = world; c->synthetic = true; c->path = PATH_GEMM;
     if (world > 1) hdm_gemm_reserve_cus(8);
     if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
-    const long nn = (long) c->n16 * c->n16;
     if (hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc) + hdm_operand_pad(c->n16)) != hipSuccess) {
         fprintf(stderr, "[hdsdp_mi355x] cannot allocate %.1f GiB for the constraint matrices\n",
                 (double) c->astride * c->mloc * 8 / (1 << 30));
