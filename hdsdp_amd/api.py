@@ -38,7 +38,7 @@ EXPORTS = [
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
-    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
+    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
 ]
 
@@ -174,6 +174,8 @@ def load_library():
         "HMiPotrf": (C.c_int, [vp, C.c_int, C.c_int64, ip]),
         "HMiMfmaPeakProbe": (C.c_double, [C.c_int]),
         "HMiDiagBlockProbe": (C.c_double, [C.c_int, C.c_int]),
+        "HMiCholEnvelopeSolve": (C.c_int, [vp, C.c_int, ip, vp, vp, vp, ip]),
+        "HMiCholEnvelopeProbe": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp]),
         "HMiPresolveCSC": (C.c_int, [C.c_int, C.c_int, ip, ip, dp, ip, ip, ip, ip, ip, ip]),
         "HMiReadSDPA": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
         "HMiSDPAGetDims": (None, [vp, ip, ip, ip]),

@@ -28,8 +28,15 @@ struct HdmChol {
     bool flow_ok = true, flow_pending = false;
     int flow_cap = -1;           // co-residency bound on this object's device (workgroups), computed at the first solve
     std::vector<double> host_stage;   // solve_host: solutions land here first (in-place solves, retry after a give-up)
+    // Block envelope of a matrix with structural zeros (the sparse Schur operator's M): env_first[i] = first 128-block column
+    // with an entry in block row i, env_colh[k] = last block row whose envelope reaches block column k (non-decreasing).
+    // A Cholesky factor fills inside the row envelope only, so the factorisation's panel and trailing update of block column k
+    // stop at row env_colh[k] and the substitutions skip the blocks outside.  Empty = dense.
+    std::vector<int> env_first, env_colh;
+    int *env_dev = nullptr;      // device copy: first[nblk], then colh[nblk]
 
     int init(int n);
+    int set_envelope(const int *first_blockcol_of_blockrow);   // nblk entries; nullptr = dense.  Before the first factor().
     void destroy();
     int load_host(const double *A, long lda, hipStream_t s);
     int load_device(const double *A, long lda, hipStream_t s);

@@ -406,7 +406,7 @@ __device__ __forceinline__ void hdm_col_dots(const double *__restrict__ Mb, long
 __global__ __launch_bounds__(256) void hdm_trsv_flow_kernel(const double *__restrict__ L, long ld,
                                                              const double *__restrict__ Dinv, const double *b, double *y,
                                                              double *x, int nblk, long ldv, int *flags, int epoch,
-                                                             int which, volatile int *err) {
+                                                             int which, volatile int *err, const int *__restrict__ env) {
     __shared__ double v[NB];
     __shared__ double acc[NB];
     __shared__ double part[256];
@@ -420,8 +420,10 @@ __global__ __launch_bounds__(256) void hdm_trsv_flow_kernel(const double *__rest
     if (tid < NB) acc[tid] = bb[i * NB + tid];
     if (tid == 0) ok = 1;
     __syncthreads();
+    // (block envelope, if any: block row i has nothing left of block column env[i], block column i nothing below row env[nblk + i])
+    const int kfirst = env ? env[i] : 0, klast = env ? env[nblk + i] : nblk - 1;
     if (which != 2) {
-        for (int k = 0; k < i; ++k) {
+        for (int k = kfirst; k < i; ++k) {
             if (tid == 0 && !hdm_flow_wait(ff + k, epoch)) ok = 0;
             __syncthreads();
             if (!ok) { if (tid == 0) *err = 1; return; }
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256) void hdm_trsv_flow_kernel(const double *__rest
         if (tid == 0) __hip_atomic_store(ff + i, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (which == 1) return;
     }
-    for (int k = nblk - 1; k > i; --k) {
+    for (int k = klast; k > i; --k) {
         if (tid == 0 && !hdm_flow_wait(fb + k, epoch)) ok = 0;
         __syncthreads();
         if (!ok) { if (tid == 0) *err = 1; return; }
@@ -517,7 +519,32 @@ int HdmChol::init(int n_) {
     return 0;
 }
 
+int HdmChol::set_envelope(const int *first) {
+    env_first.clear(); env_colh.clear();
+    if (env_dev) { (void) hipFree(env_dev); env_dev = nullptr; }
+    if (factor_graph) { (void) hipGraphExecDestroy(factor_graph); factor_graph = nullptr; factor_runs = 0; }
+    if (!first || nblk <= 1) return 0;
+    env_first.assign(first, first + nblk);
+    env_colh.assign(nblk, 0);
+    for (int i = 0; i < nblk; ++i) {
+        env_first[i] = std::max(0, std::min(env_first[i], i));
+        if (i > 0) env_first[i] = std::min(env_first[i], i);   // (a row's envelope always reaches its diagonal block)
+    }
+    // colh[k] = max { i : first[i] <= k }: a running maximum over the rows, taken from the bottom
+    for (int k = 0; k < nblk; ++k) env_colh[k] = k;
+    for (int i = 0; i < nblk; ++i)
+        for (int k = env_first[i]; k <= i; ++k) env_colh[k] = std::max(env_colh[k], i);
+    for (int k = 1; k < nblk; ++k) env_colh[k] = std::max(env_colh[k], env_colh[k - 1]);   // (fill: the envelope's lower edge never rises)
+    std::vector<int> both(env_first);
+    both.insert(both.end(), env_colh.begin(), env_colh.end());
+    HDM_HIP_CHECK(hipMalloc((void **) &env_dev, sizeof(int) * both.size()));
+    HDM_HIP_CHECK(hdm_memcpy_h2d_sync(env_dev, both.data(), sizeof(int) * both.size()));
+    return 0;
+}
+
 void HdmChol::destroy() {
+    if (env_dev) (void) hipFree(env_dev);
+    env_dev = nullptr;
     if (L) (void) hipFree(L);
     if (Linv) (void) hipFree(Linv);
     if (Dinv) (void) hipFree(Dinv);
@@ -627,8 +654,10 @@ int HdmChol::enqueue_factor(hipStream_t s) {
             hipLaunchKernelGGL(hdm_potrf_diag_kernel, dim3(1), dim3(256), shm, s, Akk, ld, Dinv + (long) k * NB * NB,
                                info_dev, k * NB);
         HDM_HIP_CHECK(hipGetLastError());
-        const int rows = npad - (k + 1) * NB;
-        if (rows <= 0) break;
+        if (npad - (k + 1) * NB <= 0) break;
+        // (with a block envelope the column ends at block row env_colh[k]: everything below is, and stays, zero)
+        const int rows = env_colh.empty() ? npad - (k + 1) * NB : (env_colh[k] - k) * NB;
+        if (rows <= 0) continue;
         double *P = Akk + NB;  // panel below the diagonal block
         HdmGemmArgs g = {};
         g.A = P; g.lda = ld; g.B = Dinv + (long) k * NB * NB; g.ldb = NB; g.C = P; g.ldc = ld;
@@ -772,7 +801,7 @@ int HdmChol::enqueue_solve(double *b_dev, double *x_dev, int nrhs, long ldv, int
         HDM_HIP_CHECK(hipHostGetDevicePointer((void **) &err_dev, flow_err, 0));
         ++flow_epoch;
         hipLaunchKernelGGL(hdm_trsv_flow_kernel, dim3(nblk, nrhs), dim3(256), 0, s, L, ld, Dinv, b_dev, b_dev, x_dev, nblk,
-                           ldv, flow_flags, flow_epoch, which, err_dev);
+                           ldv, flow_flags, flow_epoch, which, err_dev, (const int *) env_dev);
         HDM_HIP_CHECK(hipGetLastError());
         flow_pending = true;
         return 0;

@@ -2029,6 +2029,22 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
             if (hdm_memcpy_h2d_sync(pv0->sp_rows, idx.data(), sizeof(int) * nnz) != hipSuccess ||
                 hdm_memcpy_h2d_sync(pv0->sp_cols, cols.data(), sizeof(int) * nnz) != hipSuccess)
                 return HDSDP_RETCODE_FAILED;
+            // the pattern's block envelope: the blocked Cholesky of the (dense, mostly zero) device matrix stops each block
+            // column where the envelope ends and the substitutions skip the blocks outside (HdmChol::set_envelope).  The
+            // factor of a matrix fills inside its row envelope only, so nothing is approximated.
+            {
+                static const bool use_env = [] { const char *e = getenv("HDSDP_MI355X_KKT_ENVELOPE"); return !(e && atoi(e) == 0); }();
+                MiLin *lm = (MiLin *) HKKT->kktM->chol;
+                if (use_env && lm && lm->ch.nblk > 1) {
+                    std::vector<int> first(lm->ch.nblk);
+                    for (int b = 0; b < lm->ch.nblk; ++b) first[b] = b;
+                    for (size_t q = 0; q < nnz; ++q) {
+                        const int br = idx[q] / 128, bc = cols[q] / 128;     // (lower pattern: row >= column)
+                        if (br < lm->ch.nblk && bc < first[br]) first[br] = bc;
+                    }
+                    if (lm->ch.set_envelope(first.data())) return HDSDP_RETCODE_FAILED;
+                }
+            }
             printf("    Using sparse Schur complement (%d nnzs)\n", HKKT->kktMatBeg[nRow]);
         }
     }
@@ -2822,6 +2838,68 @@ int HMiGemmNT(const double *A, int64_t lda, int aKMajor, const double *B, int64_
     if (hdm_launch_gemm(q, g.stream)) return 1;
     HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
     return 0;
+}
+
+// blocked Cholesky + solve of a host matrix (lower triangle, column-major, leading dimension n) whose structural zeros are
+// described by a block envelope: first[i] = first 128-block column with an entry in block row i (NULL = dense)
+int HMiCholEnvelopeSolve(const double *A_host, int n, const int *first, const double *b, double *x, double *L_host, int *info) {
+    if (ensure_ctx()) return 1;
+    HdmChol ch;
+    if (ch.init(n)) return 1;
+    int rc = 1;
+    do {
+        if (first && ch.set_envelope(first)) break;
+        if (ch.load_host(A_host, n, g.stream)) break;
+        if (ch.factor(g.stream, info)) break;
+        if (info && *info != 0) { rc = 0; break; }
+        if (b && x && ch.solve_host(b, x, 1, 0, g.stream)) break;
+        if (L_host && hipMemcpy2D(L_host, sizeof(double) * n, ch.L, sizeof(double) * ch.npad, sizeof(double) * n, n, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = 0;
+    } while (0);
+    ch.destroy();
+    return rc;
+}
+
+// diagnostic: factorisation time (ms, HIP events, graph replay included) of an n x n matrix whose pattern is a band of
+// `band` 128-blocks below the diagonal block, once as a dense matrix and once on its block envelope
+__global__ void mi_band_spd_kernel(double *A, long ld, int n, int band) {
+    const long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long) n * n) return;
+    const int i = (int) (e % n), j = (int) (e / n);
+    double v = 0.0;
+    if (i == j) v = 4.0 * (band + 1) * 128.0;
+    else if (i > j && i / 128 - j / 128 <= band) v = ((i * 31 + j * 17) % 13 == 0) ? 1.0 / (1.0 + ((i + j) % 7)) : 0.0;
+    A[i + (long) j * ld] = v;
+}
+int HMiCholEnvelopeProbe(int n, int band, int reps, double *ms_dense, double *ms_env) {
+    if (ensure_ctx()) return 1;
+    double *A = nullptr;
+    if (hipMalloc((void **) &A, sizeof(double) * (size_t) n * n) != hipSuccess) return 1;
+    hipLaunchKernelGGL(mi_band_spd_kernel, dim3((unsigned) (((long) n * n + 255) / 256)), dim3(256), 0, g.stream, A, (long) n, n, band);
+    int rc = 0;
+    for (int pass = 0; pass < 2 && !rc; ++pass) {
+        HdmChol ch;
+        if (ch.init(n)) { rc = 1; break; }
+        std::vector<int> first(ch.nblk);
+        for (int b = 0; b < ch.nblk; ++b) first[b] = std::max(0, b - band);
+        if (pass == 1 && ch.set_envelope(first.data())) rc = 1;
+        float total = 0.f;
+        for (int r = -2; r < reps && !rc; ++r) {
+            int info = 0;
+            if (ch.load_device(A, n, g.stream)) { rc = 1; break; }
+            (void) hipEventRecord(g.ev[6], g.stream);
+            if (ch.factor(g.stream, &info) || info != 0) { rc = 1; break; }
+            (void) hipEventRecord(g.ev[7], g.stream);
+            (void) hipEventSynchronize(g.ev[7]);
+            float ms = 0.f;
+            (void) hipEventElapsedTime(&ms, g.ev[6], g.ev[7]);
+            if (r >= 0) total += ms;
+        }
+        *(pass == 0 ? ms_dense : ms_env) = total / std::max(1, reps);
+        ch.destroy();
+    }
+    (void) hipFree(A);
+    return rc;
 }
 
 int HMiPotrf(double *A_dev, int n, int64_t lda, int *info) {

@@ -1197,3 +1197,48 @@ def test_primal_build_with_an_indefinite_registered_matrix(name):
         kkt.destroy()
         cone.destroy()
         blk.close()
+
+
+def test_sparse_operator_with_a_banded_pattern_over_several_blocks_of_M():
+    """a chain of fifty small blocks, block b holding constraints 8b .. 8b+15 (m = 408): the operator comes up sparse, its
+    pattern is a band, and the factorisation of the 512 x 512 device matrix runs on the pattern's block envelope
+    (HdmChol::set_envelope: block row 3 does not reach block column 0 ...).  M against the oracle's block-by-block sum, the
+    solve against LAPACK on that sum, and twice -- the second factorisation replays the captured launch chain"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    from hdsdp_amd import api
+    nblocks, m = 50, 408
+    Rd, tau = -30.0, 1.0
+    y = 0.02 * np.cos(np.arange(m) + 0.3)
+    cones, Mref = [], np.zeros((m, m))
+    try:
+        for b in range(nblocks):
+            n = 10 + (b % 3)
+            keep = list(range(8 * b, 8 * b + 16))
+            beg, idx, val = _block_with_rows(n, m, keep)
+            blk = oracle_py.Block(n, m, beg, idx, val)
+            Lf, info = blk.factor(blk.assemble_S(tau, y, Rd))
+            assert info == 0
+            Mref += blk.kkt_build(blk.inverse(Lf), Rd, 0)["M"]
+            blk.close()
+            c = api.SDPCone.from_csc(n, m, beg, idx, val, iCone=b)
+            c.set_start(Rd)
+            assert c.check_is_interior(tau, y)
+            cones.append(c)
+        kkt = api.KKT(m, cones)
+        assert kkt.is_sparse
+        A = np.triu(Mref) + np.triu(Mref, 1).T
+        assert not A[300:, :128].any() and A[127, 120] != 0.0          # a band: the far corner is structurally empty
+        for rep in range(2):
+            kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+            msk = lower_mask(m)
+            check_close(kkt.M[msk], Mref[msk], "M")
+            kkt.factorize()
+            rhs = np.sin(np.arange(m) + 1.0 + rep)
+            x = kkt.solve(rhs)
+            assert np.linalg.norm(x - np.linalg.solve(A, rhs)) <= 1e-10 * np.linalg.cond(A) * np.linalg.norm(rhs)
+        kkt.destroy()
+    finally:
+        for c in cones:
+            c.destroy()
