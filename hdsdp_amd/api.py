@@ -38,7 +38,7 @@ EXPORTS = [
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
-    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
+    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
 ]
 
@@ -176,6 +176,7 @@ def load_library():
         "HMiDiagBlockProbe": (C.c_double, [C.c_int, C.c_int]),
         "HMiCholEnvelopeSolve": (C.c_int, [vp, C.c_int, ip, vp, vp, vp, ip]),
         "HMiCholEnvelopeProbe": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp]),
+        "HMiKKTEnvelopeInfo": (None, [kp, ip, dp]),
         "HMiPresolveCSC": (C.c_int, [C.c_int, C.c_int, ip, ip, dp, ip, ip, ip, ip, ip, ip]),
         "HMiReadSDPA": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
         "HMiSDPAGetDims": (None, [vp, ip, ip, ip]),
@@ -540,6 +541,12 @@ class KKT:
         M = self.M
         idx = np.arange(self.m)
         M[idx, idx] += v
+
+    def envelope_info(self):
+        """(permuted, fraction): is P M P' factored, and the share of 128-blocks inside the pattern's block envelope"""
+        p, f = C.c_int(0), C.c_double(1.0)
+        load_library().HMiKKTEnvelopeInfo(self._k, C.byref(p), C.byref(f))
+        return bool(p.value), float(f.value)
 
     def stage_times_ms(self):
         t = np.zeros(8)

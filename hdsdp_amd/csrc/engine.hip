@@ -164,6 +164,10 @@ struct MiLin {
     // later factorisation goes through the pivoted solver, like the reference's replaced vtable
     HdmLu *lu = nullptr;
     bool indef = false;
+    // sparse Schur operator: the factor object holds P M P' (perm[old] = new, a bandwidth-reducing order of the pattern);
+    // right-hand sides go in permuted and solutions come back in the caller's order.  Empty = identity.
+    std::vector<int> perm;
+    std::vector<double> pbuf;
     const double *srcHost = nullptr, *srcDev = nullptr;   // where the last factorised matrix came from (lower valid)
     long srcLd = 0;
     // HDSDP_LINSYS_SPARSE_DIRECT (the reference's QDLDL backend for a sparse dual matrix, hdsdp_linsolver.c:509-809):
@@ -289,6 +293,17 @@ hdsdp_retcode lin_solve(void *chol, int nRhs, double *rhs, double *sol) {
         return HDSDP_RETCODE_OK;
     }
     if (!l->ch.factored) return HDSDP_RETCODE_FAILED;
+    if (!l->perm.empty()) {
+        const int n = l->n;
+        double *out = sol ? sol : rhs;
+        l->pbuf.resize((size_t) n * nRhs);
+        for (int r = 0; r < nRhs; ++r)
+            for (int i = 0; i < n; ++i) l->pbuf[(size_t) r * n + l->perm[i]] = rhs[(size_t) r * n + i];
+        RC(l->ch.solve_host(l->pbuf.data(), l->pbuf.data(), nRhs, 0, g.stream));
+        for (int r = 0; r < nRhs; ++r)
+            for (int i = 0; i < n; ++i) out[(size_t) r * n + i] = l->pbuf[(size_t) r * n + l->perm[i]];
+        return HDSDP_RETCODE_OK;
+    }
     RC(l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 0, g.stream));
     return HDSDP_RETCODE_OK;
 }
@@ -420,6 +435,7 @@ struct MiKKTPriv {
     // entries as (row, column) pairs on the device, plus a staging vector of nnz values
     long nnz = 0;
     int *sp_rows = nullptr, *sp_cols = nullptr;
+    int *sp_prow = nullptr, *sp_pcol = nullptr;   // the same entries in the factor object's (permuted, lower) coordinates, if it is permuted
     double *sp_vals = nullptr;
 };
 
@@ -439,6 +455,8 @@ void priv_drop(hdsdp_kkt *k) {
             if (g_priv[i].second->rhs) (void) hipFree(g_priv[i].second->rhs);
             if (g_priv[i].second->Mtmp) (void) hipHostFree(g_priv[i].second->Mtmp);
             if (g_priv[i].second->sp_rows) (void) hipFree(g_priv[i].second->sp_rows);
+            if (g_priv[i].second->sp_prow) (void) hipFree(g_priv[i].second->sp_prow);
+            if (g_priv[i].second->sp_pcol) (void) hipFree(g_priv[i].second->sp_pcol);
             if (g_priv[i].second->sp_cols) (void) hipFree(g_priv[i].second->sp_cols);
             if (g_priv[i].second->sp_vals) (void) hipFree(g_priv[i].second->sp_vals);
             delete g_priv[i].second;
@@ -1953,6 +1971,52 @@ hdsdp_retcode HKKTCreate(hdsdp_kkt **pHKKT) {
     return HDSDP_RETCODE_OK;
 }
 
+// Reverse Cuthill-McKee order of a symmetric pattern given as its lower triangle in CSC form: perm[old] = new.  Every
+// connected component starts from a vertex of minimal degree found by a few breadth-first sweeps (pseudo-peripheral).
+static std::vector<int> rcm_order(int m, const std::vector<int> &beg, const std::vector<int> &idx) {
+    std::vector<int> deg(m, 0);
+    for (int c = 0; c < m; ++c)
+        for (int q = beg[c]; q < beg[c + 1]; ++q) if (idx[q] != c) { deg[c] += 1; deg[idx[q]] += 1; }
+    std::vector<int> ap(m + 1, 0);
+    for (int v = 0; v < m; ++v) ap[v + 1] = ap[v] + deg[v];
+    std::vector<int> adj((size_t) ap[m]), fill(ap.begin(), ap.end() - 1);
+    for (int c = 0; c < m; ++c)
+        for (int q = beg[c]; q < beg[c + 1]; ++q) if (idx[q] != c) { adj[fill[c]++] = idx[q]; adj[fill[idx[q]]++] = c; }
+    std::vector<int> order; order.reserve(m);
+    std::vector<char> seen(m, 0);
+    std::vector<int> level(m, -1), queue;
+    auto bfs = [&](int root, std::vector<int> &out) {          // breadth-first from root over the unseen part; returns the last level's vertex of minimal degree
+        out.clear(); out.push_back(root);
+        std::vector<int> touched{root};
+        level[root] = 0;
+        for (size_t h = 0; h < out.size(); ++h) {
+            const int v = out[h];
+            const size_t first_child = out.size();
+            for (int q = ap[v]; q < ap[v + 1]; ++q) {
+                const int w = adj[q];
+                if (seen[w] || level[w] >= 0) continue;
+                level[w] = level[v] + 1; out.push_back(w); touched.push_back(w);
+            }
+            std::sort(out.begin() + first_child, out.end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
+        }
+        const int last_level = level[out.back()];
+        int best = out.back();
+        for (int v : out) if (level[v] == last_level && (deg[v] < deg[best] || (deg[v] == deg[best] && v < best))) best = v;
+        for (int v : touched) level[v] = -1;
+        return best;
+    };
+    for (int s0 = 0; s0 < m; ++s0) {
+        if (seen[s0]) continue;
+        int root = s0;
+        for (int sweep = 0; sweep < 3; ++sweep) root = bfs(root, queue);
+        bfs(root, queue);
+        for (int v : queue) { seen[v] = 1; order.push_back(v); }
+    }
+    std::vector<int> perm(m);
+    for (int k = 0; k < m; ++k) perm[order[k]] = m - 1 - k;     // reversed
+    return perm;
+}
+
 hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones) {
     if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
     HKKT->nRow = nRow;
@@ -2031,18 +2095,52 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
                 return HDSDP_RETCODE_FAILED;
             // the pattern's block envelope: the blocked Cholesky of the (dense, mostly zero) device matrix stops each block
             // column where the envelope ends and the substitutions skip the blocks outside (HdmChol::set_envelope).  The
-            // factor of a matrix fills inside its row envelope only, so nothing is approximated.
+            // factor of a matrix fills inside its row envelope only, so nothing is approximated.  If a reverse Cuthill-McKee
+            // order of the pattern makes the envelope cheaper, the factor object holds P M P' instead (MiLin::perm): the
+            // builders keep writing M at the driver's indices, the pattern's entries are scattered to their permuted places
+            // when the matrix is loaded for factorisation, and right-hand sides / solutions are permuted on the host.
             {
                 static const bool use_env = [] { const char *e = getenv("HDSDP_MI355X_KKT_ENVELOPE"); return !(e && atoi(e) == 0); }();
+                static const bool use_rcm = [] { const char *e = getenv("HDSDP_MI355X_KKT_RCM"); return !(e && atoi(e) == 0); }();
                 MiLin *lm = (MiLin *) HKKT->kktM->chol;
                 if (use_env && lm && lm->ch.nblk > 1) {
-                    std::vector<int> first(lm->ch.nblk);
-                    for (int b = 0; b < lm->ch.nblk; ++b) first[b] = b;
-                    for (size_t q = 0; q < nnz; ++q) {
-                        const int br = idx[q] / 128, bc = cols[q] / 128;     // (lower pattern: row >= column)
-                        if (br < lm->ch.nblk && bc < first[br]) first[br] = bc;
-                    }
-                    if (lm->ch.set_envelope(first.data())) return HDSDP_RETCODE_FAILED;
+                    const int nb = lm->ch.nblk;
+                    auto envelope = [&](const std::vector<int> *perm, std::vector<int> &first) {   // returns the factorisation's cost in block products
+                        first.resize(nb);
+                        for (int b = 0; b < nb; ++b) first[b] = b;
+                        for (size_t q = 0; q < nnz; ++q) {
+                            int r = idx[q], c = cols[q];
+                            if (perm) { r = (*perm)[r]; c = (*perm)[c]; if (r < c) std::swap(r, c); }
+                            const int br = r / 128, bc = c / 128;
+                            if (bc < first[br]) first[br] = bc;
+                        }
+                        std::vector<int> colh(nb);
+                        for (int k = 0; k < nb; ++k) colh[k] = k;
+                        for (int b = 0; b < nb; ++b) for (int k = first[b]; k <= b; ++k) colh[k] = std::max(colh[k], b);
+                        double cost = 0.0;
+                        for (int k = 0; k < nb; ++k) { const double h = colh[k] - k; cost += 1.0 + h + 0.5 * h * (h + 1.0); }
+                        return cost;
+                    };
+                    std::vector<int> first_nat, first_rcm, perm;
+                    const double cost_nat = envelope(nullptr, first_nat);
+                    double cost_rcm = INFINITY;
+                    if (use_rcm) { perm = rcm_order(nRow, beg, idx); cost_rcm = envelope(&perm, first_rcm); }
+                    if (cost_rcm < 0.8 * cost_nat) {
+                        std::vector<int> prow(nnz), pcol(nnz);
+                        for (size_t q = 0; q < nnz; ++q) {
+                            int r = perm[idx[q]], c = perm[cols[q]];
+                            if (r < c) std::swap(r, c);
+                            prow[q] = r; pcol[q] = c;
+                        }
+                        if (hipMalloc((void **) &pv0->sp_prow, sizeof(int) * std::max<size_t>(1, nnz)) != hipSuccess ||
+                            hipMalloc((void **) &pv0->sp_pcol, sizeof(int) * std::max<size_t>(1, nnz)) != hipSuccess)
+                            return HDSDP_RETCODE_MEMORY;
+                        if (hdm_memcpy_h2d_sync(pv0->sp_prow, prow.data(), sizeof(int) * nnz) != hipSuccess ||
+                            hdm_memcpy_h2d_sync(pv0->sp_pcol, pcol.data(), sizeof(int) * nnz) != hipSuccess)
+                            return HDSDP_RETCODE_FAILED;
+                        lm->perm = perm;
+                        if (lm->ch.set_envelope(first_rcm.data())) return HDSDP_RETCODE_FAILED;
+                    } else if (lm->ch.set_envelope(first_nat.data())) return HDSDP_RETCODE_FAILED;
                 }
             }
             printf("    Using sparse Schur complement (%d nnzs)\n", HKKT->kktMatBeg[nRow]);
@@ -2236,6 +2334,17 @@ hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
     if (l->indef) return lin_factor_indef(l);     // switched earlier: stays switched (hdsdp_linsolver.c:1838)
     if (pv->mirror && !HKKT->isKKTSparse) {
         if (l->ch.load_host(HKKT->kktMatElem, HKKT->nRow, g.stream)) return HDSDP_RETCODE_FAILED;
+    } else if (HKKT->isKKTSparse && !l->perm.empty()) {
+        // the factor object holds P M P': the pattern's entries (already in sp_vals when they came up from the host CSC,
+        // gathered from the device matrix otherwise) go to their permuted places in a zeroed image
+        if (!pv->mirror && pv->nnz > 0)
+            hipLaunchKernelGGL(mi_csc_gather_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->Mdev,
+                               (long) l->ch.npad, pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
+        if (hipMemsetAsync(l->ch.L, 0, sizeof(double) * (size_t) l->ch.npad * l->ch.npad, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
+        if (pv->nnz > 0)
+            hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->ch.L,
+                               (long) l->ch.npad, pv->sp_prow, pv->sp_pcol, pv->nnz, pv->sp_vals);
+        if (l->ch.finish_load(g.stream)) return HDSDP_RETCODE_FAILED;
     } else {
         if (l->ch.load_device(l->Mdev, l->ch.npad, g.stream)) return HDSDP_RETCODE_FAILED;
     }
@@ -2814,6 +2923,21 @@ hdsdp_retcode HMiKKTPhaseA(hdsdp_kkt *HKKT, double barHsdTau, double *rowDual, d
     for (int i = 0; i < 6; ++i) g.stage_ms[i] = (stamp[i + 1] - stamp[i]) * 1e-5;   // HMiGetStageTimes: 100 MHz ticks -> ms
     g.stage_ms[6] = (stamp[6] > stamp[0]) ? stamp[7] / ((stamp[6] - stamp[0]) * 10.0) : 0.0;   // shader clock during the pass, GHz
     return HDSDP_RETCODE_OK;
+}
+
+// how the operator's matrix will be factored: *permuted = 1 if the factor object holds P M P' (reverse Cuthill-McKee order of
+// the sparse pattern), *fraction = blocks inside the pattern's block envelope / blocks of the dense lower triangle (1 = dense)
+void HMiKKTEnvelopeInfo(hdsdp_kkt *HKKT, int *permuted, double *fraction) {
+    if (permuted) *permuted = 0;
+    if (fraction) *fraction = 1.0;
+    if (!HKKT || !HKKT->kktM) return;
+    MiLin *l = (MiLin *) HKKT->kktM->chol;
+    if (permuted) *permuted = l->perm.empty() ? 0 : 1;
+    if (fraction && !l->ch.env_colh.empty()) {
+        double in = 0.0, all = 0.0;
+        for (int k = 0; k < l->ch.nblk; ++k) { in += l->ch.env_colh[k] - k + 1; all += l->ch.nblk - k; }
+        *fraction = in / all;
+    }
 }
 
 int HMiGetCallStats(double *seconds, int64_t *calls, int n) {

@@ -1199,11 +1199,15 @@ def test_primal_build_with_an_indefinite_registered_matrix(name):
         blk.close()
 
 
-def test_sparse_operator_with_a_banded_pattern_over_several_blocks_of_M():
+@pytest.mark.parametrize("scrambled", [False, True], ids=["band-in-the-drivers-order", "band-after-reordering"])
+def test_sparse_operator_with_a_banded_pattern_over_several_blocks_of_M(scrambled):
     """a chain of fifty small blocks, block b holding constraints 8b .. 8b+15 (m = 408): the operator comes up sparse, its
     pattern is a band, and the factorisation of the 512 x 512 device matrix runs on the pattern's block envelope
-    (HdmChol::set_envelope: block row 3 does not reach block column 0 ...).  M against the oracle's block-by-block sum, the
-    solve against LAPACK on that sum, and twice -- the second factorisation replays the captured launch chain"""
+    (HdmChol::set_envelope: block row 3 does not reach block column 0 ...).  Scrambled: the same chain with the constraints
+    renumbered at random -- the pattern is a band only after a reverse Cuthill-McKee reordering, which HKKTInit finds and
+    keeps inside the factor object (P M P' is factored, right-hand sides and solutions are permuted).  M against the oracle's
+    block-by-block sum, the solve against LAPACK on that sum, and twice -- the second factorisation replays the captured
+    launch chain"""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import oracle_py
@@ -1212,10 +1216,11 @@ def test_sparse_operator_with_a_banded_pattern_over_several_blocks_of_M():
     Rd, tau = -30.0, 1.0
     y = 0.02 * np.cos(np.arange(m) + 0.3)
     cones, Mref = [], np.zeros((m, m))
+    renum = np.random.default_rng(7).permutation(m) if scrambled else np.arange(m)
     try:
         for b in range(nblocks):
             n = 10 + (b % 3)
-            keep = list(range(8 * b, 8 * b + 16))
+            keep = sorted(int(renum[k]) for k in range(8 * b, 8 * b + 16))
             beg, idx, val = _block_with_rows(n, m, keep)
             blk = oracle_py.Block(n, m, beg, idx, val)
             Lf, info = blk.factor(blk.assemble_S(tau, y, Rd))
@@ -1229,7 +1234,12 @@ def test_sparse_operator_with_a_banded_pattern_over_several_blocks_of_M():
         kkt = api.KKT(m, cones)
         assert kkt.is_sparse
         A = np.triu(Mref) + np.triu(Mref, 1).T
-        assert not A[300:, :128].any() and A[127, 120] != 0.0          # a band: the far corner is structurally empty
+        permuted, fraction = kkt.envelope_info()
+        assert permuted == scrambled and fraction <= 0.8, (permuted, fraction)
+        if not scrambled:
+            assert not A[300:, :128].any() and A[127, 120] != 0.0      # a band: the far corner is structurally empty
+        else:
+            assert A[300:, :128].any()                                   # no band in this numbering
         for rep in range(2):
             kkt.build_up(api.KKT_TYPE_INFEASIBLE)
             msk = lower_mask(m)
