@@ -412,6 +412,12 @@ struct MiCone {
     // writes into it, the others stop after the all-reduce
     bool kkt_owner = true;
     int kkt_counted = 0;       // progress of the aggregated-pattern queries (cone_add_sym_nz)
+    // Where the dual matrix and the step matrix stand (single-device blocks): S = T(pS), dS = T(pD) for the linear map
+    // T(tau, y, eye) = tau C - sum y_i A_i + eye I.  A request for T(p) with p = pS + alpha pD is answered by S + alpha dS
+    // (one pass over n^2) instead of a sweep over all m constraint matrices (cone_assemble).
+    std::vector<double> pS, pD;          // tau, eye, then the mloc multipliers
+    bool pS_ok = false, pD_ok = false;
+    int aff_chain = 0;                   // updates of S in place since its last full assembly
     // fused single-launch Phase-A pass of a small rank-one block (small.hip): factors as a CSR, built on first use
     struct SmallPlan {
         int state = 0;         // 0 = not looked at, 1 = ready, -1 = not eligible
@@ -660,7 +666,59 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
     double *yo = c->yhost;
     bool any = false;
     for (int q = 0; q < c->mloc; ++q) { yo[q] = y_host ? y_host[c->own[q]] : 0.0; any |= (yo[q] != 0.0); }
+    const double eye_now = eye_override ? *eye_override : (-c->Rd + c->perturb);
+    // ---- shortcut (see MiCone::pS).  The reference's line searches and correctors ask for the dual matrix twice at the same
+    // point (interior check, then barrier) and at points y + alpha dy along the direction whose dS the ratio test has just
+    // assembled: each a 32 GB sweep at n = m = 2000 (6 ms), 14 % of a whole solve's device time.  The request is compared
+    // with what the buffers hold, component by component; anything else takes the sweep.
+    // Default (1): only the exact case -- the same point again -- is short-cut, so every number is the one a sweep would have
+    // produced.  2: also points on the line through the last ratio test's direction (S + alpha dS); the results then differ
+    // from a sweep's in the last bits, which is enough to send the end game of a badly conditioned instance down another
+    // path (gpp100 through the reference's driver: same dual objective, a primal estimate 3e-4 further away).  0: off.
+    static const int aff_mode = [] { const char *e = getenv("HDSDP_MI355X_AFFINE_S"); return e ? atoi(e) : 1; }();
+    const bool track = aff_mode > 0 && c->world == 1;
+    if (track && target != c->dS && c->pS_ok) {
+        const int np = c->mloc + 2;
+        auto comp = [&](int i) { return i == 0 ? tau : i == 1 ? eye_now : yo[i - 2]; };
+        bool same = true;
+        for (int i = 0; i < np && same; ++i) same = (comp(i) == c->pS[i]);
+        if (same && target == c->S) return 0;                                  // S already is T(p)
+        double alpha = 0.0;
+        bool hit = same;
+        if (!same && c->pD_ok && aff_mode >= 2) {
+            int kmax = 0;
+            for (int i = 1; i < np; ++i) if (fabs(c->pD[i]) > fabs(c->pD[kmax])) kmax = i;
+            if (c->pD[kmax] != 0.0) {
+                alpha = (comp(kmax) - c->pS[kmax]) / c->pD[kmax];
+                hit = std::isfinite(alpha);
+                for (int i = 0; i < np && hit; ++i) {
+                    const double d = comp(i) - c->pS[i], e = alpha * c->pD[i];
+                    hit = fabs(d - e) <= 1.8e-15 * (fabs(comp(i)) + fabs(c->pS[i]) + fabs(e));
+                }
+            }
+        }
+        if (hit && same) {                                                     // the same point into the other buffer: a copy
+            HDM_HIP_CHECK(hipMemcpyAsync(target, c->S, sizeof(double) * (size_t) c->n16 * c->n16, hipMemcpyDeviceToDevice, g.stream));
+            return 0;
+        }
+        if (hit && c->dS && (target != c->S || c->aff_chain < 16)) {
+            if (hdm_axpy_mat(target, c->S, c->dS, alpha, (long) c->n16 * c->n16, g.stream)) return 1;
+            if (target == c->S) {
+                for (int i = 0; i < np; ++i) c->pS[i] = comp(i);
+                c->aff_chain += 1;
+            }
+            return 0;
+        }
+    }
     HDM_HIP_CHECK(hipMemcpyAsync(c->ydev, yo, sizeof(double) * c->mloc, hipMemcpyHostToDevice, g.stream));
+    if (track && (target == c->S || target == c->dS)) {
+        std::vector<double> &pp = (target == c->S) ? c->pS : c->pD;
+        pp.resize((size_t) c->mloc + 2);
+        pp[0] = tau; pp[1] = eye_now;
+        for (int q = 0; q < c->mloc; ++q) pp[2 + q] = yo[q];
+        (target == c->S ? c->pS_ok : c->pD_ok) = true;
+        if (target == c->S) c->aff_chain = 0;
+    }
     const double lead = (c->rank == 0) ? 1.0 : 0.0;
     if (hdm_sym_combine(c->Afull, c->astride, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
                         lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)), target, c->n, c->n16, c->n16, g.stream)) return 1;
@@ -729,6 +787,7 @@ hdsdp_retcode cone_axpy_check(void *cd, double dStep, int whichBuffer, int *isIn
     if (!c->dS) return HDSDP_RETCODE_FAILED;
     const long cnt = (long) c->n16 * c->n16;
     double *target = (whichBuffer == 0) ? c->S : c->Scheck;
+    if (whichBuffer == 0) c->pS_ok = false;          // S moves without a point being named: the next request assembles it
     RC(hdm_axpy_mat(target, c->S, c->dS, dStep, cnt, g.stream));
     return (whichBuffer == 0) ? cone_factor_S(c, isInterior) : cone_factor_check(c, isInterior);
 }
@@ -2884,6 +2943,7 @@ hdsdp_retcode HMiKKTPhaseA(hdsdp_kkt *HKKT, double barHsdTau, double *rowDual, d
     a.y = sp.io_dev; a.b = sp.io_dev + m; a.out = sp.io_dev + 2 * (size_t) m;
     a.tau = barHsdTau; a.eye = -c->Rd + c->perturb; a.Rd = c->Rd;
     a.Sout = c->S; a.lds = c->n16;
+    c->pS_ok = false;                                  // (the pass writes S itself)
     a.LS = ls->ch.L; a.WS = ls->ch.Dinv; a.M = lm->Mdev; a.ldm = lm->ch.npad; a.LM = lm->ch.L; a.WM = lm->ch.Dinv;
     if (ls->ch.npad != SMALL_P || lm->ch.npad != SMALL_P) return HDSDP_RETCODE_FAILED;
     // (the operator's accumulators as HKKTBuildUp(KKT_TYPE_INFEASIBLE) leaves them, hdsdp_schur.c:141-165, :256-268: the
