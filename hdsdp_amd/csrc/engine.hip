@@ -2183,7 +2183,9 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
                     std::vector<int> first_nat, first_rcm, perm;
                     const double cost_nat = envelope(nullptr, first_nat);
                     double cost_rcm = INFINITY;
-                    if (use_rcm) { perm = rcm_order(nRow, beg, idx); cost_rcm = envelope(&perm, first_rcm); }
+                    // (the reordering is looked for where it can pay: patterns up to 5e7 entries -- its adjacency lists take 8 bytes per
+                    // entry on the host -- that do not already fill most of the triangle)
+                    if (use_rcm && nnz <= 50000000 && (double) nnz < 0.15 * (double) nRow * nRow) { perm = rcm_order(nRow, beg, idx); cost_rcm = envelope(&perm, first_rcm); }
                     if (cost_rcm < 0.8 * cost_nat) {
                         std::vector<int> prow(nnz), pcol(nnz);
                         for (size_t q = 0; q < nnz; ++q) {
