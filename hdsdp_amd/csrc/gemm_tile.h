@@ -824,9 +824,10 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
 // Why.  Per-workgroup stamps of the one-tile-per-workgroup launch (tools/wg_timeline.py, profiles/r02_e_wg_residency.txt)
 // show that a CU spends 16 % of congruence step 2's time with ONE workgroup on it and 3.4 % with none (step 1: 15 % / 1.5 %,
 // Gram: 8.5 % / 0): after a workgroup ends, the next one starts on that CU 24 us later on average (a tile lasts 250 us), on
-// every XCD alike.  Workgroups are dealt to the XCDs round-robin and IN ORDER: a free slot on one XCD is not refilled until
-// every XCD before it in the deal has taken its workgroup, so each XCD waits for the slowest of eight at every hand-over.
-// That gap -- not barriers, LDS or the loop -- is most of the matrix-pipe idle time the counters showed (9-12 %).
+// every XCD alike.  Our reading: workgroups are dealt to the XCDs round-robin and IN ORDER, so a free slot on one XCD is not
+// refilled until every XCD before it in the deal has taken its workgroup, and each XCD waits for the slowest of eight at
+// every hand-over.  That gap -- not barriers, LDS or the loop -- is most of the matrix-pipe idle time the counters showed
+// (9-12 %).
 //
 // Queues.  One atomic counter per XCD (cnt[8], zeroed by the host before the launch): XCD x's workgroups (x read from
 // HW_REG_XCC_ID, nothing assumed about the dispatcher) draw idx = cnt[x]++, which decodes exactly like the workgroup id
