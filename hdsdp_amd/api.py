@@ -38,7 +38,7 @@ EXPORTS = [
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
     "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
-    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
+    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiRcmOrder", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
 ]
 
@@ -177,6 +177,7 @@ def load_library():
         "HMiCholEnvelopeSolve": (C.c_int, [vp, C.c_int, ip, vp, vp, vp, ip]),
         "HMiCholEnvelopeProbe": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp]),
         "HMiKKTEnvelopeInfo": (None, [kp, ip, dp]),
+        "HMiRcmOrder": (C.c_int, [C.c_int, ip, ip, ip]),
         "HMiPresolveCSC": (C.c_int, [C.c_int, C.c_int, ip, ip, dp, ip, ip, ip, ip, ip, ip]),
         "HMiReadSDPA": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
         "HMiSDPAGetDims": (None, [vp, ip, ip, ip]),

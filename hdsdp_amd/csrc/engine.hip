@@ -2987,6 +2987,16 @@ hdsdp_retcode HMiKKTPhaseA(hdsdp_kkt *HKKT, double barHsdTau, double *rowDual, d
     return HDSDP_RETCODE_OK;
 }
 
+// host only (no device call): the reverse Cuthill-McKee order HKKTInit looks at for a sparse Schur pattern; lower-triangular CSC in,
+// perm[old] = new out
+int HMiRcmOrder(int m, const int *colBeg, const int *rowIdx, int *perm) {
+    if (m <= 0 || !colBeg || !rowIdx || !perm) return 1;
+    std::vector<int> beg(colBeg, colBeg + m + 1), idx(rowIdx, rowIdx + colBeg[m]);
+    const std::vector<int> p = rcm_order(m, beg, idx);
+    for (int i = 0; i < m; ++i) perm[i] = p[i];
+    return 0;
+}
+
 // how the operator's matrix will be factored: *permuted = 1 if the factor object holds P M P' (reverse Cuthill-McKee order of
 // the sparse pattern), *fraction = blocks inside the pattern's block envelope / blocks of the dense lower triangle (1 = dense)
 void HMiKKTEnvelopeInfo(hdsdp_kkt *HKKT, int *permuted, double *fraction) {

@@ -381,6 +381,8 @@ int HMiPotrf(double *A_dev, int n, int64_t lda, int *info);  /* in place, lower 
 /* blocked Cholesky + one solve of a host matrix (lower triangle, column-major, ld = n) with a block envelope: first[i] = first
    128-block column with an entry in block row i, NULL = dense; L_host (n x n) receives the factor if not NULL */
 int HMiCholEnvelopeSolve(const double *A_host, int n, const int *first, const double *b, double *x, double *L_host, int *info);
+/* host only: the reverse Cuthill-McKee order HKKTInit considers for a sparse Schur pattern (lower-triangular CSC in, perm[old] = new out) */
+int HMiRcmOrder(int m, const int *colBeg, const int *rowIdx, int *perm);
 /* how the operator's matrix will be factored: *permuted = 1 if the factor object holds P M P' (reverse Cuthill-McKee order of the
    sparse pattern), *fraction = 128-blocks inside the pattern's block envelope / blocks of the dense lower triangle */
 void HMiKKTEnvelopeInfo(hdsdp_kkt *HKKT, int *permuted, double *fraction);

@@ -176,3 +176,38 @@ def test_reference_minus_two_files_links_against_the_library():
     assert not [w for w in wanted if w not in have]
     r = subprocess.run(["ldd", "-r", so], capture_output=True, text=True)
     assert "undefined symbol" not in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
+
+
+def test_rcm_order_recovers_a_band_and_is_a_permutation():
+    """host logic of the sparse Schur operator (engine.hip: rcm_order, no device call): a banded pattern whose rows were renumbered
+    at random -- two disconnected chains and an isolated row -- comes back with a bandwidth close to the original one, and
+    the result is a permutation whatever the pattern (empty, diagonal only, dense)"""
+    import ctypes as C
+    from hdsdp_amd import api
+    lib = api.load_library()
+    ip = C.POINTER(C.c_int)
+
+    def order(m, pairs):
+        cols = [[] for _ in range(m)]
+        for r, c in set((max(a, b), min(a, b)) for a, b in pairs) | set((i, i) for i in range(m)):
+            cols[c].append(r)
+        beg, idx = [0], []
+        for c in range(m):
+            idx += sorted(cols[c]); beg.append(len(idx))
+        beg, idx = np.array(beg, dtype=np.int32), np.array(idx, dtype=np.int32)
+        perm = np.zeros(m, dtype=np.int32)
+        assert lib.HMiRcmOrder(m, beg.ctypes.data_as(ip), idx.ctypes.data_as(ip), perm.ctypes.data_as(ip)) == 0
+        assert sorted(perm.tolist()) == list(range(m))
+        return perm
+
+    rng = np.random.default_rng(3)
+    m, half = 601, 300
+    band = [(i, j) for i in range(half) for j in range(max(0, i - 6), i)]                     # chain 1: rows 0..299, bandwidth 6
+    band += [(half + i, half + j) for i in range(half) for j in range(max(0, i - 3), i)]      # chain 2: rows 300..599, bandwidth 3
+    renum = rng.permutation(m)                                                                 # row 600 stays isolated
+    scr = [(int(renum[a]), int(renum[b])) for a, b in band]
+    assert max(abs(a - b) for a, b in scr) > 300
+    perm = order(m, scr)
+    assert max(abs(int(perm[a]) - int(perm[b])) for a, b in scr) <= 16
+    for pairs in ([], [(i, j) for i in range(40) for j in range(i)]):
+        order(40, pairs)
