@@ -1235,7 +1235,8 @@ def test_sparse_operator_with_a_banded_pattern_over_several_blocks_of_M(scramble
         assert kkt.is_sparse
         A = np.triu(Mref) + np.triu(Mref, 1).T
         permuted, fraction = kkt.envelope_info()
-        assert permuted == scrambled and fraction <= 0.8, (permuted, fraction)
+        if os.environ.get("HDSDP_MI355X_KKT_ENVELOPE", "1") != "0" and os.environ.get("HDSDP_MI355X_KKT_RCM", "1") != "0":
+            assert permuted == scrambled and fraction <= 0.8, (permuted, fraction)
         if not scrambled:
             assert not A[300:, :128].any() and A[127, 120] != 0.0      # a band: the far corner is structurally empty
         else:
