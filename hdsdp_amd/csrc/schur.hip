@@ -242,6 +242,51 @@ __global__ void hdm_sym_combine_kernel(const double *__restrict__ A, long astrid
     S[i + (long) j * lds_] = acc;
 }
 
+// The same sum walked in STORAGE order: thread t of a workgroup owns skyline positions s0 + t, + 256, + 512, + 768, so a
+// workgroup reads 8 KB of consecutive memory from every constraint matrix (the element-indexed kernel above reads 2 KB
+// pieces, one per column segment, and half of its workgroups -- the ones above the diagonal -- leave at once), with four
+// independent accumulators per thread (16-byte loads over 16 KB per workgroup measured slower: 6.2 ms against 5.84).  Positions are decoded to (i, j) only once, for the store; the stored zeros of the
+// diagonal blocks' upper triangles are skipped there.
+__global__ __launch_bounds__(256) void hdm_sym_combine_sky_kernel(const double *__restrict__ A, long astride, int m,
+                                                                  const double *__restrict__ y, const double *__restrict__ C,
+                                                                  double tau, double eye, double *__restrict__ S, int n, int lda,
+                                                                  long lds_, long sky) {
+    const long s0 = (long) blockIdx.x * 1024 + threadIdx.x;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (s0 + 768 < sky) {                          // (workgroup-uniform except in the last workgroup)
+        const double *p = A + s0;
+#pragma unroll 4
+        for (int c = 0; c < m; ++c, p += astride) {
+            const double yc = y[c];
+            acc[0] -= yc * p[0]; acc[1] -= yc * p[256]; acc[2] -= yc * p[512]; acc[3] -= yc * p[768];
+        }
+    } else {
+        for (int c = 0; c < m; ++c) {
+            const double yc = y[c];
+            const double *p = A + (long) c * astride + s0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (s0 + 256 * q < sky) acc[q] -= yc * p[256 * q];
+        }
+    }
+    const int tlast = (lda + 127) / 128 - 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long sp = s0 + 256 * q;
+        if (sp >= sky) continue;
+        int t = 0;
+        while (t < tlast && hdm_sky_panel(t + 1, lda) <= sp) ++t;
+        const long local = sp - hdm_sky_panel(t, lda);
+        const int ldp = lda - 128 * t;
+        const int i = 128 * t + (int) (local % ldp), j = 128 * t + (int) (local / ldp);
+        if (i < j || i >= n || j >= n) continue;
+        double v = acc[q];
+        if (i == j) v *= 2.0;
+        v += tau * C[i + (long) j * lda];
+        if (i == j) v += eye;
+        S[i + (long) j * lds_] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // rank-one (M2) path.  U = Linv * [a_1 .. a_m] (n x m), Gm = U^T U  =>  Gm_ij = a_i' S^-1 a_j
 //   M_ij = s_i s_j Gm_ij^2 ; ASinv_i = s_i Gm_ii ; ASinvRdSinv_i = Rd s_i |S^-1 a_i|^2 = Rd s_i |Linv^T u_i|^2
@@ -466,6 +511,14 @@ int hdm_extract(const double *G, long ldg, long R, long pI, const int *rows_seg,
 
 int hdm_sym_combine(const double *A, long astride, int m, const double *y, const double *C, double tau, double eye,
                     double *S, int n, long lda, long lds_, hipStream_t s) {
+    static const bool sky_order = [] { const char *e = getenv("HDM_SYM_COMBINE_SKY"); return !(e && atoi(e) == 0); }();
+    const long sky = hdm_sky_size((int) lda);
+    if (sky_order && m > 0) {
+        hipLaunchKernelGGL(hdm_sym_combine_sky_kernel, dim3((unsigned) ((sky + 1023) / 1024)), dim3(256), 0, s, A, astride, m, y, C,
+                           tau, eye, S, n, (int) lda, lds_, sky);
+        HDM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     long tot = (long) n * n;
     hipLaunchKernelGGL(hdm_sym_combine_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, A, astride, m, y,
                        C, tau, eye, S, n, lda, lds_);

@@ -2,6 +2,7 @@
 """achieved HBM rate of the two memory-bound passes over the resident constraint data at n=m=2000:
 S assembly with y != 0 (hdm_sym_combine_kernel) and the corrector's <A_i, S^-1>, <A_i, S^-2> (hdm_sym_dot2_kernel)"""
 import os, sys, time
+os.environ["HDSDP_MI355X_AFFINE_S"] = "0"   # every call assembles (the engine would otherwise recognise the repeated point)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hdsdp_amd import api
