@@ -40,19 +40,36 @@ KERNEL_SYMBOL = {1: KERNEL_NAME + "<false, true, 1, 64>", 2: KERNEL_NAME + "<fal
 
 
 def traffic_bytes_per_launch(role):
+    """(bytes per launch or None, description of the source).  The newest profiles/*_traffic.json BY ITS OWN TIMESTAMP
+    (`taken_utc`, written by tools/prof_summary.py --traffic) is used, and only if it was measured on the kernel sources
+    this build was made from (`kernel_source_sha`) with the same launch form (`persist`): anything else gives None and
+    says why, so a stale number never reaches the bench line."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if not files or os.environ.get("HDM_VAR"):
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            ks = json.load(f)["kernels"]
-    except Exception:
-        return None, None
-    hits = [v for k, v in ks.items() if KERNEL_SYMBOL[role].replace(" ", "") in k.replace(" ", "")]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from prof_summary import kernel_source_sha
+    if os.environ.get("HDM_VAR"):
+        return None, "diagnostic variant (HDM_VAR set)"
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except Exception:
+            continue
+        if "taken_utc" in d and (best is None or d["taken_utc"] > best[1]["taken_utc"]):
+            best = (f, d)
+    if best is None:
+        return None, "no profiles/*_traffic.json carries a timestamp and a kernel source hash"
+    f, d = best
+    tag = "%s (taken %s on kernel sources %s)" % (os.path.basename(f), d["taken_utc"], d.get("kernel_source_sha"))
+    if d.get("kernel_source_sha") != kernel_source_sha(ROOT):
+        return None, "stale: " + tag + ", this build is " + kernel_source_sha(ROOT)
+    if bool(d.get("persist", True)) != PERSIST:
+        return None, "other launch form: " + tag
+    hits = [v for k, v in d["kernels"].items() if KERNEL_SYMBOL[role].replace(" ", "") in k.replace(" ", "")]
     if len(hits) != 1:
-        return None, os.path.basename(files[-1])
-    return hits[0]["bytes_per_launch"], os.path.basename(files[-1])
+        return None, "kernel symbol not found in " + tag
+    return hits[0]["bytes_per_launch"], tag
 
 
 def survey_flops(n, m):
@@ -77,7 +94,52 @@ def survey_equiv(n, m, world, kms, kln, steps):
                      "tflops": round(0.5 * m * (m + 1) / world * n * (n + 1) / max(gram_ms, 1e-9) / 1e9, 2)}}
 
 
-def cpu_baseline(n, m, budget_cols=8):
+def workload_label(n, m):
+    """BASELINE.json's configs by (n, m): nothing else may call itself configs[3] or configs[4]"""
+    fam = "synthetic dense SDP n=%d m=%d (SURVEY 8(d) splitmix64 family, state y=0 tau=1 Rd=-10n), one Phase-A pass per step" % (n, m)
+    if (n, m) == (2000, 2000):
+        return "configs[3]: " + fam
+    if (n, m) == (2000, 8000):
+        return "configs[4]: " + fam + ", constraint rows sharded over the GPUs"
+    return "custom (not a BASELINE config): " + fam
+
+
+def golden_check(n, m, kkt, sol, rhs):
+    """compare the run with the independent host-fp64 fixtures (tests/golden/, read-only data): n = m = 2000 against
+    full2000.npz (the two checksums of the Phase-A solutions), n = 2000, m = 8000 against full8000_rows.npz (rows of M,
+    both vectors, and rows of the residual M d = rhs with the fixture's rows of M and the device's solutions).  Returns
+    (details, ok) or (None, None) when no fixture exists for this size."""
+    gdir = os.path.join(ROOT, "tests", "golden")
+    if (n, m) == (2000, 2000) and os.path.exists(os.path.join(gdir, "full2000.npz")):
+        g = np.load(os.path.join(gdir, "full2000.npz"))
+        d = {"sum_d2": float(np.sum(sol[1])), "sum_d1w": float(np.dot(np.arange(1, m + 1), sol[0])),
+             "golden_sum_d2": float(g["bench_sum_d2"]), "golden_sum_d1w": float(g["bench_sum_d1w"]), "fixture": "full2000.npz"}
+        ok = (abs(d["sum_d2"] - d["golden_sum_d2"]) <= 1e-9 * abs(d["golden_sum_d2"]) and
+              abs(d["sum_d1w"] - d["golden_sum_d1w"]) <= 1e-9 * abs(d["golden_sum_d1w"]))
+        return d, bool(ok)
+    if (n, m) == (2000, 8000) and os.path.exists(os.path.join(gdir, "full8000_rows.npz")):
+        g = np.load(os.path.join(gdir, "full8000_rows.npz"))
+        rows = np.asarray(g["bench_rows"])
+        Mg = np.asarray(g["bench_M_rows"])
+        Md = kkt.rows(rows)
+        ex = kkt.export()
+        scale = float(np.max(np.abs(Mg)))
+        d = {"fixture": "full8000_rows.npz", "rows": int(rows.size),
+             "sum_M_rows": float(np.sum(Md)), "golden_sum_M_rows": float(g["bench_sum_M_rows"]),
+             "max_err_M_rows": float(np.max(np.abs(Md - Mg)) / scale),
+             "max_err_ASinv": float(np.max(np.abs(ex["ASinv"] - g["bench_ASinv"])) / np.max(np.abs(g["bench_ASinv"]))),
+             "max_err_ASinvRdSinv": float(np.max(np.abs(ex["ASinvRdSinv"] - g["bench_ASinvRdSinv"])) /
+                                          np.max(np.abs(g["bench_ASinvRdSinv"]))),
+             # rows of M d - rhs with the FIXTURE's rows of M: an independent check of the factorisation and the solves
+             "max_residual_rows": float(max(np.max(np.abs(Mg @ x - np.asarray(r)[rows])) / np.max(np.abs(r))
+                                            for x, r in zip(sol, rhs)))}
+        ok = (d["max_err_M_rows"] < 1e-10 and d["max_err_ASinv"] < 1e-10 and d["max_err_ASinvRdSinv"] < 1e-10 and
+              d["max_residual_rows"] < 1e-8)
+        return d, bool(ok)
+    return None, None
+
+
+def cpu_baseline(n, m, budget_cols=16):
     """Time the CPU side on this host: the real reference (oracle/_ref, kind "reference") when it was
     built, else the plain-C restatement (kind "port").  Bounded sample: the same n, `budget_cols`
     constraint matrices; extrapolated to m with the reference's own operation count."""
@@ -138,23 +200,64 @@ def main():
     ap.add_argument("--m", type=int, default=2000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default=None, help="collective backend for N>1 (default nccl = RCCL)")
+    ap.add_argument("--loopback", action="store_true",
+                    help="--gpus N on fewer than N devices: shards share devices (a rehearsal; n_gpus then reports the devices "
+                         "really used, never N)")
     args = ap.parse_args()
 
     import torch
     from hdsdp_amd import api, dist as hdist
 
     rank, world, local = hdist.init_process_group_from_env(args.backend)
-    if world != args.gpus and world > 1:
+    if world > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("LOCAL_RANK", str(local))
     lib = api.load_library()
-    if lib.HMiDeviceInit(local) != 0:
-        raise SystemExit("no MI355X visible: bench.py has no CPU fallback")
-    torch.cuda.set_device(local % torch.cuda.device_count())
     n, m = args.n, args.m
+    # How N GPUs are driven.  Under torchrun (WORLD_SIZE set): one process per GPU, collectives through torch.distributed
+    # (hdsdp_amd/dist.py).  `--gpus N` WITHOUT torchrun: the in-process device group behind the C ABI (HMiSetDevices: the
+    # path the reference's single-threaded driver uses), N shards on N devices over RCCL.  Either way the line reports
+    # the devices really used, and a request that cannot be met is an error, not a one-GPU run with an N-GPU label.
+    shards, mode, transport = world, ("torchrun" if world > 1 else "single"), None
+    ndev = torch.cuda.device_count()
+    if world == 1 and args.gpus > 1:
+        if ndev < args.gpus and not args.loopback:
+            raise SystemExit(f"--gpus {args.gpus} requested but {ndev} device(s) visible (use --loopback for a rehearsal "
+                             f"on shared devices, or launch with torchrun)")
+        ids = [r % max(1, ndev) for r in range(args.gpus)]
+        api.set_devices(ids, shard_min_dim=0)
+        gids, transport = api.device_group()
+        if len(gids) != args.gpus:
+            raise SystemExit(f"device group has {len(gids)} shards, {args.gpus} requested")
+        shards, mode = args.gpus, "in-process device group (HMiSetDevices)"
+        devices_used = len(set(gids))
+    else:
+        if lib.HMiDeviceInit(local) != 0:
+            raise SystemExit("no MI355X visible: bench.py has no CPU fallback")
+        devices_used = world
+    if ndev == 0:
+        raise SystemExit("no MI355X visible: bench.py has no CPU fallback")
+    torch.cuda.set_device(local % ndev)
+    if devices_used != args.gpus and not args.loopback:
+        raise SystemExit(f"--gpus {args.gpus} requested, {devices_used} device(s) in use")
+
+    # BASELINE configs 2-3 (mcp100, gpp100 "on 1 MI355X"): parity cases, not the headline -- one timed line each so that the
+    # driver-run record carries them (tools/small_configs.py).  Measured FIRST, on a quiet device: round 2 measured them
+    # right after giving 100 GB back to the runtime and the first config came out at 0.44 ms instead of 0.17.
+    small = None
+    if world == 1 and shards == 1 and (n, m) == (2000, 2000):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import small_configs
+            small = [small_configs.measure(nm, reps=30, cpu=not args.no_cpu) for nm in ("mcp100_A", "gpp100_A")]
+        except Exception as e:  # never lose the headline line over the extras
+            small = {"error": str(e)}
+        lib.HMiDeviceSynchronize()
 
     t0 = time.time()
     cone = api.SDPCone.synthetic(n, m, rank=rank, world=world)
+    if mode.startswith("in-process") and cone.shard_count() != shards:
+        raise SystemExit(f"the block was not sharded ({cone.shard_count()} shard(s), {shards} requested)")
     ex = hdist.Exchange(cone) if world > 1 else None
     kkt = api.KKT(m, [cone], host_mirror=False)
     cone.set_start(-10.0 * n)
@@ -225,12 +328,12 @@ def main():
     dom = max((1, 2, 3), key=lambda r: kms[r])
     dom_ms = kms[dom] / max(1, kln[dom])
     achieved = (kfl[dom] / max(1, kln[dom])) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    traffic = traffic_bytes_per_launch(dom) if (n, m, world, shards) == (2000, 2000, 1, 1) else (None, "measured for n=m=2000 on one GPU only")
     roofline = {
         "bound": "mfma", "kernel": names[dom],
         "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-        "traffic": traffic_bytes_per_launch(dom)[0] if (n, m, world) == (2000, 2000, 1) else None,
-        "traffic_source": traffic_bytes_per_launch(dom)[1] if (n, m, world) == (2000, 2000, 1) else None,
+        "traffic": traffic[0], "traffic_source": traffic[1],
         "avg_launch_ms": round(float(dom_ms), 4), "launches": int(kln[dom]),
         "flops_per_launch": float(kfl[dom] / max(1, kln[dom])),
         # the same launch priced with SURVEY 8(d)'s per-unit figure (the reference's M3 count: 3 n^3 per constraint
@@ -243,12 +346,16 @@ def main():
     }
     out = {
         "metric": "IPM iterations/sec (Schur build+factor+solve), n=%d m=%d dense SDP" % (n, m),
-        "value": round(value, 4), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 4), "unit": "it/s", "n_gpus": devices_used, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[3]: synthetic dense SDP n=%d m=%d (SURVEY 8(d) splitmix64 family, "
-                               "state y=0 tau=1 Rd=-10n), one Phase-A pass per step" % (n, m),
-                   "n": n, "m": m, "parallelism": "rows%d" % world,
+        "config": {"workload": workload_label(n, m),
+                   "n": n, "m": m, "parallelism": "rows%d" % shards,
+                   # how the GPUs were driven and what really ran: N requested, shards of the row deal, distinct devices in
+                   # use, ranks of the RCCL communicator that carried the exchange (0 = device copies or one GPU)
+                   "gpus_requested": args.gpus, "shards": shards, "devices_used": devices_used, "driver": mode,
+                   "rccl_ranks": (world if (world > 1 and torch.distributed.get_backend() == "nccl") else
+                                  (shards if transport == 1 else 0)),
                    "stage_ms": {k: round(v / args.steps * 1e3, 3) for k, v in stage.items()},
                    "setup_s": round(setup_s, 1),
                    "whole_step_tflops_survey_count": round(survey_flops(n, m) / (ms_per_step * 1e-3) / 1e12, 2),
@@ -256,21 +363,19 @@ def main():
         "roofline": roofline,
         "checksum": {"sum_d2": float(np.sum(sol[1])), "sum_d1w": float(np.dot(np.arange(1, m + 1), sol[0]))},
     }
+    try:
+        rhs_last = (b, kkt.export()["ASinv"], kkt.export()["ASinvRdSinv"])
+        det, ok = golden_check(n, m, kkt, sol, rhs_last)
+    except Exception as e:
+        det, ok = {"error": str(e)}, False
+    if det is not None:
+        out["checksum"].update(det)
+    out["checksum_ok"] = ok          # None: no independent fixture exists for this (n, m)
     if ex is not None:
         out["config"]["exchange_bytes_per_step"] = {"all_to_all": ex.bytes_a2a // (args.steps + args.warmup),
                                                     "all_reduce": ex.bytes_ar // (args.steps + args.warmup)}
-    if world == 1 and (n, m) == (2000, 2000):
-        # BASELINE configs 2-3 (mcp100, gpp100 "on 1 MI355X"): parity cases, not the headline -- one timed line each so that
-        # the driver-run record carries them: a Phase-A pass call by call through the reference's operator surface, the same
-        # pass as ONE fused launch (csrc/small.hip, HMiKKTPhaseA), achieved GB/s against the ~0.2 MB of algorithmic bytes,
-        # and the plain-C oracle port on one host core (tools/small_configs.py)
-        try:
-            kkt.destroy(); cone.destroy()          # give the 100 GB back before the small cones are made
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import small_configs
-            out["small_configs"] = [small_configs.measure(nm, reps=30, cpu=not args.no_cpu) for nm in ("mcp100_A", "gpp100_A")]
-        except Exception as e:  # never lose the headline line over the extras
-            out["small_configs"] = {"error": str(e)}
+    if small is not None:
+        out["small_configs"] = small
     if not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(n, m)
         out["cpu_baseline_blas3"] = cpu_baseline_blas3(n, m)

@@ -35,7 +35,7 @@ EXPORTS = [
     "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetCoeffNorm", "HMiConeGetObjNorm",
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
     "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
-    "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiDeviceInit",
+    "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiKKTGetRows", "HMiDeviceInit",
     "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
     "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiRcmOrder", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
@@ -153,6 +153,7 @@ def load_library():
         "HMiConeGetExchangeBuffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]),
         "HMiConeSetExchangeBuffers": (C.c_int, [vp, vp, vp]),
         "HMiKKTDeviceMatrix": (vp, [kp, C.POINTER(C.c_int64)]),
+        "HMiKKTGetRows": (C.c_int, [kp, C.c_int, ip, dp]),
         "HMiSetDevices": (C.c_int, [C.c_int, ip]),
         "HMiGetDeviceGroup": (C.c_int, [ip, C.c_int, ip]),
         "HMiSetShardMinDim": (None, [C.c_int]),
@@ -532,6 +533,13 @@ class KKT:
                 D[j, idx[beg[j]:beg[j + 1]]] = val[beg[j]:beg[j + 1]]
             return D
         return np.ctypeslib.as_array(k.kktMatElem, shape=(self.m, self.m))
+
+    def rows(self, rows):
+        """full symmetric rows of the DEVICE copy of M after a build (works with the host mirror off)"""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        out = np.zeros((rows.size, self.m))
+        _check(load_library().HMiKKTGetRows(self._k, int(rows.size), _iptr(rows), _dptr(out)), "HMiKKTGetRows")
+        return out
 
     def add_to_diag(self, v):
         """what the y-box cone does through kktDiag[] (interface/hdsdp_conic_bound.c:201-229)"""

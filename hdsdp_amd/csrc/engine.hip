@@ -101,6 +101,10 @@ const char *g_stat_name[ST_N] = {"HKKTBuildUp (M-forming types)", "HKKTBuildUp (
                                  "cone: ratio test", "cone: primal recovery + utilities", "HFpLinsys* called by CPU cones"};
 double g_stat_sec[ST_N];
 long g_stat_calls[ST_N];
+// the same time by entry point (the outermost entry's function name), printed under the categories
+struct StatFn { const char *name; int k; double sec; long calls; };
+StatFn g_stat_fn[64];
+int g_stat_nfn = 0;
 thread_local int t_stat_depth = 0;
 static bool stat_trace() { static int t = -1; if (t < 0) { const char *e = getenv("HDSDP_MI355X_TRACE"); t = (e && atoi(e)) ? 1 : 0; } return t == 1; }
 struct StatScope {
@@ -121,8 +125,13 @@ struct StatScope {
             fprintf(stderr, "[hdsdp_mi355x trace] %s -> %s\n", name, e == hipSuccess ? "ok" : hipGetErrorName(e));
         }
         if (on) {
-            g_stat_sec[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            g_stat_sec[k] += dt;
             g_stat_calls[k] += 1;
+            int f = 0;
+            while (f < g_stat_nfn && g_stat_fn[f].name != name) ++f;
+            if (f == g_stat_nfn && g_stat_nfn < 64) g_stat_fn[g_stat_nfn++] = StatFn{name, k, 0.0, 0};
+            if (f < 64) { g_stat_fn[f].sec += dt; g_stat_fn[f].calls += 1; }
         }
     }
 };
@@ -130,8 +139,13 @@ void stats_print_at_exit() {
     double tot = 0.0;
     for (int k = 0; k < ST_N; ++k) tot += g_stat_sec[k];
     fprintf(stderr, "[hdsdp_mi355x] wall time below the C ABI: %.3f s\n", tot);
-    for (int k = 0; k < ST_N; ++k)
-        if (g_stat_calls[k]) fprintf(stderr, "[hdsdp_mi355x]   %-78s %8ld calls %10.3f s\n", g_stat_name[k], g_stat_calls[k], g_stat_sec[k]);
+    for (int k = 0; k < ST_N; ++k) {
+        if (!g_stat_calls[k]) continue;
+        fprintf(stderr, "[hdsdp_mi355x]   %-78s %8ld calls %10.3f s\n", g_stat_name[k], g_stat_calls[k], g_stat_sec[k]);
+        for (int f = 0; f < g_stat_nfn; ++f)
+            if (g_stat_fn[f].k == k)
+                fprintf(stderr, "[hdsdp_mi355x]       %-74s %8ld calls %10.3f s\n", g_stat_fn[f].name, g_stat_fn[f].calls, g_stat_fn[f].sec);
+    }
 }
 
 #define HIP_RC(expr)                                                                             \
@@ -938,6 +952,7 @@ void cone_scal(void *cd, double dScal) {
     if (c->CL) hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((c->astride + 255) / 256)), dim3(256), 0, g.stream, c->CL, c->astride, dScal);
     c->objScal *= dScal;
     c->norms_ready = false;
+    c->pS_ok = c->pD_ok = false;     // S and dS were assembled with the old objective: no short-cut from them (cone_assemble)
     (void) hipStreamSynchronize(g.stream);
 }
 
@@ -1538,13 +1553,22 @@ __global__ void mi_low_norms_kernel(const double *__restrict__ A, long astride, 
     __shared__ double ra[4], rf[4];
     const double *M = A + (long) blockIdx.x * astride;
     double sa = 0.0, sf = 0.0;
-    for (long e = threadIdx.x; e < (long) n * n; e += 256) {
-        const int i = (int) (e % n), j = (int) (e / n);
-        if (i < j) continue;
-        // A_L form lives in skyline storage (hdm_common.h), a full symmetric matrix in a plain square
-        double v = a_l_form ? M[hdm_sky_off(i, j, (int) ld)] : M[i + (long) j * ld];
-        if (i == j) { if (a_l_form) v *= 2.0; sa += fabs(v); sf += v * v; }
-        else { sa += 2.0 * fabs(v); sf += 2.0 * v * v; }
+    if (a_l_form) {
+        // A_L form in skyline storage (hdm_common.h): everything that is stored and not zero is an entry on or below the
+        // diagonal, so one linear pass over the matrix's storage does it (this loop once walked the n x n index space with
+        // a division and the skyline offset per element: 1.0 s for 2000 matrices at n = 2000, now HBM-bound).  Off-diagonal
+        // entries count twice; the diagonal is stored halved: |2v| = 2|v| as well, and (2v)^2 = 2v^2 + 2v^2 -- the second
+        // half comes from the short loop over the diagonal.
+        const long cnt = hdm_sky_size((int) ld);
+        for (long e = threadIdx.x; e < cnt; e += 256) { const double v = M[e]; sa += 2.0 * fabs(v); sf += 2.0 * v * v; }
+        for (int i = threadIdx.x; i < n; i += 256) { const double v = M[hdm_sky_off(i, i, (int) ld)]; sf += 2.0 * v * v; }
+    } else {
+        for (int j = 0; j < n; ++j)
+            for (int i = j + threadIdx.x; i < n; i += 256) {
+                const double v = M[i + (long) j * ld];
+                if (i == j) { sa += fabs(v); sf += v * v; }
+                else { sa += 2.0 * fabs(v); sf += 2.0 * v * v; }
+            }
     }
     for (int off = 32; off > 0; off >>= 1) { sa += __shfl_down(sa, off, 64); sf += __shfl_down(sf, off, 64); }
     if ((threadIdx.x & 63) == 0) { ra[threadIdx.x >> 6] = sa; rf[threadIdx.x >> 6] = sf; }
@@ -2521,6 +2545,24 @@ void *HMiKKTDeviceMatrix(hdsdp_kkt *HKKT, int64_t *ld) {
     if (ld) *ld = l;
     return p;
 }
+hdsdp_retcode HMiKKTGetRows(hdsdp_kkt *HKKT, int nRows, const int *rows, double *out) {
+    // full symmetric rows of the device copy of M (lower triangle valid): row i = M[i, 0..i] followed by M[i+1.., i]
+    MiKKTPriv *pv = priv_of(HKKT);
+    long ld = 0;
+    const double *Mdev = kkt_Mdev(HKKT, &ld);
+    const int m = HKKT->nRow;
+    if (!Mdev || !pv->Mdev_valid) return HDSDP_RETCODE_FAILED;
+    HIP_RC(hipStreamSynchronize(g.stream));
+    for (int r = 0; r < nRows; ++r) {
+        const int i = rows[r];
+        if (i < 0 || i >= m) return HDSDP_RETCODE_FAILED;
+        double *o = out + (size_t) r * m;
+        HIP_RC(hipMemcpy2D(o, sizeof(double), Mdev + i, sizeof(double) * (size_t) ld, sizeof(double), (size_t) i + 1, hipMemcpyDeviceToHost));
+        if (i + 1 < m)
+            HIP_RC(hipMemcpy(o + i + 1, Mdev + (i + 1) + (size_t) i * ld, sizeof(double) * (size_t) (m - i - 1), hipMemcpyDeviceToHost));
+    }
+    return HDSDP_RETCODE_OK;
+}
 
 }  // extern "C"
 
@@ -3017,7 +3059,7 @@ int HMiGetCallStats(double *seconds, int64_t *calls, int n) {
     return ST_N;
 }
 const char *HMiCallStatName(int k) { return (k >= 0 && k < ST_N) ? g_stat_name[k] : ""; }
-void HMiResetCallStats(void) { for (int k = 0; k < ST_N; ++k) { g_stat_sec[k] = 0.0; g_stat_calls[k] = 0; } }
+void HMiResetCallStats(void) { for (int k = 0; k < ST_N; ++k) { g_stat_sec[k] = 0.0; g_stat_calls[k] = 0; } g_stat_nfn = 0; }
 int HMiRcclSelfTest(int device) {
     if (ensure_ctx()) return 1;
     return rccl_self_test(device < 0 ? g_main.device : device);

@@ -12,11 +12,18 @@
 //
 // The two collectives of the sharded build are implemented here behind the same hooks
 // (hmi_alltoall_piece_fn / hmi_alltoall_wait_fn / hmi_allreduce_fn) the process-per-GPU mode fills from Python:
+//   transport COPIES : device-to-device copies (one per destination) and a fixed-order sum kernel.  The DEFAULT: between
+//                      peer-accessible devices (xGMI: the copies are direct device-to-device transfers) and the only
+//                      choice when several shards share one device (HDSDP_MI355X_LOOPBACK=1: a rehearsal of world = N
+//                      on a 1-GPU box, which is where every line of it has been run and checked).
 //   transport RCCL   : ncclCommInitAll over the group's devices; the piecewise all-to-all is a grouped ncclSend/ncclRecv
-//                      per piece on a side stream, the all-reduce ncclAllReduce on the engine stream;
-//   transport COPIES : device-to-device copies (one per destination) and a fixed-order sum kernel; the only choice when
-//                      several shards share one device (HDSDP_MI355X_LOOPBACK=1: a rehearsal of world = N on a 1-GPU
-//                      box) and a fallback between peer-accessible devices.
+//                      per piece on a side stream, the all-reduce ncclAllReduce on the engine stream.  OPT-IN
+//                      (HDSDP_MI355X_TRANSPORT=rccl), or chosen by itself when the devices are not peer-accessible: this
+//                      pool has no multi-GPU box, so between two devices it has only ever run as a one-rank self-test
+//                      (HMiRcclSelfTest) -- UNVERIFIED ON HARDWARE until tests/test_gpu_group.py::
+//                      test_config5_at_size_on_eight_devices[rccl] has passed somewhere.  Its waits poll and watch the
+//                      group's failure flag; a failed shard aborts the communicators so that nobody blocks in a collective
+//                      a peer will never join, and the group refuses further work.
 // (engine.hip includes <atomic>, <condition_variable>, <functional>, <mutex>, <thread> and <rccl/rccl.h> at global scope)
 
 enum { GRP_COPIES = 0, GRP_RCCL = 1 };
@@ -43,6 +50,7 @@ struct MiGroup {
     std::vector<int> rc;
     bool quit = false;
     std::atomic<bool> failed{false};
+    bool dead = false;               // a collective was aborted (RCCL communicators gone): the group takes no more jobs
     // barrier among the workers
     std::mutex bmu;
     std::condition_variable bcv;
@@ -60,6 +68,26 @@ struct MiGroup {
         return failed.load() ? 1 : 0;
     }
     void fail() { failed.store(true); std::lock_guard<std::mutex> lk(bmu); bcv.notify_all(); }
+    // wait for an event / a stream's work without blocking in the runtime: a peer that failed will never enqueue its half
+    // of a collective, so the wait watches the failure flag; with RCCL the communicators are aborted then (that is what
+    // releases a kernel already spinning on the peer) and the group is dead
+    int wait_event(hipEvent_t ev, int r) {
+        for (long spins = 0;; ++spins) {
+            const hipError_t e = hipEventQuery(ev);
+            if (e == hipSuccess) return 0;
+            if (e != hipErrorNotReady) { (void) hipGetLastError(); fail(); return 1; }
+            if (failed.load()) {
+                if (transport == 1 /* GRP_RCCL */ && r >= 0 && r < (int) comm.size() && comm[r]) {
+                    (void) ncclCommAbort(comm[r]);
+                    comm[r] = nullptr;
+                    dead = true;
+                }
+                return 1;
+            }
+            if (spins < 2000) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
 
     void worker(int r) {
         if (hipSetDevice(dev[r]) != hipSuccess) fprintf(stderr, "[hdsdp_mi355x] shard %d: cannot select device %d\n", r, dev[r]);
@@ -86,7 +114,10 @@ struct MiGroup {
     }
     // run f(r) on every worker and wait; 0 iff all returned 0
     int run(std::function<int(int)> f) {
+        if (dead) { fprintf(stderr, "[hdsdp_mi355x] the device group was shut down by an earlier failure\n"); return 1; }
         failed.store(false);
+        // a failed job may have left workers counted at the barrier: every job starts from a clean one
+        { std::lock_guard<std::mutex> lk(bmu); bcount = 0; ++bgen; }
         std::unique_lock<std::mutex> lk(mu);
         job = std::move(f);
         done = 0;
@@ -148,37 +179,64 @@ int group_setup(int n, const int *ids, int transport_request) {
     for (int a = 0; a < n; ++a)
         for (int b = a + 1; b < n; ++b)
             if (ids[a] == ids[b]) G->shared_device = true;
-    G->transport = G->shared_device ? GRP_COPIES : GRP_RCCL;
-    if (transport_request == GRP_COPIES) G->transport = GRP_COPIES;
-    if (transport_request == GRP_RCCL && G->shared_device) {
+    // every error below leaves through `bail`: what was created is destroyed and the caller's thread is back on its device
+    auto bail = [&](const char *what) {
+        if (what) fprintf(stderr, "[hdsdp_mi355x] HMiSetDevices: %s\n", what);
+        for (auto c : G->comm) if (c) (void) ncclCommDestroy(c);
+        for (int r = 0; r < (int) G->ctx.size(); ++r) {
+            if (!G->ctx[r].init) continue;
+            (void) hipSetDevice(ids[r]);
+            if (G->cstream[r]) (void) hipStreamDestroy(G->cstream[r]);
+            if (G->ctx[r].stream) (void) hipStreamDestroy(G->ctx[r].stream);
+            for (int i = 0; i < 8; ++i) (void) hipEventDestroy(G->ctx[r].ev[i]);
+        }
+        (void) hipGetLastError();
+        delete G;
+        (void) hipSetDevice(g_main.device);
+        return 1;
+    };
+    // transport: device copies unless RCCL is asked for (transport_request, or HDSDP_MI355X_TRANSPORT=rccl) -- see the header
+    if (transport_request < 0) if (const char *t = getenv("HDSDP_MI355X_TRANSPORT")) transport_request = (strcmp(t, "rccl") == 0) ? GRP_RCCL : GRP_COPIES;
+    G->transport = (transport_request == GRP_RCCL && !G->shared_device) ? GRP_RCCL : GRP_COPIES;
+    if (transport_request == GRP_RCCL && G->shared_device)
         fprintf(stderr, "[hdsdp_mi355x] RCCL needs one device per shard; shards share a device here: using device copies\n");
-    }
     G->ctx.resize(n);
     G->cstream.assign(n, nullptr);
     G->rc.assign(n, 0);
     G->ar_ptr.assign(n, nullptr); G->ar_tmp.assign(n, nullptr); G->ar_cap.assign(n, 0);
     for (int r = 0; r < n; ++r) {
-        if (ctx_open(G->ctx[r], ids[r])) return 1;
-        if (hipStreamCreateWithFlags(&G->cstream[r], hipStreamNonBlocking) != hipSuccess) return 1;
+        if (ctx_open(G->ctx[r], ids[r])) return bail("cannot open a context on one of the devices");
+        if (hipStreamCreateWithFlags(&G->cstream[r], hipStreamNonBlocking) != hipSuccess) return bail("cannot create the exchange stream");
     }
     if (!G->shared_device && G->transport == GRP_COPIES) {
-        // the sum kernel of the copy transport reads the other shards' buffers in place
-        for (int a = 0; a < n; ++a)
-            for (int b = 0; b < n; ++b) {
+        // the copies go device to device and the sum kernel reads the other shards' buffers in place: peer access both ways
+        bool peers = true;
+        for (int a = 0; a < n && peers; ++a)
+            for (int b = 0; b < n && peers; ++b) {
                 if (a == b) continue;
                 int can = 0;
                 (void) hipDeviceCanAccessPeer(&can, ids[a], ids[b]);
-                if (!can) { fprintf(stderr, "[hdsdp_mi355x] devices %d and %d are not peer-accessible: the copy transport cannot be used\n", ids[a], ids[b]); return 1; }
-                (void) hipSetDevice(ids[a]);
-                hipError_t e = hipDeviceEnablePeerAccess(ids[b], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void) hipGetLastError(); return 1; }
-                (void) hipGetLastError();
+                if (!can) peers = false;
             }
+        if (!peers) {
+            if (transport_request == GRP_COPIES) return bail("the devices are not peer-accessible: the copy transport cannot be used");
+            fprintf(stderr, "[hdsdp_mi355x] devices are not peer-accessible: using the RCCL transport (unverified between devices on this pool)\n");
+            G->transport = GRP_RCCL;
+        } else {
+            for (int a = 0; a < n; ++a)
+                for (int b = 0; b < n; ++b) {
+                    if (a == b) continue;
+                    (void) hipSetDevice(ids[a]);
+                    hipError_t e = hipDeviceEnablePeerAccess(ids[b], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return bail("hipDeviceEnablePeerAccess failed");
+                    (void) hipGetLastError();
+                }
+        }
     }
     if (G->transport == GRP_RCCL) {
         G->comm.assign(n, nullptr);
         ncclResult_t e = ncclCommInitAll(G->comm.data(), n, G->dev.data());
-        if (e != ncclSuccess) { fprintf(stderr, "[hdsdp_mi355x] ncclCommInitAll failed: %s\n", ncclGetErrorString(e)); return 1; }
+        if (e != ncclSuccess) { fprintf(stderr, "[hdsdp_mi355x] ncclCommInitAll failed: %s\n", ncclGetErrorString(e)); return bail(nullptr); }
     }
     (void) hipSetDevice(ids[0]);
     hdm_flow_set_shared_device(G->shared_device ? 1 : 0);
@@ -211,9 +269,7 @@ int group_configure_from_env() {
     int ids[GRP_MAX_SHARDS];
     if (n > GRP_MAX_SHARDS) return 1;
     for (int r = 0; r < n; ++r) ids[r] = loop ? (r % ndev) : r;
-    int tr = -1;
-    if (const char *t = getenv("HDSDP_MI355X_TRANSPORT")) tr = (strcmp(t, "rccl") == 0) ? GRP_RCCL : GRP_COPIES;
-    return group_setup(n, ids, tr);
+    return group_setup(n, ids, -1);
 }
 
 bool group_wants_block(int nRow, int nCol, const int *beg, const int *idx, const double *val) {
@@ -246,7 +302,7 @@ int grp_a2a_start(void *vx, int64_t off, int64_t cnt, int piece) {
     }
     if (!cg->pev[r][piece] && hipEventCreateWithFlags(&cg->pev[r][piece], hipEventDisableTiming) != hipSuccess) return 1;
     if (G->transport == GRP_RCCL) {
-        if (ncclGroupStart() != ncclSuccess) return 1;
+        if (!G->comm[r] || ncclGroupStart() != ncclSuccess) return 1;
         for (int d = 0; d < W; ++d) {
             if (ncclSend(c->AhatLoc + d * chunk + off, (size_t) cnt, ncclDouble, d, G->comm[r], G->cstream[r]) != ncclSuccess) return 1;
             if (ncclRecv(c->AhatAll + d * chunk + off, (size_t) cnt, ncclDouble, d, G->comm[r], G->cstream[r]) != ncclSuccess) return 1;
@@ -269,13 +325,13 @@ int grp_a2a_wait(void *vx, int piece) {
     MiGroup *G = cg->G;
     const int r = x->r, W = G->W;
     if (G->transport == GRP_RCCL)   // my receives are part of my own grouped call
-        return hipEventSynchronize(cg->pev[r][piece]) == hipSuccess ? 0 : 1;
+        return G->wait_event(cg->pev[r][piece], r);
     for (int q = 0; q < W; ++q) {
         while (cg->posted[q][piece].load(std::memory_order_acquire) < cg->xgen[r]) {
             if (G->failed.load()) return 1;
             std::this_thread::yield();
         }
-        if (hipEventSynchronize(cg->pev[q][piece]) != hipSuccess) return 1;
+        if (G->wait_event(cg->pev[q][piece], r)) return 1;
     }
     return 0;
 }
@@ -298,8 +354,10 @@ int grp_allreduce(void *vx, void *buf, int64_t count) {
     hipStream_t s = G->ctx[r].stream;
     if (r == 0) cg->bytes_ar += (long) count * 8;
     if (G->transport == GRP_RCCL) {
-        if (ncclAllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, G->comm[r], s) != ncclSuccess) return 1;
-        return hipStreamSynchronize(s) == hipSuccess ? 0 : 1;
+        if (!G->comm[r] || ncclAllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, G->comm[r], s) != ncclSuccess) return 1;
+        hipEvent_t ev = G->ctx[r].ev[7];
+        if (hipEventRecord(ev, s) != hipSuccess) return 1;
+        return G->wait_event(ev, r);
     }
     const int64_t per = (count + W - 1) / W;
     const int64_t lo = std::min<int64_t>(count, (int64_t) r * per), hi = std::min<int64_t>(count, lo + per);
@@ -482,7 +540,11 @@ hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCo
     for (int r = 0; r < G->W; ++r)
         if (rcs[r] != HDSDP_RETCODE_OK || !cg->shard[r]) {
             fprintf(stderr, "[hdsdp_mi355x] shard %d of the block could not be created\n", r);
-            return rcs[r] != HDSDP_RETCODE_OK ? rcs[r] : HDSDP_RETCODE_FAILED;   // (what was allocated stays with the process)
+            const hdsdp_retcode bad = rcs[r] != HDSDP_RETCODE_OK ? rcs[r] : HDSDP_RETCODE_FAILED;
+            // give back what the other shards took (tens of GB per device at n = 2000), each on its own device's thread
+            (void) grun(cg, [&](int q, MiCone *) { if (cg->shard[q]) { void *p = cg->shard[q]; cone_destroy_data(&p); cg->shard[q] = nullptr; } return 0; });
+            delete cg;
+            return bad;
         }
     int pieces = 8;
     if (const char *e = getenv("HDSDP_MI355X_A2A_PIECES")) pieces = std::max(1, std::min(GRP_MAX_PIECES, atoi(e)));

@@ -298,6 +298,9 @@ void HMiConeGetExchangeStats(hdsdp_cone *cone, int *pieces, int *stagedLaunches)
 hdsdp_retcode HMiConeGetExchangeBuffers(hdsdp_cone *cone, void **sendBuf, void **recvBuf, int64_t *chunkCount);
 hdsdp_retcode HMiConeSetExchangeBuffers(hdsdp_cone *cone, void *sendBuf, void *recvBuf);
 void *HMiKKTDeviceMatrix(hdsdp_kkt *HKKT, int64_t *ld);   /* device pointer of M (m x m, lower valid) */
+/* nRows full symmetric rows of the device copy of M after a build (out: nRows x m doubles, row by row): what a caller that
+ * keeps M on the device (host mirror off, m = 8000: 512 MB) needs for a row-subset check against tests/golden/full8000_rows.npz */
+hdsdp_retcode HMiKKTGetRows(hdsdp_kkt *HKKT, int nRows, const int *rows, double *out);
 
 /* ======================  several GPUs behind the C ABI (one process, one caller thread)  ======================
  * The reference's driver is a single-threaded process (tests/sdpasolve.c; interface/hdsdp_algo.c:1082-1101 calls

@@ -211,3 +211,24 @@ def test_rcm_order_recovers_a_band_and_is_a_permutation():
     assert max(abs(int(perm[a]) - int(perm[b])) for a, b in scr) <= 16
     for pairs in ([], [(i, j) for i in range(40) for j in range(i)]):
         order(40, pairs)
+
+
+def test_bench_labels_follow_the_size_and_a_gpu_count_it_cannot_meet_is_an_error():
+    """bench.py may call a run configs[3] / configs[4] only at those sizes, and `--gpus N` without N devices (and without
+    torchrun) must fail instead of timing one GPU under an N-GPU label"""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.workload_label(2000, 2000).startswith("configs[3]")
+    assert bench.workload_label(2000, 8000).startswith("configs[4]")
+    assert bench.workload_label(2000, 4000).startswith("custom")
+    assert bench.workload_label(1000, 8000).startswith("custom")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-cpu"], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "--gpus 8 requested" in (r.stderr + r.stdout), (r.stderr + r.stdout)[-500:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -210,29 +210,93 @@ def test_two_sharded_blocks_in_one_operator(group):
             assert float(np.max(np.abs(ref[k] - got[k]))) / den < 1e-11, k
 
 
-def test_full_size_two_shards_against_host_fp64(group, monkeypatch):
-    """n = m = 2000 (BASELINE configs[3]) sharded over two in-process shards on one GPU, against the independent host
-    fp64 fixture (tests/golden/full2000.npz): the exchange layout, the K-sharded Gram and the all-reduce at the headline
-    size, where segment edges, 16 tile columns and eight exchange pieces all come into play"""
+@pytest.mark.parametrize("world,need_gib", [(2, 200), (8, 235)])
+def test_full_size_shards_against_host_fp64(world, need_gib, group, monkeypatch):
+    """n = m = 2000 (BASELINE configs[3]) sharded over two and over EIGHT in-process shards on one GPU, against the
+    independent host fp64 fixture (tests/golden/full2000.npz): the exchange layout, the K-sharded Gram and the all-reduce
+    at the headline size, where segment edges, 16 tile columns and eight exchange pieces all come into play -- with eight
+    shards exactly the staging an 8-GPU node runs (250 rows per shard in one launch group, step 2 by packed-index range,
+    eight pieces), only the transport differs (device copies instead of RCCL)"""
     import torch
     from hdsdp_amd import api
     from test_gpu_parity import check_full_size_state
     free, total = torch.cuda.mem_get_info()
-    if free < 200 * (1 << 30):
-        pytest.skip("needs about 200 GiB of free HBM for two shards of the full-size problem on one device")
-    monkeypatch.setenv("HDM_TCAP_GIB", "8")        # congruence batches of 250 rows: the intermediates of two shards fit
+    if free < need_gib * (1 << 30):
+        pytest.skip(f"needs about {need_gib} GiB of free HBM for {world} shards of the full-size problem on one device")
+    monkeypatch.setenv("HDM_TCAP_GIB", "8")        # congruence batches of 250 rows: the intermediates of all shards fit
     g = load_golden("full2000")
     n, m = int(g["n"]), int(g["m"])
-    group(2)
+    group(world)
     cone = api.SDPCone.synthetic(n, m)
     try:
-        assert cone.shard_count() == 2
+        assert cone.shard_count() == world
         kkt = api.KKT(m, [cone])
         check_full_size_state(cone, kkt, g, "bench")
+        pieces, staged = cone.exchange_stats()
+        assert pieces > 1 and staged > 1, (pieces, staged)
         check_full_size_state(cone, kkt, g, "hard")
         kkt.destroy()
     finally:
         cone.destroy()
+
+
+def test_config5_rows_eight_shards_against_host_fp64(group, monkeypatch):
+    """m = 8000 constraint rows over eight in-process shards at n = 1000 -- the largest block dimension at which
+    BASELINE configs[4]'s row count fits the one GPU of the test box -- against an INDEPENDENT host answer
+    (tests/golden/rows_1000x8000.npz, oracle/row_subset_golden.py: rows of M from B_i = S^-1 A_i S^-1 and <B_i, A_j>,
+    no congruence, no Gram product, no sharding): rows of M from every shard's share, both vectors in full, log det S,
+    and rows of the residual of the three Phase-A solves"""
+    import torch
+    from hdsdp_amd import api
+    from test_gpu_parity import check_row_subset_state
+    free, total = torch.cuda.mem_get_info()
+    if free < 200 * (1 << 30):
+        pytest.skip("needs about 200 GiB of free HBM for eight shards of n = 1000, m = 8000 on one device")
+    monkeypatch.setenv("HDM_TCAP_GIB", "8")
+    g = load_golden("rows_1000x8000")
+    n, m = int(g["n"]), int(g["m"])
+    group(8)
+    cone = api.SDPCone.synthetic(n, m)
+    try:
+        assert cone.shard_count() == 8
+        kkt = api.KKT(m, [cone], host_mirror=False)
+        check_row_subset_state(cone, kkt, g, "bench")
+        check_row_subset_state(cone, kkt, g, "hard")
+        kkt.destroy()
+    finally:
+        cone.destroy()
+
+
+def test_config5_at_size_on_eight_devices():
+    """BASELINE configs[4] itself: n = 2000, m = 8000, constraint rows over 8 MI355X (in-process device group over RCCL),
+    against tests/golden/full8000_rows.npz (host fp64, oracle/row_subset_golden.py: rows [0, 64) -- eight per rank -- and
+    the tile-edge rows of M, both vectors in full, log det S, residual rows of the three solves, at the bench state and at
+    cond(S) = 1e3).  Needs eight devices (136 GB of constraint data, 130 GB of transformed rows); skipped by name on a
+    smaller box -- the one-GPU rehearsals above cover the same code with m = 8000 at n = 1000 and eight shards at
+    n = m = 2000."""
+    import torch
+    from hdsdp_amd import api
+    from test_gpu_parity import check_row_subset_state
+    ndev = torch.cuda.device_count()
+    if ndev < 8:
+        pytest.skip(f"BASELINE configs[4] (n=2000, m=8000) needs 8 devices, {ndev} visible: never run at size on this pool")
+    g = load_golden("full8000_rows")
+    n, m = int(g["n"]), int(g["m"])
+    api.set_devices(list(range(8)), shard_min_dim=0)
+    try:
+        ids, transport = api.device_group()
+        assert ids == list(range(8)) and transport == 1          # RCCL between distinct devices
+        cone = api.SDPCone.synthetic(n, m)
+        try:
+            assert cone.shard_count() == 8
+            kkt = api.KKT(m, [cone], host_mirror=False)
+            check_row_subset_state(cone, kkt, g, "bench")
+            check_row_subset_state(cone, kkt, g, "hard")
+            kkt.destroy()
+        finally:
+            cone.destroy()
+    finally:
+        api.set_devices([0])
 
 
 def test_shard_plan_predicts_what_the_engine_allocates(group):

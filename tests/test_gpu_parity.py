@@ -352,6 +352,36 @@ def check_full_size_state(cone, kkt, g, st, tol_scale=1.0):
     return {"sum_d2": float(np.sum(sols[1])), "sum_d1w": float(np.dot(np.arange(1, m + 1), sols[0]))}
 
 
+def check_row_subset_state(cone, kkt, g, st):
+    """one state of a row-subset fixture (oracle/row_subset_golden.py: tests/golden/full8000_rows.npz for BASELINE
+    configs[4], rows_1000x8000.npz for its one-GPU rehearsal) against the engine: log det S, complete rows of M taken
+    from the DEVICE copy (HMiKKTGetRows; the operator may run with the host mirror off), both vectors in full, and --
+    since the host cannot afford the three solutions at m = 8000 -- rows of the residual M d = rhs formed with the
+    FIXTURE's rows of M and the device's solutions."""
+    from hdsdp_amd import api
+    m = int(g["m"])
+    y, Rd = np.asarray(g[st + "_y"]), float(g[st + "_Rd"])
+    cone.set_start(Rd)
+    assert cone.check_is_interior(1.0, y), st
+    ld = cone.log_barrier(1.0)
+    assert abs(ld - float(g[st + "_logdetS"])) <= 1e-12 * abs(float(g[st + "_logdetS"])) + 1e-9, st
+    b = cone.traces()
+    assert np.max(np.abs(b - g[st + "_b"])) <= 1e-12 * np.max(np.abs(b))
+    kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+    ex = kkt.export()
+    rows = np.asarray(g[st + "_rows"])
+    Mg = np.asarray(g[st + "_M_rows"])
+    check_close(kkt.rows(rows), Mg, st + " rows of M")
+    check_close(ex["ASinv"], g[st + "_ASinv"], st + " ASinv")
+    check_close(ex["ASinvRdSinv"], g[st + "_ASinvRdSinv"], st + " ASinvRdSinv")
+    assert abs(ex["TraceSinv"] - float(g[st + "_TraceSinv"])) <= 1e-10 * abs(float(g[st + "_TraceSinv"])), st
+    kkt.factorize()
+    for rhs, name in ((b, "d1"), (ex["ASinv"], "d2"), (ex["ASinvRdSinv"], "d3")):
+        x = kkt.solve(rhs)
+        res = Mg @ x - np.asarray(rhs)[rows]
+        assert np.max(np.abs(res)) <= 1e-8 * np.max(np.abs(rhs)), (st, name, float(np.max(np.abs(res))))
+
+
 def test_full_size_against_host_fp64_at_nontrivial_states():
     """BASELINE configs[3], n = m = 2000, at two states whose dual matrix is NOT a multiple of the identity: the state
     bench.py times (y = 0, Rd = -10 n: S = C + 20000 I with the dense objective C) and a harder one (non-zero y, Rd just

@@ -230,3 +230,55 @@ def test_full_size_golden_is_what_the_generator_and_fp64_blas_say():
                 ref = float(np.sum(oracle_py.synth_matrix(n, j) * B))
                 assert abs(ref - g[st + "_M_rows"][q, j]) <= 1e-9 * np.max(np.abs(g[st + "_diag_M"])), (st, i, j)
             assert abs(g[st + "_M_rows"][q, i] - g[st + "_diag_M"][i]) == 0.0
+
+
+def test_row_subset_generator_agrees_with_the_pinned_oracle():
+    """oracle/row_subset_golden.py (the generator of tests/golden/full8000_rows.npz and rows_1000x8000.npz) at a size the
+    pinned oracle can check in full: its rows of M, both vectors, log det S and the traces equal the reference-faithful
+    column builders' (oracle/hdsdp_oracle.c) at both states"""
+    import row_subset_golden as rs
+    n, m = 96, 200
+    res = rs.generate(n, m, 2, lambda s: None)
+    beg, idx, val, b = oracle_py.synth_csc(n, m)
+    blk = oracle_py.Block(n, m, beg, idx, val)
+    try:
+        for st in ("bench", "hard"):
+            y, Rd = res[st + "_y"], res[st + "_Rd"]
+            Lf, info = blk.factor(blk.assemble_S(1.0, y, Rd))
+            assert info == 0
+            ref = blk.kkt_build(blk.inverse(Lf), Rd, 0)
+            M = ref["M"]
+            Mf = np.triu(M) + np.triu(M, 1).T          # C-order view of a column-major lower triangle
+            rows = res[st + "_rows"]
+            assert np.max(np.abs(Mf[rows, :] - res[st + "_M_rows"])) <= 1e-12 * np.max(np.abs(Mf))
+            for k in ("ASinv", "ASinvRdSinv"):
+                assert np.max(np.abs(ref[k] - res[st + "_" + k])) <= 1e-12 * np.max(np.abs(ref[k]))
+            assert abs(res[st + "_logdetS"] - blk.logdet(Lf)) <= 1e-12 * abs(blk.logdet(Lf))
+            assert np.max(np.abs(b - res[st + "_b"])) <= 1e-12
+    finally:
+        blk.close()
+
+
+def test_config5_row_fixture_is_what_the_definition_says():
+    """tests/golden/full8000_rows.npz (BASELINE configs[4], n = 2000, m = 8000) spot-checked at the bench state: the
+    objective of the 8000-constraint instance is regenerated, S^-1 formed by a plain inverse, and entries of two fixture
+    rows recomputed as tr(A_i S^-1 A_j S^-1), with the vectors' entries beside them"""
+    g = load_golden("full8000_rows")
+    n, m = int(g["n"]), int(g["m"])
+    assert (n, m) == (2000, 8000)
+    rows = [int(r) for r in g["bench_rows"]]
+    assert rows[:64] == list(range(64))              # SURVEY 8(d): row subset [0, 64), eight rows per rank of the cyclic deal
+    y0, Cm = oracle_py.synth_objective(n, m)
+    Rd = float(g["bench_Rd"])
+    Sinv = np.linalg.inv(Cm - Rd * np.eye(n))
+    Sinv = 0.5 * (Sinv + Sinv.T)
+    scale = float(np.max(np.abs(g["bench_M_rows"])))
+    for q in (5, len(rows) - 1):
+        i = rows[q]
+        Ai = oracle_py.synth_matrix(n, i)
+        B = Sinv @ Ai @ Sinv
+        for j in (0, 4097, m - 1):
+            Aj = oracle_py.synth_matrix(n, j)
+            assert abs(float(np.sum(Aj * B)) - g["bench_M_rows"][q, j]) <= 1e-10 * scale, (i, j)
+            assert abs(float(np.sum(Aj * Sinv)) - g["bench_ASinv"][j]) <= 1e-10 * np.max(np.abs(g["bench_ASinv"]))
+            assert abs(float(np.trace(Aj)) - g["bench_b"][j]) <= 1e-12 * n

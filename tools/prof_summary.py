@@ -15,6 +15,20 @@ def short(name):
     return name[:100]
 
 
+GEMM_SOURCES = ("gemm_tile.h", "gemm_f64.hip", "gemm_persist.hip", "gemm_persist.h", "hdm_common.h")
+
+
+def kernel_source_sha(root=None):
+    """digest of the GEMM kernels' sources: a traffic file is only valid for the kernel generation it was measured on"""
+    import hashlib
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in GEMM_SOURCES:
+        with open(os.path.join(root, "hdsdp_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def traffic(dirs):
     """--traffic <FETCH_SIZE run dir> <WRITE_SIZE run dir>: HBM bytes per launch of every kernel as JSON, the way
     /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (separate --pmc passes; the counters are in KiB;
@@ -38,7 +52,10 @@ def traffic(dirs):
         fk, wk = v["FETCH_SIZE"][1] / nf, v["WRITE_SIZE"][1] / nw
         out[k.replace("void ", "")] = {"fetch_kib": fk, "write_kib": wk, "launches": nf,
                                        "bytes_per_launch": (2.0 * fk + wk) * 1024.0}
-    print(json.dumps({"unit": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024", "kernels": out}, indent=1))
+    import time
+    print(json.dumps({"unit": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024",
+                      "kernel_source_sha": kernel_source_sha(), "persist": os.environ.get("HDM_PERSIST", "1") != "0",
+                      "taken_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "kernels": out}, indent=1))
 
 
 def main():
