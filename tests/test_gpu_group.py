@@ -233,7 +233,9 @@ def test_full_size_shards_against_host_fp64(world, need_gib, group, monkeypatch)
         kkt = api.KKT(m, [cone])
         check_full_size_state(cone, kkt, g, "bench")
         pieces, staged = cone.exchange_stats()
-        assert pieces > 1 and staged > 1, (pieces, staged)
+        assert pieces > 1, pieces
+        if world == 8:      # a shard's 250 rows are one launch group: step 2 ran by packed-index range, piece by piece
+            assert staged > 1, (pieces, staged)
         check_full_size_state(cone, kkt, g, "hard")
         kkt.destroy()
     finally:
