@@ -685,11 +685,17 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
     // point (interior check, then barrier) and at points y + alpha dy along the direction whose dS the ratio test has just
     // assembled: each a 32 GB sweep at n = m = 2000 (6 ms), 14 % of a whole solve's device time.  The request is compared
     // with what the buffers hold, component by component; anything else takes the sweep.
-    // Default (1): only the exact case -- the same point again -- is short-cut, so every number is the one a sweep would have
-    // produced.  2: also points on the line through the last ratio test's direction (S + alpha dS); the results then differ
-    // from a sweep's in the last bits, which is enough to send the end game of a badly conditioned instance down another
-    // path (gpp100 through the reference's driver: same dual objective, a primal estimate 3e-4 further away).  0: off.
-    static const int aff_mode = [] { const char *e = getenv("HDSDP_MI355X_AFFINE_S"); return e ? atoi(e) : 1; }();
+    // 1: only the exact case -- the same point again -- is short-cut, so every number is the one a sweep would have produced.
+    // 2: also points on the line through the last ratio test's direction (S + alpha dS); the results then differ from a
+    // sweep's in the last bits (as a sweep's differ from the reference's own summation order).  0: off.
+    // Default: 2 where a sweep costs something -- 16 MiB of constraint data or more, i.e. from about n = m = 160 on; at
+    // n = m = 2000 the reference's line searches and correctors ask for 344 such points per solve, 6 ms each -- and 1 on
+    // small blocks, where the sweep is free and the end game of a badly conditioned instance can turn on the last bits
+    // (gpp100 through the reference's driver in mode 2: same dual objective, a primal estimate 3e-4 further away).
+    // HDSDP_MI355X_AFFINE_S=0/1/2 overrides.
+    static const int aff_env = [] { const char *e = getenv("HDSDP_MI355X_AFFINE_S"); return e ? atoi(e) : -1; }();
+    const long sweep_bytes = (long) c->mloc * c->n * (c->n + 1) * 4;
+    const int aff_mode = aff_env >= 0 ? aff_env : (sweep_bytes >= (16L << 20) ? 2 : 1);
     const bool track = aff_mode > 0 && c->world == 1;
     if (track && target != c->dS && c->pS_ok) {
         const int np = c->mloc + 2;
@@ -899,7 +905,10 @@ int cone_data_norms(MiCone *c, double *rows_abs, double *rows_fro, double *obj_a
         return 0;
     }
     double ra = 0.0, rf2 = 0.0, oa = 0.0, of2 = 0.0;
-    if (!c->synthetic) {
+    // (a block on the congruence + Gram path has its data resident in A_L form: one HBM-bound pass over it instead of a host
+    // loop over the CSC entries, which took 1.0 s of the driver's presolve at n = m = 2000)
+    const bool on_device = c->synthetic || (c->path == PATH_GEMM && c->Afull);
+    if (!on_device) {
         for (int i = 0; i < c->m; ++i) { double a_, f_; coeff_norms(c->blk.rows[i], c->n, &a_, &f_); ra += a_; rf2 += f_; }
         coeff_norms(c->blk.obj, c->n, &oa, &of2);
         oa *= c->objScal; of2 *= c->objScal * c->objScal;

@@ -51,10 +51,13 @@ struct GlibcRand {
 
 // single workgroup: three-term recurrence + normalisation of one Lanczos step (hdsdp_lanczos.c:199-218)
 //   w -= hprev * Vprev ;  alp = -<w, Vk> ;  w += alp * Vk ;  nrm = |w| ;  Vnext = vnext = w / nrm  (if nrm > 0)
-__global__ __launch_bounds__(1024) void hdm_lanczos_step_kernel(double *__restrict__ w, const double *__restrict__ Vprev,
-                                                                double hprev, const double *__restrict__ Vk,
-                                                                double *__restrict__ Vnext, double *__restrict__ vnext,
-                                                                int n, double *__restrict__ out) {
+// w arrives as the `nchunk` partial sums of the operator's last product (hdm_gemv_n_kernel), summed here in chunk order;
+// hprev is read from DEVICE memory (the previous step's norm), so the steps between two Ritz checks are queued back to
+// back and the host reads their (alpha, beta) pairs with one synchronisation per group instead of one per step.
+__global__ __launch_bounds__(1024) void hdm_lanczos_step_kernel(const double *__restrict__ part, int nchunk, double *__restrict__ w,
+                                                                const double *__restrict__ Vprev, const double *__restrict__ hprev_dev,
+                                                                const double *__restrict__ Vk, double *__restrict__ Vnext,
+                                                                double *__restrict__ vnext, int n, double *__restrict__ out) {
     __shared__ double red[16];
     __shared__ double bc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,9 +71,11 @@ __global__ __launch_bounds__(1024) void hdm_lanczos_step_kernel(double *__restri
         __syncthreads();
         return r;
     };
+    const double hprev = Vprev ? *hprev_dev : 0.0;
     double s = 0.0;
     for (int i = tid; i < n; i += 1024) {
-        double x = w[i];
+        double x = 0.0;
+        for (int c = 0; c < nchunk; ++c) x += part[(long) c * n + i];
         if (Vprev) x -= hprev * Vprev[i];
         w[i] = x;
         s += x * Vk[i];
@@ -98,6 +103,7 @@ __global__ __launch_bounds__(1024) void hdm_lanczos_step_kernel(double *__restri
 // from L2; vectors live in LDS.  Sums are taken in a fixed order.  out: (alpha, beta) per step, then the number of steps done
 // (a zero norm ends the group early, as it ends the reference's loop).
 #define LZ_FUSED_MAX 256
+#define LZ_NCHUNK 32       // column chunks of the operator's last product (partial sums, reduced in chunk order)
 __global__ __launch_bounds__(1024) void hdm_lanczos_fused_kernel(const double *__restrict__ Linv, long ldl,
                                                                  const double *__restrict__ dS, long ldd, int n,
                                                                  double *__restrict__ V, long ldv, int k0, int nsteps, double hprev,
@@ -405,14 +411,14 @@ void HdmLanczos::destroy() {
 // dedicated kernels (the first version went through the 128 x 128-tile GEMM with an 8-column block: 0.7 ms per
 // application at n = 2000, launch- and tile-latency bound)
 int HdmLanczos::apply(const double *Linv, long ldl, const double *dS, long ldd, const double *in, double *out, hipStream_t s) {
-    const int nchunk = 32;
+    const int nchunk = LZ_NCHUNK;
     // t1 = Linv^T v            (column dots of the lower-triangular Linv)
     hipLaunchKernelGGL(hdm_gemv_t_kernel, dim3((n16 + 3) / 4), dim3(256), 0, s, Linv, ldl, n16, 1, 1.0, in, b1);
     // t2 = -dS t1              (dS is symmetric: column dots again)
     hipLaunchKernelGGL(hdm_gemv_t_kernel, dim3((n16 + 3) / 4), dim3(256), 0, s, dS, ldd, n16, 0, -1.0, b1, b2);
     // w = Linv t2              (rows across lanes, 32 column chunks, deterministic two-level sum)
     hipLaunchKernelGGL(hdm_gemv_n_kernel, dim3((n16 + 255) / 256, nchunk), dim3(256), 0, s, Linv, ldl, n16, 1, nchunk, b2, part);
-    hipLaunchKernelGGL(hdm_gemv_n_reduce_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, part, n16, nchunk, 1.0, out);
+    if (out) hipLaunchKernelGGL(hdm_gemv_n_reduce_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, part, n16, nchunk, 1.0, out);   // (out == nullptr: the caller sums the partials itself)
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -449,6 +455,7 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
     std::vector<double> d, Y;
     static const bool fuse_env = [] { const char *e = getenv("HDM_LANCZOS_FUSED"); return !(e && atoi(e) == 0); }();
     const bool fused = fuse_env && n16 <= LZ_FUSED_MAX && checkFreq >= 1;
+    static const bool group_env = [] { const char *e = getenv("HDM_LANCZOS_GROUP"); return !(e && atoi(e) == 0); }();   // 0: one synchronisation per step (A/B)
     double grp[2 * 8 + 1] = {0.0};               // (alpha, beta) of the current group of steps, fused form
     int grp_k0 = -1, grp_n = 0;
     for (k = 0; k < md; ++k) {
@@ -465,12 +472,28 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
             }
             hs[0] = grp[2 * (k - grp_k0)]; hs[1] = grp[2 * (k - grp_k0) + 1];
         } else {
-            if (apply(Linv, ldl, dS, ldd, bv, bw, s)) return 1;
-            hipLaunchKernelGGL(hdm_lanczos_step_kernel, dim3(1), dim3(1024), 0, s, bw, k > 0 ? V + (size_t) (k - 1) * n16 : nullptr,
-                               hprev, V + (size_t) k * n16, V + (size_t) (k + 1) * n16, bv, n16, scal);
-            HDM_HIP_CHECK(hipGetLastError());
-            HDM_HIP_CHECK(hipMemcpyAsync(hs, scal, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
-            HDM_HIP_CHECK(hipStreamSynchronize(s));
+            // large blocks: the steps up to the next Ritz check are queued back to back (4 launches each: three products and
+            // the recurrence, which takes the previous step's norm from device memory); one copy and one synchronisation
+            // per group.  A zero norm inside a group ends the reference's loop at that step: the host stops there too and
+            // what the later steps of the group computed is never looked at.
+            if (grp_k0 < 0 || k >= grp_k0 + grp_n) {
+                grp_k0 = k;
+                grp_n = group_env ? std::min(std::min(checkFreq - (k % checkFreq), md - k), 8) : 1;
+                for (int q = 0; q < grp_n; ++q) {
+                    const int kk = k + q;
+                    if (apply(Linv, ldl, dS, ldd, bv, nullptr, s)) return 1;
+                    hipLaunchKernelGGL(hdm_lanczos_step_kernel, dim3(1), dim3(1024), 0, s, part, LZ_NCHUNK, bw,
+                                       kk > 0 ? V + (size_t) (kk - 1) * n16 : nullptr,
+                                       q > 0 ? scal + 44 + 2 * (q - 1) + 1 : scal + 43,
+                                       V + (size_t) kk * n16, V + (size_t) (kk + 1) * n16, bv, n16, scal + 44 + 2 * q);
+                }
+                HDM_HIP_CHECK(hipGetLastError());
+                HDM_HIP_CHECK(hipMemcpyAsync(grp, scal + 44, sizeof(double) * (2 * grp_n), hipMemcpyDeviceToHost, s));
+                // the last norm of this group is the next group's hprev: keep it where the next group's first step reads it
+                HDM_HIP_CHECK(hipMemcpyAsync(scal + 43, scal + 44 + 2 * (grp_n - 1) + 1, sizeof(double), hipMemcpyDeviceToDevice, s));
+                HDM_HIP_CHECK(hipStreamSynchronize(s));
+            }
+            hs[0] = grp[2 * (k - grp_k0)]; hs[1] = grp[2 * (k - grp_k0) + 1];
         }
         const double vAlp = hs[0], normPres = hs[1];
         Hm(k, k) = -vAlp;

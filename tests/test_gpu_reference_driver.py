@@ -75,12 +75,27 @@ def test_reference_driver_runs_on_the_engine(inst, attach, tmp_path):
         dims = [int(v) for v in inst[3:].split("x")]
         fname = str(tmp_path / (inst + ".dat-s"))
         write_synth_sdpa(dims[0], dims[-1], fname)
-    r = subprocess.run([EXE, fname], capture_output=True, text=True,
-                       timeout=600, env=dict(os.environ, HDSDP_DROP_ATTACH=attach))
+    env = dict(os.environ, HDSDP_DROP_ATTACH=attach)
+    if inst.startswith("blocks"):
+        env["SYEV_GUARD_VERBOSE"] = "1"     # every dsyevr call of the instances round 1's abort was seen on goes on record
+    r = subprocess.run([EXE, fname], capture_output=True, text=True, timeout=600, env=env)
     out = r.stdout + r.stderr
-    for line in out.splitlines():
-        if "OVERRUN" in line:
-            print(line)     # informational: dsyevr used more of W than the reference's caller provides
+    # what oracle/syev_guard.c saw on THIS box's MKL (dsyevr writing past the two entries interface/hdsdp.c:811 provides):
+    # kept as a file that travels back from the GPU box (gpurun_out/ is pulled), one per case, from the one normal run
+    guard = [l for l in out.splitlines() if l.startswith("syev_guard:")]
+    gdir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", "syev_guard")
+    try:
+        os.makedirs(gdir, exist_ok=True)
+        over = [l for l in guard if "OVERRUN" in l]
+        with open(os.path.join(gdir, f"{inst}_attach{attach}.txt"), "w") as f:
+            f.write(f"# {inst} attach={attach}: {len(guard)} syev_guard line(s) reported, {len(over)} OVERRUN line(s); rc {r.returncode}\n")
+            for l in over[:40]:
+                f.write(l + "\n")
+            f.write("# last reported calls\n")
+            for l in guard[-6:]:
+                f.write(l + "\n")
+    except OSError:
+        pass
     assert r.returncode == 0, out[-3000:]
     assert ("attached to the MI355X engine" in out) == (attach == "1")
     assert "SDP Status: Primal dual optimal" in out, out[-3000:]
