@@ -1,6 +1,10 @@
 """Build the HIP extension (gfx950) in-tree.
 
-    python -m hdsdp_amd.build            # hdsdp_amd/libhdsdp_mi355x.so
+    python -m hdsdp_amd.build                  # hdsdp_amd/libhdsdp_mi355x.so  (the product: tested code paths only)
+    python -m hdsdp_amd.build --diagnostics    # hdsdp_amd/libhdsdp_mi355x_diag.so: the same sources with -DHDM_DIAGNOSTICS
+                                               # (stamped kernels, wrong-result timing ablations, A/B bodies selected by
+                                               # HDM_VAR / HDM_CONG2_DIRECT).  Measurement tools load it through
+                                               # HDSDP_MI355X_LIB; the package, the tests and bench.py never do.
 
 hipcc cross-compiles without a GPU.  The built .so files are git-ignored but travel to the GPU box.
 """
@@ -26,13 +30,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True):
+def build_library(force=False, verbose=True, diagnostics=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    if not force and not _stale(LIB, srcs + hdrs):
-        return LIB
+    lib = LIB.replace(".so", "_diag.so") if diagnostics else LIB
+    if not force and not _stale(lib, srcs + hdrs):
+        return lib
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build_diag" if diagnostics else "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
@@ -42,6 +47,8 @@ def build_library(force=False, verbose=True):
         if not force and not _stale(o, [s] + hdrs):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", s, "-o", o]
+        if diagnostics:
+            cmd.insert(1, "-DHDM_DIAGNOSTICS")
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))
@@ -50,12 +57,12 @@ def build_library(force=False, verbose=True):
             raise RuntimeError(f"hipcc failed on {s}")
     # RCCL (the in-process device group's transport, csrc/group_impl.h) is linked, not dlopen'ed: the library's collectives
     # are part of the product, and a missing librccl should fail at load time, not in the middle of a solve
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl", "-lpthread"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
+    build_library(force="--force" in sys.argv, diagnostics="--diagnostics" in sys.argv)

@@ -177,27 +177,27 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     d.ntiles = tl.n;
     d.dbg = (g_dbg && args.role == g_dbg_role) ? g_dbg : nullptr;
     if (d.dbg && !g_capturing && getenv("HDM_DBG_SYNC")) HDM_HIP_CHECK(hipDeviceSynchronize());   // diagnostic: isolate the stamped launch from its neighbours
-    // HDM_VAR selects a kernel variant for A/B runs and diagnostics (tools/ab_env.sh, tools/wg_timeline.py):
-    //   64 (default) = rotated, explicitly interleaved K loop; 0 = the earlier loop (global loads, 64 MFMAs, LDS
-    //   writes, barrier per stage) kept for same-box A/B runs; +32 = per-workgroup s_memtime stamps;
-    //   192 = 64 + timing-only ablation in which every tile stages rows 0..127 (all operand traffic L2-resident);
-    //   576 = 64 + timing-only ablation of step 2 without its main tiles' stores (persistent form only).
+    // Kernel variants.  The shipped library carries ONE loop for the three Schur roles (variant 64: rotated, explicitly
+    // interleaved K loop, persistent and one-workgroup-per-tile forms) and the masked loop of generic launches (variant 0).
+    // A -DHDM_DIAGNOSTICS build (python -m hdsdp_amd.build --diagnostics) adds what the measurement tools select with HDM_VAR /
+    // HDM_CONG2_DIRECT -- and nothing else can: 0 = the earlier loop for the roles (same-box A/B); +32 = per-workgroup
+    // s_memtime stamps (tools/wg_timeline*.py); 192 = timing-only ablation in which every tile stages rows 0..127 (all
+    // operand traffic L2-resident, WRONG RESULTS); 576 = step 2 without its main tiles' stores (WRONG RESULTS, persistent form
+    // only); 320 = the LDS-free, barrier-free step-2 body (cong2_direct_body; bit-identical results; measured twice on one box:
+    // same time with one workgroup per tile, 1.4 % slower than the LDS loop with persistent workgroups).
+    int var = 64;
+#ifdef HDM_DIAGNOSTICS
     static const int g_env_var = [] { const char *e = getenv("HDM_VAR"); return e ? atoi(e) : -1; }();
-    int var = g_env_var >= 0 ? g_env_var : 64;
+    if (g_env_var >= 0) var = g_env_var;
     if (var == 576 && args.role != HDM_ROLE_CONG2) var = 64;
     if (args.role == HDM_ROLE_CONG2) {
-        // HDM_CONG2_DIRECT=1: the main tiles of step 2 take the LDS-free, barrier-free body (cong2_direct_body, variant
-        // 64 + 256; persistent form only) instead of the LDS loop.  Bit-identical results, all parity tests green with it.
-        // Measured twice on one box, same build: with one workgroup per tile (profiles/r02_b_direct_ab.txt) it kept the matrix
-        // pipe 91 % busy against 88 %, the chip answered with a lower clock and the step time was the same to 0.3 %; with
-        // persistent workgroups it is 1.4 % SLOWER than the LDS loop (162.6 vs 160.3 ms).  Off by default.  The body assumes
-        // the SYR2K form the engine launches: U x W^T + W x U^T, both M-major, blocked epilogue, K limit by column tile.
         static const int g_direct = [] { const char *e = getenv("HDM_CONG2_DIRECT"); return e ? atoi(e) : 0; }();
         const bool direct = g_direct && var == 64 && args.A2 && !args.a_kmajor && !args.b_kmajor &&
                             args.epilogue == HDM_EPI_BLOCKED && args.lower_only && args.klimit == HDM_KLIM_BY_N &&
                             args.A2 == args.B && args.B2 == args.A;
         if (direct) var = 320;
     }
+#endif
     long nwg = (long) tl.n * (args.batch >= 8 ? ((args.batch + 7) & ~7) : args.batch);
     // roles 1-3 with a batch: persistent workgroups drawing tiles from per-XCD counters (hdm_gemm_persist_kernel), where
     // the variant has a persistent form (gemm_persist.hip); the grid is then what the chip holds
@@ -224,6 +224,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
         if (hdm_launch_persist(args.a_kmajor != 0, args.b_kmajor != 0, args.role, var, grid, block, stream, d, cnt)) return 1;
     } else {
 #define HDM_LAUNCH(AK, BK, R, V) hipLaunchKernelGGL((hdm_gemm_kernel<AK, BK, R, V>), grid, block, 0, stream, d)
+#ifdef HDM_DIAGNOSTICS
 #define HDM_LAUNCH_V(AK, BK, R)                                   \
     switch (var) {                                                \
         case 32: HDM_LAUNCH(AK, BK, R, 32); break;                \
@@ -232,6 +233,9 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
         case 0: HDM_LAUNCH(AK, BK, R, 0); break;                  \
         default: HDM_LAUNCH(AK, BK, R, 64);                       \
     }
+#else
+#define HDM_LAUNCH_V(AK, BK, R) HDM_LAUNCH(AK, BK, R, 64)
+#endif
         switch (args.role) {
             case HDM_ROLE_CONG1: HDM_LAUNCH_V(false, true, HDM_ROLE_CONG1); break;   // U = Linv * A_L (A_L k-contiguous)
             case HDM_ROLE_CONG2: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG2); break;  // At = U Linv^T + Linv U^T
@@ -240,7 +244,9 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
                 if (lay == 3) HDM_LAUNCH(true, true, HDM_ROLE_GENERIC, 0);
                 else if (lay == 2) HDM_LAUNCH(true, false, HDM_ROLE_GENERIC, 0);
                 else if (lay == 1) HDM_LAUNCH(false, true, HDM_ROLE_GENERIC, 0);
+#ifdef HDM_DIAGNOSTICS
                 else if (var == 32) HDM_LAUNCH(false, false, HDM_ROLE_GENERIC, 32);   // diagnostic stamps, tools/wg_timeline_gemm.py
+#endif
                 else HDM_LAUNCH(false, false, HDM_ROLE_GENERIC, 0);
         }
     }

@@ -27,7 +27,10 @@ struct HdmGemmDev {
 // SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE in profiles/r01_a_*).
 //   M-major tile [k][i]: chunk c -> k = c >> 6, i = (c & 63) * 2
 //   K-major tile [i][k]: chunk c -> i = c >> 3, k = (c & 7) * 2
-template <bool KM>
+// DUAL: the stream can continue on a second operand (the SYR2K form of congruence step 2, generic launches with A2/B2).
+// Single-product kernels (congruence step 1, Gram) carry no second pointer, strides or countdown: seven registers per stager
+// that the step-1 kernel was spilling to scratch and reloading inside its K loops.
+template <bool KM, bool DUAL = true>
 struct Stager {
     const double *p;  // this thread's chunk 0 of the current k block
     long qstride;     // elements between the thread's 4 chunks
@@ -53,8 +56,10 @@ struct Stager {
             kstep = (long) HDM_BK * ld;
             okmask = (x0 + i2 < rows) ? 0xFu : 0u;  // rows is even: the 2-double chunk is fully in or out
         }
-        left = -1;  // single product: never switches
-        p2 = p; qstride2 = qstride; kstep2 = kstep;
+        if (DUAL) {
+            left = -1;  // single product: never switches
+            p2 = p; qstride2 = qstride; kstep2 = kstep;
+        }
     }
     const double *p2;  // second operand (dual-product mode): the stream continues there after `left` loads
     long qstride2, kstep2;
@@ -78,7 +83,7 @@ struct Stager {
         for (int q = 0; q < 4; ++q)
             r[q] = (okmask >> q) & 1u ? *reinterpret_cast<const double2 *>(p + q * qstride) : make_double2(0.0, 0.0);
         p += kstep;
-        if (--left == 0) { p = p2; qstride = qstride2; kstep = kstep2; }
+        if (DUAL) { if (--left == 0) { p = p2; qstride = qstride2; kstep = kstep2; } }
     }
     // No row mask: rows past the matrix edge read whatever follows (the engine's operand buffers carry
     // HDM_OPERAND_PAD bytes of slack, hdm_common.h).  Sound because output element (i, j) depends only on row i of
@@ -93,7 +98,7 @@ struct Stager {
         // beyond the end of the K loop re-reads valid memory instead of running off the matrix (branch-free)
         remain -= 1;
         p += (remain > 0) ? kstep : 0;
-        if (--left == 0) { p = p2; qstride = qstride2; kstep = kstep2; }
+        if (DUAL) { if (--left == 0) { p = p2; qstride = qstride2; kstep = kstep2; } }
     }
     int remain = 1 << 30;
 };
@@ -157,6 +162,30 @@ template <int W, int RV> struct EdgeCells {
     static constexpr int si[16] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7};
     static constexpr int sj[16] = {2 * W, 2 * W + 1, 2 * W, 2 * W + 1, 2 * W, 2 * W + 1, 2 * W, 2 * W + 1,
                                    2 * W, 2 * W + 1, 2 * W, 2 * W + 1, 2 * W, 2 * W + 1, 2 * W, 2 * W + 1};
+};
+
+// The LAST diagonal tile of a lower-only product is both: diagonal and short (n = 2000: 80 rows = 5 sub-tile rows, the Gram
+// operand 88 = 6).  Run as a full diagonal tile it costs 36 cells where RV (RV + 1) / 2 are needed (15 of 36 at RV = 5) -- and
+// it is the diagonal tile with the LONGEST K range of step 2 (0.75 % of that kernel's MFMAs at n = 2000).  The needed cells,
+// numbered row by row, are dealt round-robin to the four waves: 4 + 4 + 4 + 3 at RV = 5.
+struct HdmCellList { int nc; int si[16]; int sj[16]; };
+constexpr HdmCellList hdm_diag_edge_cells(int W, int RV) {
+    HdmCellList L{};
+    L.nc = 0;
+    for (int k = 0; k < 16; ++k) { L.si[k] = 0; L.sj[k] = 0; }
+    int c = 0;
+    for (int i = 0; i < RV; ++i)
+        for (int j = 0; j <= i; ++j, ++c)
+            if ((c & 3) == W) { L.si[L.nc] = i; L.sj[L.nc] = j; L.nc += 1; }
+    return L;
+}
+template <int W, int RV> struct DiagEdgeCells {
+    static constexpr HdmCellList L = hdm_diag_edge_cells(W, RV);
+    static constexpr int NC = L.nc;
+    static constexpr int si[16] = {L.si[0], L.si[1], L.si[2], L.si[3], L.si[4], L.si[5], L.si[6], L.si[7],
+                                   L.si[8], L.si[9], L.si[10], L.si[11], L.si[12], L.si[13], L.si[14], L.si[15]};
+    static constexpr int sj[16] = {L.sj[0], L.sj[1], L.sj[2], L.sj[3], L.sj[4], L.sj[5], L.sj[6], L.sj[7],
+                                   L.sj[8], L.sj[9], L.sj[10], L.sj[11], L.sj[12], L.sj[13], L.sj[14], L.sj[15]};
 };
 
 // tri = 1: diagonal tile of a lower-only product (entries above the diagonal are neither scaled nor stored)
@@ -244,8 +273,8 @@ template <class T> constexpr int cell_frag_count() {
 // whole K loop + epilogue of a cell-dealt tile (at most 16 accumulators), same rotated stage as the main loop: the
 // barrier sits before the fourth k-step, whose MFMAs cover the LDS reads of the next stage's first k-step and the issue
 // of the look-ahead global loads; unmasked branch-free staging loads (callers: roles 1-3 only).
-template <class T, bool AKM, bool BKM>
-__device__ __forceinline__ void cell_tile(const HdmGemmArgs &a, Stager<AKM> &stA, Stager<BKM> &stB, double *sA, double *sB,
+template <class T, bool AKM, bool BKM, class STA, class STB>
+__device__ __forceinline__ void cell_tile(const HdmGemmArgs &a, STA &stA, STB &stB, double *sA, double *sB,
                                           int nst, int tid, int z, int m0, int n0, int l15, int lq, int rv, int tri) {
     hdm_d4 acc[4][4];
 #pragma unroll
@@ -458,8 +487,9 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
         for (int i = 0; i < 4; ++i) acc[j][i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
 
     const int kt0 = (int) (kbeg / HDM_BK), kt1 = (int) (kend / HDM_BK);
-    Stager<AKM> stA;
-    Stager<BKM> stB;
+    constexpr bool DUAL = (ROLE == HDM_ROLE_CONG2 || ROLE == HDM_ROLE_GENERIC);
+    Stager<AKM, DUAL> stA;
+    Stager<BKM, DUAL> stB;
     // VAR & 128: timing-only ablation (wrong results): every tile stages rows 0..127, so all operand traffic hits in L2
     long ldb = a.ldb;
     if (ROLE == HDM_ROLE_CONG1 && a.b_sky) {
@@ -471,8 +501,8 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
     }
     stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, (VAR & 128) ? 0 : m0, kt0, tid);
     stB.init(B, ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, (VAR & 128) ? 0 : n0, kt0, tid);
-    const int npass = a.A2 ? 2 : 1;
-    if (a.A2) {
+    const int npass = (DUAL && a.A2) ? 2 : 1;
+    if (DUAL && a.A2) {
         stA.chain(a.A2 + (long) z * a.strideA2, a.lda2, m0, kt0, tid, kt1 - kt0);
         stB.chain(a.B2 + (long) z * a.strideB2, a.ldb2, n0, kt0, tid, kt1 - kt0);
     }
@@ -493,6 +523,20 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
     // diagonal tiles.  A generic diagonal tile on this path once read 16 KB past a 2 KB operand: a device fault.)
     if (ROLE != HDM_ROLE_GENERIC && a.lower_only && tm == tn) {   // workgroup-uniform: diagonal tile, 36-cell scheme
         const int nst = (kt1 - kt0) * npass;
+        const int rvd = (a.M - m0 + 15) >> 4;                      // valid sub-tile rows (= columns) of this tile
+        if (rvd < 8) {                                             // the last, short diagonal tile: only its needed cells
+#define HDM_DEDGE(RV)                                                                                                      \
+    switch (wave) {                                                                                                        \
+        case 0: cell_tile<DiagEdgeCells<0, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rvd, 1); break;  \
+        case 1: cell_tile<DiagEdgeCells<1, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rvd, 1); break;  \
+        case 2: cell_tile<DiagEdgeCells<2, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rvd, 1); break;  \
+        default: cell_tile<DiagEdgeCells<3, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rvd, 1); break; \
+    }
+            if (rvd <= 4) { HDM_DEDGE(4) } else if (rvd == 5) { HDM_DEDGE(5) } else if (rvd == 6) { HDM_DEDGE(6) } else { HDM_DEDGE(7) }
+#undef HDM_DEDGE
+            HDM_CELL_STAMP(3)
+            return;
+        }
         switch (wave) {
             case 0: cell_tile<DiagCells<0>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
             case 1: cell_tile<DiagCells<1>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
