@@ -13,6 +13,8 @@ struct HdmChol {
     double *vec = nullptr;   // 4 * npad scratch vectors
     int *info_dev = nullptr;
     bool factored = false, have_inv = false;
+    bool logdet_ok = false;  // log det of the factored matrix is known (single-launch small-block check): 2 sum log L_kk
+    double logdet_val = 0.0;
     // The factorisation (3 launches per 128-block) and the block substitutions (2 launches per block) are chains of
     // short dependent launches with fixed arguments: after one eager run they can be captured into a hipGraph and
     // replayed (policy and measurements: hdm_graph_level in chol.hip).  A failed capture falls back to eager launches.

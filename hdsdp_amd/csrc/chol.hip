@@ -198,8 +198,10 @@ __global__ __launch_bounds__(256) void hdm_potrf_diag_kernel(double *__restrict_
 // kernel stays for A/B runs (HDM_DIAG_SWEEP=0).  A non-positive pivot is not patched here: everything after it turns into
 // NaNs (the caller reads `info` and discards the factor).
 #define DIAG_SWEEP_LDS_DOUBLES (SMALL_P * (SMALL_P + 1) + 2 * SMALL_P)
+// nv: rows of this block that belong to the matrix (the rest is the identity padding, which needs no pivots: a 21 x 21 block
+// -- truss1's largest -- is 6 four-pivot steps instead of 32, and the reference's driver factors such blocks thousands of times)
 __global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_kernel(double *__restrict__ A, long ld, double *__restrict__ Dinv,
-                                                                    int *__restrict__ info, int col0) {
+                                                                    int *__restrict__ info, int col0, int nv) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *img = sm;                                  // 128 x 129 staging image; its head doubles as the sweep's block images
     double *rsv = sm + SMALL_P * (SMALL_P + 1);
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_kernel(double *__re
         for (int c = 0; c < SM_NC; ++c) a[r][c] = img[(ty + 16 * r) + (tx + 32 * c) * ldi];
     __syncthreads();
     double unused;
-    const int bad = sm_sweep<false>(SMALL_P, a, rr, img, rsv, ty, tx, &unused);
+    const int bad = sm_sweep<false>(nv, a, rr, img, rsv, ty, tx, &unused);
     if (bad && tid == 0) atomicCAS(info, 0, col0 + bad);
     __syncthreads();
     sm_store_one<true>(SMALL_P, a, img, A, ld, ty, tx, tid);
@@ -487,7 +489,7 @@ double hdm_diag_block_probe(int variant, int reps, hipStream_t s) {
         hipLaunchKernelGGL(hdm_probe_spd_block_kernel, dim3(NB * NB / 256), dim3(256), 0, s, A, (long) NB);
         (void) hipEventRecord(e0, s);
         if (variant)
-            hipLaunchKernelGGL(hdm_potrf_diag_sweep_kernel, dim3(1), dim3(SM_T), DIAG_SWEEP_LDS_DOUBLES * sizeof(double), s, A, (long) NB, D, info, 0);
+            hipLaunchKernelGGL(hdm_potrf_diag_sweep_kernel, dim3(1), dim3(SM_T), DIAG_SWEEP_LDS_DOUBLES * sizeof(double), s, A, (long) NB, D, info, 0, NB);
         else
             hipLaunchKernelGGL(hdm_potrf_diag_kernel, dim3(1), dim3(256), (NB * NB + LDW * PB) * sizeof(double), s, A, (long) NB, D, info, 0);
         (void) hipEventRecord(e1, s);
@@ -584,6 +586,7 @@ int HdmChol::finish_load(hipStream_t s) {
     }
     factored = false;
     have_inv = false;
+    logdet_ok = false;
     return 0;
 }
 
@@ -649,7 +652,7 @@ int HdmChol::enqueue_factor(hipStream_t s) {
         double *Akk = L + (long) k * NB * (ld + 1);
         if (diag_sweep)
             hipLaunchKernelGGL(hdm_potrf_diag_sweep_kernel, dim3(1), dim3(SM_T), DIAG_SWEEP_LDS_DOUBLES * sizeof(double), s, Akk, ld,
-                               Dinv + (long) k * NB * NB, info_dev, k * NB);
+                               Dinv + (long) k * NB * NB, info_dev, k * NB, std::max(1, std::min(NB, n - k * NB)));
         else
             hipLaunchKernelGGL(hdm_potrf_diag_kernel, dim3(1), dim3(256), shm, s, Akk, ld, Dinv + (long) k * NB * NB,
                                info_dev, k * NB);

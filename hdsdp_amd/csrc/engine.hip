@@ -102,7 +102,7 @@ const char *g_stat_name[ST_N] = {"HKKTBuildUp (M-forming types)", "HKKTBuildUp (
 double g_stat_sec[ST_N];
 long g_stat_calls[ST_N];
 // the same time by entry point (the outermost entry's function name), printed under the categories
-struct StatFn { const char *name; int k; double sec; long calls; };
+struct StatFn { const char *name; int k; double sec; long calls; double mx; };
 StatFn g_stat_fn[64];
 int g_stat_nfn = 0;
 thread_local int t_stat_depth = 0;
@@ -130,8 +130,8 @@ struct StatScope {
             g_stat_calls[k] += 1;
             int f = 0;
             while (f < g_stat_nfn && g_stat_fn[f].name != name) ++f;
-            if (f == g_stat_nfn && g_stat_nfn < 64) g_stat_fn[g_stat_nfn++] = StatFn{name, k, 0.0, 0};
-            if (f < 64) { g_stat_fn[f].sec += dt; g_stat_fn[f].calls += 1; }
+            if (f == g_stat_nfn && g_stat_nfn < 64) g_stat_fn[g_stat_nfn++] = StatFn{name, k, 0.0, 0, 0.0};
+            if (f < 64) { g_stat_fn[f].sec += dt; g_stat_fn[f].calls += 1; if (dt > g_stat_fn[f].mx) g_stat_fn[f].mx = dt; }
         }
     }
 };
@@ -144,7 +144,8 @@ void stats_print_at_exit() {
         fprintf(stderr, "[hdsdp_mi355x]   %-78s %8ld calls %10.3f s\n", g_stat_name[k], g_stat_calls[k], g_stat_sec[k]);
         for (int f = 0; f < g_stat_nfn; ++f)
             if (g_stat_fn[f].k == k)
-                fprintf(stderr, "[hdsdp_mi355x]       %-74s %8ld calls %10.3f s\n", g_stat_fn[f].name, g_stat_fn[f].calls, g_stat_fn[f].sec);
+                fprintf(stderr, "[hdsdp_mi355x]       %-74s %8ld calls %10.3f s   (longest call %.1f ms)\n", g_stat_fn[f].name, g_stat_fn[f].calls,
+                        g_stat_fn[f].sec, 1e3 * g_stat_fn[f].mx);
     }
 }
 
@@ -387,6 +388,8 @@ struct MiCone {
     double *S = nullptr, *Scheck = nullptr;  // n x n (ld n16) dual matrix buffers
     double *ydev = nullptr;
     double *yhost = nullptr;   // pinned staging of the owned multipliers (the upload is asynchronous)
+    double *chk_host = nullptr, *chk_dev = nullptr;   // mapped pinned block of the single-launch small-block check: y[mloc], then info, log det
+    bool fac_ok = false; int fac_psd = 0;             // the dual factor object holds the factorisation of S = T(pS) (result: fac_psd)
     double *corr = nullptr;    // sharded corrector build: this cone's 2m dot products before they join the operator's
     hdsdp_linsys_fp *dualFactor = nullptr;
     HdmChol *primal = nullptr; // KKT_TYPE_PRIMAL: factor object of the registered primal matrix (lazy)
@@ -749,13 +752,71 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
     return 0;
 }
 
+hdsdp_retcode cone_factor_S(MiCone *c, int *isPsd);
+hdsdp_retcode cone_factor_check(MiCone *c, int *isPsd);
+hdsdp_retcode cone_checker(MiCone *c, HdmChol **out);
+
+// Interior check of a SMALL block (n <= 128, at most 1 MB of resident constraint data) in ONE launch and one synchronisation:
+// assembly, Cholesky with the triangular inverse, pivot information and log det S (small.hip: hdm_small_check_kernel).  The
+// same point asked for again -- the reference's line search asks "interior?" and then for the barrier at the point it has just
+// checked -- is answered from what the factor object holds, with no device work at all.
+// Returns 0 when it has answered (*isPsd set), 1 when the block is not eligible (the caller takes the call-by-call route).
+int cone_small_check(MiCone *c, double tau, const double *y_host, const double *eye_override, int whichBuffer, int *isPsd, hdsdp_retcode *rc) {
+    static const bool on = [] { const char *e = getenv("HDSDP_MI355X_SMALL_CHECK"); return !(e && atoi(e) == 0); }();
+    *rc = HDSDP_RETCODE_OK;
+    // (a single workgroup walks the resident constraint data: up to 1 MB of it in general, 4 MB for blocks of dimension <= 64,
+    // where the call-by-call assembly's few workgroups are latency-bound themselves -- theta1: 0.45 ms per check)
+    const long resident = (long) c->mloc * c->n16 * c->n16;
+    if (!on || c->world != 1 || !c->Afull || c->n16 > SMALL_P || resident > ((c->n16 <= 64) ? (1L << 19) : (1L << 17))) return 1;
+    HdmChol *ch = &((MiLin *) c->dualFactor->chol)->ch;
+    if (whichBuffer != 0) { if (cone_checker(c, &ch) != HDSDP_RETCODE_OK) return 1; }
+    if (ch->npad != SMALL_P || ch->nblk != 1) return 1;
+    const double eye_now = eye_override ? *eye_override : (-c->Rd + c->perturb);
+    const int np = c->mloc + 2;
+    if (!c->chk_host) {
+        if (hipHostMalloc((void **) &c->chk_host, sizeof(double) * (size_t) (c->mloc + 4), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **) &c->chk_dev, c->chk_host, 0) != hipSuccess) { (void) hipGetLastError(); c->chk_host = nullptr; return 1; }
+    }
+    double *yo = c->chk_host;
+    bool same = (whichBuffer == 0 && c->pS_ok && (int) c->pS.size() == np && c->pS[0] == tau && c->pS[1] == eye_now);
+    for (int q = 0; q < c->mloc; ++q) {
+        const double v = y_host ? y_host[c->own[q]] : 0.0;
+        if (same && c->pS[2 + q] != v) same = false;
+        yo[q] = v;
+    }
+    if (same && c->fac_ok) { if (isPsd) *isPsd = c->fac_psd; return 0; }      // S = T(p) and its factor are in place
+    HdmSmallCheckArgs a = {};
+    a.n = c->n; a.n16 = c->n16; a.m = c->mloc; a.A = c->Afull; a.astride = c->astride; a.C = c->Cfull;
+    a.y = c->chk_dev; a.tau = tau; a.eye = eye_now;
+    a.Sout = (whichBuffer == 0) ? c->S : c->Scheck;
+    a.L = ch->L; a.W = ch->Dinv; a.out = c->chk_dev + c->mloc;
+    yo[c->mloc] = -1.0;
+    if (hdm_small_check(a, g.stream) || hipStreamSynchronize(g.stream) != hipSuccess) { *rc = HDSDP_RETCODE_FAILED; return 0; }
+    const int info = (int) yo[c->mloc];
+    if (info < 0) { *rc = HDSDP_RETCODE_FAILED; return 0; }
+    ch->factored = (info == 0); ch->have_inv = false;
+    ch->logdet_ok = (info == 0); ch->logdet_val = yo[c->mloc + 1];
+    if (whichBuffer == 0) {
+        c->dualFactor->nFactorizes += 1;
+        c->pS.resize((size_t) np);
+        c->pS[0] = tau; c->pS[1] = eye_now;
+        for (int q = 0; q < c->mloc; ++q) c->pS[2 + q] = yo[q];
+        c->pS_ok = true; c->aff_chain = 0;
+        c->fac_ok = true; c->fac_psd = (info == 0);
+    }
+    if (isPsd) *isPsd = (info == 0);
+    return 0;
+}
+
 void cone_update(void *cd, double tau, double *y) {
     StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
+    ((MiCone *) cd)->fac_ok = false;          // S moves, its factor does not follow
     cone_assemble((MiCone *) cd, tau, y, ((MiCone *) cd)->S);
 }
 
 hdsdp_retcode cone_factor_S(MiCone *c, int *isPsd) {
     MiLin *l = (MiLin *) c->dualFactor->chol;
+    c->fac_ok = false;
     RC(l->ch.load_device(c->S, c->n16, g.stream));
     int info = 0;
     RC(l->ch.factor(g.stream, &info));
@@ -794,6 +855,10 @@ hdsdp_retcode cone_interior_expert(void *cd, double dCCoef, double dACoefScal, d
     for (int i = 0; i < c->m; ++i) ys[i] = -dACoefScal * (dACoef ? dACoef[i] : 0.0);   // cone_assemble subtracts
     const double eye = dEyeCoef + c->perturb;
     double *target = (whichBuffer == 0) ? c->S : c->Scheck;
+    {
+        hdsdp_retcode rcs;
+        if (cone_small_check(c, dCCoef, ys.data(), &eye, whichBuffer, isInterior, &rcs) == 0) return rcs;
+    }
     if (cone_assemble(c, dCCoef, ys.data(), target, &eye)) return HDSDP_RETCODE_FAILED;
     HIP_RC(hipStreamSynchronize(g.stream));   // ys is read by an asynchronous copy
     return (whichBuffer == 0) ? cone_factor_S(c, isInterior) : cone_factor_check(c, isInterior);
@@ -807,7 +872,7 @@ hdsdp_retcode cone_axpy_check(void *cd, double dStep, int whichBuffer, int *isIn
     if (!c->dS) return HDSDP_RETCODE_FAILED;
     const long cnt = (long) c->n16 * c->n16;
     double *target = (whichBuffer == 0) ? c->S : c->Scheck;
-    if (whichBuffer == 0) c->pS_ok = false;          // S moves without a point being named: the next request assembles it
+    if (whichBuffer == 0) { c->pS_ok = false; c->fac_ok = false; }   // S moves without a point being named: the next request assembles it
     RC(hdm_axpy_mat(target, c->S, c->dS, dStep, cnt, g.stream));
     return (whichBuffer == 0) ? cone_factor_S(c, isInterior) : cone_factor_check(c, isInterior);
 }
@@ -819,6 +884,10 @@ void cone_set_perturb(void *cd, double dDualPerturb) { ((MiCone *) cd)->perturb 
 hdsdp_retcode cone_interior(void *cd, double tau, double *y, int *isInterior) {
     StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
     MiCone *c = (MiCone *) cd;
+    {
+        hdsdp_retcode rcs;
+        if (cone_small_check(c, tau, y, nullptr, 0, isInterior, &rcs) == 0) return rcs;
+    }
     RC(cone_assemble(c, tau, y, c->S));
     return cone_factor_S(c, isInterior);
 }
@@ -829,8 +898,16 @@ hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, dou
     MiCone *c = (MiCone *) cd;
     if (y) {   // only with BUFFER_DUALVAR (the reference asserts it)
         int psd = 0;
-        RC(cone_assemble(c, tau, y, c->S));
-        if (cone_factor_S(c, &psd) != HDSDP_RETCODE_OK || !psd) return HDSDP_RETCODE_FAILED;
+        hdsdp_retcode rcs;
+        if (cone_small_check(c, tau, y, nullptr, 0, &psd, &rcs) == 0) { if (rcs != HDSDP_RETCODE_OK || !psd) return HDSDP_RETCODE_FAILED; }
+        else {
+            RC(cone_assemble(c, tau, y, c->S));
+            if (cone_factor_S(c, &psd) != HDSDP_RETCODE_OK || !psd) return HDSDP_RETCODE_FAILED;
+        }
+    }
+    {   // a factor that came from the single-launch check brought its log det along
+        const HdmChol *fq = (whichBuffer == 0) ? &((MiLin *) c->dualFactor->chol)->ch : c->checker;
+        if (fq && fq->factored && fq->logdet_ok) { *logdet = fq->logdet_val; return HDSDP_RETCODE_OK; }
     }
     std::vector<double> d(c->n);
     if (whichBuffer == 0) {
@@ -875,7 +952,11 @@ hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAda
         if (c->lanczos->init(c->n)) return HDSDP_RETCODE_MEMORY;
     }
     int steps = 0;
+    static const bool dbg = [] { const char *e = getenv("HDSDP_MI355X_RATIO_DEBUG"); return e && atoi(e); }();
+    const auto t0 = std::chrono::steady_clock::now();
     if (c->lanczos->solve(fac->Linv, fac->npad, c->dS, c->n16, g.stream, maxStep, &steps)) return HDSDP_RETCODE_FAILED;
+    if (dbg) fprintf(stderr, "[hdsdp_mi355x ratio] n %d: %d Lanczos steps, step %.6e, solve %.1f us\n", c->n, steps, *maxStep,
+                     1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return HDSDP_RETCODE_OK;
 }
 
@@ -1872,6 +1953,7 @@ void cone_destroy_data(void **pcd) {
     HFpLinsysDestroy(&c->dualFactor);
     if (c->primal) { c->primal->destroy(); delete c->primal; }
     if (c->lanczos) { c->lanczos->destroy(); delete c->lanczos; }
+    if (c->chk_host) (void) hipHostFree(c->chk_host);
     if (c->checker) { c->checker->destroy(); delete c->checker; }
     for (hipEvent_t e : c->piece_ev) if (e) (void) hipEventDestroy(e);
     if (c->dS) (void) hipFree(c->dS);

@@ -9,7 +9,7 @@ struct HdmLanczos {
     int nComputed = 0;        // calls so far: the second and later calls warm-start (hdsdp_lanczos.c:166-181)
     double *V = nullptr;      // n16 x (maxdim + 1) Lanczos basis
     double *bv = nullptr, *b1 = nullptr, *b2 = nullptr, *bw = nullptr, *bz = nullptr;   // n16 x 8 vector blocks (column 0 used)
-    double *warm = nullptr, *tmp = nullptr, *scal = nullptr;
+    double *warm = nullptr, *tmp = nullptr, *scal = nullptr, *startd = nullptr;   // startd: device copy of `start`, zero padded
     double *part = nullptr;   // 32 x n16 partial sums of the plain matrix-vector product
     std::vector<double> start;   // the reference's pseudo-random start vector (host)
 

@@ -185,6 +185,306 @@ __global__ __launch_bounds__(1024) void hdm_lanczos_fused_kernel(const double *_
     if (tid == 0) out[2 * nsteps] = (double) done;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Small blocks (n16 <= 256): the WHOLE ratio test in ONE single-workgroup launch and one synchronisation.
+//
+// HLanczosSolve (hdsdp_lanczos.c:161-292) step for step -- start vector (fresh, or warm start + 1e-3 x the pseudo-random
+// vector), up to 30 Lanczos steps, a Ritz check every third step, the two residual applications, the acceptance rule --
+// with the small symmetric eigenproblem solved in the kernel too: the (k+1) x (k+1) matrix is TRIDIAGONAL (alpha on the
+// diagonal, the norms beside it), so wave 0 runs the implicit QL iteration with the rotations' scalar recurrence computed
+// redundantly by every lane and lane r keeping row r of the eigenvector matrix (the reference calls dsyevr on the same
+// matrix stored densely; the multi-launch path uses a host Jacobi: eigenvalues agree to rounding).  The multi-launch form
+// (a group of three steps per launch, Ritz checks on the host) costs 6-12 launches and as many synchronisations per ratio
+// test: 0.53 ms on a 100 x 100 block, half of what the reference's driver spends below the C ABI on mcp100 / gpp100 and
+// 40 % on truss1 (2247 ratio tests).
+// out: [0] step, [1] Lanczos steps done, [2] status (0 ok, 1 failed: zero norm without convergence).
+// RESIDENT = true (n16 <= 128): the two matrices are first packed into LDS (lower triangles, column by column: 2 x 66 KB at
+// n16 = 128) and the 30-50 operator applications of a test read them there; from global memory every application is three
+// dependent passes of L2 round trips -- 12 us each at n = 100, 0.42 ms per ratio test on mcp100.
+#define LZ_MD 30
+#define LZ_RESIDENT_MAX 128
+template <bool RESIDENT>
+__global__ __launch_bounds__(1024) void hdm_lanczos_whole_kernel(const double *__restrict__ Linv, long ldl, const double *__restrict__ dS,
+                                                                 long ldd, int n, double *__restrict__ V, long ldv,
+                                                                 const double *__restrict__ start, double *__restrict__ warm, int fresh,
+                                                                 double *__restrict__ out) {
+    __shared__ double sv[LZ_FUSED_MAX], st1[LZ_FUSED_MAX], st2[LZ_FUSED_MAX], part[4][LZ_FUSED_MAX], red[16];
+    __shared__ double hd[LZ_MD + 2], he[LZ_MD + 2], td[LZ_MD + 2], te[LZ_MD + 2], Z[32 * 32], y1[32], y2[32];
+    __shared__ double bc, sh_eig1, sh_eig2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) double lz_dyn[];
+    double *Lp = lz_dyn, *Dp = lz_dyn + (RESIDENT ? (long) n * (n + 1) / 2 : 0);   // packed lower triangles: (i, j) at j n - j (j - 1) / 2 + i - j
+    if (RESIDENT) {
+        for (int j = wave; j < n; j += 16) {
+            const long cj = (long) j * n - (long) j * (j - 1) / 2;
+            for (int i = j + lane; i < n; i += 64) { Lp[cj + i - j] = Linv[i + (long) j * ldl]; Dp[cj + i - j] = dS[i + (long) j * ldd]; }
+        }
+        __syncthreads();
+    }
+    auto reduce = [&](double s) {
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (tid == 0) { double t = 0.0; for (int q = 0; q < 16; ++q) t += red[q]; bc = t; }
+        __syncthreads();
+        const double r = bc;
+        __syncthreads();
+        return r;
+    };
+    // w = Linv ( -dS ( Linv^T sv ) ): element tid of the result (0 beyond n); sv must be in place and visible
+    auto apply = [&]() -> double {
+        if (RESIDENT) {
+            // n <= 128: thread (r8, c8) = row or column r8, eighth c8 of the summation range; no shuffles anywhere (a wave per
+            // column with a shuffle tree per column made a product 3 us of serialised cross-lane latency, 8 us per Lanczos step)
+            double *part8 = &part[0][0];                     // 8 x 128
+            const int r8 = tid & 127, c8 = tid >> 7, cw8 = (n + 7) / 8, q0 = c8 * cw8, q1 = min(n, q0 + cw8);
+            const int cr = r8 * n - r8 * (r8 - 1) / 2;       // start of column r8 in the packed triangles
+            {                                                // t1 = Linv^T v: column r8, rows of the chunk below the diagonal
+                double a0 = 0.0, a1 = 0.0;
+                if (r8 < n) {
+                    const double *col = Lp + cr - r8;
+                    int i = max(r8, q0);
+                    for (; i + 1 < q1; i += 2) { a0 += col[i] * sv[i]; a1 += col[i + 1] * sv[i + 1]; }
+                    if (i < q1) a0 += col[i] * sv[i];
+                }
+                part8[c8 * 128 + r8] = a0 + a1;
+            }
+            __syncthreads();
+            if (tid < n) {
+                double t = 0.0;
+                for (int c = 0; c < 8; ++c) t += part8[c * 128 + tid];
+                st1[tid] = t;
+            }
+            __syncthreads();
+            {                                                // t2 = -dS t1: row r8 of the symmetric matrix (row part left of the diagonal, column part below)
+                double a0 = 0.0;
+                if (r8 < n) {
+                    const double *col = Dp + cr - r8;
+                    int ci = q0 * n - q0 * (q0 - 1) / 2;       // start of column i, advanced with i
+                    for (int i = q0; i < q1; ++i) {
+                        a0 += ((i >= r8) ? col[i] : Dp[ci + (r8 - i)]) * st1[i];
+                        ci += n - i;
+                    }
+                }
+                part8[c8 * 128 + r8] = a0;
+            }
+            __syncthreads();
+            if (tid < n) {
+                double t = 0.0;
+                for (int c = 0; c < 8; ++c) t += part8[c * 128 + tid];
+                st2[tid] = -t;
+            }
+            __syncthreads();
+            {                                                // w = Linv t2: row r8, columns of the chunk up to the diagonal
+                double a0 = 0.0;
+                if (r8 < n) {
+                    const int j1 = min(q1, r8 + 1);
+                    int cj = q0 * n - q0 * (q0 - 1) / 2;
+                    for (int j = q0; j < j1; ++j) { a0 += Lp[cj + (r8 - j)] * st2[j]; cj += n - j; }
+                }
+                part8[c8 * 128 + r8] = a0;
+            }
+            __syncthreads();
+            double xr = 0.0;
+            if (tid < n) for (int c = 0; c < 8; ++c) xr += part8[c * 128 + tid];
+            __syncthreads();
+            return xr;
+        }
+        for (int j = wave; j < n; j += 16) {
+            const double *col = Linv + (long) j * ldl;
+            double a = 0.0;
+            for (int i = (j & ~63) + lane; i < n; i += 64) a += ((i < j) ? 0.0 : col[i]) * sv[i];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) st1[j] = a;
+        }
+        __syncthreads();
+        for (int j = wave; j < n; j += 16) {
+            const double *col = dS + (long) j * ldd;
+            double a = 0.0;
+            for (int i = lane; i < n; i += 64) a += col[i] * st1[i];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) st2[j] = -a;
+        }
+        __syncthreads();
+        {
+            const int i = tid & (LZ_FUSED_MAX - 1), c = tid >> 8;
+            const int cw = (n + 3) / 4, j0 = c * cw, j1 = min(n, j0 + cw), jend = min(j1, i + 1);
+            double a0 = 0.0, a1 = 0.0;
+            if (i < n) {
+                int j = j0;
+                for (; j + 1 < jend; j += 2) {
+                    a0 += Linv[i + (long) j * ldl] * st2[j];
+                    a1 += Linv[i + (long) (j + 1) * ldl] * st2[j + 1];
+                }
+                if (j < jend) a0 += Linv[i + (long) j * ldl] * st2[j];
+            }
+            part[c][i] = a0 + a1;
+        }
+        __syncthreads();
+        double x = 0.0;
+        if (tid < n) x = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+        __syncthreads();
+        return x;
+    };
+    // ---- start vector (:166-181), normalised into V[:, 0]
+    double v0 = 0.0;
+    if (tid < n) v0 = fresh ? start[tid] : warm[tid] + 1e-03 * start[tid];
+    {
+        const double nr = sqrt(reduce(v0 * v0));
+        const double inv = nr > 0.0 ? 1.0 / nr : 0.0;
+        if (tid < n) V[tid] = v0 * inv;
+    }
+    if (tid < LZ_MD + 2) { hd[tid] = 0.0; he[tid] = 0.0; }
+    __threadfence_block();
+    __syncthreads();
+    const int md = LZ_MD, checkFreq = 3;
+    double step = 0.0, hprev = 0.0;
+    int k = 0, status = 0;
+    for (k = 0; k < md; ++k) {
+        if (tid < n) sv[tid] = V[tid + (long) k * ldv];
+        __syncthreads();
+        double x = apply();
+        double vk = 0.0;
+        if (tid < n) {
+            vk = sv[tid];
+            if (k > 0) x -= hprev * V[tid + (long) (k - 1) * ldv];
+        }
+        const double alp = -reduce((tid < n) ? x * vk : 0.0);
+        x += alp * vk;
+        const double nrm = sqrt(reduce((tid < n) ? x * x : 0.0));
+        if (nrm > 0.0 && tid < n) V[tid + (long) (k + 1) * ldv] = x * (1.0 / nrm);
+        if (tid == 0) { hd[k] = -alp; he[k] = (nrm > 0.0) ? nrm : 0.0; }
+        hprev = (nrm > 0.0) ? nrm : 0.0;
+        __threadfence_block();
+        __syncthreads();
+        if (!((k + 1) % checkFreq == 0 || k > md - 1 || nrm == 0.0)) continue;
+        // ---- Ritz values of the leading kp x kp tridiagonal matrix: implicit QL with eigenvectors, wave 0
+        const int kp = k + 1;
+        if (wave == 0) {
+            // The tridiagonal matrix lives in REGISTERS, entry i in lane i; the scalar recurrence of a rotation fetches what it
+            // needs with v_readlane (a few cycles) instead of an LDS round trip per operand, and takes one reciprocal square
+            // root per rotation instead of a square root and a division: the chain of ~1100 dependent rotations of a 30 x 30
+            // problem was 0.3 ms of LDS latency and long-latency arithmetic, and the checks of a 30-step test 1 ms altogether.
+            if (lane < 32)
+                for (int c = 0; c < kp; ++c) Z[lane + 32 * c] = (lane == c) ? 1.0 : 0.0;
+            double dreg = (lane < kp) ? hd[lane] : 0.0, ereg = (lane < kp - 1) ? he[lane] : 0.0;
+            auto rl = [](double x, int i) {
+                int lo = __double2loint(x), hi = __double2hiint(x);
+                lo = __builtin_amdgcn_readlane(lo, i); hi = __builtin_amdgcn_readlane(hi, i);
+                return __hiloint2double(hi, lo);
+            };
+            __builtin_amdgcn_wave_barrier();
+            for (int l = 0; l < kp; ++l) {
+                for (int iter = 0; iter < 64; ++iter) {
+                    int mm = l;
+                    for (; mm < kp - 1; ++mm) {
+                        const double dd = fabs(rl(dreg, mm)) + fabs(rl(dreg, mm + 1));
+                        if (fabs(rl(ereg, mm)) <= 2.220446049250313e-16 * dd) break;
+                    }
+                    if (mm == l) break;
+                    const double dl = rl(dreg, l), el = rl(ereg, l);
+                    double g = (rl(dreg, l + 1) - dl) / (2.0 * el);
+                    double r = sqrt(fma(g, g, 1.0));
+                    g = rl(dreg, mm) - dl + el / (g + copysign(r, g));
+                    double s = 1.0, c = 1.0, p = 0.0;
+                    int i = mm - 1;
+                    bool under = false;
+                    for (; i >= l; --i) {
+                        const double tei = rl(ereg, i);
+                        double f = s * tei;
+                        const double b = c * tei;
+                        const double h2 = fma(f, f, g * g);
+                        if (h2 == 0.0) {
+                            if (lane == i + 1) { dreg -= p; ereg = 0.0; }
+                            if (lane == mm) ereg = 0.0;
+                            under = true;
+                            break;
+                        }
+                        double rinv = __builtin_amdgcn_rsq(h2);
+                        rinv = rinv * (1.5 - 0.5 * h2 * rinv * rinv);
+                        rinv = rinv * (1.5 - 0.5 * h2 * rinv * rinv);
+                        r = h2 * rinv;
+                        if (lane == i + 1) ereg = r;
+                        s = f * rinv; c = g * rinv;
+                        g = rl(dreg, i + 1) - p;
+                        r = (rl(dreg, i) - g) * s + 2.0 * c * b;
+                        p = s * r;
+                        if (lane == i + 1) dreg = g + p;
+                        g = c * r - b;
+                        if (lane < kp) {                       // row `lane` of the eigenvector matrix
+                            f = Z[lane + 32 * (i + 1)];
+                            Z[lane + 32 * (i + 1)] = s * Z[lane + 32 * i] + c * f;
+                            Z[lane + 32 * i] = c * Z[lane + 32 * i] - s * f;
+                        }
+                    }
+                    if (under) continue;
+                    if (lane == l) { dreg -= p; ereg = g; }
+                    if (lane == mm) ereg = 0.0;
+                }
+            }
+            if (lane < kp) td[lane] = dreg;
+            __builtin_amdgcn_wave_barrier();
+            // the two largest eigenvalues and their vectors
+            int i1 = 0;
+            for (int c = 1; c < kp; ++c) if (td[c] > td[i1]) i1 = c;
+            int i2 = (kp > 1) ? (i1 == 0 ? 1 : 0) : i1;
+            for (int c = 0; c < kp; ++c) if (c != i1 && td[c] > td[i2]) i2 = c;
+            // sign convention: the component of largest magnitude is positive -- what LAPACK's tridiagonal eigenvector routines
+            // return (dstein scales that way, dstemr's twisted factorisation puts a positive 1 at the twist index) and what the
+            // multi-launch path's Jacobi vectors have always shown on the reference's goldens.  The sign of y1 matters: the
+            // NEXT ratio test is warm-started from Op (V y1) + 1e-3 x the pseudo-random vector (:166-181).
+            double sg1 = 1.0, sg2 = 1.0;
+            {
+                double b1 = 0.0, b2 = 0.0;
+                for (int r = 0; r < kp; ++r) {
+                    const double u = Z[r + 32 * i1], v = Z[r + 32 * i2];
+                    if (fabs(u) > fabs(b1)) b1 = u;
+                    if (fabs(v) > fabs(b2)) b2 = v;
+                }
+                if (b1 < 0.0) sg1 = -1.0;
+                if (b2 < 0.0) sg2 = -1.0;
+            }
+            if (lane < kp) { y1[lane] = sg1 * Z[lane + 32 * i1]; y2[lane] = sg2 * Z[lane + 32 * i2]; }
+            if (lane == 0) { sh_eig1 = td[i1]; sh_eig2 = td[i2]; }
+        }
+        __threadfence_block();
+        __syncthreads();
+        const double eig1 = sh_eig1, eig2 = sh_eig2;
+        const double resiVal = fabs(he[k] * y1[k]);
+        if (resiVal < 1e-04 || k >= md - 1) {
+            // z1 = V y1 ; z2 = Op z1 ; warm start <- z2 ; resiVal1 = | z2 - eig1 z1 |
+            double z = 0.0;
+            if (tid < n) for (int c = 0; c < kp; ++c) z += V[tid + (long) c * ldv] * y1[c];
+            if (tid < n) sv[tid] = z;
+            __syncthreads();
+            double w = apply();
+            if (tid < n) warm[tid] = w;
+            double d = (tid < n) ? w - eig1 * z : 0.0;
+            const double r1 = sqrt(reduce(d * d));
+            // z2' = V y2 ; resiVal2 = | Op z2' - eig1 z2' |   (the reference uses eig1 here too, :262-266)
+            z = 0.0;
+            if (tid < n) for (int c = 0; c < kp; ++c) z += V[tid + (long) c * ldv] * y2[c];
+            if (tid < n) sv[tid] = z;
+            __syncthreads();
+            w = apply();
+            d = (tid < n) ? w - eig1 * z : 0.0;
+            const double r2 = sqrt(reduce(d * d));
+            const double resiDiff = eig1 - eig2 - r2;
+            double gam = (resiDiff > 0) ? resiDiff : 1e-16;
+            const double sq = r1 * r1 / gam;
+            gam = r1 < sq ? r1 : sq;
+            if (gam < 1e-03 || gam + eig1 <= 0.5) {
+                step = (gam + eig1 <= 0.0) ? INFINITY : 1.0 / (gam + eig1);
+                break;
+            } else {
+                if (nrm == 0.0) { status = 1; break; }
+                step = 1.0 / (gam + eig1);
+            }
+        }
+    }
+    if (tid == 0) { out[0] = step; out[1] = (double) k; out[2] = (double) status; }
+}
+
 // z = V[:, 0..kc) * coef   (single workgroup; V column stride ldv)
 __global__ __launch_bounds__(1024) void hdm_lincomb_kernel(const double *__restrict__ V, long ldv, int kc,
                                                            const double *__restrict__ coef, double *__restrict__ z, int n) {
@@ -397,14 +697,20 @@ int HdmLanczos::init(int n_) {
     HDM_HIP_CHECK(hdm_memset_sync(tmp, 0, sizeof(double) * (size_t) n16));
     start.resize(n);
     hdm_lanczos_start_vector(n, start.data());
+    {   // device copy of the start vector, zero padded (the single-launch form builds its own first vector)
+        std::vector<double> sp(n16, 0.0);
+        for (int i = 0; i < n; ++i) sp[i] = start[i];
+        HDM_HIP_CHECK(hipMalloc((void **) &startd, sizeof(double) * (size_t) n16));
+        HDM_HIP_CHECK(hipMemcpy(startd, sp.data(), sizeof(double) * (size_t) n16, hipMemcpyHostToDevice));
+    }
     nComputed = 0;
     return 0;
 }
 
 void HdmLanczos::destroy() {
-    for (double *b : {V, bv, b1, b2, bw, bz, warm, tmp, scal, part})
+    for (double *b : {V, bv, b1, b2, bw, bz, warm, tmp, scal, part, startd})
         if (b) (void) hipFree(b);
-    V = bv = b1 = b2 = bw = bz = warm = tmp = scal = part = nullptr;
+    V = bv = b1 = b2 = bw = bz = warm = tmp = scal = part = startd = nullptr;
 }
 
 // out (column 0 of a vector block) = Linv * ( -dS * ( Linv^T * in ) ): three HBM-bound matrix-vector products with
@@ -424,6 +730,35 @@ int HdmLanczos::apply(const double *Linv, long ldl, const double *dS, long ldd, 
 }
 
 int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, hipStream_t s, double *maxStep, int *steps) {
+    static const bool whole_env = [] { const char *e = getenv("HDM_LANCZOS_WHOLE"); return !(e && atoi(e) == 0); }();   // 0: the multi-launch forms (A/B, tests)
+    if (whole_env && n16 <= LZ_FUSED_MAX && maxdim == LZ_MD) {
+        // small block: the whole test in one launch (hdm_lanczos_whole_kernel); three doubles come back
+        if (n16 <= LZ_RESIDENT_MAX) {
+            const size_t dyn = sizeof(double) * (size_t) n16 * (n16 + 1);      // two packed triangles
+            static thread_local int configured_dev = -1;
+            int dev = 0;
+            HDM_HIP_CHECK(hipGetDevice(&dev));
+            if (configured_dev != dev) {
+                HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_lanczos_whole_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int) (sizeof(double) * LZ_RESIDENT_MAX * (LZ_RESIDENT_MAX + 1))));
+                configured_dev = dev;
+            }
+            hipLaunchKernelGGL(hdm_lanczos_whole_kernel<true>, dim3(1), dim3(1024), dyn, s, Linv, ldl, dS, ldd, n16, V, (long) n16, startd,
+                               warm, nComputed == 0 ? 1 : 0, scal + 60);
+        } else {
+            hipLaunchKernelGGL(hdm_lanczos_whole_kernel<false>, dim3(1), dim3(1024), 0, s, Linv, ldl, dS, ldd, n16, V, (long) n16, startd,
+                               warm, nComputed == 0 ? 1 : 0, scal + 60);
+        }
+        HDM_HIP_CHECK(hipGetLastError());
+        double r[3] = {0.0, 0.0, 1.0};
+        HDM_HIP_CHECK(hipMemcpyAsync(r, scal + 60, sizeof(r), hipMemcpyDeviceToHost, s));
+        HDM_HIP_CHECK(hipStreamSynchronize(s));
+        if (r[2] != 0.0) return 1;
+        nComputed += 1;
+        if (maxStep) *maxStep = r[0];
+        if (steps) *steps = (int) r[1];
+        return 0;
+    }
     const int md = maxdim, nh = md + 1;
     std::vector<double> H((size_t) nh * nh, 0.0);
     auto Hm = [&](int i, int j) -> double & { return H[(size_t) j * nh + i]; };
@@ -506,6 +841,12 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
                 for (int i = 0; i < kp; ++i) U[(size_t) j * kp + i] = 0.5 * (Hm(i, j) + Hm(j, i));
             jacobi_eig(kp, U, d, Y);
             const double eig1 = d[kp - 1], eig2 = kp > 1 ? d[kp - 2] : d[kp - 1];
+            // (sign convention as in the single-launch form: largest-magnitude component positive)
+            for (int col : {kp - 1, kp > 1 ? kp - 2 : kp - 1}) {
+                double *yc = &Y[(size_t) col * kp], big = 0.0;
+                for (int r = 0; r < kp; ++r) if (fabs(yc[r]) > fabs(big)) big = yc[r];
+                if (big < 0.0) for (int r = 0; r < kp; ++r) yc[r] = -yc[r];
+            }
             const double *y1 = &Y[(size_t) (kp - 1) * kp], *y2 = kp > 1 ? &Y[(size_t) (kp - 2) * kp] : y1;
             const double resiVal = fabs(Hm(kp, k) * y1[k]);
             if (resiVal < 1e-04 || k >= md - 1) {

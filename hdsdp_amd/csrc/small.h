@@ -25,5 +25,23 @@ struct HdmSmallArgs {
                                         // then 8 phase stamps (s_memrealtime, 100 MHz)
 };
 
+// One launch for an interior check of a small block (n <= 128, any device path): S = tau C - sum y_i A_i + eye I from the
+// resident A_L-form constraint matrices (n16 x n16 each, n16 <= 128: skyline storage is a plain square there), the Cholesky
+// factor with the triangular inverse, the pivot information and log det S.  What the call-by-call form does in seven
+// operations and two synchronisations (pinned copy of y, assembly kernel, rectangle copy into the factor object, padding
+// kernel, memset, sweep kernel, copy back): 88 us on a 100 x 100 block, 56 us on truss1's 21 x 21 ones, of which the
+// reference's driver runs thousands.
+struct HdmSmallCheckArgs {
+    int n, n16, m;                      // block dimension, its leading dimension, constraint matrices resident
+    const double *A; long astride;      // m matrices in A_L form (strict lower + half diagonal), column-major n16 x n16
+    const double *C;                    // objective, full symmetric, ld n16
+    const double *y;                    // m multipliers (mapped host or device)
+    double tau, eye;
+    double *Sout;                       // the dual matrix buffer (lower triangle written), ld n16
+    double *L, *W;                      // 128 x 128: Cholesky factor and its inverse (HdmChol::L, ::Dinv)
+    double *out;                        // [0] info (0, or first non-positive pivot + 1), [1] log det S
+};
+int hdm_small_check(const HdmSmallCheckArgs &args, hipStream_t s);
+
 size_t hdm_small_lds_bytes();
 int hdm_small_phase_a(const HdmSmallArgs &args, hipStream_t s);

@@ -328,6 +328,71 @@ __global__ __launch_bounds__(SM_T) void hdm_small_phase_a_kernel(HdmSmallArgs p)
 #undef SM_STAMP
 }
 
+// ---- interior check of a small block in one launch (see small.h) ------------------------------------------------------
+__global__ __launch_bounds__(SM_T) void hdm_small_check_kernel(HdmSmallCheckArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int ld = SMALL_P + 1;
+    double *Xl = sm;                                   // S, full symmetric: 128 x 129 (its head: the sweep's block images)
+    double *rsv = sm + (long) SMALL_P * ld;            // 128 deferred scale factors
+    double *yl = rsv + SMALL_P;                        // the multipliers, staged once
+    const int n = p.n, n16 = p.n16, m = p.m;
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    for (int q = tid; q < m; q += SM_T) yl[q] = p.y[q];
+    __syncthreads();
+    // lower triangle, column by column: thread = row (tid mod 128) of the columns tid / 128, + 4, ...
+    const int ei = tid & (SMALL_P - 1), ej0 = tid >> 7;
+    if (ei < n) {
+        for (int j = ej0; j <= ei; j += SM_T / SMALL_P) {
+            const double *a = p.A + ei + (long) j * n16;
+            double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // eight loads in flight per thread
+            int q = 0;
+            for (; q + 7 < m; q += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] -= yl[q + u] * a[(long) (q + u) * p.astride];
+            }
+            for (; q < m; ++q) acc[0] -= yl[q] * a[(long) q * p.astride];
+            double v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            if (ei == j) v *= 2.0;                     // A_L form: half the diagonal is stored
+            v += p.tau * p.C[ei + (long) j * n16];
+            if (ei == j) v += p.eye;
+            Xl[ei + j * ld] = v;
+            Xl[j + ei * ld] = v;
+            p.Sout[ei + (long) j * n16] = v;
+        }
+    }
+    __syncthreads();
+    double a[SM_NR][SM_NC], rr[SM_NR][SM_NC];
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r)
+#pragma unroll
+        for (int c = 0; c < SM_NC; ++c) {
+            const int i = ty + 16 * r, j = tx + 32 * c;
+            a[r][c] = (i < n && j < n) ? Xl[i + j * ld] : ((i == j) ? 1.0 : 0.0);
+        }
+    __syncthreads();
+    double logdet = 0.0;
+    const int info = sm_sweep(n, a, rr, Xl, rsv, ty, tx, &logdet);
+    if (tid == 0) { p.out[0] = (double) info; p.out[1] = logdet; }
+    if (info) return;
+    sm_store_factor(n, a, rr, Xl, p.L, p.W, ty, tx, tid);
+}
+
+int hdm_small_check(const HdmSmallCheckArgs &args, hipStream_t s) {
+    if (args.n < 1 || args.n > SMALL_P || args.n16 > SMALL_P || args.m < 0 || args.m > 4096) return 1;
+    const size_t lds = sizeof(double) * ((size_t) SMALL_P * (SMALL_P + 1) + SMALL_P + (size_t) std::max(1, args.m));
+    if (lds > 160 * 1024) return 1;
+    static thread_local int configured_dev = -1;
+    int dev = 0;
+    HDM_HIP_CHECK(hipGetDevice(&dev));
+    if (configured_dev != dev) {
+        HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_small_check_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured_dev = dev;
+    }
+    hipLaunchKernelGGL(hdm_small_check_kernel, dim3(1), dim3(SM_T), lds, s, args);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 size_t hdm_small_lds_bytes() {
     return sizeof(double) * ((size_t) SMALL_P * (SMALL_P + 1) + SMALL_NDENSE * SMALL_P + 5 * SMALL_P + SMALL_P * SMALL_SPMAX + SMALL_P) +
            sizeof(int) * ((size_t) SMALL_P * SMALL_SPMAX + (SMALL_P + 4) + 2 * SMALL_P);
