@@ -17,7 +17,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libhdsdp_mi355x.so")
-SOURCES = ["gemm_f64.hip", "gemm_persist.hip", "chol.hip", "schur.hip", "lanczos.hip", "lu.hip", "small.hip", "engine.hip", "coeff.cpp", "sdpa.cpp"]
+SOURCES = ["gemm_f64.hip", "gemm_persist.hip", "chol.hip", "schur.hip", "lanczos.hip", "lu.hip", "small.hip", "engine.hip", "probes.hip", "coeff.cpp", "sdpa.cpp"]
 # every header under csrc/ is a dependency of every object (a header missing from a hand-kept list once left a stale
 # library in place after an edit)
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "hdsdp_mi355x.h")]
@@ -46,7 +46,8 @@ def build_library(force=False, verbose=True, diagnostics=False):
         objs.append(o)
         if not force and not _stale(o, [s] + hdrs):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", s, "-o", o]
+        # -fvisibility=hidden: the library exports what include/hdsdp_mi355x.h declares (default visibility there) and nothing else
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip", "-c", s, "-o", o]
         if diagnostics:
             cmd.insert(1, "-DHDM_DIAGNOSTICS")
         if verbose:

@@ -92,3213 +92,33 @@ int ensure_ctx() {
 }
 
 
-// ---- where a caller's wall time goes inside the library (HMiGetCallStats; HDSDP_MI355X_CALL_STATS=1 prints the table at
-// exit): only the caller's thread counts, and only the outermost entry (HKKTBuildUp calls the cones' slots, the cones
-// call HFpLinsys*), so the categories add up to the time the driver spent below the C ABI
-enum { ST_BUILD_M = 0, ST_BUILD_CORR, ST_FACTORIZE, ST_SOLVE, ST_ASSEMBLE_FACTOR, ST_RATIO, ST_PRIMAL_UTIL, ST_LINSYS, ST_N };
-const char *g_stat_name[ST_N] = {"HKKTBuildUp (M-forming types)", "HKKTBuildUp (corrector)", "HKKTFactorize", "HKKTSolve",
-                                 "cone: S assembly + factor (update, interior checks, barrier, line search)",
-                                 "cone: ratio test", "cone: primal recovery + utilities", "HFpLinsys* called by CPU cones"};
-double g_stat_sec[ST_N];
-long g_stat_calls[ST_N];
-// the same time by entry point (the outermost entry's function name), printed under the categories
-struct StatFn { const char *name; int k; double sec; long calls; double mx; };
-StatFn g_stat_fn[64];
-int g_stat_nfn = 0;
-thread_local int t_stat_depth = 0;
-static bool stat_trace() { static int t = -1; if (t < 0) { const char *e = getenv("HDSDP_MI355X_TRACE"); t = (e && atoi(e)) ? 1 : 0; } return t == 1; }
-struct StatScope {
-    int k;
-    bool on = false;
-    std::chrono::steady_clock::time_point t0;
-    const char *name;
-    StatScope(int k_, const char *name_) : k(k_), name(name_) {
-        if (t_ctx) return;                       // worker threads of a device group run below an entry that is already timed
-        on = (t_stat_depth++ == 0);
-        if (on) t0 = std::chrono::steady_clock::now();
-    }
-    ~StatScope() {
-        if (t_ctx) return;
-        --t_stat_depth;
-        if (on && stat_trace()) {                // HDSDP_MI355X_TRACE=1: drain the device after every entry and say which
-            const hipError_t e = hipDeviceSynchronize();
-            fprintf(stderr, "[hdsdp_mi355x trace] %s -> %s\n", name, e == hipSuccess ? "ok" : hipGetErrorName(e));
-        }
-        if (on) {
-            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            g_stat_sec[k] += dt;
-            g_stat_calls[k] += 1;
-            int f = 0;
-            while (f < g_stat_nfn && g_stat_fn[f].name != name) ++f;
-            if (f == g_stat_nfn && g_stat_nfn < 64) g_stat_fn[g_stat_nfn++] = StatFn{name, k, 0.0, 0, 0.0};
-            if (f < 64) { g_stat_fn[f].sec += dt; g_stat_fn[f].calls += 1; if (dt > g_stat_fn[f].mx) g_stat_fn[f].mx = dt; }
-        }
-    }
-};
-void stats_print_at_exit() {
-    double tot = 0.0;
-    for (int k = 0; k < ST_N; ++k) tot += g_stat_sec[k];
-    fprintf(stderr, "[hdsdp_mi355x] wall time below the C ABI: %.3f s\n", tot);
-    for (int k = 0; k < ST_N; ++k) {
-        if (!g_stat_calls[k]) continue;
-        fprintf(stderr, "[hdsdp_mi355x]   %-78s %8ld calls %10.3f s\n", g_stat_name[k], g_stat_calls[k], g_stat_sec[k]);
-        for (int f = 0; f < g_stat_nfn; ++f)
-            if (g_stat_fn[f].k == k)
-                fprintf(stderr, "[hdsdp_mi355x]       %-74s %8ld calls %10.3f s   (longest call %.1f ms)\n", g_stat_fn[f].name, g_stat_fn[f].calls,
-                        g_stat_fn[f].sec, 1e3 * g_stat_fn[f].mx);
-    }
-}
-
-#define HIP_RC(expr)                                                                             \
-    do {                                                                                         \
-        hipError_t _e = (expr);                                                                  \
-        if (_e != hipSuccess) {                                                                  \
-            fprintf(stderr, "[hdsdp_mi355x] HIP error %s at %s:%d\n", hipGetErrorName(_e), __FILE__, __LINE__); \
-            return HDSDP_RETCODE_FAILED;                                                         \
-        }                                                                                        \
-    } while (0)
-
-#define RC(x)                                    \
-    do {                                         \
-        if ((x) != 0) return HDSDP_RETCODE_FAILED; \
-    } while (0)
-
-// =============================================================================================
-// linear-system objects
-// =============================================================================================
-struct MiLin {
-    int n = 0;
-    linsys_type type = HDSDP_LINSYS_DENSE_DIRECT;
-    HdmChol ch;
-    double *work = nullptr;  // npad x npad device scratch (Invert)
-    double relTol = 0, absTol = 0;
-    int maxIter = -1;
-    // Schur systems: M lives here (device, ld = ch.npad) before factorisation
-    double *Mdev = nullptr;
-    // symmetric-indefinite fallback (HFpLinsysSwitchToIndefinite, hdsdp_linsolver.c:1827-1857): once switched, every
-    // later factorisation goes through the pivoted solver, like the reference's replaced vtable
-    HdmLu *lu = nullptr;
-    bool indef = false;
-    // sparse Schur operator: the factor object holds P M P' (perm[old] = new, a bandwidth-reducing order of the pattern);
-    // right-hand sides go in permuted and solutions come back in the caller's order.  Empty = identity.
-    std::vector<int> perm;
-    std::vector<double> pbuf;
-    const double *srcHost = nullptr, *srcDev = nullptr;   // where the last factorised matrix came from (lower valid)
-    long srcLd = 0;
-    // HDSDP_LINSYS_SPARSE_DIRECT (the reference's QDLDL backend for a sparse dual matrix, hdsdp_linsolver.c:509-809):
-    // the matrix arrives as a lower-triangular CSC and is factored densely on the device.  Result-equivalent for every
-    // caller: QDLDL's forward / backward solves carry the D^-1/2 scaling (:669-721), i.e. they ARE the Cholesky factor's,
-    // GetDiag returns sqrt(D) (:746-756), Invert the full inverse (:758-772); a fill-reducing order only changes the
-    // factor by an orthogonal similarity, which neither logdet nor the Lanczos spectrum sees.
-    bool csc_in = false;
-    std::vector<int> cscBeg, cscIdx;
-    std::vector<double> dense;
-};
-
-hdsdp_retcode lin_create(void **pchol, int nCol) {
-    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
-    MiLin *l = new MiLin();
-    l->n = nCol;
-    if (l->ch.init(nCol)) { delete l; return HDSDP_RETCODE_MEMORY; }
-    *pchol = l;
-    return HDSDP_RETCODE_OK;
-}
-void lin_setparam(void *chol, void *param) { (void) chol; (void) param; }
-hdsdp_retcode lin_symbolic(void *chol, int *colMatBeg, int *colMatIdx) {
-    MiLin *l = (MiLin *) chol;
-    if (l->csc_in && colMatBeg && colMatIdx) {   // keep the pattern: later calls may pass it again or not at all
-        l->cscBeg.assign(colMatBeg, colMatBeg + l->n + 1);
-        l->cscIdx.assign(colMatIdx, colMatIdx + colMatBeg[l->n]);
-    }
-    return HDSDP_RETCODE_OK;
-}
-// lower-triangular CSC -> dense n x n column-major (lower triangle valid), on the host: a format conversion of n^2 doubles
-const double *lin_densify(MiLin *l, const int *colMatBeg, const int *colMatIdx, const double *colMatElem) {
-    const int *beg = colMatBeg ? colMatBeg : (l->cscBeg.empty() ? nullptr : l->cscBeg.data());
-    const int *idx = colMatIdx ? colMatIdx : (l->cscIdx.empty() ? nullptr : l->cscIdx.data());
-    if (!beg || !idx || !colMatElem) return nullptr;
-    const size_t n = (size_t) l->n;
-    l->dense.assign(n * n, 0.0);
-    for (size_t j = 0; j < n; ++j)
-        for (int p = beg[j]; p < beg[j + 1]; ++p) {
-            const size_t i = (size_t) idx[p];
-            if (i >= j) l->dense[i + j * n] = colMatElem[p];
-            else l->dense[j + i * n] = colMatElem[p];     // an upper entry, should a caller hand one over
-        }
-    return l->dense.data();
-}
-
-hdsdp_retcode lin_factor_host(MiLin *l, const double *A, int *info) {
-    RC(l->ch.load_host(A, l->n, g.stream));
-    RC(l->ch.factor(g.stream, info));
-    return HDSDP_RETCODE_OK;
-}
-// lapackIndefiniteLinSolverNumeric (hdsdp_linsolver.c:1706-1727): copy + pivoted factorisation; a singular matrix fails
-hdsdp_retcode lin_factor_indef(MiLin *l) {
-    if (!l->lu) {
-        l->lu = new HdmLu();
-        if (l->lu->init(l->n)) { l->lu->destroy(); delete l->lu; l->lu = nullptr; return HDSDP_RETCODE_MEMORY; }
-    }
-    if (l->srcDev) RC(l->lu->load_device_lower(l->srcDev, l->srcLd, g.stream));
-    else if (l->srcHost) RC(l->lu->load_host_lower(l->srcHost, l->srcLd, g.stream));
-    else return HDSDP_RETCODE_FAILED;
-    int info = 0;
-    RC(l->lu->factor(g.stream, &info));
-    return info == 0 ? HDSDP_RETCODE_OK : HDSDP_RETCODE_FAILED;
-}
-// linalg/hdsdp_linsolver.c:1082-1110 (copy + dpotrf; info != 0 is a failure here)
-hdsdp_retcode lin_numeric(void *chol, int *colMatBeg, int *colMatIdx, double *colMatElem) {
-    MiLin *l = (MiLin *) chol;
-    if (l->csc_in) {
-        colMatElem = const_cast<double *>(lin_densify(l, colMatBeg, colMatIdx, colMatElem));
-        if (!colMatElem) return HDSDP_RETCODE_FAILED;
-    }
-    l->srcHost = colMatElem; l->srcDev = nullptr; l->srcLd = l->n;
-    if (l->indef) return lin_factor_indef(l);
-    int info = 0;
-    if (lin_factor_host(l, colMatElem, &info) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
-    return info == 0 ? HDSDP_RETCODE_OK : HDSDP_RETCODE_FAILED;
-}
-// HFpLinsysSwitchToIndefinite (hdsdp_linsolver.c:1827-1857): only the Schur system (DENSE_ITERATIVE) has this way out;
-// the matrix is re-read from where the failed factorisation took it
-hdsdp_retcode lin_switch_indefinite(hdsdp_linsys_fp *HLin) {
-    MiLin *l = (MiLin *) HLin->chol;
-    HLin->LinType = HDSDP_LINSYS_DENSE_INDEFINITE;
-    l->indef = true;
-    return lin_factor_indef(l);
-}
-// linalg/hdsdp_linsolver.c:1112-1144 (info > 0 => "not PSD" is a value, not an error)
-hdsdp_retcode lin_psdcheck(void *chol, int *colMatBeg, int *colMatIdx, double *colMatElem, int *isPsd) {
-    MiLin *l = (MiLin *) chol;
-    if (l->csc_in) {
-        colMatElem = const_cast<double *>(lin_densify(l, colMatBeg, colMatIdx, colMatElem));
-        if (!colMatElem) return HDSDP_RETCODE_FAILED;
-    }
-    if (l->indef) return HDSDP_RETCODE_FAILED;   // :1729-1739, no PSD check on the pivoted factor
-    int info = 0;
-    if (lin_factor_host(l, colMatElem, &info) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
-    *isPsd = (info == 0) ? 1 : 0;
-    return HDSDP_RETCODE_OK;
-}
-// :1146-1196 dtrsm with L / L^T ; solVec == NULL => in place
-void lin_fsolve(void *chol, int nRhs, double *rhs, double *sol) {
-    MiLin *l = (MiLin *) chol;
-    if (l->indef) return;                        // :1741-1759, no half solves with the pivoted factor
-    // the slot returns void (hdsdp_linsolver.h:22): a device failure can only be reported, and poisons the output so that
-    // the caller's next NaN check (e.g. HFpLinsysSolve, :2085-2110) sees it
-    if (l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 1, g.stream)) {
-        fprintf(stderr, "[hdsdp_mi355x] forward substitution failed on the device\n");
-        (sol ? sol : rhs)[0] = NAN;
-    }
-}
-void lin_bsolve(void *chol, int nRhs, double *rhs, double *sol) {
-    MiLin *l = (MiLin *) chol;
-    if (l->indef) return;
-    if (l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 2, g.stream)) {
-        fprintf(stderr, "[hdsdp_mi355x] backward substitution failed on the device\n");
-        (sol ? sol : rhs)[0] = NAN;
-    }
-}
-// :1198-1225 dpotrs
-hdsdp_retcode lin_solve(void *chol, int nRhs, double *rhs, double *sol) {
-    MiLin *l = (MiLin *) chol;
-    if (l->indef) {                              // :1761-1780 dsytrs
-        if (!l->lu || !l->lu->factored) return HDSDP_RETCODE_FAILED;
-        RC(l->lu->solve_host(rhs, sol ? sol : rhs, nRhs, g.stream));
-        return HDSDP_RETCODE_OK;
-    }
-    if (!l->ch.factored) return HDSDP_RETCODE_FAILED;
-    if (!l->perm.empty()) {
-        const int n = l->n;
-        double *out = sol ? sol : rhs;
-        l->pbuf.resize((size_t) n * nRhs);
-        for (int r = 0; r < nRhs; ++r)
-            for (int i = 0; i < n; ++i) l->pbuf[(size_t) r * n + l->perm[i]] = rhs[(size_t) r * n + i];
-        RC(l->ch.solve_host(l->pbuf.data(), l->pbuf.data(), nRhs, 0, g.stream));
-        for (int r = 0; r < nRhs; ++r)
-            for (int i = 0; i < n; ++i) out[(size_t) r * n + i] = l->pbuf[(size_t) r * n + l->perm[i]];
-        return HDSDP_RETCODE_OK;
-    }
-    RC(l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 0, g.stream));
-    return HDSDP_RETCODE_OK;
-}
-// :1227-1236
-hdsdp_retcode lin_getdiag(void *chol, double *diag) {
-    MiLin *l = (MiLin *) chol;
-    if (l->indef) return HDSDP_RETCODE_FAILED;   // :1782-1788
-    RC(l->ch.get_diag(diag, g.stream));
-    return HDSDP_RETCODE_OK;
-}
-// :1238-1260 dpotri + HUtilMatSymmetrize: full symmetric inverse into dFullMatrix (n x n)
-void lin_invert(void *chol, double *dFull, double *) {
-    MiLin *l = (MiLin *) chol;
-    if (l->indef) return;                        // :1790-1797
-    HdmChol &c = l->ch;
-    if (!l->work) {
-        if (hipMalloc((void **) &l->work, sizeof(double) * (size_t) c.npad * c.npad) != hipSuccess) return;
-    }
-    if (c.inverse_full(l->work, c.npad, g.stream)) return;
-    (void) hipMemcpy2DAsync(dFull, sizeof(double) * c.n, l->work, sizeof(double) * c.npad, sizeof(double) * c.n, c.n,
-                            hipMemcpyDeviceToHost, g.stream);
-    (void) hipStreamSynchronize(g.stream);
-}
-void lin_destroy(void **pchol) {
-    if (!pchol || !*pchol) return;
-    MiLin *l = (MiLin *) *pchol;
-    l->ch.destroy();
-    if (l->lu) { l->lu->destroy(); delete l->lu; }
-    if (l->work) (void) hipFree(l->work);
-    if (l->Mdev) (void) hipFree(l->Mdev);
-    delete l;
-    *pchol = nullptr;
-}
-
-// =============================================================================================
-// MI355X SDP cone
-// =============================================================================================
-enum { PATH_GEMM = 0, PATH_R1 = 1, PATH_SPARSE = 2 };
-
-struct MiKKTPriv;
-
-struct MiCone {
-    int n = 0, m = 0;          // block dimension, global number of constraints
-    int rank = 0, world = 1;   // row sharding: constraint i is owned by rank i % world
-    int mloc = 0;              // constraints owned here
-    int n16 = 0;               // n rounded up to 16 (MFMA sub-tile)
-    int nblk = 0;              // n16 / 16
-    long npb = 0;              // p-blocks of the blocked congruence layout: nblk(nblk+1)/2 * 16
-    long npb_loc = 0;          // p-blocks per rank (K range of the local Gram part)
-    int Lr = 0;                // rows per segment of the Gram operand (local rows + 3 augmented, padded)
-    int path = PATH_GEMM;
-    bool synthetic = false;
-    MiBlockData blk;           // presolve results (empty rows for synthetic)
-    std::vector<int> own;      // global indices of the owned constraints
-    // device data
-    double *Afull = nullptr;   // mloc x (n16 x n16) constraint matrices in A_L form: strict lower + half diagonal
-    double *Cfull = nullptr;   // n16 x n16 objective, full symmetric
-    double *CL = nullptr;      // objective in A_L form (GEMM path, HSD builds)
-    double *Avec = nullptr;    // n16 x mloc16 rank-one factors (R1 path)
-    double *sgn = nullptr;     // mloc signs (R1 path)
-    int mloc16 = 0;
-    long astride = 0;          // elements per constraint matrix in Afull (skyline storage of the A_L form, hdm_common.h)
-    int *sp_rp = nullptr, *sp_ti = nullptr, *sp_tj = nullptr;  // sparse path: triplets of the owned rows
-    double *sp_tv = nullptr;
-    int *rows_seg = nullptr;   // world*Lr: segment-ordered Gram row -> global constraint (-1 pad, -2.. aug)
-    int *rows_own = nullptr;   // mloc: owned row -> global constraint
-    double *S = nullptr, *Scheck = nullptr;  // n x n (ld n16) dual matrix buffers
-    double *ydev = nullptr;
-    double *yhost = nullptr;   // pinned staging of the owned multipliers (the upload is asynchronous)
-    double *chk_host = nullptr, *chk_dev = nullptr;   // mapped pinned block of the single-launch small-block check: y[mloc], then info, log det
-    bool fac_ok = false; int fac_psd = 0;             // the dual factor object holds the factorisation of S = T(pS) (result: fac_psd)
-    double *corr = nullptr;    // sharded corrector build: this cone's 2m dot products before they join the operator's
-    hdsdp_linsys_fp *dualFactor = nullptr;
-    HdmChol *primal = nullptr; // KKT_TYPE_PRIMAL: factor object of the registered primal matrix (lazy)
-    HdmLanczos *lanczos = nullptr;  // ratio test state (lazy); dS lives in `dS`
-    double nrm[4] = {0, 0, 0, 0}; bool norms_ready = false;   // data norms (rows abs / Frobenius, objective abs / Frobenius)
-    double objScal = 1.0;           // product of the coneScal factors applied to C
-    HdmChol *checker = nullptr;     // second factor object (primal recovery works on S without the residual term)
-    double *dS = nullptr;
-    double *Xup = nullptr;          // uploaded primal matrix of the cone utilities
-    double *Pr1 = nullptr, *Pr2 = nullptr;   // primal recovery scratch (npad x npad each; Xinv / Yinv are sized per builder path)
-    double Rd = 0.0, perturb = 0.0;
-    double *trA = nullptr;     // host: tr(A_i) of all m constraints (b of the synthetic family)
-    // work space
-    int Bc = 8;                // constraints per congruence batch
-    double *T = nullptr;       // Bc x n16 x n16
-    double *AhatLoc = nullptr; // [world*npb_loc][Lr][16] congruence output of the owned rows
-    double *AhatAll = nullptr; // [world][npb_loc][Lr][16] after the transpose (== AhatLoc when world == 1)
-    bool ext_ahat = false;     // buffers supplied by the caller (torch-owned, for RCCL)
-    double *slabs = nullptr;   // nsplit x R x R
-    double *Gm = nullptr;      // R x R augmented Gram (lower valid)
-    int nsplit = 1;
-    long R = 0;                // world * Lr
-    // R1 work
-    double *U = nullptr, *V = nullptr, *Gr1 = nullptr, *Ct = nullptr, *W = nullptr, *Xinv = nullptr, *Yinv = nullptr;
-    // exchange hooks (world > 1)
-    hmi_alltoall_fn alltoall = nullptr;
-    hmi_alltoall_piece_fn a2a_start = nullptr;   // piecewise exchange overlapped with the Gram product (optional)
-    hmi_alltoall_wait_fn a2a_wait = nullptr;
-    int a2a_pieces = 1;
-    hipEvent_t piece_ev[64] = {};                // staged exchange: congruence step 2 finished the p-blocks of piece k
-    int last_pieces = 1, last_staged = 0;        // HMiConeGetExchangeStats
-    hmi_allreduce_fn allreduce = nullptr;
-    void *xctx = nullptr;
-    bool work_ready = false;
-    bool shared_ts = false;    // T and the Gram slabs are one buffer (one GPU): T's diagonal-tile uppers are re-zeroed per batch
-    // single-process multi-device mode: the shards of one block share ONE Schur operator (the caller's); only shard 0
-    // writes into it, the others stop after the all-reduce
-    bool kkt_owner = true;
-    int kkt_counted = 0;       // progress of the aggregated-pattern queries (cone_add_sym_nz)
-    // Where the dual matrix and the step matrix stand (single-device blocks): S = T(pS), dS = T(pD) for the linear map
-    // T(tau, y, eye) = tau C - sum y_i A_i + eye I.  A request for T(p) with p = pS + alpha pD is answered by S + alpha dS
-    // (one pass over n^2) instead of a sweep over all m constraint matrices (cone_assemble).
-    std::vector<double> pS, pD;          // tau, eye, then the mloc multipliers
-    bool pS_ok = false, pD_ok = false;
-    int aff_chain = 0;                   // updates of S in place since its last full assembly
-    // fused single-launch Phase-A pass of a small rank-one block (small.hip): factors as a CSR, built on first use
-    struct SmallPlan {
-        int state = 0;         // 0 = not looked at, 1 = ready, -1 = not eligible
-        int *fp = nullptr, *fi = nullptr, *dense_of = nullptr, *dense_rows = nullptr;
-        double *fv = nullptr, *sgn = nullptr;
-        int ndense = 0;
-        double *io_host = nullptr, *io_dev = nullptr;   // mapped pinned block: y[m], b[m] in; 4 + 5 m doubles out
-    } small;
-};
-
-struct MiKKTPriv {
-    int mirror = 1;
-    double *vecs = nullptr;   // device: ASinv[m], ASinvRdSinv[m], ASinvCSinv[m], scal[4]
-    double *rhs = nullptr;
-    bool Mdev_valid = false;  // device M holds the result of the last BuildUp
-    // cones of HKKT->cones[] whose coneBuildSchur is this engine's (they accumulate on the device) and the others (the
-    // reference's CPU cones: they accumulate into the host fields, hdsdp_conic_*.c)
-    int n_engine = 0, n_foreign = 0;
-    double *Mtmp = nullptr;   // pinned m x m staging buffer for the mixed case (device part added to the host part)
-    // sparse Schur operator (isKKTSparse, hdsdp_schur.c:46-139): the host matrix is the aggregated CSC pattern; its
-    // entries as (row, column) pairs on the device, plus a staging vector of nnz values
-    long nnz = 0;
-    int *sp_rows = nullptr, *sp_cols = nullptr;
-    int *sp_prow = nullptr, *sp_pcol = nullptr;   // the same entries in the factor object's (permuted, lower) coordinates, if it is permuted
-    double *sp_vals = nullptr;
-};
-
-// the kkt private state hangs off kktM->chol's MiLin (Mdev) plus a side struct keyed by the kkt pointer
-std::vector<std::pair<hdsdp_kkt *, MiKKTPriv *>> g_priv;
-MiKKTPriv *priv_of(hdsdp_kkt *k) {
-    for (auto &p : g_priv)
-        if (p.first == k) return p.second;
-    MiKKTPriv *n = new MiKKTPriv();
-    g_priv.push_back({k, n});
-    return n;
-}
-void priv_drop(hdsdp_kkt *k) {
-    for (size_t i = 0; i < g_priv.size(); ++i)
-        if (g_priv[i].first == k) {
-            if (g_priv[i].second->vecs) (void) hipFree(g_priv[i].second->vecs);
-            if (g_priv[i].second->rhs) (void) hipFree(g_priv[i].second->rhs);
-            if (g_priv[i].second->Mtmp) (void) hipHostFree(g_priv[i].second->Mtmp);
-            if (g_priv[i].second->sp_rows) (void) hipFree(g_priv[i].second->sp_rows);
-            if (g_priv[i].second->sp_prow) (void) hipFree(g_priv[i].second->sp_prow);
-            if (g_priv[i].second->sp_pcol) (void) hipFree(g_priv[i].second->sp_pcol);
-            if (g_priv[i].second->sp_cols) (void) hipFree(g_priv[i].second->sp_cols);
-            if (g_priv[i].second->sp_vals) (void) hipFree(g_priv[i].second->sp_vals);
-            delete g_priv[i].second;
-            g_priv.erase(g_priv.begin() + i);
-            return;
-        }
-}
-
-// single-process multi-device mode (group_impl.h): a group cone's slots fan out to one MiCone per device
-hdsdp_retcode gc_build_schur(void *cd, int iCone, void *kktv, int typeKKT);
-MiCone *cone_data(hdsdp_cone *cone);   // the block's device data; for a group cone that of shard 0
-int group_configure_from_env();
-bool group_wants_block(int nRow, int nCol, const int *beg, const int *idx, const double *val);
-hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *beg, const int *idx,
-                                const double *val, bool synthetic);
-
-int cone_alloc_common(MiCone *c) {
-    c->n16 = (int) hdm_roundup(c->n, 16);
-    c->astride = hdm_sky_size(c->n16);
-    c->nblk = c->n16 / 16;
-    c->npb = (long) c->nblk * (c->nblk + 1) / 2 * 16;
-    c->npb_loc = (c->npb + c->world - 1) / c->world;
-    c->own.clear();
-    // One GPU: constraints that are zero on this block (most of them in a many-block problem; the reference's
-    // "sparse SDP cone", hdsdp_conic_sdp.c:1814-1886, loops over the non-zero ones only) are left out of the device
-    // data altogether: no congruence, no Gram rows, nothing written to their rows of M.  Sharded blocks keep the plain
-    // cyclic deal (row i on rank i % world) that the exchange layout is built on.
-    const bool compact = (c->world == 1 && !c->synthetic && (int) c->blk.rows.size() == c->m);
-    for (int i = c->rank; i < c->m; i += c->world)
-        if (!compact || c->blk.rows[i].type != MI_COEFF_ZERO) c->own.push_back(i);
-    c->mloc = (int) c->own.size();
-    int maxloc = compact ? c->mloc : (c->m + c->world - 1) / c->world;
-    c->Lr = (c->world == 1) ? (int) hdm_roundup(maxloc + 3, 8) : (int) hdm_roundup(maxloc + 3, HDM_TILE);
-    c->R = (long) c->world * c->Lr;
-    const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
-    HDM_HIP_CHECK(hipMalloc((void **) &c->S, nn));
-    HDM_HIP_CHECK(hipMalloc((void **) &c->Scheck, nn));
-    HDM_HIP_CHECK(hipMalloc((void **) &c->Cfull, nn));
-    HDM_HIP_CHECK(hdm_memset_sync(c->Cfull, 0, nn));
-    HDM_HIP_CHECK(hipMalloc((void **) &c->ydev, sizeof(double) * (size_t) std::max(1, c->m)));
-    std::vector<int> rs((size_t) c->R, -1);
-    for (int gq = 0; gq < c->world; ++gq) {
-        int cnt = 0;
-        if (compact) { for (int i : c->own) rs[cnt++] = i; }
-        else for (int i = gq; i < c->m; i += c->world) rs[(size_t) gq * c->Lr + cnt++] = i;
-        if (gq == 0) { rs[cnt] = -2; rs[cnt + 1] = -3; rs[cnt + 2] = -4; }  // I, S, C rows
-    }
-    HDM_HIP_CHECK(hipMalloc((void **) &c->rows_seg, sizeof(int) * (size_t) c->R));
-    HDM_HIP_CHECK(hdm_memcpy_h2d_sync(c->rows_seg, rs.data(), sizeof(int) * (size_t) c->R));
-    HDM_HIP_CHECK(hipMalloc((void **) &c->rows_own, sizeof(int) * (size_t) std::max(1, c->mloc)));
-    HDM_HIP_CHECK(hdm_memcpy_h2d_sync(c->rows_own, c->own.data(), sizeof(int) * (size_t) c->mloc));
-    if (HFpLinsysCreate(&c->dualFactor, c->n, HDSDP_LINSYS_DENSE_DIRECT) != HDSDP_RETCODE_OK) return 1;
-    return 0;
-}
-
-int cone_alloc_gemm_work(MiCone *c) {
-    const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
-    // batch size: as many constraints per launch as 32 GiB of intermediates allow, at most 1024 (each launch pays a
-    // dispatch ramp and a tail: measured step time 400.9 / 396.8 / 393.2 / 393.2 ms at 256 / 512 / 1000 / 2000 per launch on
-    // one box).  The launches are evened out (2000 rows -> 2 x 1000, a rank's 250 rows -> one launch); the kernel's
-    // XCD-local decode pads a batch to a multiple of 8 itself.  If the allocation fails the batch is halved.
-    long tcap = 32;   // GiB of intermediates
-    if (const char *e = getenv("HDM_TCAP_GIB")) tcap = atol(e);
-    long bc = (long) (((double) tcap * (1L << 30)) / (double) nn);
-    long bcmax = 1024;
-    if (const char *e = getenv("HDM_BC")) bcmax = atol(e);
-    bc = std::max(1L, std::min(bc, bcmax));
-    const long rows = std::max(1, c->mloc);
-    for (;;) {
-        const long launches = (rows + bc - 1) / bc;
-        bc = (rows + launches - 1) / launches;
-        c->Bc = (int) bc;
-        if (hipMalloc((void **) &c->T, nn * (size_t) c->Bc + hdm_operand_pad(c->n16)) == hipSuccess) break;
-        (void) hipGetLastError();
-        c->T = nullptr;
-        if (bc <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the congruence intermediates\n"); return 1; }
-        bc /= 2;
-    }
-    HDM_HIP_CHECK(hdm_memset_sync(c->T, 0, nn * (size_t) c->Bc));  // step 1 writes lower tiles only; the rest must read as 0
-    const size_t ahat = sizeof(double) * (size_t) c->world * c->npb_loc * c->Lr * 16;
-    if (!c->AhatLoc) {
-        HDM_HIP_CHECK(hipMalloc((void **) &c->AhatLoc, ahat + sizeof(double) * HDM_OPERAND_PAD_DOUBLES));
-        HDM_HIP_CHECK(hdm_memset_sync(c->AhatLoc, 0, ahat));
-        if (c->world == 1) c->AhatAll = c->AhatLoc;
-        else {
-            HDM_HIP_CHECK(hipMalloc((void **) &c->AhatAll, ahat + sizeof(double) * HDM_OPERAND_PAD_DOUBLES));
-            HDM_HIP_CHECK(hdm_memset_sync(c->AhatAll, 0, ahat));
-        }
-    }
-    // Gram split-K: the grid is tiles x nsplit workgroups on 512 resident slots (256 CUs x 2).  The split index
-    // is the fast workgroup index, and workgroups are dealt round-robin over the 8 XCDs: with nsplit a multiple
-    // of 8 every XCD keeps to its own K ranges, so the ~64 tiles it runs concurrently share their row/column
-    // panels in that XCD's L2 (profiles/r01_a: with nsplit = 15 the Gram kernel fetched 513 GB per launch,
-    // i.e. every tile load went to the fabric).  Short K ranges (small problems): among the multiples of 8 pick the
-    // one whose last scheduling round is fullest; long K ranges are handled below.
-    const long RT = (c->R + HDM_TILE - 1) / HDM_TILE;
-    const long tiles = RT * (RT + 1) / 2;
-    const long kblocks = c->npb_loc;
-    const long slab_cap = std::max(1L, (long) ((4LL << 30) / (sizeof(double) * (double) c->R * c->R)));  // <= 4 GiB of slabs
-    const long kcap = std::max(1L, kblocks / 64);
-    long ns = 1;
-    double best = -1.0;
-    for (long cand = 1; cand <= 64 && cand <= slab_cap && cand <= kcap; ++cand) {
-        if (cand > 8 && cand % 8) continue;
-        const double rounds = (double) (tiles * cand) / 512.0;
-        double eff = rounds / std::ceil(rounds);
-        if (rounds < 2.0) eff *= 0.5 + 0.25 * rounds;  // too few workgroups to hide the tail
-        if (cand < 8 && kcap >= 8 && slab_cap >= 8) eff *= 0.5;  // prefer XCD-aligned splits when possible
-        if (eff > best + 1e-9) { best = eff; ns = cand; }
-    }
-    // Long K ranges: many SHORT splits.  Co-resident workgroups progress at slightly different rates (about 2 %), so
-    // over a long tile they drift out of the few-stage window in which the XCD's L2 still holds a neighbour's operand
-    // panel; with short tiles every round restarts aligned.  Measured Gram kernel at n = m = 2000: 129.9 / 124.6 /
-    // 121.1 / 116.6 ms at 64 / 256 / 512 / 1024 splits.  The price is nsplit x R^2 doubles of slabs (<= 40 GiB).
-    {
-        const long big_cap = (long) ((40LL << 30) / (sizeof(double) * (double) c->R * c->R));
-        const long byk = kblocks / 96;   // >= 96 k blocks (of 16) per workgroup keeps prologue + epilogue under 4 %
-        if (byk >= 128) {
-            const long big = std::min(std::min(1024L, byk), big_cap) & ~7L;
-            if (big > ns) ns = big;
-        }
-    }
-    if (const char *e = getenv("HDM_NSPLIT")) ns = std::max(1L, std::min(atol(e), kblocks / 16));   // A/B knob
-    // One GPU: the congruence intermediates T are dead by the time the Gram product writes its split-K slabs, so the two
-    // share ONE buffer (the larger of the two sizes: 33 GB instead of 32 + 33 GB at n = m = 2000).  The only thing step 2
-    // reads of T that step 1 does not write is the strict upper triangle of T's diagonal tiles: with the buffer shared
-    // it is re-zeroed before every batch (hdm_zero_diag_upper, 1 GB of stores per 1000 matrices) instead of once at
-    // allocation.  Sharded builds keep them apart: there the Gram splits of the early exchange pieces run while step 2
-    // still reads T for the later ones.  HDM_SHARE_T_SLABS=0 keeps two buffers (A/B runs).
-    bool share = (c->world == 1);
-    if (const char *e = getenv("HDM_SHARE_T_SLABS")) share = share && atoi(e) != 0;
-    if (share) {
-        const size_t tbytes = nn * (size_t) c->Bc + hdm_operand_pad(c->n16);
-        for (;;) {
-            c->nsplit = (int) ns;
-            const size_t sbytes = sizeof(double) * (size_t) c->R * c->R * c->nsplit;
-            if (sbytes <= tbytes) { c->slabs = c->T; c->shared_ts = true; break; }
-            // the slabs are the bigger of the two: one buffer of their size serves both
-            (void) hipFree(c->T);
-            c->T = nullptr;
-            if (hipMalloc((void **) &c->T, sbytes + hdm_operand_pad(c->n16)) == hipSuccess) { c->slabs = c->T; c->shared_ts = true; break; }
-            (void) hipGetLastError();
-            if (hipMalloc((void **) &c->T, tbytes) != hipSuccess) { (void) hipGetLastError(); c->T = nullptr; return 1; }
-            if (ns <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the Gram slabs\n"); return 1; }
-            ns = std::max(8L, (ns / 2) & ~7L);
-        }
-    }
-    // the slabs are the one allocation here that is a tuning choice: halve the split count until it fits
-    for (; !c->shared_ts;) {
-        c->nsplit = (int) ns;
-        if (hipMalloc((void **) &c->slabs, sizeof(double) * (size_t) c->R * c->R * c->nsplit) == hipSuccess) break;
-        (void) hipGetLastError();
-        c->slabs = nullptr;
-        if (ns <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the Gram slabs\n"); return 1; }
-        ns = std::max(8L, (ns / 2) & ~7L);
-    }
-    HDM_HIP_CHECK(hipMalloc((void **) &c->Gm, sizeof(double) * (size_t) c->R * c->R));
-    // the "S row" (At = I) never changes
-    if (c->rank == 0) {
-        if (hdm_blocked_eye(c->AhatLoc, c->Lr, c->mloc + 1, c->nblk, c->n, g.stream)) return 1;
-    }
-    return 0;
-}
-
-// --- vtable slots ---------------------------------------------------------------------------
-void cone_setstart(void *cd, double rResi) { ((MiCone *) cd)->Rd = rResi; }  // hdsdp_conic_sdp.c:1546-1550
-int cone_getdim(void *cd) { return ((MiCone *) cd)->n; }
-// rows of M this block contributes to: all m for a dense block (:1404-1405), the k rows on which the block has data for
-// a block most constraints are zero on (the reference's sparse SDP cone, :1479-1480) -- what HKKTInit weighs against
-// 0.3 m^2 when it chooses between the dense Schur matrix and the aggregated-pattern CSC
-int cone_kkt_rows(const MiCone *c) {
-    const bool compact = (c->world == 1 && !c->synthetic && (int) c->blk.rows.size() == c->m);
-    // the reference makes a block a sparse SDP cone iff at most 0.3 m of the constraints have data on it
-    // (HUserDataChooseCone, hdsdp_user_data.c:82-86; HDSDP_SPARSE_CONE_THRESHOLD); its dense cone claims all of M
-    return (compact && (double) c->mloc <= 0.3 * (double) c->m) ? c->mloc : c->m;
-}
-int64_t cone_getsymnnz(void *cd) { MiCone *c = (MiCone *) cd; const int64_t k = cone_kkt_rows(c); return k * k; }
-// the two pattern queries of HKKTAllocSparseKKT (hdsdp_schur.c:46-139), with the protocol of the reference's sparse SDP
-// cone (sdpSparseConeAddSymNnzImpl / sdpSparseConeGetSymMapping, hdsdp_conic_sdp.c:2086-2170): columns are visited in
-// order; in the column of its next row the block marks that row and all its later ones.  The positions handed back in
-// the second call are not kept: the engine's builders write a dense device matrix at global (row, column) indices and
-// the operator gathers the pattern's entries from it.
-void cone_add_sym_nz(void *cd, int iCol, int *schurMatCol) {
-    MiCone *c = (MiCone *) cd;
-    if (c->kkt_counted >= c->mloc || c->own[c->kkt_counted] != iCol) return;
-    for (int e = c->kkt_counted; e < c->mloc; ++e) schurMatCol[c->own[e]] = 1;
-}
-void cone_get_kkt_map(void *cd, int iCol, int *schurMatCol) {
-    (void) schurMatCol;
-    MiCone *c = (MiCone *) cd;
-    if (c->kkt_counted < c->mloc && c->own[c->kkt_counted] == iCol) c->kkt_counted += 1;
-}
-
-// S <- tau*C - sum y_i A_i - Rd*I (+ perturb)   hdsdp_conic_sdp.c:343-402, :1616-1633
-// Sharded: every rank sums its own rows (rank 0 also adds tau*C and the identity term), then all-reduce.
-int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, const double *eye_override = nullptr) {
-    // the upload below is asynchronous: the source is a pinned buffer of the cone, and the previous upload from it has
-    // been consumed by the time it is rewritten (every caller synchronises on the factorisation that follows)
-    if (!c->yhost) HDM_HIP_CHECK(hipHostMalloc((void **) &c->yhost, sizeof(double) * (size_t) std::max(1, c->mloc), hipHostMallocDefault));
-    HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
-    double *yo = c->yhost;
-    bool any = false;
-    for (int q = 0; q < c->mloc; ++q) { yo[q] = y_host ? y_host[c->own[q]] : 0.0; any |= (yo[q] != 0.0); }
-    const double eye_now = eye_override ? *eye_override : (-c->Rd + c->perturb);
-    // ---- shortcut (see MiCone::pS).  The reference's line searches and correctors ask for the dual matrix twice at the same
-    // point (interior check, then barrier) and at points y + alpha dy along the direction whose dS the ratio test has just
-    // assembled: each a 32 GB sweep at n = m = 2000 (6 ms), 14 % of a whole solve's device time.  The request is compared
-    // with what the buffers hold, component by component; anything else takes the sweep.
-    // 1: only the exact case -- the same point again -- is short-cut, so every number is the one a sweep would have produced.
-    // 2: also points on the line through the last ratio test's direction (S + alpha dS); the results then differ from a
-    // sweep's in the last bits (as a sweep's differ from the reference's own summation order).  0: off.
-    // Default: 2 where a sweep costs something -- 16 MiB of constraint data or more, i.e. from about n = m = 160 on; at
-    // n = m = 2000 the reference's line searches and correctors ask for 344 such points per solve, 6 ms each -- and 1 on
-    // small blocks, where the sweep is free and the end game of a badly conditioned instance can turn on the last bits
-    // (gpp100 through the reference's driver in mode 2: same dual objective, a primal estimate 3e-4 further away).
-    // HDSDP_MI355X_AFFINE_S=0/1/2 overrides.
-    static const int aff_env = [] { const char *e = getenv("HDSDP_MI355X_AFFINE_S"); return e ? atoi(e) : -1; }();
-    const long sweep_bytes = (long) c->mloc * c->n * (c->n + 1) * 4;
-    const int aff_mode = aff_env >= 0 ? aff_env : (sweep_bytes >= (16L << 20) ? 2 : 1);
-    const bool track = aff_mode > 0 && c->world == 1;
-    if (track && target != c->dS && c->pS_ok) {
-        const int np = c->mloc + 2;
-        auto comp = [&](int i) { return i == 0 ? tau : i == 1 ? eye_now : yo[i - 2]; };
-        bool same = true;
-        for (int i = 0; i < np && same; ++i) same = (comp(i) == c->pS[i]);
-        if (same && target == c->S) return 0;                                  // S already is T(p)
-        double alpha = 0.0;
-        bool hit = same;
-        if (!same && c->pD_ok && aff_mode >= 2) {
-            int kmax = 0;
-            for (int i = 1; i < np; ++i) if (fabs(c->pD[i]) > fabs(c->pD[kmax])) kmax = i;
-            if (c->pD[kmax] != 0.0) {
-                alpha = (comp(kmax) - c->pS[kmax]) / c->pD[kmax];
-                hit = std::isfinite(alpha);
-                for (int i = 0; i < np && hit; ++i) {
-                    const double d = comp(i) - c->pS[i], e = alpha * c->pD[i];
-                    hit = fabs(d - e) <= 1.8e-15 * (fabs(comp(i)) + fabs(c->pS[i]) + fabs(e));
-                }
-            }
-        }
-        if (hit && same) {                                                     // the same point into the other buffer: a copy
-            HDM_HIP_CHECK(hipMemcpyAsync(target, c->S, sizeof(double) * (size_t) c->n16 * c->n16, hipMemcpyDeviceToDevice, g.stream));
-            return 0;
-        }
-        if (hit && c->dS && (target != c->S || c->aff_chain < 16)) {
-            if (hdm_axpy_mat(target, c->S, c->dS, alpha, (long) c->n16 * c->n16, g.stream)) return 1;
-            if (target == c->S) {
-                for (int i = 0; i < np; ++i) c->pS[i] = comp(i);
-                c->aff_chain += 1;
-            }
-            return 0;
-        }
-    }
-    HDM_HIP_CHECK(hipMemcpyAsync(c->ydev, yo, sizeof(double) * c->mloc, hipMemcpyHostToDevice, g.stream));
-    if (track && (target == c->S || target == c->dS)) {
-        std::vector<double> &pp = (target == c->S) ? c->pS : c->pD;
-        pp.resize((size_t) c->mloc + 2);
-        pp[0] = tau; pp[1] = eye_now;
-        for (int q = 0; q < c->mloc; ++q) pp[2 + q] = yo[q];
-        (target == c->S ? c->pS_ok : c->pD_ok) = true;
-        if (target == c->S) c->aff_chain = 0;
-    }
-    const double lead = (c->rank == 0) ? 1.0 : 0.0;
-    if (hdm_sym_combine(c->Afull, c->astride, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
-                        lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)), target, c->n, c->n16, c->n16, g.stream)) return 1;
-    if (c->world > 1) {
-        HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
-        if (!c->allreduce || c->allreduce(c->xctx, target, (int64_t) c->n16 * c->n16)) return 1;
-    }
-    return 0;
-}
-
-hdsdp_retcode cone_factor_S(MiCone *c, int *isPsd);
-hdsdp_retcode cone_factor_check(MiCone *c, int *isPsd);
-hdsdp_retcode cone_checker(MiCone *c, HdmChol **out);
-
-// Interior check of a SMALL block (n <= 128, at most 1 MB of resident constraint data) in ONE launch and one synchronisation:
-// assembly, Cholesky with the triangular inverse, pivot information and log det S (small.hip: hdm_small_check_kernel).  The
-// same point asked for again -- the reference's line search asks "interior?" and then for the barrier at the point it has just
-// checked -- is answered from what the factor object holds, with no device work at all.
-// Returns 0 when it has answered (*isPsd set), 1 when the block is not eligible (the caller takes the call-by-call route).
-int cone_small_check(MiCone *c, double tau, const double *y_host, const double *eye_override, int whichBuffer, int *isPsd, hdsdp_retcode *rc) {
-    static const bool on = [] { const char *e = getenv("HDSDP_MI355X_SMALL_CHECK"); return !(e && atoi(e) == 0); }();
-    *rc = HDSDP_RETCODE_OK;
-    // (a single workgroup walks the resident constraint data: up to 1 MB of it in general, 4 MB for blocks of dimension <= 64,
-    // where the call-by-call assembly's few workgroups are latency-bound themselves -- theta1: 0.45 ms per check)
-    const long resident = (long) c->mloc * c->n16 * c->n16;
-    if (!on || c->world != 1 || !c->Afull || c->n16 > SMALL_P || resident > ((c->n16 <= 64) ? (1L << 19) : (1L << 17))) return 1;
-    HdmChol *ch = &((MiLin *) c->dualFactor->chol)->ch;
-    if (whichBuffer != 0) { if (cone_checker(c, &ch) != HDSDP_RETCODE_OK) return 1; }
-    if (ch->npad != SMALL_P || ch->nblk != 1) return 1;
-    const double eye_now = eye_override ? *eye_override : (-c->Rd + c->perturb);
-    const int np = c->mloc + 2;
-    if (!c->chk_host) {
-        if (hipHostMalloc((void **) &c->chk_host, sizeof(double) * (size_t) (c->mloc + 4), hipHostMallocMapped) != hipSuccess ||
-            hipHostGetDevicePointer((void **) &c->chk_dev, c->chk_host, 0) != hipSuccess) { (void) hipGetLastError(); c->chk_host = nullptr; return 1; }
-    }
-    double *yo = c->chk_host;
-    bool same = (whichBuffer == 0 && c->pS_ok && (int) c->pS.size() == np && c->pS[0] == tau && c->pS[1] == eye_now);
-    for (int q = 0; q < c->mloc; ++q) {
-        const double v = y_host ? y_host[c->own[q]] : 0.0;
-        if (same && c->pS[2 + q] != v) same = false;
-        yo[q] = v;
-    }
-    if (same && c->fac_ok) { if (isPsd) *isPsd = c->fac_psd; return 0; }      // S = T(p) and its factor are in place
-    HdmSmallCheckArgs a = {};
-    a.n = c->n; a.n16 = c->n16; a.m = c->mloc; a.A = c->Afull; a.astride = c->astride; a.C = c->Cfull;
-    a.y = c->chk_dev; a.tau = tau; a.eye = eye_now;
-    a.Sout = (whichBuffer == 0) ? c->S : c->Scheck;
-    a.L = ch->L; a.W = ch->Dinv; a.out = c->chk_dev + c->mloc;
-    yo[c->mloc] = -1.0;
-    if (hdm_small_check(a, g.stream) || hipStreamSynchronize(g.stream) != hipSuccess) { *rc = HDSDP_RETCODE_FAILED; return 0; }
-    const int info = (int) yo[c->mloc];
-    if (info < 0) { *rc = HDSDP_RETCODE_FAILED; return 0; }
-    ch->factored = (info == 0); ch->have_inv = false;
-    ch->logdet_ok = (info == 0); ch->logdet_val = yo[c->mloc + 1];
-    if (whichBuffer == 0) {
-        c->dualFactor->nFactorizes += 1;
-        c->pS.resize((size_t) np);
-        c->pS[0] = tau; c->pS[1] = eye_now;
-        for (int q = 0; q < c->mloc; ++q) c->pS[2 + q] = yo[q];
-        c->pS_ok = true; c->aff_chain = 0;
-        c->fac_ok = true; c->fac_psd = (info == 0);
-    }
-    if (isPsd) *isPsd = (info == 0);
-    return 0;
-}
-
-void cone_update(void *cd, double tau, double *y) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
-    ((MiCone *) cd)->fac_ok = false;          // S moves, its factor does not follow
-    cone_assemble((MiCone *) cd, tau, y, ((MiCone *) cd)->S);
-}
-
-hdsdp_retcode cone_factor_S(MiCone *c, int *isPsd) {
-    MiLin *l = (MiLin *) c->dualFactor->chol;
-    c->fac_ok = false;
-    RC(l->ch.load_device(c->S, c->n16, g.stream));
-    int info = 0;
-    RC(l->ch.factor(g.stream, &info));
-    c->dualFactor->nFactorizes += 1;
-    if (isPsd) *isPsd = (info == 0);
-    return HDSDP_RETCODE_OK;
-}
-
-// the second factor object ("dualChecker" of the reference, def_hdsdp_conic.h): trial points of the line search and the
-// primal recovery are factored here so that the factor of the current S stays valid
-hdsdp_retcode cone_checker(MiCone *c, HdmChol **out) {
-    if (!c->checker) {
-        c->checker = new HdmChol();
-        if (c->checker->init(c->n)) return HDSDP_RETCODE_MEMORY;
-    }
-    *out = c->checker;
-    return HDSDP_RETCODE_OK;
-}
-
-hdsdp_retcode cone_factor_check(MiCone *c, int *isPsd) {
-    HdmChol *ch = nullptr;
-    RC(cone_checker(c, &ch));
-    int info = 0;
-    if (ch->load_device(c->Scheck, c->n16, g.stream) || ch->factor(g.stream, &info)) return HDSDP_RETCODE_FAILED;
-    if (isPsd) *isPsd = (info == 0);
-    return HDSDP_RETCODE_OK;
-}
-
-// sdpDenseConeInteriorCheckExpert (hdsdp_conic_sdp.c:2192-2207): B = dCCoef*C + dACoefScal*sum_i dACoef_i A_i + dEyeCoef*I
-// (+ the perturbation unless the target is the step buffer, :383-385) into the chosen buffer, then the PSD check
-hdsdp_retcode cone_interior_expert(void *cd, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef,
-                                   int whichBuffer, int *isInterior) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
-    MiCone *c = (MiCone *) cd;
-    std::vector<double> ys(std::max(1, c->m), 0.0);
-    for (int i = 0; i < c->m; ++i) ys[i] = -dACoefScal * (dACoef ? dACoef[i] : 0.0);   // cone_assemble subtracts
-    const double eye = dEyeCoef + c->perturb;
-    double *target = (whichBuffer == 0) ? c->S : c->Scheck;
-    {
-        hdsdp_retcode rcs;
-        if (cone_small_check(c, dCCoef, ys.data(), &eye, whichBuffer, isInterior, &rcs) == 0) return rcs;
-    }
-    if (cone_assemble(c, dCCoef, ys.data(), target, &eye)) return HDSDP_RETCODE_FAILED;
-    HIP_RC(hipStreamSynchronize(g.stream));   // ys is read by an asynchronous copy
-    return (whichBuffer == 0) ? cone_factor_S(c, isInterior) : cone_factor_check(c, isInterior);
-}
-
-// sdpDenseConeAddStepToBufferAndCheck (hdsdp_conic_sdp.c:2333-2361): S + dStep*dS with the dS of the last ratio test;
-// BUFFER_DUALVAR updates S in place, BUFFER_DUALCHECK leaves S alone and factors the trial point in the checker
-hdsdp_retcode cone_axpy_check(void *cd, double dStep, int whichBuffer, int *isInterior) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
-    MiCone *c = (MiCone *) cd;
-    if (!c->dS) return HDSDP_RETCODE_FAILED;
-    const long cnt = (long) c->n16 * c->n16;
-    double *target = (whichBuffer == 0) ? c->S : c->Scheck;
-    if (whichBuffer == 0) { c->pS_ok = false; c->fac_ok = false; }   // S moves without a point being named: the next request assembles it
-    RC(hdm_axpy_mat(target, c->S, c->dS, dStep, cnt, g.stream));
-    return (whichBuffer == 0) ? cone_factor_S(c, isInterior) : cone_factor_check(c, isInterior);
-}
-
-void cone_reduce_resi(void *cd, double resiReduction) { ((MiCone *) cd)->Rd = resiReduction; }   // :2224-2228
-void cone_set_perturb(void *cd, double dDualPerturb) { ((MiCone *) cd)->perturb = dDualPerturb; }  // :2236-2241
-
-// hdsdp_conic_sdp.c:2172-2180
-hdsdp_retcode cone_interior(void *cd, double tau, double *y, int *isInterior) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
-    MiCone *c = (MiCone *) cd;
-    {
-        hdsdp_retcode rcs;
-        if (cone_small_check(c, tau, y, nullptr, 0, isInterior, &rcs) == 0) return rcs;
-    }
-    RC(cone_assemble(c, tau, y, c->S));
-    return cone_factor_S(c, isInterior);
-}
-
-// hdsdp_conic_sdp.c:2252-2291
-hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, double *logdet) {
-    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
-    MiCone *c = (MiCone *) cd;
-    if (y) {   // only with BUFFER_DUALVAR (the reference asserts it)
-        int psd = 0;
-        hdsdp_retcode rcs;
-        if (cone_small_check(c, tau, y, nullptr, 0, &psd, &rcs) == 0) { if (rcs != HDSDP_RETCODE_OK || !psd) return HDSDP_RETCODE_FAILED; }
-        else {
-            RC(cone_assemble(c, tau, y, c->S));
-            if (cone_factor_S(c, &psd) != HDSDP_RETCODE_OK || !psd) return HDSDP_RETCODE_FAILED;
-        }
-    }
-    {   // a factor that came from the single-launch check brought its log det along
-        const HdmChol *fq = (whichBuffer == 0) ? &((MiLin *) c->dualFactor->chol)->ch : c->checker;
-        if (fq && fq->factored && fq->logdet_ok) { *logdet = fq->logdet_val; return HDSDP_RETCODE_OK; }
-    }
-    std::vector<double> d(c->n);
-    if (whichBuffer == 0) {
-        if (HFpLinsysGetDiag(c->dualFactor, d.data()) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
-    } else {
-        if (!c->checker || !c->checker->factored || c->checker->get_diag(d.data(), g.stream)) return HDSDP_RETCODE_FAILED;
-    }
-    double s = 0.0;
-    for (int i = 0; i < c->n; ++i) s += log(d[i]);
-    *logdet = 2.0 * s;
-    return HDSDP_RETCODE_OK;
-}
-
-// sdpDenseConeRatioTestImpl (hdsdp_conic_sdp.c:1640-1686): dS = dTauStep*C - sum dy_i A_i + dAdaRatio*Rd*I, then the
-// largest alpha with S + alpha dS >= 0 by Lanczos on L^-1 (-dS) L^-T (lanczos.hip).  L is the factor of the chosen
-// buffer: the current S (BUFFER_DUALVAR) or the trial point factored last in the checker (BUFFER_DUALCHECK).
-hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAdaRatio, int whichBuffer, double *maxStep) {
-    StatScope stat_(ST_RATIO, __func__);
-    MiCone *c = (MiCone *) cd;
-    MiLin *l = (MiLin *) c->dualFactor->chol;
-    HdmChol *fac = (whichBuffer == 0) ? &l->ch : c->checker;   // LTarget, :1661-1665
-    if (!fac || !fac->factored) return HDSDP_RETCODE_FAILED;
-    const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
-    if (!c->dS) {
-        HIP_RC(hipMalloc((void **) &c->dS, nn));
-        HIP_RC(hdm_memset_sync(c->dS, 0, nn));
-    }
-    const double eye = dAdaRatio * c->Rd;
-    if (cone_assemble(c, dTauStep, dy, c->dS, &eye)) return HDSDP_RETCODE_FAILED;
-    if (c->n == 1) {   // :1668-1675
-        double s0 = 0.0, d0 = 0.0;
-        HIP_RC(hipMemcpyAsync(&d0, c->dS, sizeof(double), hipMemcpyDeviceToHost, g.stream));
-        HIP_RC(hipMemcpyAsync(&s0, (whichBuffer == 0) ? c->S : c->Scheck, sizeof(double), hipMemcpyDeviceToHost, g.stream));
-        HIP_RC(hipStreamSynchronize(g.stream));
-        *maxStep = (d0 > 0.0) ? INFINITY : (-s0 / d0);
-        return HDSDP_RETCODE_OK;
-    }
-    RC(hdm_mirror_lower(c->dS, c->n16, c->n, g.stream));
-    if (fac->invert_factor(g.stream)) return HDSDP_RETCODE_FAILED;
-    if (!c->lanczos) {
-        c->lanczos = new HdmLanczos();
-        if (c->lanczos->init(c->n)) return HDSDP_RETCODE_MEMORY;
-    }
-    int steps = 0;
-    static const bool dbg = [] { const char *e = getenv("HDSDP_MI355X_RATIO_DEBUG"); return e && atoi(e); }();
-    const auto t0 = std::chrono::steady_clock::now();
-    if (c->lanczos->solve(fac->Linv, fac->npad, c->dS, c->n16, g.stream, maxStep, &steps)) return HDSDP_RETCODE_FAILED;
-    if (dbg) fprintf(stderr, "[hdsdp_mi355x ratio] n %d: %d Lanczos steps, step %.6e, solve %.1f us\n", c->n, steps, *maxStep,
-                     1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    return HDSDP_RETCODE_OK;
-}
-
-// ---- the remaining cone utilities of the reference's vtable (hdsdp_conic.c:137-153) ------------------------------------
-// norms of the data: |A|_abs = sum |a_ij|, |A|_F over the full symmetric matrices (hdsdp_sdpdata.c:208-309 computes the same
-// numbers per storage class); the synthetic family has no host copy, its norms come from one pass over the device data
-
-static void coeff_norms(const MiCoeff &a, int n, double *abs_, double *fro2) {
-    // raw lower-triangular entries (packed index): diagonal once, off-diagonal twice
-    double sa = 0.0, sf = 0.0;
-    long colstart = 0;
-    int col = 0;
-    for (size_t k = 0; k < a.idx.size(); ++k) {
-        const long pidx = a.idx[k];
-        while (col < n && pidx >= colstart + (n - col)) { colstart += n - col; ++col; }
-        const bool diag = (pidx == colstart);
-        const double v = a.val[k];
-        sa += diag ? fabs(v) : 2.0 * fabs(v);
-        sf += diag ? v * v : 2.0 * v * v;
-    }
-    *abs_ = sa; *fro2 = sf;
-}
-
-int cone_data_norms(MiCone *c, double *rows_abs, double *rows_fro, double *obj_abs, double *obj_fro) {
-    if (c->norms_ready) {
-        *rows_abs = c->nrm[0]; *rows_fro = c->nrm[1]; *obj_abs = c->nrm[2]; *obj_fro = c->nrm[3];
-        return 0;
-    }
-    double ra = 0.0, rf2 = 0.0, oa = 0.0, of2 = 0.0;
-    // (a block on the congruence + Gram path has its data resident in A_L form: one HBM-bound pass over it instead of a host
-    // loop over the CSC entries, which took 1.0 s of the driver's presolve at n = m = 2000)
-    const bool on_device = c->synthetic || (c->path == PATH_GEMM && c->Afull);
-    if (!on_device) {
-        for (int i = 0; i < c->m; ++i) { double a_, f_; coeff_norms(c->blk.rows[i], c->n, &a_, &f_); ra += a_; rf2 += f_; }
-        coeff_norms(c->blk.obj, c->n, &oa, &of2);
-        oa *= c->objScal; of2 *= c->objScal * c->objScal;
-    } else {
-        double *tmp = nullptr;
-        HDM_HIP_CHECK(hipMalloc((void **) &tmp, sizeof(double) * 4));
-        HDM_HIP_CHECK(hipMemsetAsync(tmp, 0, sizeof(double) * 4, g.stream));
-        if (c->mloc > 0)
-            hipLaunchKernelGGL(mi_low_norms_kernel, dim3(c->mloc), dim3(256), 0, g.stream, c->Afull, c->astride,
-                               c->n, (long) c->n16, c->mloc, 1, tmp);
-        hipLaunchKernelGGL(mi_low_norms_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, 0L, c->n, (long) c->n16, 1, 0, tmp + 2);
-        double h[4];
-        HDM_HIP_CHECK(hipMemcpyAsync(h, tmp, sizeof(h), hipMemcpyDeviceToHost, g.stream));
-        HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
-        (void) hipFree(tmp);
-        ra = h[0]; rf2 = h[1]; oa = h[2]; of2 = h[3];
-        if (c->world > 1 && c->allreduce) {   // rows are sharded: sum the two row totals over the ranks
-            double *dv = nullptr;
-            HDM_HIP_CHECK(hipMalloc((void **) &dv, sizeof(double) * 2));
-            double two[2] = {ra, rf2};
-            HDM_HIP_CHECK(hipMemcpy(dv, two, sizeof(two), hipMemcpyHostToDevice));
-            if (c->allreduce(c->xctx, dv, 2)) return 1;
-            HDM_HIP_CHECK(hipMemcpy(two, dv, sizeof(two), hipMemcpyDeviceToHost));
-            (void) hipFree(dv);
-            ra = two[0]; rf2 = two[1];
-        }
-    }
-    c->nrm[0] = ra; c->nrm[1] = sqrt(rf2); c->nrm[2] = oa; c->nrm[3] = sqrt(of2);
-    c->norms_ready = true;
-    return cone_data_norms(c, rows_abs, rows_fro, obj_abs, obj_fro);
-}
-
-double cone_coeff_norm(void *cd, int whichNorm) {
-    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeGetCoeffNorm, hdsdp_conic_sdp.c:1568-1586 (ABS_NORM 1, FRO_NORM 2)
-    double v[4];
-    if (cone_data_norms((MiCone *) cd, v, v + 1, v + 2, v + 3)) return NAN;
-    return whichNorm == 1 ? v[0] : v[1];
-}
-double cone_obj_norm(void *cd, int whichNorm) {
-    StatScope stat_(ST_PRIMAL_UTIL, __func__);     // sdpDenseConeGetObjNorm, :1558-1561
-    double v[4];
-    if (cone_data_norms((MiCone *) cd, v, v + 1, v + 2, v + 3)) return NAN;
-    return whichNorm == 1 ? v[2] : v[3];
-}
-void cone_scal(void *cd, double dScal) {
-    StatScope stat_(ST_PRIMAL_UTIL, __func__);             // sdpDenseConeScal, :1604-1614: the objective is scaled, nothing else
-    MiCone *c = (MiCone *) cd;
-    const long cnt = (long) c->n16 * c->n16;
-    hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, g.stream, c->Cfull, cnt, dScal);
-    if (c->CL) hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((c->astride + 255) / 256)), dim3(256), 0, g.stream, c->CL, c->astride, dScal);
-    c->objScal *= dScal;
-    c->norms_ready = false;
-    c->pS_ok = c->pD_ok = false;     // S and dS were assembled with the old objective: no short-cut from them (cone_assemble)
-    (void) hipStreamSynchronize(g.stream);
-}
-
-// X (host, n x n column-major, symmetric) -> the device scratch matrix Xup (ld = npad of the dual factor)
-static int cone_upload_X(MiCone *c, const double *X, long *ldx) {
-    MiLin *l = (MiLin *) c->dualFactor->chol;
-    const long ld = l->ch.npad;
-    const size_t np2 = sizeof(double) * (size_t) ld * ld;
-    if (!c->Xup) HDM_HIP_CHECK(hipMalloc((void **) &c->Xup, np2));   // (Xinv / Yinv belong to the builders, sized per path)
-    HDM_HIP_CHECK(hipMemsetAsync(c->Xup, 0, np2, g.stream));
-    HDM_HIP_CHECK(hipMemcpy2DAsync(c->Xup, sizeof(double) * ld, X, sizeof(double) * c->n, sizeof(double) * c->n, c->n,
-                                   hipMemcpyHostToDevice, g.stream));
-    *ldx = ld;
-    return 0;
-}
-
-// sdpDenseConeBuildPrimalXSXDirection (hdsdp_conic_sdp.c:2021-2040 -> fds_trimultiply, dense_opts.c:102-132), the cone's
-// coneBuildPrimalDirection slot used by the primal refinement (hdsdp_psdp.c:236,295):  XSX += X^T D X  (full symmetric
-// n x n, host), D = the dual matrix (iDualMat != 0) or the dual step dS of the last ratio test, both resident.  Two
-// plain MFMA GEMMs on the device; only X goes up and the n x n product comes back.
-void cone_build_primal_dir(void *cd, void *kktv, double *X, double *XSX, int iDualMat) {
-    StatScope stat_(ST_PRIMAL_UTIL, __func__);
-    (void) kktv;
-    MiCone *c = (MiCone *) cd;
-    const int n = c->n;
-    long ldx = 0;
-    const double *D = iDualMat ? c->S : c->dS;
-    if (!D) { fprintf(stderr, "[hdsdp_mi355x] primal direction: no dual step has been formed yet\n"); return; }
-    if (cone_upload_X(c, X, &ldx)) return;
-    const size_t np2 = sizeof(double) * (size_t) ldx * ldx;
-    if (!c->Pr1 && hipMalloc((void **) &c->Pr1, np2) != hipSuccess) return;
-    if (!c->Pr2 && hipMalloc((void **) &c->Pr2, np2) != hipSuccess) return;
-    // Pr1 <- D as a full symmetric matrix (the resident copy has its lower triangle valid), zero padded
-    if (hipMemsetAsync(c->Pr1, 0, np2, g.stream) != hipSuccess) return;
-    if (hipMemcpy2DAsync(c->Pr1, sizeof(double) * ldx, D, sizeof(double) * c->n16, sizeof(double) * n, n,
-                         hipMemcpyDeviceToDevice, g.stream) != hipSuccess) return;
-    if (hdm_mirror_lower(c->Pr1, ldx, n, g.stream)) return;
-    HdmGemmArgs q = {};
-    q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE; q.ldc = ldx;
-    // T = D X   (B operand element (j, k) = X(k, j): K-major)
-    q.A = c->Pr1; q.lda = ldx; q.a_kmajor = 0; q.B = c->Xup; q.ldb = ldx; q.b_kmajor = 1; q.C = c->Pr2;
-    if (hdm_launch_gemm(q, g.stream)) return;
-    // P = X^T T   (A operand element (i, k) = X(k, i): K-major; B operand element (j, k) = T(k, j): K-major)
-    q.A = c->Xup; q.lda = ldx; q.a_kmajor = 1; q.B = c->Pr2; q.ldb = ldx; q.b_kmajor = 1; q.C = c->Pr1;
-    if (hdm_launch_gemm(q, g.stream)) return;
-    std::vector<double> h((size_t) n * n);
-    if (hipMemcpy2DAsync(h.data(), sizeof(double) * n, c->Pr1, sizeof(double) * ldx, sizeof(double) * n, n,
-                         hipMemcpyDeviceToHost, g.stream) != hipSuccess) return;
-    if (hipStreamSynchronize(g.stream) != hipSuccess) return;
-    for (size_t e = 0; e < h.size(); ++e) XSX[e] += h[e];
-}
-
-void cone_a_times_x(void *cd, double *X, double *ATimesX) {
-    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeATimesX, :2470-2477: y_i += <A_i, X>
-    MiCone *c = (MiCone *) cd;
-    long ldx = 0;
-    double *out = nullptr;
-    if (cone_upload_X(c, X, &ldx)) return;
-    if (hipMalloc((void **) &out, sizeof(double) * 2 * (size_t) c->m) != hipSuccess) return;
-    (void) hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t) c->m, g.stream);
-    // A is stored in A_L form: <A, X> = 2 <A_L, X> for symmetric X
-    if (hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xup, nullptr, ldx, out, out + c->m,
-                     c->rows_own, 2.0, 0.0, g.stream) == 0) {
-        if (c->world > 1 && c->allreduce) { (void) hipStreamSynchronize(g.stream); (void) c->allreduce(c->xctx, out, c->m); }
-        std::vector<double> h(c->m);
-        if (hipMemcpyAsync(h.data(), out, sizeof(double) * c->m, hipMemcpyDeviceToHost, g.stream) == hipSuccess &&
-            hipStreamSynchronize(g.stream) == hipSuccess)
-            for (int i = 0; i < c->m; ++i) ATimesX[i] += h[i];
-    }
-    (void) hipFree(out);
-}
-
-static double cone_dot_with(MiCone *c, const double *dev, long ldd, int lower_valid, double *X) {
-    long ldx = 0;
-    double *out = nullptr, h = NAN;
-    if (cone_upload_X(c, X, &ldx)) return NAN;
-    if (hipMalloc((void **) &out, sizeof(double)) != hipSuccess) return NAN;
-    (void) hipMemsetAsync(out, 0, sizeof(double), g.stream);
-    if (lower_valid) hipLaunchKernelGGL(mi_lower_dot_kernel, dim3(1), dim3(256), 0, g.stream, dev, ldd, c->Xup, ldx, c->n, out);
-    else hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, dev, ldd, c->Xup, ldx, c->n, 0, 1.0, out);
-    if (hipMemcpyAsync(&h, out, sizeof(double), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
-        hipStreamSynchronize(g.stream) != hipSuccess) h = NAN;
-    (void) hipFree(out);
-    return h;
-}
-double cone_trace_cx(void *cd, double *X) {
-    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeTraceCX, :2520-2523
-    MiCone *c = (MiCone *) cd;
-    return cone_dot_with(c, c->Cfull, c->n16, 0, X);
-}
-double cone_x_dot_s(void *cd, double *X) {
-    StatScope stat_(ST_PRIMAL_UTIL, __func__);    // sdpDenseConeXDotS, :2549-2560 (S is lower-valid: fds_dot_fds, dense_opts.c:134-156)
-    MiCone *c = (MiCone *) cd;
-    return cone_dot_with(c, c->S, c->n16, 1, X);
-}
-void cone_get_dual(void *cd, double *dConeDual, double *dummy) {
-    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeGetDual, :2494-2506: S, symmetrised
-    (void) dummy;
-    MiCone *c = (MiCone *) cd;
-    const int n = c->n;
-    if (hipMemcpy2DAsync(dConeDual, sizeof(double) * n, c->S, sizeof(double) * c->n16, sizeof(double) * n, n,
-                         hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) return;
-    for (int j = 0; j < n; ++j)
-        for (int i = j + 1; i < n; ++i) dConeDual[(size_t) j + (size_t) i * n] = dConeDual[(size_t) i + (size_t) j * n];
-}
-
-// sdpDenseConeGetPrimal (hdsdp_conic_sdp.c:2393-2446), the cone's conePRecover slot:
-//     X = mu * L^-T ( sym( L^-1 dS L^-T ) + I ) L^-1,   S = C - sum y_i A_i = L L^T (no residual term),  dS = sum dy_i A_i.
-// The reference does four triangular solves with n right-hand sides on the checker factor; here S is factored into a
-// second resident factor object, inverted once, and the four products are plain MFMA GEMMs with the explicit Linv.
-// Like the reference, an S that is not positive definite prints a message and leaves the output untouched.
-void cone_precover(void *cd, double dBarrierMu, double *y, double *dy, double *X, double *aux) {
-    StatScope stat_(ST_PRIMAL_UTIL, __func__);
-    (void) aux;
-    MiCone *c = (MiCone *) cd;
-    const double zero = 0.0;
-    const int n = c->n;
-    const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
-    auto fail = [](const char *what) { fprintf(stderr, "[hdsdp_mi355x] primal recovery: %s\n", what); };
-    if (cone_assemble(c, 1.0, y, c->Scheck, &zero)) return fail("S assembly failed");
-    HdmChol *chp = nullptr;
-    if (cone_checker(c, &chp) != HDSDP_RETCODE_OK) return fail("out of memory");
-    HdmChol &ch = *chp;
-    int info = 0;
-    if (ch.load_device(c->Scheck, c->n16, g.stream) || ch.factor(g.stream, &info)) return fail("factorisation failed");
-    if (info != 0) { printf("Recovery step is infeasible\n"); return; }
-    if (!c->dS) {
-        if (hipMalloc((void **) &c->dS, nn) != hipSuccess || hdm_memset_sync(c->dS, 0, nn) != hipSuccess) return fail("out of memory");
-    }
-    std::vector<double> ndy(c->m);
-    for (int i = 0; i < c->m; ++i) ndy[i] = -dy[i];           // cone_assemble subtracts: dS = + sum dy_i A_i
-    if (cone_assemble(c, 0.0, ndy.data(), c->dS, &zero)) return fail("dS assembly failed");
-    if (hipStreamSynchronize(g.stream) != hipSuccess) return fail("stream");   // ndy is read by an async copy
-    if (hdm_mirror_lower(c->dS, c->n16, n, g.stream)) return fail("mirror");
-    if (ch.invert_factor(g.stream)) return fail("triangular inverse failed");
-    const size_t np2 = sizeof(double) * (size_t) ch.npad * ch.npad;
-    if (!c->Pr1 && hipMalloc((void **) &c->Pr1, np2) != hipSuccess) return fail("out of memory");
-    if (!c->Pr2 && hipMalloc((void **) &c->Pr2, np2) != hipSuccess) return fail("out of memory");
-    HdmGemmArgs q = {};
-    q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE; q.ldc = ch.npad;
-    // T1 = W dS          (W = Linv)
-    q.A = ch.Linv; q.lda = ch.npad; q.a_kmajor = 0; q.B = c->dS; q.ldb = c->n16; q.b_kmajor = 0; q.C = c->Pr1;
-    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
-    // Z = T1 W^T
-    q.A = c->Pr1; q.lda = ch.npad; q.a_kmajor = 0; q.B = ch.Linv; q.ldb = ch.npad; q.b_kmajor = 0; q.C = c->Pr2;
-    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
-    if (hdm_sym_scale(c->Pr2, ch.npad, c->n16, 1.0, 1.0, g.stream)) return fail("sym");
-    // T2 = W^T Z
-    q.A = ch.Linv; q.lda = ch.npad; q.a_kmajor = 1; q.B = c->Pr2; q.ldb = ch.npad; q.b_kmajor = 0; q.C = c->Pr1;
-    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
-    // X = T2 W
-    q.A = c->Pr1; q.lda = ch.npad; q.a_kmajor = 0; q.B = ch.Linv; q.ldb = ch.npad; q.b_kmajor = 1; q.C = c->Pr2;
-    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
-    if (hdm_sym_scale(c->Pr2, ch.npad, n, 0.0, dBarrierMu, g.stream)) return fail("sym");
-    if (hipMemcpy2DAsync(X, sizeof(double) * n, c->Pr2, sizeof(double) * ch.npad, sizeof(double) * n, n,
-                         hipMemcpyDeviceToHost, g.stream) != hipSuccess) return fail("copy");
-    (void) hipStreamSynchronize(g.stream);
-}
-
-// --- the GPU Schur builder ---------------------------------------------------------------------
-// share of step 2's work that falls into the tile columns of `mask` (tile (tm, tn), tm >= tn, runs tn + 1 K blocks)
-double cong2_mask_share(int NT, unsigned long long mask) {
-    if (!mask || NT > 64) return 1.0;
-    double all = 0.0, sel = 0.0;
-    for (int tn = 0; tn < NT; ++tn) {
-        const double w = (double) (NT - tn) * (tn + 1);
-        all += w;
-        if ((mask >> tn) & 1ULL) sel += w;
-    }
-    return all > 0.0 ? sel / all : 1.0;
-}
-
-// phase 0: both steps; 1: step 1 only; 2: step 2 only (count <= Bc, T still holds step 1's output), optionally only the
-// output tiles of the tile columns in `colmask` -- the multi-GPU build runs step 2 by packed-index range so that the
-// finished ranges can leave for the other ranks while the rest is still being computed
-// `asrc_span`: elements readable from Asrc (the buffer's operand slack included), for the launcher's check of the
-// unmasked tile loads
-int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, long asrc_span, int count, long row0,
-                    int phase = 0, unsigned long long colmask = 0) {
-    // rows row0 .. row0+count-1 of AhatLoc  <-  blocked( Linv * A * Linv^T ),  A = A_L + A_L^T given in A_L form:
-    //   step 1  U  = Linv * A_L                 (lower x lower = lower triangular: k in [col tile, row tile], n^3/3)
-    //   step 2  At = U * Linv^T + Linv * U^T    (SYR2K form, lower tiles, k <= col tile, 2n^3/3)
-    // i.e. n^3 flops per constraint instead of the 4/3 n^3 of (Linv A) Linv^T, and half the intermediate traffic.
-    const long nn = (long) c->n16 * c->n16;
-    const double n3 = (double) c->n * c->n * c->n;
-    for (int b0 = 0; b0 < count; b0 += c->Bc) {
-        const int nb = std::min(c->Bc, count - b0);
-        HdmGemmArgs k1 = {};
-        k1.A = ch.Linv; k1.lda = ch.npad; k1.strideA = 0;
-        k1.B = Asrc + (long) b0 * astride; k1.ldb = c->n16; k1.strideB = astride; k1.b_kmajor = 1; k1.b_sky = 1;
-        k1.C = c->T; k1.ldc = c->n16; k1.strideC = nn;
-        k1.M = c->n16; k1.N = c->n16; k1.K = c->n16; k1.batch = nb; k1.alpha = 1.0;
-        k1.klimit = HDM_KLIM_BAND; k1.lower_only = 1; k1.epilogue = HDM_EPI_STORE; k1.role = HDM_ROLE_CONG1;
-        k1.flops = (double) nb * n3 / 3.0;
-        const long linv_span = (long) ch.npad * ch.npad;
-        const long t_span = nn * c->Bc + (long) (hdm_operand_pad(c->n16) / sizeof(double));
-        k1.spanA = linv_span; k1.spanB = asrc_span - (long) b0 * astride;
-        if (phase != 2 && c->shared_ts && hdm_zero_diag_upper(c->T, nn, c->n16, nb, g.stream)) return 1;
-        if (phase != 2 && hdm_launch_gemm(k1, g.stream)) return 1;
-        if (phase == 1) continue;
-        HdmGemmArgs k2 = {};
-        k2.A = c->T; k2.lda = c->n16; k2.strideA = nn;
-        k2.B = ch.Linv; k2.ldb = ch.npad; k2.strideB = 0;
-        k2.A2 = ch.Linv; k2.lda2 = ch.npad; k2.strideA2 = 0;
-        k2.B2 = c->T; k2.ldb2 = c->n16; k2.strideB2 = nn;
-        k2.C = c->AhatLoc; k2.M = c->n16; k2.N = c->n16; k2.K = c->n16; k2.batch = nb; k2.alpha = 1.0;
-        k2.klimit = HDM_KLIM_BY_N; k2.lower_only = 1; k2.epilogue = HDM_EPI_BLOCKED;
-        k2.blk_row_stride = c->Lr; k2.blk_row0 = row0 + b0; k2.nblk = c->nblk; k2.role = HDM_ROLE_CONG2;
-        k2.tile_col_mask = colmask;
-        k2.spanA = t_span; k2.spanB = linv_span; k2.spanA2 = linv_span; k2.spanB2 = t_span;
-        k2.flops = (double) nb * n3 * 2.0 / 3.0 * cong2_mask_share((c->n16 + HDM_TILE - 1) / HDM_TILE, colmask);
-        if (hdm_launch_gemm(k2, g.stream)) return 1;
-    }
-    return 0;
-}
-
-// Gram partial sums of the K splits [z0, z0 + nz): slabs z0.. <- Ahat * Ahat^T over their share of this rank's p-range
-int gram_splits(MiCone *c, int z0, int nz) {
-    HdmGemmArgs gq = {};
-    gq.A = c->AhatAll; gq.B = c->AhatAll; gq.a_kmajor = 1; gq.b_kmajor = 1;
-    gq.lda = 16; gq.ldb = 16; gq.a_kblk = (long) c->Lr * 16; gq.b_kblk = (long) c->Lr * 16;
-    if (c->world > 1) { gq.seg_rows = c->Lr; gq.seg_extra = c->npb_loc * c->Lr * 16 - (long) c->Lr * 16; }
-    gq.ldc = c->R; gq.M = (int) c->R; gq.N = (int) c->R; gq.K = (int) (c->npb_loc * 16);
-    gq.lower_only = 1; gq.epilogue = HDM_EPI_SLAB; gq.batch = nz;
-    const long chunk = (c->npb_loc + c->nsplit - 1) / c->nsplit;
-    gq.k_chunk = chunk * 16; gq.slab_stride = c->R * c->R; gq.alpha = 1.0; gq.role = HDM_ROLE_GRAM;
-    gq.k_base = (long) z0 * gq.k_chunk;
-    gq.spanA = gq.spanB = (long) c->world * c->npb_loc * c->Lr * 16 + HDM_OPERAND_PAD_DOUBLES;
-    gq.C = c->slabs + (long) z0 * gq.slab_stride;
-    {   // (m+3)(m+4)/2 inner products of length n(n+1)/2 (this rank's share), 2 flops each
-        const double rows = (double) c->m + 3.0;
-        gq.flops = rows * (rows + 1.0) * 0.5 * ((double) c->n * (c->n + 1) * 0.5) * 2.0 / c->world * ((double) nz / c->nsplit);
-    }
-    return hdm_launch_gemm(gq, g.stream);
-}
-
-int gram_all(MiCone *c) {
-    // Gm(lower) = sum over this rank's p-range of Ahat * Ahat^T, rows in segment order
-    if (gram_splits(c, 0, c->nsplit)) return 1;
-    return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, c->R, g.stream);
-}
-
-// world > 1: the all-to-all that re-shards Ahat from "by constraint" to "by packed-index range", and the Gram product.
-// With the piecewise hooks registered the exchange runs in pieces along the packed index and the Gram splits of a piece
-// start as soon as it has arrived, while the later pieces are still on the links.
-// number of pieces of the piecewise exchange (whole groups of Gram K splits)
-int exchange_pieces(const MiCone *c) {
-    int P = (c->a2a_start && c->a2a_wait) ? c->a2a_pieces : 1;
-    if (const char *e = getenv("HDSDP_MI355X_A2A_PIECES")) P = std::max(1, atoi(e));
-    if (!(c->a2a_start && c->a2a_wait)) P = 1;
-    while (P > 1 && (c->nsplit % P)) --P;
-    return P;
-}
-// p-blocks [lo, hi) of every destination's chunk that piece k of P carries
-void piece_range(const MiCone *c, int k, int P, long *lo, long *hi) {
-    const long chunk = (c->npb_loc + c->nsplit - 1) / c->nsplit;   // p-blocks per split
-    const int zper = c->nsplit / P;
-    *lo = std::min<long>(c->npb_loc, (long) k * zper * chunk);
-    *hi = (k == P - 1) ? c->npb_loc : std::min<long>(c->npb_loc, (long) (k + 1) * zper * chunk);
-}
-// Tile columns of congruence step 2 whose output piece k needs.  P-block q belongs to the 16 x 16 sub-block q / 16 of the
-// blocked lower triangle, sub-blocks are numbered column by column (column bj starts at bj*nblk - bj(bj-1)/2), and tile
-// column tn produces the sub-block columns 8 tn .. 8 tn + 7: a range of p-blocks is a range of tile columns.
-unsigned long long piece_tile_cols(const MiCone *c, int k, int P) {
-    long lo, hi;
-    piece_range(c, k, P, &lo, &hi);
-    auto col_of = [&](long sub) {
-        int bj = 0;
-        while (bj + 1 < c->nblk && (long) (bj + 1) * c->nblk - (long) (bj + 1) * bj / 2 <= sub) ++bj;
-        return bj;
-    };
-    unsigned long long mask = 0;
-    for (int d = 0; d < c->world; ++d) {
-        const long g0 = (long) d * c->npb_loc + lo, g1 = std::min<long>(c->npb, (long) d * c->npb_loc + hi);
-        if (g0 >= g1) continue;
-        for (int tn = col_of(g0 / 16) / 8; tn <= col_of((g1 - 1) / 16) / 8; ++tn) mask |= 1ULL << tn;
-    }
-    return mask;
-}
-
-// `staged`: congruence step 2 was launched piece by piece and c->piece_ev[k] marks the point where piece k's p-blocks
-// are final, so piece k can leave while the later tile columns are still being computed; otherwise the whole stream
-// is drained first.
-hdsdp_retcode exchange_and_gram(MiCone *c, bool staged = false) {
-    if (!c->alltoall && !(c->a2a_start && c->a2a_wait)) {
-        fprintf(stderr, "[hdsdp_mi355x] world > 1 but no exchange hook registered\n");
-        return HDSDP_RETCODE_FAILED;
-    }
-    if (!staged) HIP_RC(hipStreamSynchronize(g.stream));
-    const int P = exchange_pieces(c);
-    if (P <= 1) {
-        if (staged) HIP_RC(hipStreamSynchronize(g.stream));
-        if (c->alltoall) { if (c->alltoall(c->xctx)) return HDSDP_RETCODE_FAILED; }
-        else {
-            if (c->a2a_start(c->xctx, 0, (int64_t) c->npb_loc * c->Lr * 16, 0) || c->a2a_wait(c->xctx, 0)) return HDSDP_RETCODE_FAILED;
-        }
-        return gram_all(c) ? HDSDP_RETCODE_FAILED : HDSDP_RETCODE_OK;
-    }
-    const int zper = c->nsplit / P;
-    for (int k = 0; k < P; ++k) {
-        long lo, hi;
-        piece_range(c, k, P, &lo, &hi);
-        const int64_t off = (int64_t) lo * c->Lr * 16, end = (int64_t) hi * c->Lr * 16;   // doubles inside a chunk
-        if (staged) HIP_RC(hipEventSynchronize(c->piece_ev[k]));
-        if (c->a2a_start(c->xctx, off, end - off, k)) {
-            if (k == 0 && c->alltoall) {
-                // the piecewise flavour is not available in this process group: one blocking exchange from now on
-                fprintf(stderr, "[hdsdp_mi355x] piecewise all-to-all failed to start; using the blocking exchange\n");
-                c->a2a_pieces = 1; c->a2a_start = nullptr; c->a2a_wait = nullptr;
-                HIP_RC(hipStreamSynchronize(g.stream));
-                if (c->alltoall(c->xctx)) return HDSDP_RETCODE_FAILED;
-                return gram_all(c) ? HDSDP_RETCODE_FAILED : HDSDP_RETCODE_OK;
-            }
-            return HDSDP_RETCODE_FAILED;
-        }
-    }
-    for (int k = 0; k < P; ++k) {
-        if (c->a2a_wait(c->xctx, k)) return HDSDP_RETCODE_FAILED;
-        if (gram_splits(c, k * zper, zper)) return HDSDP_RETCODE_FAILED;
-    }
-    return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, c->R, g.stream) ? HDSDP_RETCODE_FAILED
-                                                                                                 : HDSDP_RETCODE_OK;
-}
-
-hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT, HdmChol *chOverride = nullptr);
-double *kkt_Mdev(hdsdp_kkt *kkt, long *ld);
-hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
-hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
-
-// KKT_TYPE_PRIMAL (hdsdp_conic_sdp.c:1745-1753; driver hdsdp_psdp.c:156,203,420): the builder runs on the registered
-// primal matrix X in place of S^-1.  S^-1 = Linv^T Linv enters every path only through the lower-triangular Linv, so
-// X is brought to the same form: factor the index-reversed matrix J X J = F F^T on the device, then W = J F^T J is
-// lower triangular with W^T W = X and takes Linv's place in the GEMM path (all strategies give the same numbers, and
-// the reference itself re-routes M2 columns for this type, :1782-1788).  X must be positive definite, which a
-// primal interior point is; an indefinite X is reported like a failed dpotrf.
-// KKT_TYPE_PRIMAL with a registered matrix that is NOT positive definite (the primal refinement does hand such iterates
-// over, hdsdp_psdp.c:203,420; the reference's trace formulas do not care): no triangular factor exists, so the product is
-// formed the way the reference's M3 column does it, one owned row at a time:  B_i = X A_i X  (three plain MFMA GEMMs on
-// the A_L form: X A = X A_L + X A_L^T),  then  M_ij = <A_j, B_i>  for all j in one pass over the resident constraint data.
-// 4 n^3 + m n^2 flops per row instead of the congruence path's n^3 + m n^2 / 2: a fallback, used only on this condition.
-hdsdp_retcode build_primal_general(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, const double *X) {
-    if (c->world > 1) {
-        fprintf(stderr, "[hdsdp_mi355x] KKT_TYPE_PRIMAL: an indefinite primal matrix is not supported on a sharded block\n");
-        return HDSDP_RETCODE_FAILED;
-    }
-    const int n = c->n, m = kkt->nRow;
-    long ldx = 0, ldm = 0;
-    RC(cone_upload_X(c, X, &ldx));
-    const size_t np2 = sizeof(double) * (size_t) ldx * ldx;
-    if (!c->Pr1) HIP_RC(hipMalloc((void **) &c->Pr1, np2));
-    if (!c->Pr2) HIP_RC(hipMalloc((void **) &c->Pr2, np2));
-    double *Mdev = kkt_Mdev(kkt, &ldm), *row = nullptr, *ALsq = nullptr;
-    HIP_RC(hipMalloc((void **) &row, sizeof(double) * (size_t) m));
-    HIP_RC(hipMalloc((void **) &ALsq, sizeof(double) * (size_t) c->n16 * c->n16 + hdm_operand_pad(c->n16)));
-    HdmGemmArgs q = {};
-    q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE; q.ldc = ldx;
-    // vectors: ASinv_i = <A_i, X>, ASinvRdSinv_i = Rd <A_i, X^2>   (Pr2 <- X X^T)
-    q.A = c->Xup; q.lda = ldx; q.B = c->Xup; q.ldb = ldx; q.C = c->Pr2;
-    hdsdp_retcode rc = HDSDP_RETCODE_OK;
-    if (hdm_launch_gemm(q, g.stream) ||
-        hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xup, c->Pr2, ldx, pv->vecs, pv->vecs + m,
-                     c->rows_own, 2.0, 2.0 * c->Rd, g.stream))
-        rc = HDSDP_RETCODE_FAILED;
-    for (int qi = 0; qi < c->mloc && rc == HDSDP_RETCODE_OK; ++qi) {
-        // this fallback multiplies with A_L as a generic operand in both orientations: unpack the row's skyline storage
-        // into a square scratch matrix first
-        if (hdm_sky_to_square(c->Afull + (long) qi * c->astride, ALsq, c->n16, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
-        const double *AL = ALsq;
-        // Pr1 = X A_L            (B operand element (j, k) = A_L(k, j): K-major)
-        q.A = c->Xup; q.lda = ldx; q.a_kmajor = 0; q.B = AL; q.ldb = c->n16; q.b_kmajor = 1; q.C = c->Pr1; q.beta = 0.0;
-        if (hdm_launch_gemm(q, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
-        // Pr1 += X A_L^T         (B operand element (j, k) = A_L(j, k): M-major)
-        q.b_kmajor = 0; q.beta = 1.0;
-        if (hdm_launch_gemm(q, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
-        // Pr2 = Pr1 X            (B operand element (j, k) = X(k, j): K-major)
-        q.A = c->Pr1; q.lda = ldx; q.B = c->Xup; q.ldb = ldx; q.b_kmajor = 1; q.C = c->Pr2; q.beta = 0.0;
-        if (hdm_launch_gemm(q, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
-        if (hipMemsetAsync(row, 0, sizeof(double) * (size_t) m, g.stream) != hipSuccess ||
-            hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Pr2, nullptr, ldx, row, row,
-                         c->rows_own, 2.0, 0.0, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
-        hipLaunchKernelGGL(mi_put_row_kernel, dim3((m + 255) / 256), dim3(256), 0, g.stream, Mdev, ldm, c->own[qi], row, m);
-    }
-    if (hipStreamSynchronize(g.stream) != hipSuccess) rc = HDSDP_RETCODE_FAILED;
-    (void) hipFree(row);
-    (void) hipFree(ALsq);
-    if (rc != HDSDP_RETCODE_OK) return rc;
-    if (c->Rd != 0.0) {                      // dTraceSinv += tr X (hdsdp_conic_sdp.c:1767-1769)
-        double tr = 0.0;
-        for (int i = 0; i < n; ++i) tr += X[(size_t) i * (n + 1)];
-        kkt->dTraceSinv += tr;
-    }
-    return HDSDP_RETCODE_OK;
-}
-
-hdsdp_retcode build_primal(MiCone *c, int iCone, hdsdp_kkt *kkt, MiKKTPriv *pv) {
-    if (!kkt->dPrimalX || !kkt->dPrimalX[iCone]) return HDSDP_RETCODE_FAILED;   // :1747-1750
-    const double *X = kkt->dPrimalX[iCone];
-    const int n = c->n;
-    if (!c->primal) {
-        c->primal = new HdmChol();
-        if (c->primal->init(n)) return HDSDP_RETCODE_MEMORY;
-    }
-    std::vector<double> Xr((size_t) n * n);
-    for (int j = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) Xr[(size_t) i + (size_t) j * n] = X[(size_t) (n - 1 - i) + (size_t) (n - 1 - j) * n];
-    HdmChol &ch = *c->primal;
-    int info = 0;
-    if (ch.load_host(Xr.data(), n, g.stream)) return HDSDP_RETCODE_FAILED;
-    HIP_RC(hipStreamSynchronize(g.stream));   // Xr is pageable host memory going out of scope
-    if (ch.factor(g.stream, &info)) return HDSDP_RETCODE_FAILED;
-    if (info != 0) return build_primal_general(c, kkt, pv, X);   // X is not positive definite: no factor to lean on
-    if (ch.set_reverse_inverse(g.stream)) return HDSDP_RETCODE_FAILED;
-    return build_gemm_path(c, kkt, pv, KKT_TYPE_PRIMAL, &ch);
-}
-
-hdsdp_retcode cone_build_schur(void *cd, int iCone, void *kktv, int typeKKT) {
-    (void) iCone;
-    MiCone *c = (MiCone *) cd;
-    hdsdp_kkt *kkt = (hdsdp_kkt *) kktv;
-    MiKKTPriv *pv = priv_of(kkt);
-    if (typeKKT == KKT_TYPE_PRIMAL) return build_primal(c, iCone, kkt, pv);
-    MiLin *l = (MiLin *) c->dualFactor->chol;
-    if (!l->ch.factored) {
-        fprintf(stderr, "[hdsdp_mi355x] BuildSchur: the dual matrix has no valid Cholesky factor\n");
-        return HDSDP_RETCODE_FAILED;
-    }
-    if (c->path == PATH_R1) return build_r1_path(c, kkt, pv, typeKKT);
-    if (c->path == PATH_SPARSE) return build_sparse_path(c, kkt, pv, typeKKT);
-    return build_gemm_path(c, kkt, pv, typeKKT);
-}
-hdsdp_retcode cone_build_schur_fixed(void *cd, int iCone, void *kktv, int typeKKT, int strategy) {
-    (void) strategy;  // all strategies are the same numbers (reference invariant, hdsdp_utils.c:536-707)
-    return cone_build_schur(cd, iCone, kktv, typeKKT);
-}
-
-double *kkt_Mdev(hdsdp_kkt *kkt, long *ld) {
-    MiLin *l = (MiLin *) kkt->kktM->chol;
-    if (ld) *ld = l->ch.npad;
-    return l->Mdev;
-}
-
-hdsdp_retcode corrector_components(MiCone *c, HdmChol &ch, MiKKTPriv *pv, int m) {
-    // ASinv_i = <A_i, S^-1>, ASinvRdSinv_i = Rd <A_i, S^-2>   (hdsdp_conic_sdp.c:1035-1056)
-    const size_t nn = sizeof(double) * (size_t) ch.npad * ch.npad;
-    if (!c->Xinv) { if (hipMalloc((void **) &c->Xinv, nn) != hipSuccess) return HDSDP_RETCODE_MEMORY; }
-    if (!c->Yinv) { if (hipMalloc((void **) &c->Yinv, nn) != hipSuccess) return HDSDP_RETCODE_MEMORY; }
-    RC(ch.inverse_full(c->Xinv, ch.npad, g.stream));
-    const double *Y = nullptr;
-    if (c->Rd != 0.0) {
-        HdmGemmArgs q = {};  // Y = X * X^T = S^-2
-        q.A = c->Xinv; q.lda = ch.npad; q.B = c->Xinv; q.ldb = ch.npad; q.C = c->Yinv; q.ldc = ch.npad;
-        q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE;
-        RC(hdm_launch_gemm(q, g.stream));
-        Y = c->Yinv;
-    }
-    // A is stored in A_L form: <A, X> = 2 <A_L, X>
-    if (c->world == 1) {
-        RC(hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, pv->vecs,
-                        pv->vecs + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));
-        return HDSDP_RETCODE_OK;
-    }
-    // Sharded block: pv->vecs is the accumulator of the whole operator (every engine cone adds into it), so the sum
-    // over the ranks runs on this cone's own contribution only and is added afterwards; reducing pv->vecs itself would
-    // multiply what the cones before this one have put there by the number of ranks.
-    if (!c->corr) HIP_RC(hipMalloc((void **) &c->corr, sizeof(double) * 2 * (size_t) m));
-    HIP_RC(hipMemsetAsync(c->corr, 0, sizeof(double) * 2 * (size_t) m, g.stream));
-    RC(hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, c->corr,
-                    c->corr + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));
-    HIP_RC(hipStreamSynchronize(g.stream));
-    if (!c->allreduce || c->allreduce(c->xctx, c->corr, (int64_t) 2 * m)) return HDSDP_RETCODE_FAILED;
-    if (c->kkt_owner) RC(hdm_axpy_mat(pv->vecs, pv->vecs, c->corr, 1.0, 2L * m, g.stream));
-    HIP_RC(hipStreamSynchronize(g.stream));
-    return HDSDP_RETCODE_OK;
-}
-
-hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT, HdmChol *chOverride) {
-    MiLin *l = (MiLin *) c->dualFactor->chol;
-    HdmChol &ch = chOverride ? *chOverride : l->ch;
-    const int m = kkt->nRow;
-    if (typeKKT == KKT_TYPE_CORRECTOR) return corrector_components(c, ch, pv, m);
-    if (!c->work_ready) {
-        if (cone_alloc_gemm_work(c)) return HDSDP_RETCODE_MEMORY;
-        c->work_ready = true;
-    }
-    HIP_RC(hipEventRecord(g.ev[0], g.stream));
-    RC(ch.invert_factor(g.stream));
-    HIP_RC(hipEventRecord(g.ev[1], g.stream));
-    const long opad = (long) (hdm_operand_pad(c->n16) / sizeof(double));       // slack behind Afull / CL / T (allocation sites)
-    const long afull_span = c->astride * std::max(1, c->mloc) + opad;
-    // Multi-GPU: run step 2 of the owned rows by packed-index range, in the order of the exchange pieces, so that a piece
-    // crosses the links while the later ranges are still being computed (at two ranks the all-to-all moves 8 GB per
-    // rank over a single link, more than the Gram product alone can hide).  Needs the piecewise exchange hooks, all
-    // owned rows in one launch group and at most 64 tile columns.  HDSDP_MI355X_STAGED_A2A=0: drain, then exchange.
-    const int NT = (c->n16 + HDM_TILE - 1) / HDM_TILE;
-    int P = (c->world > 1) ? exchange_pieces(c) : 1;
-    bool staged = c->world > 1 && P > 1 && P <= 64 && c->mloc <= c->Bc && NT <= 64;
-    if (const char *e = getenv("HDSDP_MI355X_STAGED_A2A")) staged = staged && atoi(e) != 0;
-    c->last_pieces = P; c->last_staged = 0;
-    if (!staged) RC(congruence_rows(c, ch, c->Afull, c->astride, afull_span, c->mloc, 0));
-    if (c->rank == 0) {
-        // "I row": A = I => T = Linv, At = Linv Linv^T.  Reuse step 2 with T := Linv.
-        HdmGemmArgs k2 = {};
-        k2.A = ch.Linv; k2.lda = ch.npad; k2.B = ch.Linv; k2.ldb = ch.npad; k2.C = c->AhatLoc;
-        k2.M = c->n16; k2.N = c->n16; k2.K = c->n16; k2.batch = 1; k2.alpha = 1.0;
-        k2.klimit = HDM_KLIM_BY_N; k2.lower_only = 1; k2.epilogue = HDM_EPI_BLOCKED;
-        k2.blk_row_stride = c->Lr; k2.blk_row0 = c->mloc; k2.nblk = c->nblk;
-        RC(hdm_launch_gemm(k2, g.stream));
-        if (typeKKT == KKT_TYPE_HOMOGENEOUS) {
-            if (!c->CL) {
-                HIP_RC(hipMalloc((void **) &c->CL, sizeof(double) * (size_t) c->astride + hdm_operand_pad(c->n16)));
-                HIP_RC(hipMemsetAsync(c->CL, 0, sizeof(double) * (size_t) c->astride, g.stream));
-                RC(hdm_lower_half(c->Cfull, c->CL, c->n, c->n16, g.stream));
-            }
-            RC(congruence_rows(c, ch, c->CL, c->astride, c->astride + opad, 1, c->mloc + 2));
-        }
-    }
-    if (staged) {
-        RC(congruence_rows(c, ch, c->Afull, c->astride, afull_span, c->mloc, 0, 1));
-        const unsigned long long all = (NT >= 64) ? ~0ULL : ((1ULL << NT) - 1);
-        unsigned long long done = 0;
-        for (int k = 0; k < P; ++k) {
-            unsigned long long mk = (k == P - 1 ? all : piece_tile_cols(c, k, P)) & all & ~done;
-            if (mk) { RC(congruence_rows(c, ch, c->Afull, c->astride, afull_span, c->mloc, 0, 2, mk)); c->last_staged += 1; }
-            done |= mk;
-            if (!c->piece_ev[k]) HIP_RC(hipEventCreateWithFlags(&c->piece_ev[k], hipEventDisableTiming));
-            HIP_RC(hipEventRecord(c->piece_ev[k], g.stream));
-        }
-    }
-    HIP_RC(hipEventRecord(g.ev[2], g.stream));
-    if (c->world > 1) { RC(exchange_and_gram(c, staged)); }
-    else { RC(gram_all(c)); }
-    HIP_RC(hipEventRecord(g.ev[3], g.stream));
-    if (c->world > 1) {
-        HIP_RC(hipStreamSynchronize(g.stream));
-        if (!c->allreduce || c->allreduce(c->xctx, c->Gm, (int64_t) c->R * c->R)) return HDSDP_RETCODE_FAILED;
-    }
-    long ldm = 0;
-    double *Mdev = kkt_Mdev(kkt, &ldm);
-    const int hsd = (typeKKT == KKT_TYPE_HOMOGENEOUS);
-    const long pI = (c->world == 1) ? c->mloc : (c->m + c->world - 1) / c->world;  // rows owned by rank 0 = position of the "I row"
-    if (c->kkt_owner)
-        RC(hdm_extract(c->Gm, c->R, c->R, pI, c->rows_seg, Mdev, ldm, pv->vecs, pv->vecs + m, pv->vecs + 2 * m,
-                       pv->vecs + 3 * m, c->Rd, hsd, g.stream));
-    HIP_RC(hipEventRecord(g.ev[4], g.stream));
-    HIP_RC(hipEventSynchronize(g.ev[4]));
-    float ms = 0;
-    for (int i = 0; i < 4; ++i) {
-        (void) hipEventElapsedTime(&ms, g.ev[i], g.ev[i + 1]);
-        g.stage_ms[i] = ms;
-    }
-    return HDSDP_RETCODE_OK;
-}
+#include "engine_stats.h"
+#include "engine_linsys.h"
+#include "engine_cone.h"
+#include "engine_build.h"
 
 }  // namespace
 
-// kernels local to this file -------------------------------------------------------------------
-// row i of the lower triangle of M (column-major, ld): M[i, j] += v[j] for j <= i
-__global__ void mi_put_row_kernel(double *__restrict__ M, long ldm, int i, const double *__restrict__ v, int m) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < m && j <= i) M[i + (long) j * ldm] += v[j];
-}
-
-__global__ void mi_col_dot_kernel(const double *__restrict__ X, const double *__restrict__ Y, long ld, int n,
-                                  const double *__restrict__ sgn, const int *__restrict__ rows, int count,
-                                  double *__restrict__ out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int cidx = blockIdx.x * 4 + wave;
-    if (cidx >= count) return;
-    double s = 0.0;
-    for (int i = lane; i < n; i += 64) s += X[i + (long) cidx * ld] * Y[i + (long) cidx * ld];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) out[rows[cidx]] += sgn[cidx] * s;
-}
-
-__global__ void mi_mat_dot_kernel(const double *__restrict__ X, long ldx, const double *__restrict__ Y, long ldy, int n,
-                                  int diag_only, double scale, double *__restrict__ out) {
-    // single workgroup: out += scale * <X, Y> over n x n (or trace(X) if Y == nullptr and diag_only)
-    __shared__ double red[4];
-    double s = 0.0;
-    if (diag_only) {
-        for (int i = threadIdx.x; i < n; i += 256) s += X[i + (long) i * ldx];
-    } else {
-        for (long e = threadIdx.x; e < (long) n * n; e += 256) {
-            int i = (int) (e % n), j = (int) (e / n);
-            s += X[i + (long) j * ldx] * Y[i + (long) j * ldy];
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) *out += scale * (red[0] + red[1] + red[2] + red[3]);
-}
-
-// out[0] += sum |A_ij|, out[1] += sum A_ij^2 over the full symmetric matrices given by their lower triangles; a_l_form:
-// the diagonal is stored halved (engine layout of the constraint matrices).  One workgroup per matrix.
-__global__ void mi_low_norms_kernel(const double *__restrict__ A, long astride, int n, long ld, int count, int a_l_form,
-                                    double *__restrict__ out) {
-    __shared__ double ra[4], rf[4];
-    const double *M = A + (long) blockIdx.x * astride;
-    double sa = 0.0, sf = 0.0;
-    if (a_l_form) {
-        // A_L form in skyline storage (hdm_common.h): everything that is stored and not zero is an entry on or below the
-        // diagonal, so one linear pass over the matrix's storage does it (this loop once walked the n x n index space with
-        // a division and the skyline offset per element: 1.0 s for 2000 matrices at n = 2000, now HBM-bound).  Off-diagonal
-        // entries count twice; the diagonal is stored halved: |2v| = 2|v| as well, and (2v)^2 = 2v^2 + 2v^2 -- the second
-        // half comes from the short loop over the diagonal.
-        const long cnt = hdm_sky_size((int) ld);
-        for (long e = threadIdx.x; e < cnt; e += 256) { const double v = M[e]; sa += 2.0 * fabs(v); sf += 2.0 * v * v; }
-        for (int i = threadIdx.x; i < n; i += 256) { const double v = M[hdm_sky_off(i, i, (int) ld)]; sf += 2.0 * v * v; }
-    } else {
-        for (int j = 0; j < n; ++j)
-            for (int i = j + threadIdx.x; i < n; i += 256) {
-                const double v = M[i + (long) j * ld];
-                if (i == j) { sa += fabs(v); sf += v * v; }
-                else { sa += 2.0 * fabs(v); sf += 2.0 * v * v; }
-            }
-    }
-    for (int off = 32; off > 0; off >>= 1) { sa += __shfl_down(sa, off, 64); sf += __shfl_down(sf, off, 64); }
-    if ((threadIdx.x & 63) == 0) { ra[threadIdx.x >> 6] = sa; rf[threadIdx.x >> 6] = sf; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(out, ra[0] + ra[1] + ra[2] + ra[3]);
-        atomicAdd(out + 1, rf[0] + rf[1] + rf[2] + rf[3]);
-    }
-    (void) count;
-}
-
-__global__ void mi_scale_kernel(double *__restrict__ A, long count, double s) {
-    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < count) A[e] *= s;
-}
-
-// out += <S, X> with S given by its lower triangle (fds_dot_fds, dense_opts.c:134-156): 2 * (sum_{i>j} + half the diagonal)
-__global__ void mi_lower_dot_kernel(const double *__restrict__ S, long lds_, const double *__restrict__ X, long ldx, int n,
-                                    double *__restrict__ out) {
-    __shared__ double red[4];
-    double s = 0.0;
-    for (long e = threadIdx.x; e < (long) n * n; e += 256) {
-        const int i = (int) (e % n), j = (int) (e / n);
-        if (i < j) continue;
-        const double v = S[i + (long) j * lds_] * X[i + (long) j * ldx];
-        s += (i == j) ? 0.5 * v : v;
-    }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) *out += 2.0 * (red[0] + red[1] + red[2] + red[3]);
-}
-
-__device__ __forceinline__ double mi_hash_unit(unsigned x) {  // pseudo-random in (-1, 1)
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return (double) (int) x / 2147483648.0;
-}
-// same loop on full-range pseudo-random operands (data-dependent power -> sustained clock)
-__global__ __launch_bounds__(256, 2) void mi_mfma_probe_rand_kernel(double *out, int iters) {
-    hdm_d4 acc[4][4];
-    const unsigned gid = blockIdx.x * 256 + threadIdx.x;
-    for (int j = 0; j < 4; ++j)
-        for (int i = 0; i < 4; ++i)
-            for (int r = 0; r < 4; ++r) acc[j][i][r] = mi_hash_unit(gid * 64 + j * 16 + i * 4 + r);
-    double fa[4], fb[4];
-    for (int i = 0; i < 4; ++i) { fa[i] = mi_hash_unit(gid * 8 + i + 1000003u); fb[i] = mi_hash_unit(gid * 8 + 4 + i + 7000001u); }
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
-    }
-    double s = 0.0;
-    for (int j = 0; j < 4; ++j)
-        for (int i = 0; i < 4; ++i) s += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
-    if (s == 12345.678) out[0] = s;
-}
-
-__global__ void mi_mfma_probe_kernel(double *out, int iters) {
-    hdm_d4 acc[8];
-    for (int i = 0; i < 8; ++i) acc[i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
-    }
-    double s = 0.0;
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (s == 12345.678) out[0] = s;  // keep the loop alive
-}
-
-// GEMM-shaped MFMA issue probe: 16 accumulators fed by 4 + 4 operand registers exactly like the GEMM inner loop,
-// no memory traffic at all.  NW = waves per workgroup.
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void mi_mfma_probe2_kernel(double *out, int iters) {
-    hdm_d4 acc[4][4];
-    for (int j = 0; j < 4; ++j)
-        for (int i = 0; i < 4; ++i) acc[j][i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
-    double fa[4], fb[4];
-    for (int i = 0; i < 4; ++i) { fa[i] = 1.0 + threadIdx.x * 1e-9 * (i + 1); fb[i] = 1.0 - threadIdx.x * 1e-9 * (i + 2); }
-    for (int it = 0; it < iters; ++it) {
-        if (MODE == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
-        } else if (MODE == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0], fb[0], acc[j][i], 0, 0, 0);
-        } else {  // 8 accumulators only (2 x 4), GEMM operand pattern
-#pragma unroll
-            for (int rep = 0; rep < 2; ++rep)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
-        }
-    }
-    double s = 0.0;
-    for (int j = 0; j < 4; ++j)
-        for (int i = 0; i < 4; ++i) s += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
-    if (s == 12345.678) out[0] = s;
-}
-
-template <int NACC, int LB>
-__global__ __launch_bounds__(256, LB) void mi_mfma_probe3_kernel(double *out, int iters) {
-    hdm_d4 acc[NACC];
-    for (int i = 0; i < NACC; ++i) acc[i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
-    }
-    double s = 0.0;
-    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (s == 12345.678) out[0] = s;
-}
+#include "engine_kernels.h"
 
 namespace {
-
-#define TRACE_STEP(msg)                                                                                          \
-    do {                                                                                                         \
-        if (stat_trace()) {                                                                                      \
-            const hipError_t e_ = hipDeviceSynchronize();                                                        \
-            fprintf(stderr, "[hdsdp_mi355x trace]     %s (n %d, rows %d, m %d) -> %s\n", msg, c->n, c->mloc, m, \
-                    e_ == hipSuccess ? "ok" : hipGetErrorName(e_));                                              \
-        }                                                                                                        \
-    } while (0)
-hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT) {
-    // all (non-zero) constraints are rank one: A_i = s_i a_i a_i'  (reference strategy M2)
-    MiLin *l = (MiLin *) c->dualFactor->chol;
-    HdmChol &ch = l->ch;
-    const int m = kkt->nRow;
-    const int n16 = c->n16, m16 = c->mloc16;
-    RC(ch.invert_factor(g.stream));
-    TRACE_STEP("r1 step 1");
-    HdmGemmArgs u = {};  // U = Linv * Avec
-    u.A = ch.Linv; u.lda = ch.npad; u.B = c->Avec; u.ldb = n16; u.b_kmajor = 1; u.C = c->U; u.ldc = n16;
-    u.M = n16; u.N = m16; u.K = n16; u.batch = 1; u.alpha = 1.0; u.klimit = HDM_KLIM_BY_M; u.epilogue = HDM_EPI_STORE;
-    RC(hdm_launch_gemm(u, g.stream));
-    TRACE_STEP("r1 step 2");
-    HdmGemmArgs v = {};  // V = Linv^T * U = S^-1 * Avec
-    v.A = ch.Linv; v.lda = ch.npad; v.a_kmajor = 1; v.B = c->U; v.ldb = n16; v.b_kmajor = 1; v.C = c->V; v.ldc = n16;
-    v.M = n16; v.N = m16; v.K = n16; v.batch = 1; v.alpha = 1.0; v.epilogue = HDM_EPI_STORE;
-    RC(hdm_launch_gemm(v, g.stream));
-    TRACE_STEP("r1 step 3");
-    long ldm = 0;
-    double *Mdev = kkt_Mdev(kkt, &ldm);
-    if (typeKKT == KKT_TYPE_CORRECTOR) {
-        // ASinv_i = s_i a_i' S^-1 a_i = s_i <u_i,u_i>; ASinvRdSinv_i = Rd s_i |v_i|^2
-        hipLaunchKernelGGL(mi_col_dot_kernel, dim3((c->mloc + 3) / 4), dim3(256), 0, g.stream, c->U, c->U, (long) n16,
-                           n16, c->sgn, c->rows_own, c->mloc, pv->vecs);
-    TRACE_STEP("r1 step 4");
-        if (c->Rd != 0.0) RC(hdm_r1_colnorm(c->V, n16, n16, c->sgn, c->rows_own, c->mloc, c->Rd, pv->vecs + m, g.stream));
-        return HDSDP_RETCODE_OK;
-    }
-    HdmGemmArgs gq = {};  // Gr1 = U^T U
-    gq.A = c->U; gq.lda = n16; gq.a_kmajor = 1; gq.B = c->U; gq.ldb = n16; gq.b_kmajor = 1; gq.C = c->Gr1; gq.ldc = m16;
-    gq.M = m16; gq.N = m16; gq.K = n16; gq.batch = 1; gq.alpha = 1.0; gq.lower_only = 1; gq.epilogue = HDM_EPI_STORE;
-    RC(hdm_launch_gemm(gq, g.stream));
-    TRACE_STEP("r1 step 5");
-    RC(hdm_r1_hadamard(c->Gr1, m16, c->sgn, c->rows_own, c->mloc, Mdev, ldm, pv->vecs, g.stream));
-    TRACE_STEP("r1 step 6");
-    if (c->Rd != 0.0) {
-        RC(hdm_r1_colnorm(c->V, n16, n16, c->sgn, c->rows_own, c->mloc, c->Rd, pv->vecs + m, g.stream));
-    TRACE_STEP("r1 step 7");
-        // TraceSinv = |Linv|_F^2
-        hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, ch.Linv, (long) ch.npad, ch.Linv,
-                           (long) ch.npad, c->n, 0, 1.0, pv->vecs + 3 * m);
-    TRACE_STEP("r1 step 8");
-    }
-    if (typeKKT == KKT_TYPE_HOMOGENEOUS && c->rank == 0) {
-        // Ct = Linv C Linv^T (full);  ASinvCSinv_i = s_i u_i' Ct u_i;  CSinv = tr Ct; CSinvCSinv = |Ct|_F^2;
-        // CSinvRdSinv = Rd <Ct, Linv Linv^T>
-        HdmGemmArgs k1 = {};
-        k1.A = ch.Linv; k1.lda = ch.npad; k1.B = c->Cfull; k1.ldb = n16; k1.C = c->W; k1.ldc = n16;
-        k1.M = n16; k1.N = n16; k1.K = n16; k1.batch = 1; k1.alpha = 1.0; k1.klimit = HDM_KLIM_BY_M;
-        RC(hdm_launch_gemm(k1, g.stream));
-    TRACE_STEP("r1 step 9");
-        HdmGemmArgs k2 = {};
-        k2.A = c->W; k2.lda = n16; k2.B = ch.Linv; k2.ldb = ch.npad; k2.C = c->Ct; k2.ldc = n16;
-        k2.M = n16; k2.N = n16; k2.K = n16; k2.batch = 1; k2.alpha = 1.0; k2.klimit = HDM_KLIM_BY_N;
-        RC(hdm_launch_gemm(k2, g.stream));
-    TRACE_STEP("r1 step 10");
-        HdmGemmArgs w = {};  // W = Ct * U
-        w.A = c->Ct; w.lda = n16; w.B = c->U; w.ldb = n16; w.b_kmajor = 1; w.C = c->W; w.ldc = n16;
-        w.M = n16; w.N = m16; w.K = n16; w.batch = 1; w.alpha = 1.0;
-        RC(hdm_launch_gemm(w, g.stream));
-    TRACE_STEP("r1 step 11");
-        hipLaunchKernelGGL(mi_col_dot_kernel, dim3((c->mloc + 3) / 4), dim3(256), 0, g.stream, c->U, c->W, (long) n16,
-                           n16, c->sgn, c->rows_own, c->mloc, pv->vecs + 2 * m);
-    TRACE_STEP("r1 step 12");
-        hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Ct, (long) n16, nullptr, 0L, c->n, 1,
-                           1.0, pv->vecs + 3 * m + 1);
-    TRACE_STEP("r1 step 13");
-        hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Ct, (long) n16, c->Ct, (long) n16,
-                           c->n, 0, 1.0, pv->vecs + 3 * m + 2);
-    TRACE_STEP("r1 step 14");
-        if (c->Rd != 0.0) {
-            HdmGemmArgs q = {};  // Xinv := Linv Linv^T
-            q.A = ch.Linv; q.lda = ch.npad; q.B = ch.Linv; q.ldb = ch.npad; q.C = c->Xinv; q.ldc = n16;
-            q.M = n16; q.N = n16; q.K = n16; q.batch = 1; q.alpha = 1.0;
-            RC(hdm_launch_gemm(q, g.stream));
-    TRACE_STEP("r1 step 15");
-            hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Ct, (long) n16, c->Xinv,
-                               (long) n16, c->n, 0, c->Rd, pv->vecs + 3 * m + 3);
-    TRACE_STEP("r1 step 16");
-        }
-    }
-    HIP_RC(hipGetLastError());
-    return HDSDP_RETCODE_OK;
-}
-
-hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT) {
-    // every constraint is a short triplet list: gather from X = S^-1 (reference strategy M5, and the corrector /
-    // HSD components that the reference evaluates with the same gathers, hdsdp_conic_sdp.c:923-1056)
-    MiLin *l = (MiLin *) c->dualFactor->chol;
-    HdmChol &ch = l->ch;
-    const int m = kkt->nRow;
-    const long ldx = ch.npad;
-    RC(ch.inverse_full(c->Xinv, ldx, g.stream));
-    long ldm = 0;
-    double *Mdev = kkt_Mdev(kkt, &ldm);
-    RC(hdm_sparse_dot(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Xinv, ldx, c->mloc, c->rows_own, 1.0, pv->vecs, g.stream));
-    if (c->Rd != 0.0) {
-        HdmGemmArgs q = {};  // Y = X X^T = S^-2
-        q.A = c->Xinv; q.lda = ldx; q.B = c->Xinv; q.ldb = ldx; q.C = c->Yinv; q.ldc = ldx;
-        q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE;
-        RC(hdm_launch_gemm(q, g.stream));
-        RC(hdm_sparse_dot(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Yinv, ldx, c->mloc, c->rows_own, c->Rd,
-                          pv->vecs + m, g.stream));
-    }
-    if (typeKKT == KKT_TYPE_CORRECTOR) return HDSDP_RETCODE_OK;
-    if (c->Rd != 0.0)
-        hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Xinv, ldx, nullptr, 0L, c->n, 1, 1.0,
-                           pv->vecs + 3 * m);
-    RC(hdm_sparse_pairs(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Xinv, ldx, c->mloc, c->rows_own, Mdev, ldm, g.stream));
-    if (typeKKT == KKT_TYPE_HOMOGENEOUS) {
-        HdmGemmArgs w = {};  // W = X C,  Ct = W X = X C X
-        w.A = c->Xinv; w.lda = ldx; w.B = c->Cfull; w.ldb = c->n16; w.C = c->W; w.ldc = ldx;
-        w.M = c->n16; w.N = c->n16; w.K = c->n16; w.batch = 1; w.alpha = 1.0; w.epilogue = HDM_EPI_STORE;
-        RC(hdm_launch_gemm(w, g.stream));
-        HdmGemmArgs x = {};
-        x.A = c->W; x.lda = ldx; x.B = c->Xinv; x.ldb = ldx; x.C = c->Ct; x.ldc = ldx;
-        x.M = c->n16; x.N = c->n16; x.K = c->n16; x.batch = 1; x.alpha = 1.0; x.epilogue = HDM_EPI_STORE;
-        RC(hdm_launch_gemm(x, g.stream));
-        RC(hdm_sparse_dot(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Ct, ldx, c->mloc, c->rows_own, 1.0,
-                          pv->vecs + 2 * m, g.stream));
-        hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, (long) c->n16, c->Xinv, ldx, c->n,
-                           0, 1.0, pv->vecs + 3 * m + 1);
-        hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, (long) c->n16, c->Ct, ldx, c->n, 0,
-                           1.0, pv->vecs + 3 * m + 2);
-        if (c->Rd != 0.0)
-            hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, (long) c->n16, c->Yinv, ldx,
-                               c->n, 0, c->Rd, pv->vecs + 3 * m + 3);
-    }
-    HIP_RC(hipGetLastError());
-    return HDSDP_RETCODE_OK;
-}
-
-void cone_destroy_data(void **pcd) {
-    if (!pcd || !*pcd) return;
-    MiCone *c = (MiCone *) *pcd;
-    if (c->shared_ts) c->slabs = nullptr;      // one buffer, freed as T
-    double *bufs[] = {c->Afull, c->Cfull, c->CL, c->Avec, c->sgn, c->S, c->Scheck, c->ydev, c->T, c->slabs, c->Gm,
-                      c->U, c->V, c->Gr1, c->Ct, c->W, c->Xinv, c->Yinv};
-    for (double *b : bufs)
-        if (b) (void) hipFree(b);
-    if (!c->ext_ahat) {
-        if (c->AhatAll && c->AhatAll != c->AhatLoc) (void) hipFree(c->AhatAll);
-        if (c->AhatLoc) (void) hipFree(c->AhatLoc);
-    }
-    if (c->sp_rp) (void) hipFree(c->sp_rp);
-    if (c->sp_ti) (void) hipFree(c->sp_ti);
-    if (c->sp_tj) (void) hipFree(c->sp_tj);
-    if (c->sp_tv) (void) hipFree(c->sp_tv);
-    if (c->rows_seg) (void) hipFree(c->rows_seg);
-    if (c->rows_own) (void) hipFree(c->rows_own);
-    if (c->trA) free(c->trA);
-    if (c->yhost) (void) hipHostFree(c->yhost);
-    { int *ip[] = {c->small.fp, c->small.fi, c->small.dense_of, c->small.dense_rows}; for (int *q : ip) if (q) (void) hipFree(q); }
-    if (c->small.fv) (void) hipFree(c->small.fv);
-    if (c->small.sgn) (void) hipFree(c->small.sgn);
-    if (c->small.io_host) (void) hipHostFree(c->small.io_host);
-    if (c->corr) (void) hipFree(c->corr);
-    HFpLinsysDestroy(&c->dualFactor);
-    if (c->primal) { c->primal->destroy(); delete c->primal; }
-    if (c->lanczos) { c->lanczos->destroy(); delete c->lanczos; }
-    if (c->chk_host) (void) hipHostFree(c->chk_host);
-    if (c->checker) { c->checker->destroy(); delete c->checker; }
-    for (hipEvent_t e : c->piece_ev) if (e) (void) hipEventDestroy(e);
-    if (c->dS) (void) hipFree(c->dS);
-    if (c->Xup) (void) hipFree(c->Xup);
-    if (c->Pr1) (void) hipFree(c->Pr1);
-    if (c->Pr2) (void) hipFree(c->Pr2);
-    delete c;
-    *pcd = nullptr;
-}
-
-hdsdp_cone *new_cone_shell(MiCone *c, int iCone) {
-    hdsdp_cone *h = (hdsdp_cone *) calloc(1, sizeof(hdsdp_cone));
-    h->iCone = iCone;
-    h->cone = HDSDP_CONETYPE_DENSE_SDP;
-    h->coneData = c;
-    h->coneDestroyData = cone_destroy_data;
-    h->coneSetStart = cone_setstart;
-    h->coneUpdate = cone_update;
-    h->coneGetSymNnz = cone_getsymnnz;
-    h->coneAddSymNz = cone_add_sym_nz;
-    h->coneGetKKTMap = cone_get_kkt_map;
-    h->coneGetDim = cone_getdim;
-    h->coneBuildSchur = cone_build_schur;
-    h->coneBuildSchurFixed = cone_build_schur_fixed;
-    h->coneBuildPrimalDirection = cone_build_primal_dir;
-    h->coneInteriorCheck = cone_interior;
-    h->coneRatioTest = cone_ratio_test;
-    h->conePRecover = cone_precover;
-    h->coneInteriorCheckExpert = cone_interior_expert;
-    h->coneAxpyBufferAndCheck = cone_axpy_check;
-    h->coneReduceResi = cone_reduce_resi;
-    h->coneSetPerturb = cone_set_perturb;
-    h->coneGetCoeffNorm = cone_coeff_norm;
-    h->coneGetObjNorm = cone_obj_norm;
-    h->coneScal = cone_scal;
-    h->coneATimesXpy = cone_a_times_x;
-    h->coneTraceCX = cone_trace_cx;
-    h->coneXDotS = cone_x_dot_s;
-    h->coneDRecover = cone_get_dual;
-    h->coneGetBarrier = cone_barrier;
-    return h;
-}
-
+#include "engine_build_small.h"
 }  // namespace
 
 // =============================================================================================
 // exported C ABI
 // =============================================================================================
 extern "C" {
-
-const char *HMiVersion(void) { return "hdsdp-mi355x 0.1 (gfx950, fp64 MFMA)"; }
-
-int HMiDeviceInit(int device) {
-    if (g.init) return 0;
-    if (device >= 0) {
-        char buf[16];
-        snprintf(buf, sizeof(buf), "%d", device);
-        setenv("LOCAL_RANK", buf, 0);
-    }
-    return ensure_ctx();
-}
-int HMiDeviceSynchronize(void) {
-    if (ensure_ctx()) return 1;
-    HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
-    return 0;
-}
-void *HMiStream(void) { return ensure_ctx() ? nullptr : (void *) g.stream; }
-void HMiSetKernelTiming(int on) { hdm_timing_enable(on); }
-void HMiSetDebugBuffer(void *dev, int role) { hdm_set_debug_buffer((unsigned long long *) dev, role); }
-int HMiGetKernelTiming(double *ms, double *flops, int64_t *launches) {
-    long l[HDM_NROLES];
-    if (hdm_timing_collect(ms, flops, l)) return 1;
-    for (int r = 0; r < HDM_NROLES; ++r) launches[r] = l[r];
-    return 0;
-}
-void HMiGetStageTimes(double *ms, int n) {
-    for (int i = 0; i < n && i < 8; ++i) ms[i] = g.stage_ms[i];
-}
-
-// ---------------------------------------------------------------- HFpLinsys*
-hdsdp_retcode HFpLinsysCreate(hdsdp_linsys_fp **pHLin, int nCol, linsys_type Ltype) {
-    if (!pHLin) return HDSDP_RETCODE_FAILED;
-    switch (Ltype) {
-        case HDSDP_LINSYS_DENSE_DIRECT:
-        case HDSDP_LINSYS_DENSE_ITERATIVE:  // Schur system: solved by a direct blocked Cholesky here (stricter
-            break;                          // than the reference's PCG to 1e-12, hdsdp_linsolver.c:1446-1588)
-        case HDSDP_LINSYS_SPARSE_DIRECT:    // sparse dual matrix: CSC in, dense factorisation on the device (see MiLin)
-            break;
-        default:
-            fprintf(stderr, "[hdsdp_mi355x] HFpLinsysCreate: linsys_type %d is not on the accelerated path "
-                            "(sparse indefinite / iterative backends stay with the CPU reference; DENSE_INDEFINITE is only reached by switching)\n", (int) Ltype);
-            return HDSDP_RETCODE_FAILED;
-    }
-    hdsdp_linsys_fp *h = (hdsdp_linsys_fp *) calloc(1, sizeof(hdsdp_linsys_fp));
-    if (!h) return HDSDP_RETCODE_MEMORY;
-    h->nCol = nCol;
-    h->LinType = Ltype;
-    h->cholCreate = lin_create;
-    h->cholSetParam = lin_setparam;
-    h->cholSymbolic = lin_symbolic;
-    h->cholNumeric = lin_numeric;
-    h->cholPsdCheck = lin_psdcheck;
-    h->cholFSolve = lin_fsolve;
-    h->cholBSolve = lin_bsolve;
-    h->cholSolve = lin_solve;
-    h->cholGetDiag = lin_getdiag;
-    h->cholInvert = lin_invert;
-    h->cholDestroy = lin_destroy;
-    hdsdp_retcode rc = h->cholCreate(&h->chol, nCol);
-    if (rc != HDSDP_RETCODE_OK) { free(h); return rc; }
-    ((MiLin *) h->chol)->type = Ltype;
-    ((MiLin *) h->chol)->csc_in = (Ltype == HDSDP_LINSYS_SPARSE_DIRECT);
-    *pHLin = h;
-    return HDSDP_RETCODE_OK;
-}
-void HFpLinsysSetParam(hdsdp_linsys_fp *HLin, double relTol, double absTol, int nThreads, int maxIter, int nRestartFreq) {
-    (void) nThreads; (void) nRestartFreq;
-    MiLin *l = (MiLin *) HLin->chol;
-    l->relTol = relTol; l->absTol = absTol; l->maxIter = maxIter;  // recorded; the direct solve needs none
-}
-hdsdp_retcode HFpLinsysSymbolic(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx) {
-    return HLin->cholSymbolic(HLin->chol, colMatBeg, colMatIdx);
-}
-hdsdp_retcode HFpLinsysNumeric(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx, double *colMatElem) {
-    StatScope stat_(ST_LINSYS, __func__);
-    // hdsdp_linsolver.c:2029-2044: a failed factorisation of the Schur system switches to the indefinite solver
-    HLin->nFactorizes += 1;
-    hdsdp_retcode rc = HLin->cholNumeric(HLin->chol, colMatBeg, colMatIdx, colMatElem);
-    if (rc == HDSDP_RETCODE_FAILED && HLin->LinType == HDSDP_LINSYS_DENSE_ITERATIVE) {
-        fprintf(stderr, "[hdsdp_mi355x] KKT system is almost indefinite. Switch to the pivoted (LDL-equivalent) solver.\n");
-        rc = lin_switch_indefinite(HLin);
-    }
-    return rc;
-}
-hdsdp_retcode HFpLinsysSwitchToBackUp(hdsdp_linsys_fp *HLin) { (void) HLin; return HDSDP_RETCODE_OK; }
-hdsdp_retcode HFpLinsysPsdCheck(hdsdp_linsys_fp *HLin, int *colMatBeg, int *colMatIdx, double *colMatElem, int *isPsd) {
-    StatScope stat_(ST_LINSYS, __func__);
-    HLin->nFactorizes += 1;
-    return HLin->cholPsdCheck(HLin->chol, colMatBeg, colMatIdx, colMatElem, isPsd);
-}
-void HFpLinsysFSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec) {
-    StatScope stat_(ST_LINSYS, __func__);
-    HLin->nSolves += 1;
-    HLin->cholFSolve(HLin->chol, nRhs, rhsVec, solVec);
-}
-void HFpLinsysBSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec) {
-    StatScope stat_(ST_LINSYS, __func__);
-    HLin->nSolves += 1;
-    HLin->cholBSolve(HLin->chol, nRhs, rhsVec, solVec);
-}
-hdsdp_retcode HFpLinsysSolve(hdsdp_linsys_fp *HLin, int nRhs, double *rhsVec, double *solVec) {
-    StatScope stat_(ST_LINSYS, __func__);
-    // hdsdp_linsolver.c:2085-2110: NaN in the solution (or the right-hand side) counts as a failure, and a failed solve
-    // of the Schur system switches to the indefinite solver and solves again
-    hdsdp_retcode rc = HLin->cholSolve(HLin->chol, nRhs, rhsVec, solVec);
-    if (solVec && solVec[0] != solVec[0]) rc = HDSDP_RETCODE_FAILED;
-    if (rhsVec[0] != rhsVec[0]) rc = HDSDP_RETCODE_FAILED;
-    if (rc != HDSDP_RETCODE_OK && HLin->LinType == HDSDP_LINSYS_DENSE_ITERATIVE) {
-        fprintf(stderr, "[hdsdp_mi355x] KKT system is unstable. Switch to the pivoted (LDL-equivalent) solver.\n");
-        if (lin_switch_indefinite(HLin) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
-        return HFpLinsysSolve(HLin, nRhs, rhsVec, solVec);
-    }
-    HLin->nSolves += 1;
-    return rc;
-}
-hdsdp_retcode HFpLinsysGetDiag(hdsdp_linsys_fp *HLin, double *diagElem) { return HLin->cholGetDiag(HLin->chol, diagElem); }
-void HFpLinsysInvert(hdsdp_linsys_fp *HLin, double *dFullMatrix, double *dAuxiMatrix) {
-    StatScope stat_(ST_LINSYS, __func__);
-    HLin->cholInvert(HLin->chol, dFullMatrix, dAuxiMatrix);
-}
-void HFpLinsysClear(hdsdp_linsys_fp *HLin) {
-    if (!HLin) return;
-    if (HLin->cholDestroy) HLin->cholDestroy(&HLin->chol);
-    memset(HLin, 0, sizeof(hdsdp_linsys_fp));
-}
-void HFpLinsysDestroy(hdsdp_linsys_fp **pHLin) {
-    if (!pHLin || !*pHLin) return;
-    HFpLinsysClear(*pHLin);
-    free(*pHLin);
-    *pHLin = nullptr;
-}
-
-// ---------------------------------------------------------------- HKKT*
-hdsdp_retcode HKKTCreate(hdsdp_kkt **pHKKT) {
-    if (!pHKKT) return HDSDP_RETCODE_FAILED;
-    hdsdp_kkt *k = (hdsdp_kkt *) calloc(1, sizeof(hdsdp_kkt));
-    if (!k) return HDSDP_RETCODE_MEMORY;
-    *pHKKT = k;
-    return HDSDP_RETCODE_OK;
-}
-
-// Reverse Cuthill-McKee order of a symmetric pattern given as its lower triangle in CSC form: perm[old] = new.  Every
-// connected component starts from a vertex of minimal degree found by a few breadth-first sweeps (pseudo-peripheral).
-static std::vector<int> rcm_order(int m, const std::vector<int> &beg, const std::vector<int> &idx) {
-    std::vector<int> deg(m, 0);
-    for (int c = 0; c < m; ++c)
-        for (int q = beg[c]; q < beg[c + 1]; ++q) if (idx[q] != c) { deg[c] += 1; deg[idx[q]] += 1; }
-    std::vector<int> ap(m + 1, 0);
-    for (int v = 0; v < m; ++v) ap[v + 1] = ap[v] + deg[v];
-    std::vector<int> adj((size_t) ap[m]), fill(ap.begin(), ap.end() - 1);
-    for (int c = 0; c < m; ++c)
-        for (int q = beg[c]; q < beg[c + 1]; ++q) if (idx[q] != c) { adj[fill[c]++] = idx[q]; adj[fill[idx[q]]++] = c; }
-    std::vector<int> order; order.reserve(m);
-    std::vector<char> seen(m, 0);
-    std::vector<int> level(m, -1), queue;
-    auto bfs = [&](int root, std::vector<int> &out) {          // breadth-first from root over the unseen part; returns the last level's vertex of minimal degree
-        out.clear(); out.push_back(root);
-        std::vector<int> touched{root};
-        level[root] = 0;
-        for (size_t h = 0; h < out.size(); ++h) {
-            const int v = out[h];
-            const size_t first_child = out.size();
-            for (int q = ap[v]; q < ap[v + 1]; ++q) {
-                const int w = adj[q];
-                if (seen[w] || level[w] >= 0) continue;
-                level[w] = level[v] + 1; out.push_back(w); touched.push_back(w);
-            }
-            std::sort(out.begin() + first_child, out.end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
-        }
-        const int last_level = level[out.back()];
-        int best = out.back();
-        for (int v : out) if (level[v] == last_level && (deg[v] < deg[best] || (deg[v] == deg[best] && v < best))) best = v;
-        for (int v : touched) level[v] = -1;
-        return best;
-    };
-    for (int s0 = 0; s0 < m; ++s0) {
-        if (seen[s0]) continue;
-        int root = s0;
-        for (int sweep = 0; sweep < 3; ++sweep) root = bfs(root, queue);
-        bfs(root, queue);
-        for (int v : queue) { seen[v] = 1; order.push_back(v); }
-    }
-    std::vector<int> perm(m);
-    for (int k = 0; k < m; ++k) perm[order[k]] = m - 1 - k;     // reversed
-    return perm;
-}
-
-hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones) {
-    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
-    HKKT->nRow = nRow;
-    HKKT->nCones = nCones;
-    HKKT->cones = cones;
-    int maxDim = 0;
-    for (int i = 0; i < nCones; ++i) maxDim = std::max(maxDim, cones[i]->coneGetDim(cones[i]->coneData));
-    HKKT->maxConeDim = maxDim;
-    const size_t nn = (size_t) maxDim * maxDim;
-    HKKT->invBuffer = (double *) calloc(nn, sizeof(double));
-    HKKT->kktBuffer = (double *) calloc(nn, sizeof(double));
-    HKKT->kktBuffer2 = (double *) calloc(nn, sizeof(double));
-    HKKT->dASinvVec = (double *) calloc(nRow, sizeof(double));
-    HKKT->dASinvCSinvVec = (double *) calloc(nRow, sizeof(double));
-    HKKT->dASinvRdSinvVec = (double *) calloc(nRow, sizeof(double));
-    HKKT->kktDiag = (double **) calloc(nRow, sizeof(double *));
-    if (!HKKT->invBuffer || !HKKT->kktBuffer || !HKKT->kktBuffer2 || !HKKT->dASinvVec || !HKKT->dASinvCSinvVec ||
-        !HKKT->dASinvRdSinvVec || !HKKT->kktDiag)
-        return HDSDP_RETCODE_MEMORY;
-    // Dense Schur matrix (hdsdp_schur.c:11-44) or the aggregated-pattern CSC (:46-139): the reference's own rule.  A cone
-    // whose share of M reaches 0.3 m^2 entries makes it dense at once (:229-238); otherwise the columns' patterns are
-    // collected from the cones (coneAddSymNz / coneGetKKTMap) and the CSC is kept unless it grows to 0.3 m^2 (:104-108).
-    // HDSDP_MI355X_SPARSE_KKT=0 forces the dense matrix.
-    MiKKTPriv *pv0 = priv_of(HKKT);
-    HKKT->isKKTSparse = 1;
-    const int64_t nDense = (int64_t) (0.3 * (double) nRow * (double) nRow);     // HDSDP_SPARSE_SCHUR_THRESHOLD, hdsdp.h:29
-    if (const char *e = getenv("HDSDP_MI355X_SPARSE_KKT")) if (atoi(e) == 0) HKKT->isKKTSparse = 0;
-    for (int i = 0; i < nCones && HKKT->isKKTSparse; ++i) {
-        if (!cones[i]->coneGetSymNnz || !cones[i]->coneAddSymNz || !cones[i]->coneGetKKTMap ||
-            cones[i]->coneGetSymNnz(cones[i]->coneData) >= nDense) HKKT->isKKTSparse = 0;
-    }
-    if (HKKT->isKKTSparse) {
-        for (int i = 0; i < nCones; ++i)      // an engine cone may serve a second operator: its pattern walk starts over
-            if (cones[i]->coneBuildSchur == cone_build_schur) ((MiCone *) cones[i]->coneData)->kkt_counted = 0;
-        std::vector<int> beg((size_t) nRow + 1, 0), idx, col((size_t) nRow);
-        for (int iCol = 0; iCol < nRow && HKKT->isKKTSparse; ++iCol) {
-            std::fill(col.begin(), col.end(), 0);
-            for (int i = 0; i < nCones; ++i) cones[i]->coneAddSymNz(cones[i]->coneData, iCol, col.data());
-            for (int iRow = iCol; iRow < nRow; ++iRow)
-                if (col[iRow]) { col[iRow] = (int) idx.size(); idx.push_back(iRow); }
-            for (int i = 0; i < nCones; ++i) cones[i]->coneGetKKTMap(cones[i]->coneData, iCol, col.data());
-            beg[iCol + 1] = (int) idx.size();
-            if ((int64_t) idx.size() >= nDense) HKKT->isKKTSparse = 0;      // aggregation made it dense after all
-        }
-        // a constraint no cone has data for leaves an empty column: the reference stops there ("KKT solver detects an
-        // empty column", :116-121); the engine keeps such an operator usable on the dense matrix, where the row simply
-        // stays zero until a CPU cone (the bound cone's diagonal) or the regularisation fills it
-        for (int iCol = 0; iCol < nRow && HKKT->isKKTSparse; ++iCol)
-            if (beg[iCol] == beg[iCol + 1] || idx[beg[iCol]] != iCol) HKKT->isKKTSparse = 0;
-        if (HKKT->isKKTSparse) {
-            const size_t nnz = idx.size();
-            HKKT->kktMatBeg = (int *) malloc(sizeof(int) * ((size_t) nRow + 1));
-            HKKT->kktMatIdx = (int *) malloc(sizeof(int) * std::max<size_t>(1, nnz));
-            if (!HKKT->kktMatBeg || !HKKT->kktMatIdx) return HDSDP_RETCODE_MEMORY;
-            memcpy(HKKT->kktMatBeg, beg.data(), sizeof(int) * ((size_t) nRow + 1));
-            memcpy(HKKT->kktMatIdx, idx.data(), sizeof(int) * nnz);
-            if (hipHostMalloc((void **) &HKKT->kktMatElem, sizeof(double) * std::max<size_t>(1, nnz), hipHostMallocDefault) != hipSuccess)
-                return HDSDP_RETCODE_MEMORY;
-            memset(HKKT->kktMatElem, 0, sizeof(double) * nnz);
-            for (int iCol = 0; iCol < nRow; ++iCol) HKKT->kktDiag[iCol] = &HKKT->kktMatElem[beg[iCol]];
-            hdsdp_retcode rcs = HFpLinsysCreate(&HKKT->kktM, nRow, HDSDP_LINSYS_SPARSE_DIRECT);
-            if (rcs != HDSDP_RETCODE_OK) return rcs;
-            rcs = HFpLinsysSymbolic(HKKT->kktM, HKKT->kktMatBeg, HKKT->kktMatIdx);
-            if (rcs != HDSDP_RETCODE_OK) return rcs;
-            // the pattern as (row, column) pairs on the device
-            std::vector<int> cols(nnz);
-            for (int iCol = 0; iCol < nRow; ++iCol)
-                for (int q = beg[iCol]; q < beg[iCol + 1]; ++q) cols[q] = iCol;
-            pv0->nnz = (long) nnz;
-            if (hipMalloc((void **) &pv0->sp_rows, sizeof(int) * std::max<size_t>(1, nnz)) != hipSuccess ||
-                hipMalloc((void **) &pv0->sp_cols, sizeof(int) * std::max<size_t>(1, nnz)) != hipSuccess ||
-                hipMalloc((void **) &pv0->sp_vals, sizeof(double) * std::max<size_t>(1, nnz)) != hipSuccess)
-                return HDSDP_RETCODE_MEMORY;
-            if (hdm_memcpy_h2d_sync(pv0->sp_rows, idx.data(), sizeof(int) * nnz) != hipSuccess ||
-                hdm_memcpy_h2d_sync(pv0->sp_cols, cols.data(), sizeof(int) * nnz) != hipSuccess)
-                return HDSDP_RETCODE_FAILED;
-            // the pattern's block envelope: the blocked Cholesky of the (dense, mostly zero) device matrix stops each block
-            // column where the envelope ends and the substitutions skip the blocks outside (HdmChol::set_envelope).  The
-            // factor of a matrix fills inside its row envelope only, so nothing is approximated.  If a reverse Cuthill-McKee
-            // order of the pattern makes the envelope cheaper, the factor object holds P M P' instead (MiLin::perm): the
-            // builders keep writing M at the driver's indices, the pattern's entries are scattered to their permuted places
-            // when the matrix is loaded for factorisation, and right-hand sides / solutions are permuted on the host.
-            {
-                static const bool use_env = [] { const char *e = getenv("HDSDP_MI355X_KKT_ENVELOPE"); return !(e && atoi(e) == 0); }();
-                static const bool use_rcm = [] { const char *e = getenv("HDSDP_MI355X_KKT_RCM"); return !(e && atoi(e) == 0); }();
-                MiLin *lm = (MiLin *) HKKT->kktM->chol;
-                if (use_env && lm && lm->ch.nblk > 1) {
-                    const int nb = lm->ch.nblk;
-                    auto envelope = [&](const std::vector<int> *perm, std::vector<int> &first) {   // returns the factorisation's cost in block products
-                        first.resize(nb);
-                        for (int b = 0; b < nb; ++b) first[b] = b;
-                        for (size_t q = 0; q < nnz; ++q) {
-                            int r = idx[q], c = cols[q];
-                            if (perm) { r = (*perm)[r]; c = (*perm)[c]; if (r < c) std::swap(r, c); }
-                            const int br = r / 128, bc = c / 128;
-                            if (bc < first[br]) first[br] = bc;
-                        }
-                        std::vector<int> colh(nb);
-                        for (int k = 0; k < nb; ++k) colh[k] = k;
-                        for (int b = 0; b < nb; ++b) for (int k = first[b]; k <= b; ++k) colh[k] = std::max(colh[k], b);
-                        double cost = 0.0;
-                        for (int k = 0; k < nb; ++k) { const double h = colh[k] - k; cost += 1.0 + h + 0.5 * h * (h + 1.0); }
-                        return cost;
-                    };
-                    std::vector<int> first_nat, first_rcm, perm;
-                    const double cost_nat = envelope(nullptr, first_nat);
-                    double cost_rcm = INFINITY;
-                    // (the reordering is looked for where it can pay: patterns up to 5e7 entries -- its adjacency lists take 8 bytes per
-                    // entry on the host -- that do not already fill most of the triangle)
-                    if (use_rcm && nnz <= 50000000 && (double) nnz < 0.15 * (double) nRow * nRow) { perm = rcm_order(nRow, beg, idx); cost_rcm = envelope(&perm, first_rcm); }
-                    if (cost_rcm < 0.8 * cost_nat) {
-                        std::vector<int> prow(nnz), pcol(nnz);
-                        for (size_t q = 0; q < nnz; ++q) {
-                            int r = perm[idx[q]], c = perm[cols[q]];
-                            if (r < c) std::swap(r, c);
-                            prow[q] = r; pcol[q] = c;
-                        }
-                        if (hipMalloc((void **) &pv0->sp_prow, sizeof(int) * std::max<size_t>(1, nnz)) != hipSuccess ||
-                            hipMalloc((void **) &pv0->sp_pcol, sizeof(int) * std::max<size_t>(1, nnz)) != hipSuccess)
-                            return HDSDP_RETCODE_MEMORY;
-                        if (hdm_memcpy_h2d_sync(pv0->sp_prow, prow.data(), sizeof(int) * nnz) != hipSuccess ||
-                            hdm_memcpy_h2d_sync(pv0->sp_pcol, pcol.data(), sizeof(int) * nnz) != hipSuccess)
-                            return HDSDP_RETCODE_FAILED;
-                        lm->perm = perm;
-                        if (lm->ch.set_envelope(first_rcm.data())) return HDSDP_RETCODE_FAILED;
-                    } else if (lm->ch.set_envelope(first_nat.data())) return HDSDP_RETCODE_FAILED;
-                }
-            }
-            printf("    Using sparse Schur complement (%d nnzs)\n", HKKT->kktMatBeg[nRow]);
-        }
-    }
-    if (!HKKT->isKKTSparse) {
-        // pinned so the D2H/H2D of M after BuildUp / before Factorize runs at PCIe rate
-        if (hipHostMalloc((void **) &HKKT->kktMatElem, sizeof(double) * (size_t) nRow * nRow, hipHostMallocDefault) != hipSuccess)
-            return HDSDP_RETCODE_MEMORY;
-        memset(HKKT->kktMatElem, 0, sizeof(double) * (size_t) nRow * nRow);
-        hdsdp_retcode rc = HFpLinsysCreate(&HKKT->kktM, nRow, HDSDP_LINSYS_DENSE_ITERATIVE);
-        if (rc != HDSDP_RETCODE_OK) return rc;
-        double acc = 1e-12;  // KKT_ACCURACY (hdsdp.h:27); loosened for big systems exactly as hdsdp_schur.c:21-35
-        int iters = -1;
-        if (nRow > 20000) { acc *= 100.0; iters = 500; } else if (nRow > 15000) { acc *= 50.0; iters = 450; }
-        else if (nRow > 5000) { acc *= 5.0; iters = 120; }
-        HFpLinsysSetParam(HKKT->kktM, 5.0 * acc, acc, -1, iters, -1);
-        for (int i = 0; i < nRow; ++i) HKKT->kktDiag[i] = &HKKT->kktMatElem[i + (size_t) i * nRow];
-    }
-    // On the device M stays a dense m x m matrix in either case: the cones' builders write it at global (row, column)
-    // indices, the blocked Cholesky factors it densely.  What the sparse form changes is the host side -- the matrix the
-    // driver, the CPU cones (through kktMapping / kktDiag) and HKKTRegularize see is the nnz-long CSC, not m^2 doubles.
-    MiLin *l = (MiLin *) HKKT->kktM->chol;
-    const size_t mm = sizeof(double) * (size_t) l->ch.npad * l->ch.npad;
-    if (hipMalloc((void **) &l->Mdev, mm) != hipSuccess) return HDSDP_RETCODE_MEMORY;
-    if (hdm_memset_sync(l->Mdev, 0, mm) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    MiKKTPriv *pv = priv_of(HKKT);
-    if (hipMalloc((void **) &pv->vecs, sizeof(double) * (3 * (size_t) nRow + 4)) != hipSuccess) return HDSDP_RETCODE_MEMORY;
-    pv->n_engine = pv->n_foreign = 0;
-    for (int i = 0; i < nCones; ++i) {
-        if (cones[i]->coneBuildSchur == cone_build_schur || cones[i]->coneBuildSchur == gc_build_schur) pv->n_engine += 1;
-        else pv->n_foreign += 1;
-    }
-    HKKT->dPrimalX = nullptr;
-    return HDSDP_RETCODE_OK;
-}
-
-static hdsdp_retcode kkt_clean(hdsdp_kkt *HKKT, int typeKKT) {  // hdsdp_schur.c:141-165
-    const int m = HKKT->nRow;
-    MiKKTPriv *pv = priv_of(HKKT);
-    memset(HKKT->dASinvVec, 0, sizeof(double) * m);
-    memset(HKKT->dASinvRdSinvVec, 0, sizeof(double) * m);
-    if (typeKKT == KKT_TYPE_HOMOGENEOUS) {
-        memset(HKKT->dASinvCSinvVec, 0, sizeof(double) * m);
-        HKKT->dCSinv = HKKT->dCSinvCSinv = HKKT->dCSinvRdSinv = 0.0;
-    }
-    HKKT->dTraceSinv = 0.0;
-    if (hipMemsetAsync(pv->vecs, 0, sizeof(double) * (3 * (size_t) m + 4), g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    if (typeKKT != KKT_TYPE_CORRECTOR) {
-        MiLin *l = (MiLin *) HKKT->kktM->chol;
-        if (hipMemsetAsync(l->Mdev, 0, sizeof(double) * (size_t) l->ch.npad * l->ch.npad, g.stream) != hipSuccess)
-            return HDSDP_RETCODE_FAILED;
-        if (HKKT->isKKTSparse) memset(HKKT->kktMatElem, 0, sizeof(double) * (size_t) HKKT->kktMatBeg[m]);   // (CPU cones add into it)
-        // (dense host matrix: CPU cones add into it, so it starts from zero -- but with engine cones only, kkt_pull's copy
-        // of the whole m x m device matrix replaces every entry, and 8 m^2 bytes of host memset per call are saved: 4 ms at
-        // m = 2000, twice per iteration of the reference's driver)
-        else if (pv->mirror && !(pv->n_foreign == 0 && pv->n_engine > 0)) memset(HKKT->kktMatElem, 0, sizeof(double) * (size_t) m * m);
-    }
-    return HDSDP_RETCODE_OK;
-}
-
-static hdsdp_retcode kkt_pull(hdsdp_kkt *HKKT, int typeKKT) {
-    // device accumulators -> the host fields the driver and the CPU cones read (def_hdsdp_schur.h:44-61)
-    const int m = HKKT->nRow;
-    MiKKTPriv *pv = priv_of(HKKT);
-    std::vector<double> h(3 * (size_t) m + 4);
-    if (hipMemcpyAsync(h.data(), pv->vecs, sizeof(double) * h.size(), hipMemcpyDeviceToHost, g.stream) != hipSuccess)
-        return HDSDP_RETCODE_FAILED;
-    // M: every cone ACCUMULATES (hdsdp_schur.c:256-268).  The engine's cones did so on the device, foreign (CPU) cones
-    // straight into kktMatElem: with only engine cones the device matrix simply replaces the (zeroed) host one, with
-    // only foreign cones there is nothing to bring back, and in the mixed case the device part is added to the host part.
-    bool add_M = false;
-    size_t mcount = 0;     // entries of the host matrix that came back through Mtmp
-    if (typeKKT != KKT_TYPE_CORRECTOR && pv->mirror && pv->n_engine > 0) {
-        long ld = 0;
-        double *Mdev = kkt_Mdev(HKKT, &ld);
-        double *dst = HKKT->kktMatElem;
-        mcount = HKKT->isKKTSparse ? (size_t) pv->nnz : (size_t) m * m;
-        if (pv->n_foreign > 0) {
-            if (!pv->Mtmp && hipHostMalloc((void **) &pv->Mtmp, sizeof(double) * std::max<size_t>(1, mcount)) != hipSuccess) return HDSDP_RETCODE_MEMORY;
-            dst = pv->Mtmp;
-            add_M = true;
-        }
-        if (HKKT->isKKTSparse) {
-            // the pattern's entries of the dense device matrix (an engine cone only writes inside the pattern it declared)
-            if (pv->nnz > 0) {
-                hipLaunchKernelGGL(mi_csc_gather_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, Mdev, ld,
-                                   pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
-                if (hipMemcpyAsync(dst, pv->sp_vals, sizeof(double) * (size_t) pv->nnz, hipMemcpyDeviceToHost, g.stream) != hipSuccess)
-                    return HDSDP_RETCODE_FAILED;
-            }
-        } else if (hipMemcpy2DAsync(dst, sizeof(double) * m, Mdev, sizeof(double) * ld, sizeof(double) * m, m,
-                                    hipMemcpyDeviceToHost, g.stream) != hipSuccess)
-            return HDSDP_RETCODE_FAILED;
-    }
-    if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    if (add_M) {
-        if (HKKT->isKKTSparse) for (size_t q = 0; q < mcount; ++q) HKKT->kktMatElem[q] += pv->Mtmp[q];
-        else
-            for (int j = 0; j < m; ++j)                    // lower triangle, column-major
-                for (int i = j; i < m; ++i) HKKT->kktMatElem[i + (size_t) j * m] += pv->Mtmp[i + (size_t) j * m];
-    }
-    for (int i = 0; i < m; ++i) {
-        HKKT->dASinvVec[i] += h[i];
-        HKKT->dASinvRdSinvVec[i] += h[m + i];
-        if (typeKKT == KKT_TYPE_HOMOGENEOUS) HKKT->dASinvCSinvVec[i] += h[2 * (size_t) m + i];
-    }
-    if (typeKKT != KKT_TYPE_CORRECTOR) HKKT->dTraceSinv += h[3 * (size_t) m];
-    if (typeKKT == KKT_TYPE_HOMOGENEOUS) {
-        HKKT->dCSinv += h[3 * (size_t) m + 1];
-        HKKT->dCSinvCSinv += h[3 * (size_t) m + 2];
-        HKKT->dCSinvRdSinv += h[3 * (size_t) m + 3];
-    }
-    pv->Mdev_valid = (typeKKT != KKT_TYPE_CORRECTOR) ? true : pv->Mdev_valid;
-    return HDSDP_RETCODE_OK;
-}
-
-hdsdp_retcode HKKTBuildUp(hdsdp_kkt *HKKT, int typeKKT) {
-    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M, __func__);
-    hdsdp_retcode rc = kkt_clean(HKKT, typeKKT);
-    if (rc != HDSDP_RETCODE_OK) return rc;
-    for (int i = 0; i < HKKT->nCones; ++i) {
-        hdsdp_cone *c = HKKT->cones[i];
-        rc = c->coneBuildSchur(c->coneData, c->iCone, HKKT, typeKKT);  // == HConeBuildSchurComplement
-        if (stat_trace()) {
-            const hipError_t e = hipDeviceSynchronize();
-            fprintf(stderr, "[hdsdp_mi355x trace]   build type %d, cone %d of %d -> rc %d, %s\n", typeKKT, i, HKKT->nCones, (int) rc,
-                    e == hipSuccess ? "ok" : hipGetErrorName(e));
-        }
-        if (rc != HDSDP_RETCODE_OK) return rc;
-    }
-    return kkt_pull(HKKT, typeKKT);
-}
-
-hdsdp_retcode HKKTBuildUpExtraCone(hdsdp_kkt *HKKT, hdsdp_cone *cone, int typeKKT) {
-    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M, __func__);
-    // CPU cones (bound / LP, hdsdp_conic_bound.c:201-249) write straight into the host fields
-    return cone->coneBuildSchur(cone->coneData, cone->iCone, HKKT, typeKKT);
-}
-
-hdsdp_retcode HKKTBuildUpFixed(hdsdp_kkt *HKKT, int typeKKT, int kktStrategy) {
-    StatScope stat_(typeKKT == KKT_TYPE_CORRECTOR ? ST_BUILD_CORR : ST_BUILD_M, __func__);
-    hdsdp_retcode rc = kkt_clean(HKKT, typeKKT);
-    if (rc != HDSDP_RETCODE_OK) return rc;
-    for (int i = 0; i < HKKT->nCones; ++i) {
-        hdsdp_cone *c = HKKT->cones[i];
-        rc = c->coneBuildSchurFixed(c->coneData, c->iCone, HKKT, typeKKT, kktStrategy);
-        if (rc != HDSDP_RETCODE_OK) return rc;
-    }
-    return kkt_pull(HKKT, typeKKT);
-}
-
-void HKKTExport(hdsdp_kkt *HKKT, double *dKKTASinvVec, double *dKKTASinvRdSinvVec, double *dKKTASinvCSinvVec,
-                double *dCSinvCSinv, double *dCSinv, double *dCSinvRdCSinv, double *dTraceSinv) {
-    const size_t b = sizeof(double) * (size_t) HKKT->nRow;
-    if (dKKTASinvVec) memcpy(dKKTASinvVec, HKKT->dASinvVec, b);
-    if (dKKTASinvRdSinvVec) memcpy(dKKTASinvRdSinvVec, HKKT->dASinvRdSinvVec, b);
-    if (dKKTASinvCSinvVec) memcpy(dKKTASinvCSinvVec, HKKT->dASinvCSinvVec, b);
-    if (dCSinvCSinv) *dCSinvCSinv = HKKT->dCSinvCSinv;
-    if (dCSinv) *dCSinv = HKKT->dCSinv;
-    if (dCSinvRdCSinv) *dCSinvRdCSinv = HKKT->dCSinvRdSinv;
-    if (dTraceSinv) *dTraceSinv = HKKT->dTraceSinv;
-}
-
-hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
-    StatScope stat_(ST_FACTORIZE, __func__);
-    // hdsdp_schur.c:328-336.  With the host mirror on, the host matrix is authoritative (the driver and
-    // the CPU cones may have touched it through kktDiag / kktMatElem); otherwise factor the device copy.
-    MiKKTPriv *pv = priv_of(HKKT);
-    MiLin *l = (MiLin *) HKKT->kktM->chol;
-    HKKT->kktM->nFactorizes += 1;
-    int info = 0;
-    if (pv->mirror && HKKT->isKKTSparse) {
-        // the host CSC is authoritative: its values go up (nnz doubles) and are scattered over the zeroed dense device
-        // matrix, which is then factored like the dense operator's
-        if (hipMemsetAsync(l->Mdev, 0, sizeof(double) * (size_t) l->ch.npad * l->ch.npad, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-        if (pv->nnz > 0) {
-            if (hipMemcpyAsync(pv->sp_vals, HKKT->kktMatElem, sizeof(double) * (size_t) pv->nnz, hipMemcpyHostToDevice, g.stream) != hipSuccess)
-                return HDSDP_RETCODE_FAILED;
-            hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->Mdev,
-                               (long) l->ch.npad, pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
-        }
-        pv->Mdev_valid = true;
-        l->srcHost = nullptr; l->srcDev = l->Mdev; l->srcLd = l->ch.npad;
-    } else if (pv->mirror) {
-        l->srcHost = HKKT->kktMatElem; l->srcDev = nullptr; l->srcLd = HKKT->nRow;
-    } else {
-        if (!pv->Mdev_valid) return HDSDP_RETCODE_FAILED;
-        l->srcHost = nullptr; l->srcDev = l->Mdev; l->srcLd = l->ch.npad;
-    }
-    if (l->indef) return lin_factor_indef(l);     // switched earlier: stays switched (hdsdp_linsolver.c:1838)
-    if (pv->mirror && !HKKT->isKKTSparse) {
-        if (l->ch.load_host(HKKT->kktMatElem, HKKT->nRow, g.stream)) return HDSDP_RETCODE_FAILED;
-    } else if (HKKT->isKKTSparse && !l->perm.empty()) {
-        // the factor object holds P M P': the pattern's entries (already in sp_vals when they came up from the host CSC,
-        // gathered from the device matrix otherwise) go to their permuted places in a zeroed image
-        if (!pv->mirror && pv->nnz > 0)
-            hipLaunchKernelGGL(mi_csc_gather_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->Mdev,
-                               (long) l->ch.npad, pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
-        if (hipMemsetAsync(l->ch.L, 0, sizeof(double) * (size_t) l->ch.npad * l->ch.npad, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-        if (pv->nnz > 0)
-            hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->ch.L,
-                               (long) l->ch.npad, pv->sp_prow, pv->sp_pcol, pv->nnz, pv->sp_vals);
-        if (l->ch.finish_load(g.stream)) return HDSDP_RETCODE_FAILED;
-    } else {
-        if (l->ch.load_device(l->Mdev, l->ch.npad, g.stream)) return HDSDP_RETCODE_FAILED;
-    }
-    if (l->ch.factor(g.stream, &info)) return HDSDP_RETCODE_FAILED;
-    if (info != 0) {
-        // hdsdp_linsolver.c:2034-2039: the Schur system falls back to the symmetric-indefinite solver
-        fprintf(stderr, "[hdsdp_mi355x] HKKTFactorize: Schur matrix is not positive definite (pivot %d). "
-                        "Switch to the pivoted (LDL-equivalent) solver.\n", info);
-        return lin_switch_indefinite(HKKT->kktM);
-    }
-    return HDSDP_RETCODE_OK;
-}
-
-hdsdp_retcode HKKTSolve(hdsdp_kkt *HKKT, double *dRhsVec, double *dLhsVec) {
-    StatScope stat_(ST_SOLVE, __func__);
-    return HFpLinsysSolve(HKKT->kktM, 1, dRhsVec, dLhsVec);
-}
-
-void HKKTRegularize(hdsdp_kkt *HKKT, double dKKTReg) {  // hdsdp_schur.c:348-373
-    MiKKTPriv *pv = priv_of(HKKT);
-    if (!pv->mirror) {
-        // device-resident M (HMiKKTSetHostMirror(.., 0)): same rule on the device copy; the diagonal (m doubles)
-        // makes the round trip, the matrix does not
-        MiLin *l = (MiLin *) HKKT->kktM->chol;
-        if (!pv->Mdev_valid || !l->Mdev) return;
-        const int m = HKKT->nRow;
-        const size_t pitch = sizeof(double) * ((size_t) l->ch.npad + 1);
-        std::vector<double> d(m);
-        if (hipStreamSynchronize(g.stream) != hipSuccess) return;
-        if (hipMemcpy2D(d.data(), sizeof(double), l->Mdev, pitch, sizeof(double), m, hipMemcpyDeviceToHost) != hipSuccess) return;
-        double mn = INFINITY;
-        for (int i = 0; i < m; ++i) mn = std::min(mn, d[i]);
-        double reg = std::min(dKKTReg * mn, 1e-05);
-        if (reg < 1e-14) return;
-        for (int i = 0; i < m; ++i) d[i] += reg;
-        (void) hipMemcpy2D(l->Mdev, pitch, d.data(), sizeof(double), sizeof(double), m, hipMemcpyHostToDevice);
-        return;
-    }
-    double mn = INFINITY;
-    for (int i = 0; i < HKKT->nRow; ++i) mn = std::min(mn, *HKKT->kktDiag[i]);
-    dKKTReg = std::min(dKKTReg * mn, 1e-05);
-    if (dKKTReg < 1e-14) dKKTReg = 0.0;
-    for (int i = 0; i < HKKT->nRow; ++i) *HKKT->kktDiag[i] += dKKTReg;
-}
-
-void HKKTRegisterPSDP(hdsdp_kkt *HKKT, double **dPrimalX) { HKKT->dPrimalX = dPrimalX; }
-
-void HKKTClear(hdsdp_kkt *HKKT) {
-    if (!HKKT) return;
-    free(HKKT->dASinvVec); free(HKKT->dASinvCSinvVec); free(HKKT->dASinvRdSinvVec);
-    free(HKKT->invBuffer); free(HKKT->kktBuffer); free(HKKT->kktBuffer2);
-    free(HKKT->kktMatBeg); free(HKKT->kktMatIdx);
-    if (HKKT->kktMatElem) (void) hipHostFree(HKKT->kktMatElem);
-    free(HKKT->kktDiag);
-    HFpLinsysDestroy(&HKKT->kktM);
-    priv_drop(HKKT);
-    memset(HKKT, 0, sizeof(hdsdp_kkt));
-}
-
-void HKKTDestroy(hdsdp_kkt **pHKKT) {
-    if (!pHKKT || !*pHKKT) return;
-    HKKTClear(*pHKKT);
-    free(*pHKKT);
-    *pHKKT = nullptr;
-}
-
-void HMiKKTSetHostMirror(hdsdp_kkt *HKKT, int mirrorM) {
-    MiKKTPriv *pv = priv_of(HKKT);
-    if (!mirrorM && pv->n_foreign > 0) {
-        fprintf(stderr, "[hdsdp_mi355x] HMiKKTSetHostMirror(0) ignored: %d cone(s) of this operator accumulate on the host\n",
-                pv->n_foreign);
-        return;
-    }
-    pv->mirror = mirrorM;
-}
-void HMiConeSetExchangePieces(hdsdp_cone *cone, hmi_alltoall_piece_fn start, hmi_alltoall_wait_fn wait, int npieces) {
-    MiCone *c = cone_data(cone);
-    c->a2a_start = start; c->a2a_wait = wait; c->a2a_pieces = std::max(1, npieces);
-}
-void HMiConeBuildPrimalXSXDirection(hdsdp_cone *cone, double *dPrimalScalMatrix, double *dPrimalXSXBuffer, int iDualMat) {
-    cone->coneBuildPrimalDirection(cone->coneData, nullptr, dPrimalScalMatrix, dPrimalXSXBuffer, iDualMat);
-}
-void HMiConeGetExchangeStats(hdsdp_cone *cone, int *pieces, int *stagedLaunches) {
-    MiCone *c = cone_data(cone);
-    if (pieces) *pieces = c->last_pieces;
-    if (stagedLaunches) *stagedLaunches = c->last_staged;
-}
-void HMiConeSetExchange(hdsdp_cone *cone, hmi_alltoall_fn a2a, hmi_allreduce_fn ar, void *ctx) {
-    MiCone *c = cone_data(cone);
-    c->alltoall = a2a; c->allreduce = ar; c->xctx = ctx;
-}
-hdsdp_retcode HMiConeGetExchangeBuffers(hdsdp_cone *cone, void **sendBuf, void **recvBuf, int64_t *chunkCount) {
-    MiCone *c = cone_data(cone);
-    if (chunkCount) *chunkCount = (int64_t) c->npb_loc * c->Lr * 16;
-    if (sendBuf) *sendBuf = c->AhatLoc;
-    if (recvBuf) *recvBuf = c->AhatAll;
-    return HDSDP_RETCODE_OK;
-}
-hdsdp_retcode HMiConeSetExchangeBuffers(hdsdp_cone *cone, void *sendBuf, void *recvBuf) {
-    MiCone *c = cone_data(cone);
-    if (c->work_ready || !sendBuf || !recvBuf) return HDSDP_RETCODE_FAILED;
-    c->AhatLoc = (double *) sendBuf;
-    c->AhatAll = (c->world == 1) ? c->AhatLoc : (double *) recvBuf;
-    c->ext_ahat = true;
-    const size_t ahat = sizeof(double) * (size_t) c->world * c->npb_loc * c->Lr * 16;
-    if (hipMemsetAsync(c->AhatLoc, 0, ahat, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    if (c->AhatAll != c->AhatLoc && hipMemsetAsync(c->AhatAll, 0, ahat, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    return HDSDP_RETCODE_OK;
-}
-void *HMiKKTDeviceMatrix(hdsdp_kkt *HKKT, int64_t *ld) {
-    long l = 0;
-    double *p = kkt_Mdev(HKKT, &l);
-    if (ld) *ld = l;
-    return p;
-}
-hdsdp_retcode HMiKKTGetRows(hdsdp_kkt *HKKT, int nRows, const int *rows, double *out) {
-    // full symmetric rows of the device copy of M (lower triangle valid): row i = M[i, 0..i] followed by M[i+1.., i]
-    MiKKTPriv *pv = priv_of(HKKT);
-    long ld = 0;
-    const double *Mdev = kkt_Mdev(HKKT, &ld);
-    const int m = HKKT->nRow;
-    if (!Mdev || !pv->Mdev_valid) return HDSDP_RETCODE_FAILED;
-    HIP_RC(hipStreamSynchronize(g.stream));
-    for (int r = 0; r < nRows; ++r) {
-        const int i = rows[r];
-        if (i < 0 || i >= m) return HDSDP_RETCODE_FAILED;
-        double *o = out + (size_t) r * m;
-        HIP_RC(hipMemcpy2D(o, sizeof(double), Mdev + i, sizeof(double) * (size_t) ld, sizeof(double), (size_t) i + 1, hipMemcpyDeviceToHost));
-        if (i + 1 < m)
-            HIP_RC(hipMemcpy(o + i + 1, Mdev + (i + 1) + (size_t) i * ld, sizeof(double) * (size_t) (m - i - 1), hipMemcpyDeviceToHost));
-    }
-    return HDSDP_RETCODE_OK;
-}
-
+#include "engine_kkt.h"
 }  // extern "C"
 
-// sparse Schur operator: entry p of the aggregated CSC pattern <-> element (rows[p], cols[p]) of the dense device matrix
-__global__ void mi_csc_gather_kernel(const double *__restrict__ M, long ld, const int *__restrict__ rows,
-                                     const int *__restrict__ cols, long nnz, double *__restrict__ vals) {
-    const long p = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < nnz) vals[p] = M[rows[p] + (long) cols[p] * ld];
-}
-__global__ void mi_csc_scatter_kernel(double *__restrict__ M, long ld, const int *__restrict__ rows,
-                                      const int *__restrict__ cols, long nnz, const double *__restrict__ vals) {
-    const long p = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < nnz) M[rows[p] + (long) cols[p] * ld] = vals[p];
-}
-
-// device group, copy transport: out[i] = sum over the shards (in shard order) of p[q][lo + i]
-struct MiGrpPtrs { const double *p[16]; };
-__global__ void mi_grp_sum_kernel(MiGrpPtrs pl, int W, long lo, long cnt, double *__restrict__ out) {
-    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cnt) return;
-    double s = 0.0;
-    for (int q = 0; q < W; ++q) s += pl.p[q][lo + i];
-    out[i] = s;
-}
-
 namespace {
-int grp_sum_launch(const double *const *ptrs, int W, long lo, long cnt, double *out, hipStream_t s) {
-    MiGrpPtrs pl = {};
-    for (int q = 0; q < W && q < 16; ++q) pl.p[q] = ptrs[q];
-    hipLaunchKernelGGL(mi_grp_sum_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, s, pl, W, lo, cnt, out);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
-// ---------------------------------------------------------------- cone construction
-static int upload_dense_rows(MiCone *c) {
-    // densify every owned constraint into a full symmetric n16 x n16 matrix (via packed staging)
-    const long P = (long) c->n * (c->n + 1) / 2;
-    const long nn = (long) c->n16 * c->n16;
-    HDM_HIP_CHECK(hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc) + hdm_operand_pad(c->n16)));
-    HDM_HIP_CHECK(hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc)));
-    const int chunk = (int) std::max(1L, std::min<long>(64, (256L << 20) / (P * 8)));
-    double *stage_dev = nullptr, *stage_host = nullptr;
-    HDM_HIP_CHECK(hipMalloc((void **) &stage_dev, sizeof(double) * (size_t) P * chunk));
-    HDM_HIP_CHECK(hipHostMalloc((void **) &stage_host, sizeof(double) * (size_t) P * chunk, hipHostMallocDefault));
-    for (int r0 = 0; r0 < c->mloc; r0 += chunk) {
-        int nc = std::min(chunk, c->mloc - r0);
-        memset(stage_host, 0, sizeof(double) * (size_t) P * nc);
-        for (int q = 0; q < nc; ++q) {
-            const MiCoeff &co = c->blk.rows[c->own[r0 + q]];
-            for (size_t e = 0; e < co.idx.size(); ++e) stage_host[(size_t) q * P + co.idx[e]] = co.val[e];
-        }
-        HDM_HIP_CHECK(hipMemcpyAsync(stage_dev, stage_host, sizeof(double) * (size_t) P * nc, hipMemcpyHostToDevice, g.stream));
-        if (hdm_unpack_low(stage_dev, P, c->Afull + (long) r0 * c->astride, c->astride, c->n, c->n16, nc, g.stream)) return 1;
-        HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
-    }
-    {   // objective
-        memset(stage_host, 0, sizeof(double) * (size_t) P);
-        for (size_t e = 0; e < c->blk.obj.idx.size(); ++e) stage_host[c->blk.obj.idx[e]] = c->blk.obj.val[e];
-        HDM_HIP_CHECK(hipMemcpyAsync(stage_dev, stage_host, sizeof(double) * (size_t) P, hipMemcpyHostToDevice, g.stream));
-        if (hdm_unpack_sym(stage_dev, P, c->Cfull, nn, c->n, c->n16, 1, g.stream)) return 1;
-        HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
-    }
-    (void) hipFree(stage_dev);
-    (void) hipHostFree(stage_host);
-    return 0;
-}
-
-// device path a block takes by itself: the rank-one fast path iff every non-zero constraint is rank one (the reference's
-// all-M2 plans), the sparse gather path iff all rows are short triplet lists, else congruence + Gram; sharded blocks
-// (world > 1) always take the latter
-static int natural_path(const MiBlockData &blk, int nRow, int nCol, int world) {
-    int nz = 0, r1 = 0;
-    for (int i = 0; i < nRow; ++i) {
-        int t = blk.rows[i].type;
-        if (t != MI_COEFF_ZERO) nz++;
-        if (t == MI_COEFF_SPR1 || t == MI_COEFF_DSR1) r1++;
-    }
-    int path = (nz > 0 && r1 == nz && world == 1) ? PATH_R1 : PATH_GEMM;
-    if (path == PATH_GEMM && world == 1 && nz > 0) {
-        // sparse gather path: only triplet-class rows, and the pair products are far cheaper than m congruences
-        bool all_sparse = true;
-        double tot = 0.0;
-        for (int i = 0; i < nRow; ++i) {
-            int t = blk.rows[i].type;
-            if (t == MI_COEFF_DENSE || t == MI_COEFF_DSR1) all_sparse = false;
-            tot += (double) blk.rows[i].idx.size();
-        }
-        if (all_sparse && tot * tot < 0.05 * (double) nRow * nCol * (double) nCol * nCol) path = PATH_SPARSE;
-    }
-    return path;
-}
-
-// the device data of one SDP block for rank `rank` of `world` on the calling thread's context
-static hdsdp_retcode make_sdp_cone(MiCone **out, int nRow, int nCol, const int *coneMatBeg, const int *coneMatIdx,
-                                   const double *coneMatElem, int rank, int world) {
-    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
-    MiCone *c = new MiCone();
-    c->n = nCol; c->m = nRow; c->rank = rank; c->world = world;
-    if (world > 1) hdm_gemm_reserve_cus(8);   // the exchange's collectives run beside the persistent GEMM launches
-    if (mi_block_from_csc(c->blk, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem)) { delete c; return HDSDP_RETCODE_FAILED; }
-    if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
-    c->trA = (double *) calloc(nRow, sizeof(double));
-    for (int i = 0; i < nRow; ++i) {
-        const MiCoeff &co = c->blk.rows[i];
-        long d = 0; int j = 0;  // packed index of (j,j)
-        for (size_t e = 0; e < co.idx.size(); ++e) {
-            while (j < nCol && d < co.idx[e]) { d += nCol - j; ++j; }
-            if (j < nCol && d == co.idx[e]) c->trA[i] += co.val[e];
-        }
-    }
-    c->path = natural_path(c->blk, nRow, nCol, world);
-    const char *force = getenv("HDSDP_MI355X_FORCE_GEMM");
-    if (force && atoi(force)) c->path = PATH_GEMM;
-    const char *forcesp = getenv("HDSDP_MI355X_FORCE_PATH");
-    if (forcesp && world == 1) c->path = atoi(forcesp);
-    if (c->mloc == 0) c->path = PATH_GEMM;   // no constraint touches this block: only the objective's scalars remain
-    if (upload_dense_rows(c)) return HDSDP_RETCODE_MEMORY;   // dense copies also feed the S assembly
-    if (c->path == PATH_R1) {
-        c->mloc16 = (int) hdm_roundup(std::max(1, c->mloc), 16);
-        const size_t av = sizeof(double) * (size_t) c->n16 * c->mloc16;
-        std::vector<double> hA((size_t) c->n16 * c->mloc16, 0.0), hs(c->mloc16, 0.0);
-        for (int q = 0; q < c->mloc; ++q) {
-            const MiCoeff &co = c->blk.rows[c->own[q]];
-            if (co.type == MI_COEFF_ZERO) continue;
-            for (int r = 0; r < nCol; ++r) hA[(size_t) q * c->n16 + r] = co.factor[r];
-            hs[q] = co.sign;
-        }
-        if (hipMalloc((void **) &c->Avec, av) != hipSuccess || hipMalloc((void **) &c->U, av) != hipSuccess ||
-            hipMalloc((void **) &c->V, av) != hipSuccess || hipMalloc((void **) &c->W, std::max(av, sizeof(double) * (size_t) c->n16 * c->n16)) != hipSuccess ||
-            hipMalloc((void **) &c->sgn, sizeof(double) * c->mloc16) != hipSuccess ||
-            hipMalloc((void **) &c->Gr1, sizeof(double) * (size_t) c->mloc16 * c->mloc16) != hipSuccess ||
-            hipMalloc((void **) &c->Ct, sizeof(double) * (size_t) c->n16 * c->n16) != hipSuccess ||
-            hipMalloc((void **) &c->Xinv, sizeof(double) * (size_t) c->n16 * c->n16) != hipSuccess)
-            return HDSDP_RETCODE_MEMORY;
-        if (hdm_memcpy_h2d_sync(c->Avec, hA.data(), av) != hipSuccess ||
-            hdm_memcpy_h2d_sync(c->sgn, hs.data(), sizeof(double) * c->mloc16) != hipSuccess)
-            return HDSDP_RETCODE_FAILED;
-    }
-    if (c->path == PATH_SPARSE) {
-        std::vector<int> rp(c->mloc + 1, 0), ti, tj;
-        std::vector<double> tv;
-        for (int q = 0; q < c->mloc; ++q) {
-            const MiCoeff &co = c->blk.rows[c->own[q]];
-            for (size_t e = 0; e < co.idx.size(); ++e) {
-                long pk = co.idx[e];
-                int col = 0; long start = 0;
-                while (pk >= start + (nCol - col)) { start += nCol - col; ++col; }
-                ti.push_back(col + (int) (pk - start)); tj.push_back(col); tv.push_back(co.val[e]);
-            }
-            rp[q + 1] = (int) ti.size();
-        }
-        const size_t nt = std::max<size_t>(1, ti.size());
-        const size_t nn2 = sizeof(double) * (size_t) hdm_roundup(nCol, 128) * hdm_roundup(nCol, 128);
-        if (hipMalloc((void **) &c->sp_rp, sizeof(int) * rp.size()) != hipSuccess ||
-            hipMalloc((void **) &c->sp_ti, sizeof(int) * nt) != hipSuccess ||
-            hipMalloc((void **) &c->sp_tj, sizeof(int) * nt) != hipSuccess ||
-            hipMalloc((void **) &c->sp_tv, sizeof(double) * nt) != hipSuccess ||
-            hipMalloc((void **) &c->Xinv, nn2) != hipSuccess || hipMalloc((void **) &c->Yinv, nn2) != hipSuccess ||
-            hipMalloc((void **) &c->W, nn2) != hipSuccess || hipMalloc((void **) &c->Ct, nn2) != hipSuccess)
-            return HDSDP_RETCODE_MEMORY;
-        if (hdm_memcpy_h2d_sync(c->sp_rp, rp.data(), sizeof(int) * rp.size()) != hipSuccess ||
-            (ti.size() && (hdm_memcpy_h2d_sync(c->sp_ti, ti.data(), sizeof(int) * ti.size()) != hipSuccess ||
-                           hdm_memcpy_h2d_sync(c->sp_tj, tj.data(), sizeof(int) * tj.size()) != hipSuccess ||
-                           hdm_memcpy_h2d_sync(c->sp_tv, tv.data(), sizeof(double) * tv.size()) != hipSuccess)))
-            return HDSDP_RETCODE_FAILED;
-    }
-    if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    *out = c;
-    return HDSDP_RETCODE_OK;
-}
-
-static hdsdp_retcode make_synth_cone(MiCone **out, int nCol, int nRow, int rank, int world) {
-    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
-    MiCone *c = new MiCone();
-    c->n = nCol; c->m = nRow; c->rank = rank; c->world = world; c->synthetic = true; c->path = PATH_GEMM;
-    if (world > 1) hdm_gemm_reserve_cus(8);
-    if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
-    if (hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc) + hdm_operand_pad(c->n16)) != hipSuccess) {
-        fprintf(stderr, "[hdsdp_mi355x] cannot allocate %.1f GiB for the constraint matrices\n",
-                (double) c->astride * c->mloc * 8 / (1 << 30));
-        return HDSDP_RETCODE_MEMORY;
-    }
-    if (hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc)) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    for (int q = 0; q < c->mloc; ++q)  // owned rows are strided in the global numbering
-        if (hdm_synth_fill_low(c->Afull + (long) q * c->astride, c->astride, c->n, c->n16, c->own[q], 1, g.stream)) return HDSDP_RETCODE_FAILED;
-    if (hdm_synth_obj(c->Cfull, c->n, c->n16, c->m, g.stream)) return HDSDP_RETCODE_FAILED;
-    // b_i = tr(A_i): diagonal draws only (host, m*n splitmix evaluations)
-    c->trA = (double *) calloc(nRow, sizeof(double));
-    const uint64_t P = (uint64_t) nCol * (nCol + 1) / 2, gam = 0x9E3779B97F4A7C15ULL;
-    for (int i = 0; i < nRow; ++i) {
-        double tr = 0.0;
-        uint64_t k = 0;
-        for (int j = 0; j < nCol; ++j) {
-            uint64_t z = gam + (2 * ((uint64_t) i * P + k) + 1) * gam;
-            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-            z = z ^ (z >> 31);
-            tr += 2.0 * ((double) (z >> 11) / 9007199254740992.0) - 1.0;
-            k += nCol - j;
-        }
-        c->trA[i] = tr;
-    }
-    if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    *out = c;
-    return HDSDP_RETCODE_OK;
-}
-
+#include "engine_create.h"
 // single-process multi-device mode: device groups, worker threads, the two transports (device copies / RCCL) and the
 // group cone whose slots fan out to the shards
 #include "group_impl.h"
-
 }  // namespace
 
 extern "C" {
-
-hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *coneMatBeg,
-                               const int *coneMatIdx, const double *coneMatElem, int rank, int world) {
-    if (!pCone || nRow < 1 || nCol < 1 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
-    if (group_configure_from_env()) return HDSDP_RETCODE_FAILED;
-    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
-    if (rank == 0 && world == 1 && group_wants_block(nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem))
-        return group_create_cone(pCone, iCone, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem, false);
-    MiCone *c = nullptr;
-    hdsdp_retcode rc = make_sdp_cone(&c, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem, rank, world);
-    if (rc != HDSDP_RETCODE_OK) return rc;
-    *pCone = new_cone_shell(c, iCone);
-    return HDSDP_RETCODE_OK;
-}
-
-hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, int nRow, int rank, int world) {
-    if (!pCone || nRow < 1 || nCol < 1 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
-    if (group_configure_from_env()) return HDSDP_RETCODE_FAILED;
-    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
-    if (rank == 0 && world == 1 && group_wants_block(nRow, nCol, nullptr, nullptr, nullptr))
-        return group_create_cone(pCone, iCone, nRow, nCol, nullptr, nullptr, nullptr, true);
-    MiCone *c = nullptr;
-    hdsdp_retcode rc = make_synth_cone(&c, nCol, nRow, rank, world);
-    if (rc != HDSDP_RETCODE_OK) return rc;
-    *pCone = new_cone_shell(c, iCone);
-    return HDSDP_RETCODE_OK;
-}
-
-void HMiConeDestroy(hdsdp_cone **pCone) {
-    if (!pCone || !*pCone) return;
-    if ((*pCone)->coneDestroyData) (*pCone)->coneDestroyData(&(*pCone)->coneData);
-    free(*pCone);
-    *pCone = nullptr;
-}
-void HMiConeSetStart(hdsdp_cone *cone, double v) { cone->coneSetStart(cone->coneData, v); }
-void HMiConeUpdate(hdsdp_cone *cone, double tau, double *y) { cone->coneUpdate(cone->coneData, tau, y); }
-hdsdp_retcode HMiConeCheckIsInterior(hdsdp_cone *cone, double tau, double *y, int *isInterior) {
-    return cone->coneInteriorCheck(cone->coneData, tau, y, isInterior);
-}
-hdsdp_retcode HMiConeGetLogBarrier(hdsdp_cone *cone, double tau, double *y, int whichBuffer, double *logdet) {
-    return cone->coneGetBarrier(cone->coneData, tau, y, whichBuffer, logdet);
-}
-hdsdp_retcode HMiConeRatioTest(hdsdp_cone *cone, double dTauStep, double *dy, double dAdaRatio, int whichBuffer,
-                               double *maxStep) {
-    return cone->coneRatioTest(cone->coneData, dTauStep, dy, dAdaRatio, whichBuffer, maxStep);
-}
-void HMiLanczosStartVector(int n, double *v) { hdm_lanczos_start_vector(n, v); }
-hdsdp_retcode HMiConeCheckIsInteriorExpert(hdsdp_cone *cone, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef,
-                                           int whichBuffer, int *isInterior) {
-    return cone->coneInteriorCheckExpert(cone->coneData, dCCoef, dACoefScal, dACoef, dEyeCoef, whichBuffer, isInterior);
-}
-hdsdp_retcode HMiConeAddStepToBufferAndCheck(hdsdp_cone *cone, double dStep, int whichBuffer, int *isInterior) {
-    return cone->coneAxpyBufferAndCheck(cone->coneData, dStep, whichBuffer, isInterior);
-}
-double HMiConeGetCoeffNorm(hdsdp_cone *cone, int whichNorm) { return cone->coneGetCoeffNorm(cone->coneData, whichNorm); }
-double HMiConeGetObjNorm(hdsdp_cone *cone, int whichNorm) { return cone->coneGetObjNorm(cone->coneData, whichNorm); }
-void HMiConeScalByConstant(hdsdp_cone *cone, double dScal) { cone->coneScal(cone->coneData, dScal); }
-void HMiConeComputeATimesXpy(hdsdp_cone *cone, double *dConePrimal, double *dATimesX) {
-    cone->coneATimesXpy(cone->coneData, dConePrimal, dATimesX);
-}
-double HMiConeComputeXDotS(hdsdp_cone *cone, double *dConePrimal) { return cone->coneXDotS(cone->coneData, dConePrimal); }
-double HMiConeComputeTraceCX(hdsdp_cone *cone, double *dConePrimal) { return cone->coneTraceCX(cone->coneData, dConePrimal); }
-void HMiConeGetDual(hdsdp_cone *cone, double *dConeDual, double *dConeDual2) {
-    cone->coneDRecover(cone->coneData, dConeDual, dConeDual2);
-}
-void HMiConeReduceResi(hdsdp_cone *cone, double dResiReduction) { cone->coneReduceResi(cone->coneData, dResiReduction); }
-void HMiConeSetPerturb(hdsdp_cone *cone, double dDualPerturb) { cone->coneSetPerturb(cone->coneData, dDualPerturb); }
-void HMiConeGetPrimal(hdsdp_cone *cone, double dBarrierMu, double *dRowDual, double *dRowDualStep, double *dConePrimal,
-                      double *dConePrimal2) {
-    cone->conePRecover(cone->coneData, dBarrierMu, dRowDual, dRowDualStep, dConePrimal, dConePrimal2);
-}
-void HMiConeGetPresolve(hdsdp_cone *cone, int *coefType, int *coefRank, int *coefNnz, int *kktPerm, int *kktStrategy,
-                        int *objType) {
-    MiCone *c = cone_data(cone);
-    for (int i = 0; i < c->m && !c->synthetic; ++i) {
-        if (coefType) coefType[i] = c->blk.rows[i].type;
-        if (coefRank) coefRank[i] = c->blk.rows[i].rank;
-        if (coefNnz) coefNnz[i] = c->blk.rows[i].nnz;
-        if (kktPerm) kktPerm[i] = c->blk.perm[i];
-        if (kktStrategy) kktStrategy[i] = c->blk.strategy[i];
-    }
-    if (objType) *objType = c->synthetic ? MI_COEFF_DENSE : c->blk.obj.type;
-}
-hdsdp_retcode HMiPresolveCSC(int nRow, int nCol, const int *coneMatBeg, const int *coneMatIdx,
-                             const double *coneMatElem, int *coefType, int *coefRank, int *coefNnz, int *kktPerm,
-                             int *kktStrategy, int *objType) {
-    if (nRow < 1 || nCol < 1 || !coneMatBeg) return HDSDP_RETCODE_FAILED;
-    MiBlockData blk;
-    if (mi_block_from_csc(blk, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem)) return HDSDP_RETCODE_FAILED;
-    for (int i = 0; i < nRow; ++i) {
-        if (coefType) coefType[i] = blk.rows[i].type;
-        if (coefRank) coefRank[i] = blk.rows[i].rank;
-        if (coefNnz) coefNnz[i] = blk.rows[i].nnz;
-        if (kktPerm) kktPerm[i] = blk.perm[i];
-        if (kktStrategy) kktStrategy[i] = blk.strategy[i];
-    }
-    if (objType) *objType = blk.obj.type;
-    return HDSDP_RETCODE_OK;
-}
-hdsdp_retcode HMiConeGetDualMatrix(hdsdp_cone *cone, double *S) {
-    MiCone *c = cone_data(cone);
-    if (hipMemcpy2DAsync(S, sizeof(double) * c->n, c->S, sizeof(double) * c->n16, sizeof(double) * c->n, c->n,
-                         hipMemcpyDeviceToHost, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    return hipStreamSynchronize(g.stream) == hipSuccess ? HDSDP_RETCODE_OK : HDSDP_RETCODE_FAILED;
-}
-hdsdp_retcode HMiConeGetTraces(hdsdp_cone *cone, double *trA) {
-    MiCone *c = cone_data(cone);
-    if (!c->trA) return HDSDP_RETCODE_FAILED;
-    memcpy(trA, c->trA, sizeof(double) * c->m);
-    return HDSDP_RETCODE_OK;
-}
-int HMiConeGetPath(hdsdp_cone *cone) { return cone_data(cone)->path; }
-
-// ---------------------------------------------------------------- single-process multi-device mode (group_impl.h)
-int HMiSetDevices(int nDevices, const int *deviceIds) {
-    if (nDevices < 1 || !deviceIds) return 1;
-    g_group_env_done = true;     // an explicit call overrides HDSDP_MI355X_GPUS
-    int tr = -1;
-    if (const char *t = getenv("HDSDP_MI355X_TRANSPORT")) tr = (strcmp(t, "rccl") == 0) ? GRP_RCCL : GRP_COPIES;
-    return group_setup(nDevices, deviceIds, tr);
-}
-int HMiGetDeviceGroup(int *deviceIds, int maxIds, int *transport) {
-    if (!g_group) { if (transport) *transport = -1; if (deviceIds && maxIds > 0 && g_main.init) deviceIds[0] = g_main.device; return g_main.init ? 1 : 0; }
-    for (int r = 0; r < g_group->W && r < maxIds; ++r) if (deviceIds) deviceIds[r] = g_group->dev[r];
-    if (transport) *transport = g_group->transport;
-    return g_group->W;
-}
-void HMiSetShardMinDim(int nMin) { if (g_group) g_group->min_n = nMin; }
-int HMiConeGetShardCount(hdsdp_cone *cone) {
-    return (cone && cone->coneBuildSchur == gc_build_schur) ? ((MiConeGroup *) cone->coneData)->G->W : 1;
-}
-void HMiConeGetGroupTraffic(hdsdp_cone *cone, int64_t *bytesAllToAll, int64_t *bytesAllReduce) {
-    int64_t a = 0, b = 0;
-    if (cone && cone->coneBuildSchur == gc_build_schur) { MiConeGroup *cg = (MiConeGroup *) cone->coneData; a = cg->bytes_a2a; b = cg->bytes_ar; }
-    if (bytesAllToAll) *bytesAllToAll = a;
-    if (bytesAllReduce) *bytesAllReduce = b;
-}
-// ---------------------------------------------------------------- fused small-block Phase-A pass (small.hip)
-static int small_plan(MiCone *c) {
-    MiCone::SmallPlan &sp = c->small;
-    if (sp.state) return sp.state;
-    sp.state = -1;
-    if (c->path != PATH_R1 || c->world != 1 || c->synthetic || c->n > SMALL_P || c->mloc != c->m || c->m > SMALL_P) return -1;
-    const int n = c->n, m = c->m;
-    std::vector<int> fp(m + 1, 0), fi, dense_of(m, -1), dense_rows;
-    std::vector<double> fv, sg(m, 0.0);
-    for (int q = 0; q < m; ++q) {
-        const MiCoeff &co = c->blk.rows[c->own[q]];
-        if (co.type != MI_COEFF_SPR1 && co.type != MI_COEFF_DSR1) return -1;
-        int nz = 0;
-        for (int r = 0; r < n; ++r) nz += (co.factor[r] != 0.0);
-        sg[q] = co.sign;
-        if (nz > SMALL_SPMAX) {                       // dense factor: all n entries, in order
-            if ((int) dense_rows.size() >= SMALL_NDENSE) return -1;
-            dense_of[q] = (int) dense_rows.size();
-            dense_rows.push_back(q);
-            for (int r = 0; r < n; ++r) { fi.push_back(r); fv.push_back(co.factor[r]); }
-        } else {
-            for (int r = 0; r < n; ++r) if (co.factor[r] != 0.0) { fi.push_back(r); fv.push_back(co.factor[r]); }
-        }
-        fp[q + 1] = (int) fi.size();
-    }
-    dense_rows.resize(SMALL_NDENSE, 0);
-    const size_t nf = std::max<size_t>(1, fi.size());
-    if (hipMalloc((void **) &sp.fp, sizeof(int) * (m + 1)) != hipSuccess || hipMalloc((void **) &sp.fi, sizeof(int) * nf) != hipSuccess ||
-        hipMalloc((void **) &sp.fv, sizeof(double) * nf) != hipSuccess || hipMalloc((void **) &sp.sgn, sizeof(double) * m) != hipSuccess ||
-        hipMalloc((void **) &sp.dense_of, sizeof(int) * m) != hipSuccess ||
-        hipMalloc((void **) &sp.dense_rows, sizeof(int) * SMALL_NDENSE) != hipSuccess ||
-        hipHostMalloc((void **) &sp.io_host, sizeof(double) * (7 * (size_t) m + 16), hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void **) &sp.io_dev, sp.io_host, 0) != hipSuccess)
-        return -1;
-    if (hdm_memcpy_h2d_sync(sp.fp, fp.data(), sizeof(int) * (m + 1)) != hipSuccess ||
-        (fi.size() && (hdm_memcpy_h2d_sync(sp.fi, fi.data(), sizeof(int) * fi.size()) != hipSuccess ||
-                       hdm_memcpy_h2d_sync(sp.fv, fv.data(), sizeof(double) * fv.size()) != hipSuccess)) ||
-        hdm_memcpy_h2d_sync(sp.sgn, sg.data(), sizeof(double) * m) != hipSuccess ||
-        hdm_memcpy_h2d_sync(sp.dense_of, dense_of.data(), sizeof(int) * m) != hipSuccess ||
-        hdm_memcpy_h2d_sync(sp.dense_rows, dense_rows.data(), sizeof(int) * SMALL_NDENSE) != hipSuccess)
-        return -1;
-    sp.ndense = 0;
-    for (int q = 0; q < m; ++q) sp.ndense += (dense_of[q] >= 0);
-    sp.state = 1;
-    return 1;
-}
-
-int HMiKKTPhaseAEligible(hdsdp_kkt *HKKT) {
-    if (!HKKT || HKKT->nCones != 1 || HKKT->isKKTSparse) return 0;
-    hdsdp_cone *hc = HKKT->cones[0];
-    if (hc->coneBuildSchur != cone_build_schur) return 0;
-    MiCone *c = (MiCone *) hc->coneData;
-    return (c->m == HKKT->nRow && small_plan(c) == 1) ? 1 : 0;
-}
-
-hdsdp_retcode HMiKKTPhaseA(hdsdp_kkt *HKKT, double barHsdTau, double *rowDual, double *rhs, double *d1, double *d2, double *d3,
-                           int *isInterior, double *logdet) {
-    StatScope stat_(ST_BUILD_M, __func__);
-    if (!HMiKKTPhaseAEligible(HKKT)) return HDSDP_RETCODE_FAILED;
-    MiCone *c = (MiCone *) HKKT->cones[0]->coneData;
-    MiCone::SmallPlan &sp = c->small;
-    MiKKTPriv *pv = priv_of(HKKT);
-    MiLin *ls = (MiLin *) c->dualFactor->chol, *lm = (MiLin *) HKKT->kktM->chol;
-    const int m = c->m, n = c->n;
-    HIP_RC(hipStreamSynchronize(g.stream));            // the mapped block is about to be rewritten
-    double *yin = sp.io_host, *bin = sp.io_host + m, *out = sp.io_host + 2 * (size_t) m;
-    for (int i = 0; i < m; ++i) { yin[i] = rowDual ? rowDual[i] : 0.0; bin[i] = rhs ? rhs[i] : 0.0; }
-    out[0] = -1.0;
-    HdmSmallArgs a = {};
-    a.n = n; a.m = m; a.C = c->Cfull; a.ldc = c->n16;
-    a.fp = sp.fp; a.fi = sp.fi; a.fv = sp.fv; a.sgn = sp.sgn; a.dense_of = sp.dense_of; a.ndense = sp.ndense; a.dense_rows = sp.dense_rows;
-    a.y = sp.io_dev; a.b = sp.io_dev + m; a.out = sp.io_dev + 2 * (size_t) m;
-    a.tau = barHsdTau; a.eye = -c->Rd + c->perturb; a.Rd = c->Rd;
-    a.Sout = c->S; a.lds = c->n16;
-    c->pS_ok = false;                                  // (the pass writes S itself)
-    a.LS = ls->ch.L; a.WS = ls->ch.Dinv; a.M = lm->Mdev; a.ldm = lm->ch.npad; a.LM = lm->ch.L; a.WM = lm->ch.Dinv;
-    if (ls->ch.npad != SMALL_P || lm->ch.npad != SMALL_P) return HDSDP_RETCODE_FAILED;
-    // (the operator's accumulators as HKKTBuildUp(KKT_TYPE_INFEASIBLE) leaves them, hdsdp_schur.c:141-165, :256-268: the
-    // kernel itself zeroes what it does not fill of the 128 x 128 device matrix)
-    RC(hdm_small_phase_a(a, g.stream));
-    if (pv->mirror)
-        HIP_RC(hipMemcpy2DAsync(HKKT->kktMatElem, sizeof(double) * m, lm->Mdev, sizeof(double) * SMALL_P, sizeof(double) * m, m,
-                                hipMemcpyDeviceToHost, g.stream));
-    HIP_RC(hipStreamSynchronize(g.stream));
-    const int infoS = (int) out[0], infoM = (int) out[1];
-    ls->ch.factored = (infoS == 0); ls->ch.have_inv = false;
-    c->dualFactor->nFactorizes += 1;
-    if (isInterior) *isInterior = (infoS == 0);
-    if (infoS != 0) return HDSDP_RETCODE_OK;           // "not positive definite" is a value, not an error
-    if (logdet) *logdet = out[2];
-    memset(HKKT->dASinvVec, 0, sizeof(double) * m); memset(HKKT->dASinvRdSinvVec, 0, sizeof(double) * m);
-    for (int i = 0; i < m; ++i) { HKKT->dASinvVec[i] = out[4 + i]; HKKT->dASinvRdSinvVec[i] = out[4 + m + i]; }
-    HKKT->dTraceSinv = (c->Rd != 0.0) ? out[3] : 0.0;
-    pv->Mdev_valid = true;
-    lm->ch.factored = (infoM == 0); lm->ch.have_inv = false;
-    lm->srcHost = nullptr; lm->srcDev = lm->Mdev; lm->srcLd = SMALL_P;
-    HKKT->kktM->nFactorizes += 1;
-    if (infoM != 0) {
-        // the Schur matrix is not numerically positive definite: the multi-launch path's way out (pivoted solver) takes over
-        fprintf(stderr, "[hdsdp_mi355x] HMiKKTPhaseA: Schur matrix is not positive definite (pivot %d); solving through HKKTFactorize\n", infoM);
-        if (HKKTFactorize(HKKT) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
-        if (d1 && HKKTSolve(HKKT, rhs, d1) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
-        if (d2 && HKKTSolve(HKKT, HKKT->dASinvVec, d2) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
-        if (d3 && HKKTSolve(HKKT, HKKT->dASinvRdSinvVec, d3) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
-        return HDSDP_RETCODE_OK;
-    }
-    HKKT->kktM->nSolves += 3;
-    if (d1) memcpy(d1, out + 4 + 2 * (size_t) m, sizeof(double) * m);
-    if (d2) memcpy(d2, out + 4 + 3 * (size_t) m, sizeof(double) * m);
-    if (d3) memcpy(d3, out + 4 + 4 * (size_t) m, sizeof(double) * m);
-    const double *stamp = out + 4 + 5 * (size_t) m;
-    for (int i = 0; i < 6; ++i) g.stage_ms[i] = (stamp[i + 1] - stamp[i]) * 1e-5;   // HMiGetStageTimes: 100 MHz ticks -> ms
-    g.stage_ms[6] = (stamp[6] > stamp[0]) ? stamp[7] / ((stamp[6] - stamp[0]) * 10.0) : 0.0;   // shader clock during the pass, GHz
-    return HDSDP_RETCODE_OK;
-}
-
-// host only (no device call): the reverse Cuthill-McKee order HKKTInit looks at for a sparse Schur pattern; lower-triangular CSC in,
-// perm[old] = new out
-int HMiRcmOrder(int m, const int *colBeg, const int *rowIdx, int *perm) {
-    if (m <= 0 || !colBeg || !rowIdx || !perm) return 1;
-    std::vector<int> beg(colBeg, colBeg + m + 1), idx(rowIdx, rowIdx + colBeg[m]);
-    const std::vector<int> p = rcm_order(m, beg, idx);
-    for (int i = 0; i < m; ++i) perm[i] = p[i];
-    return 0;
-}
-
-// how the operator's matrix will be factored: *permuted = 1 if the factor object holds P M P' (reverse Cuthill-McKee order of
-// the sparse pattern), *fraction = blocks inside the pattern's block envelope / blocks of the dense lower triangle (1 = dense)
-void HMiKKTEnvelopeInfo(hdsdp_kkt *HKKT, int *permuted, double *fraction) {
-    if (permuted) *permuted = 0;
-    if (fraction) *fraction = 1.0;
-    if (!HKKT || !HKKT->kktM) return;
-    MiLin *l = (MiLin *) HKKT->kktM->chol;
-    if (permuted) *permuted = l->perm.empty() ? 0 : 1;
-    if (fraction && !l->ch.env_colh.empty()) {
-        double in = 0.0, all = 0.0;
-        for (int k = 0; k < l->ch.nblk; ++k) { in += l->ch.env_colh[k] - k + 1; all += l->ch.nblk - k; }
-        *fraction = in / all;
-    }
-}
-
-int HMiGetCallStats(double *seconds, int64_t *calls, int n) {
-    for (int k = 0; k < n && k < ST_N; ++k) { if (seconds) seconds[k] = g_stat_sec[k]; if (calls) calls[k] = g_stat_calls[k]; }
-    return ST_N;
-}
-const char *HMiCallStatName(int k) { return (k >= 0 && k < ST_N) ? g_stat_name[k] : ""; }
-void HMiResetCallStats(void) { for (int k = 0; k < ST_N; ++k) { g_stat_sec[k] = 0.0; g_stat_calls[k] = 0; } g_stat_nfn = 0; }
-int HMiRcclSelfTest(int device) {
-    if (ensure_ctx()) return 1;
-    return rccl_self_test(device < 0 ? g_main.device : device);
-}
-
-// ---------------------------------------------------------------- raw kernels for tests
-int HMiGemmNT(const double *A, int64_t lda, int aKMajor, const double *B, int64_t ldb, int bKMajor, double *C,
-              int64_t ldc, int M, int N, int K, double alpha, double beta, int kLimit, int lowerOnly) {
-    if (ensure_ctx()) return 1;
-    HdmGemmArgs q = {};
-    q.A = A; q.lda = lda; q.a_kmajor = aKMajor; q.B = B; q.ldb = ldb; q.b_kmajor = bKMajor; q.C = C; q.ldc = ldc;
-    q.M = M; q.N = N; q.K = K; q.alpha = alpha; q.beta = beta; q.klimit = kLimit; q.lower_only = lowerOnly;
-    q.batch = 1; q.epilogue = HDM_EPI_STORE;
-    if (hdm_launch_gemm(q, g.stream)) return 1;
-    HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
-    return 0;
-}
-
-// blocked Cholesky + solve of a host matrix (lower triangle, column-major, leading dimension n) whose structural zeros are
-// described by a block envelope: first[i] = first 128-block column with an entry in block row i (NULL = dense)
-int HMiCholEnvelopeSolve(const double *A_host, int n, const int *first, const double *b, double *x, double *L_host, int *info) {
-    if (ensure_ctx()) return 1;
-    HdmChol ch;
-    if (ch.init(n)) return 1;
-    int rc = 1;
-    do {
-        if (first && ch.set_envelope(first)) break;
-        if (ch.load_host(A_host, n, g.stream)) break;
-        if (ch.factor(g.stream, info)) break;
-        if (info && *info != 0) { rc = 0; break; }
-        if (b && x && ch.solve_host(b, x, 1, 0, g.stream)) break;
-        if (L_host && hipMemcpy2D(L_host, sizeof(double) * n, ch.L, sizeof(double) * ch.npad, sizeof(double) * n, n, hipMemcpyDeviceToHost) != hipSuccess) break;
-        rc = 0;
-    } while (0);
-    ch.destroy();
-    return rc;
-}
-
-// diagnostic: factorisation time (ms, HIP events, graph replay included) of an n x n matrix whose pattern is a band of
-// `band` 128-blocks below the diagonal block, once as a dense matrix and once on its block envelope
-__global__ void mi_band_spd_kernel(double *A, long ld, int n, int band) {
-    const long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long) n * n) return;
-    const int i = (int) (e % n), j = (int) (e / n);
-    double v = 0.0;
-    if (i == j) v = 4.0 * (band + 1) * 128.0;
-    else if (i > j && i / 128 - j / 128 <= band) v = ((i * 31 + j * 17) % 13 == 0) ? 1.0 / (1.0 + ((i + j) % 7)) : 0.0;
-    A[i + (long) j * ld] = v;
-}
-int HMiCholEnvelopeProbe(int n, int band, int reps, double *ms_dense, double *ms_env) {
-    if (ensure_ctx()) return 1;
-    double *A = nullptr;
-    if (hipMalloc((void **) &A, sizeof(double) * (size_t) n * n) != hipSuccess) return 1;
-    hipLaunchKernelGGL(mi_band_spd_kernel, dim3((unsigned) (((long) n * n + 255) / 256)), dim3(256), 0, g.stream, A, (long) n, n, band);
-    int rc = 0;
-    for (int pass = 0; pass < 2 && !rc; ++pass) {
-        HdmChol ch;
-        if (ch.init(n)) { rc = 1; break; }
-        std::vector<int> first(ch.nblk);
-        for (int b = 0; b < ch.nblk; ++b) first[b] = std::max(0, b - band);
-        if (pass == 1 && ch.set_envelope(first.data())) rc = 1;
-        float total = 0.f;
-        for (int r = -2; r < reps && !rc; ++r) {
-            int info = 0;
-            if (ch.load_device(A, n, g.stream)) { rc = 1; break; }
-            (void) hipEventRecord(g.ev[6], g.stream);
-            if (ch.factor(g.stream, &info) || info != 0) { rc = 1; break; }
-            (void) hipEventRecord(g.ev[7], g.stream);
-            (void) hipEventSynchronize(g.ev[7]);
-            float ms = 0.f;
-            (void) hipEventElapsedTime(&ms, g.ev[6], g.ev[7]);
-            if (r >= 0) total += ms;
-        }
-        *(pass == 0 ? ms_dense : ms_env) = total / std::max(1, reps);
-        ch.destroy();
-    }
-    (void) hipFree(A);
-    return rc;
-}
-
-int HMiPotrf(double *A_dev, int n, int64_t lda, int *info) {
-    if (ensure_ctx()) return 1;
-    HdmChol ch;
-    if (ch.init(n)) return 1;
-    if (ch.load_device(A_dev, lda, g.stream)) return 1;
-    if (ch.factor(g.stream, info)) return 1;
-    HDM_HIP_CHECK(hipMemcpy2DAsync(A_dev, sizeof(double) * lda, ch.L, sizeof(double) * ch.npad, sizeof(double) * n, n,
-                                   hipMemcpyDeviceToDevice, g.stream));
-    HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
-    ch.destroy();
-    return 0;
-}
-
-double HMiDiagBlockProbe(int variant, int reps) {
-    if (ensure_ctx()) return -1.0;
-    return hdm_diag_block_probe(variant, reps, g.stream);
-}
-
-double HMiMfmaPeakProbe(int iters) {
-    if (ensure_ctx()) return -1.0;
-    double *out = nullptr;
-    if (hipMalloc((void **) &out, 8) != hipSuccess) return -1.0;
-    const int blocks = 256 * 8, threads = 256;
-    hipLaunchKernelGGL(mi_mfma_probe_kernel, dim3(blocks), dim3(threads), 0, g.stream, out, 16);
-    (void) hipEventRecord(g.ev[6], g.stream);
-    hipLaunchKernelGGL(mi_mfma_probe_kernel, dim3(blocks), dim3(threads), 0, g.stream, out, iters);
-    (void) hipEventRecord(g.ev[7], g.stream);
-    (void) hipEventSynchronize(g.ev[7]);
-    float ms = 0;
-    (void) hipEventElapsedTime(&ms, g.ev[6], g.ev[7]);
-    (void) hipFree(out);
-    const double flops = (double) blocks * (threads / 64) * (double) iters * 8 * 2.0 * 16 * 16 * 4;
-    return flops / (ms * 1e-3) / 1e12;
-}
-
-// mode 0: GEMM operand pattern, mode 1: one operand pair; wgPerCu workgroups of 256 threads per CU
-double HMiMfmaIssueProbe(int mode, int wgPerCu, int iters) {
-    if (ensure_ctx()) return -1.0;
-    double *out = nullptr;
-    if (hipMalloc((void **) &out, 8) != hipSuccess) return -1.0;
-    const int blocks = 256 * wgPerCu, threads = 256;
-    for (int rep = 0; rep < 2; ++rep) {
-        if (rep == 1) (void) hipEventRecord(g.ev[6], g.stream);
-        if (mode == 300) {
-            hipLaunchKernelGGL(mi_mfma_probe_rand_kernel, dim3(blocks), dim3(threads), 0, g.stream, out, iters);
-        } else if (mode == 200) {
-            hipLaunchKernelGGL(mi_mfma_probe_kernel, dim3(blocks), dim3(threads), 0, g.stream, out, iters * 2);
-        } else if (mode >= 100) {
-            const int it3 = iters * 16 / (mode % 100);
-            switch (mode) {
-                case 104: hipLaunchKernelGGL((mi_mfma_probe3_kernel<4, 1>), dim3(blocks), dim3(threads), 0, g.stream, out, it3); break;
-                case 108: hipLaunchKernelGGL((mi_mfma_probe3_kernel<8, 1>), dim3(blocks), dim3(threads), 0, g.stream, out, it3); break;
-                case 112: hipLaunchKernelGGL((mi_mfma_probe3_kernel<12, 1>), dim3(blocks), dim3(threads), 0, g.stream, out, it3); break;
-                case 116: hipLaunchKernelGGL((mi_mfma_probe3_kernel<16, 1>), dim3(blocks), dim3(threads), 0, g.stream, out, it3); break;
-                case 124: hipLaunchKernelGGL((mi_mfma_probe3_kernel<24, 1>), dim3(blocks), dim3(threads), 0, g.stream, out, it3); break;
-                default: break;
-            }
-        } else if (mode == 0) hipLaunchKernelGGL(mi_mfma_probe2_kernel<0>, dim3(blocks), dim3(threads), 0, g.stream, out, iters);
-        else if (mode == 1) hipLaunchKernelGGL(mi_mfma_probe2_kernel<1>, dim3(blocks), dim3(threads), 0, g.stream, out, iters);
-        else hipLaunchKernelGGL(mi_mfma_probe2_kernel<2>, dim3(blocks), dim3(threads), 0, g.stream, out, iters);
-    }
-    (void) hipEventRecord(g.ev[7], g.stream);
-    (void) hipEventSynchronize(g.ev[7]);
-    float ms = 0;
-    (void) hipEventElapsedTime(&ms, g.ev[6], g.ev[7]);
-    (void) hipFree(out);
-    const double flops = (double) blocks * (threads / 64) * (double) iters * 16 * 2.0 * 16 * 16 * 4;
-    return flops / (ms * 1e-3) / 1e12;
-}
-
+#include "engine_api.h"
 }  // extern "C"

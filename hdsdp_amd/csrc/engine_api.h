@@ -1,0 +1,290 @@
+// engine_api.h -- exported C ABI, second part: the HMi* cone entries, the device group entries, the fused Phase-A pass, call statistics
+// Implementation header of engine.hip: included exactly once, there, in this order (inside extern "C"); split out of a 3 300-line file in round 3, nothing else changed.
+
+hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *coneMatBeg,
+                               const int *coneMatIdx, const double *coneMatElem, int rank, int world) {
+    if (!pCone || nRow < 1 || nCol < 1 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
+    if (group_configure_from_env()) return HDSDP_RETCODE_FAILED;
+    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
+    if (rank == 0 && world == 1 && group_wants_block(nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem))
+        return group_create_cone(pCone, iCone, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem, false);
+    MiCone *c = nullptr;
+    hdsdp_retcode rc = make_sdp_cone(&c, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem, rank, world);
+    if (rc != HDSDP_RETCODE_OK) return rc;
+    *pCone = new_cone_shell(c, iCone);
+    return HDSDP_RETCODE_OK;
+}
+
+hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, int nRow, int rank, int world) {
+    if (!pCone || nRow < 1 || nCol < 1 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
+    if (group_configure_from_env()) return HDSDP_RETCODE_FAILED;
+    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
+    if (rank == 0 && world == 1 && group_wants_block(nRow, nCol, nullptr, nullptr, nullptr))
+        return group_create_cone(pCone, iCone, nRow, nCol, nullptr, nullptr, nullptr, true);
+    MiCone *c = nullptr;
+    hdsdp_retcode rc = make_synth_cone(&c, nCol, nRow, rank, world);
+    if (rc != HDSDP_RETCODE_OK) return rc;
+    *pCone = new_cone_shell(c, iCone);
+    return HDSDP_RETCODE_OK;
+}
+
+void HMiConeDestroy(hdsdp_cone **pCone) {
+    if (!pCone || !*pCone) return;
+    if ((*pCone)->coneDestroyData) (*pCone)->coneDestroyData(&(*pCone)->coneData);
+    free(*pCone);
+    *pCone = nullptr;
+}
+void HMiConeSetStart(hdsdp_cone *cone, double v) { cone->coneSetStart(cone->coneData, v); }
+void HMiConeUpdate(hdsdp_cone *cone, double tau, double *y) { cone->coneUpdate(cone->coneData, tau, y); }
+hdsdp_retcode HMiConeCheckIsInterior(hdsdp_cone *cone, double tau, double *y, int *isInterior) {
+    return cone->coneInteriorCheck(cone->coneData, tau, y, isInterior);
+}
+hdsdp_retcode HMiConeGetLogBarrier(hdsdp_cone *cone, double tau, double *y, int whichBuffer, double *logdet) {
+    return cone->coneGetBarrier(cone->coneData, tau, y, whichBuffer, logdet);
+}
+hdsdp_retcode HMiConeRatioTest(hdsdp_cone *cone, double dTauStep, double *dy, double dAdaRatio, int whichBuffer,
+                               double *maxStep) {
+    return cone->coneRatioTest(cone->coneData, dTauStep, dy, dAdaRatio, whichBuffer, maxStep);
+}
+void HMiLanczosStartVector(int n, double *v) { hdm_lanczos_start_vector(n, v); }
+hdsdp_retcode HMiConeCheckIsInteriorExpert(hdsdp_cone *cone, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef,
+                                           int whichBuffer, int *isInterior) {
+    return cone->coneInteriorCheckExpert(cone->coneData, dCCoef, dACoefScal, dACoef, dEyeCoef, whichBuffer, isInterior);
+}
+hdsdp_retcode HMiConeAddStepToBufferAndCheck(hdsdp_cone *cone, double dStep, int whichBuffer, int *isInterior) {
+    return cone->coneAxpyBufferAndCheck(cone->coneData, dStep, whichBuffer, isInterior);
+}
+double HMiConeGetCoeffNorm(hdsdp_cone *cone, int whichNorm) { return cone->coneGetCoeffNorm(cone->coneData, whichNorm); }
+double HMiConeGetObjNorm(hdsdp_cone *cone, int whichNorm) { return cone->coneGetObjNorm(cone->coneData, whichNorm); }
+void HMiConeScalByConstant(hdsdp_cone *cone, double dScal) { cone->coneScal(cone->coneData, dScal); }
+void HMiConeComputeATimesXpy(hdsdp_cone *cone, double *dConePrimal, double *dATimesX) {
+    cone->coneATimesXpy(cone->coneData, dConePrimal, dATimesX);
+}
+double HMiConeComputeXDotS(hdsdp_cone *cone, double *dConePrimal) { return cone->coneXDotS(cone->coneData, dConePrimal); }
+double HMiConeComputeTraceCX(hdsdp_cone *cone, double *dConePrimal) { return cone->coneTraceCX(cone->coneData, dConePrimal); }
+void HMiConeGetDual(hdsdp_cone *cone, double *dConeDual, double *dConeDual2) {
+    cone->coneDRecover(cone->coneData, dConeDual, dConeDual2);
+}
+void HMiConeReduceResi(hdsdp_cone *cone, double dResiReduction) { cone->coneReduceResi(cone->coneData, dResiReduction); }
+void HMiConeSetPerturb(hdsdp_cone *cone, double dDualPerturb) { cone->coneSetPerturb(cone->coneData, dDualPerturb); }
+void HMiConeGetPrimal(hdsdp_cone *cone, double dBarrierMu, double *dRowDual, double *dRowDualStep, double *dConePrimal,
+                      double *dConePrimal2) {
+    cone->conePRecover(cone->coneData, dBarrierMu, dRowDual, dRowDualStep, dConePrimal, dConePrimal2);
+}
+void HMiConeGetPresolve(hdsdp_cone *cone, int *coefType, int *coefRank, int *coefNnz, int *kktPerm, int *kktStrategy,
+                        int *objType) {
+    MiCone *c = cone_data(cone);
+    for (int i = 0; i < c->m && !c->synthetic; ++i) {
+        if (coefType) coefType[i] = c->blk.rows[i].type;
+        if (coefRank) coefRank[i] = c->blk.rows[i].rank;
+        if (coefNnz) coefNnz[i] = c->blk.rows[i].nnz;
+        if (kktPerm) kktPerm[i] = c->blk.perm[i];
+        if (kktStrategy) kktStrategy[i] = c->blk.strategy[i];
+    }
+    if (objType) *objType = c->synthetic ? MI_COEFF_DENSE : c->blk.obj.type;
+}
+hdsdp_retcode HMiPresolveCSC(int nRow, int nCol, const int *coneMatBeg, const int *coneMatIdx,
+                             const double *coneMatElem, int *coefType, int *coefRank, int *coefNnz, int *kktPerm,
+                             int *kktStrategy, int *objType) {
+    if (nRow < 1 || nCol < 1 || !coneMatBeg) return HDSDP_RETCODE_FAILED;
+    MiBlockData blk;
+    if (mi_block_from_csc(blk, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem)) return HDSDP_RETCODE_FAILED;
+    for (int i = 0; i < nRow; ++i) {
+        if (coefType) coefType[i] = blk.rows[i].type;
+        if (coefRank) coefRank[i] = blk.rows[i].rank;
+        if (coefNnz) coefNnz[i] = blk.rows[i].nnz;
+        if (kktPerm) kktPerm[i] = blk.perm[i];
+        if (kktStrategy) kktStrategy[i] = blk.strategy[i];
+    }
+    if (objType) *objType = blk.obj.type;
+    return HDSDP_RETCODE_OK;
+}
+hdsdp_retcode HMiConeGetDualMatrix(hdsdp_cone *cone, double *S) {
+    MiCone *c = cone_data(cone);
+    if (hipMemcpy2DAsync(S, sizeof(double) * c->n, c->S, sizeof(double) * c->n16, sizeof(double) * c->n, c->n,
+                         hipMemcpyDeviceToHost, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    return hipStreamSynchronize(g.stream) == hipSuccess ? HDSDP_RETCODE_OK : HDSDP_RETCODE_FAILED;
+}
+hdsdp_retcode HMiConeGetTraces(hdsdp_cone *cone, double *trA) {
+    MiCone *c = cone_data(cone);
+    if (!c->trA) return HDSDP_RETCODE_FAILED;
+    memcpy(trA, c->trA, sizeof(double) * c->m);
+    return HDSDP_RETCODE_OK;
+}
+int HMiConeGetPath(hdsdp_cone *cone) { return cone_data(cone)->path; }
+
+// ---------------------------------------------------------------- single-process multi-device mode (group_impl.h)
+int HMiSetDevices(int nDevices, const int *deviceIds) {
+    if (nDevices < 1 || !deviceIds) return 1;
+    g_group_env_done = true;     // an explicit call overrides HDSDP_MI355X_GPUS
+    int tr = -1;
+    if (const char *t = getenv("HDSDP_MI355X_TRANSPORT")) tr = (strcmp(t, "rccl") == 0) ? GRP_RCCL : GRP_COPIES;
+    return group_setup(nDevices, deviceIds, tr);
+}
+int HMiGetDeviceGroup(int *deviceIds, int maxIds, int *transport) {
+    if (!g_group) { if (transport) *transport = -1; if (deviceIds && maxIds > 0 && g_main.init) deviceIds[0] = g_main.device; return g_main.init ? 1 : 0; }
+    for (int r = 0; r < g_group->W && r < maxIds; ++r) if (deviceIds) deviceIds[r] = g_group->dev[r];
+    if (transport) *transport = g_group->transport;
+    return g_group->W;
+}
+void HMiSetShardMinDim(int nMin) { if (g_group) g_group->min_n = nMin; }
+int HMiConeGetShardCount(hdsdp_cone *cone) {
+    return (cone && cone->coneBuildSchur == gc_build_schur) ? ((MiConeGroup *) cone->coneData)->G->W : 1;
+}
+void HMiConeGetGroupTraffic(hdsdp_cone *cone, int64_t *bytesAllToAll, int64_t *bytesAllReduce) {
+    int64_t a = 0, b = 0;
+    if (cone && cone->coneBuildSchur == gc_build_schur) { MiConeGroup *cg = (MiConeGroup *) cone->coneData; a = cg->bytes_a2a; b = cg->bytes_ar; }
+    if (bytesAllToAll) *bytesAllToAll = a;
+    if (bytesAllReduce) *bytesAllReduce = b;
+}
+// ---------------------------------------------------------------- fused small-block Phase-A pass (small.hip)
+static int small_plan(MiCone *c) {
+    MiCone::SmallPlan &sp = c->small;
+    if (sp.state) return sp.state;
+    sp.state = -1;
+    if (c->path != PATH_R1 || c->world != 1 || c->synthetic || c->n > SMALL_P || c->mloc != c->m || c->m > SMALL_P) return -1;
+    const int n = c->n, m = c->m;
+    std::vector<int> fp(m + 1, 0), fi, dense_of(m, -1), dense_rows;
+    std::vector<double> fv, sg(m, 0.0);
+    for (int q = 0; q < m; ++q) {
+        const MiCoeff &co = c->blk.rows[c->own[q]];
+        if (co.type != MI_COEFF_SPR1 && co.type != MI_COEFF_DSR1) return -1;
+        int nz = 0;
+        for (int r = 0; r < n; ++r) nz += (co.factor[r] != 0.0);
+        sg[q] = co.sign;
+        if (nz > SMALL_SPMAX) {                       // dense factor: all n entries, in order
+            if ((int) dense_rows.size() >= SMALL_NDENSE) return -1;
+            dense_of[q] = (int) dense_rows.size();
+            dense_rows.push_back(q);
+            for (int r = 0; r < n; ++r) { fi.push_back(r); fv.push_back(co.factor[r]); }
+        } else {
+            for (int r = 0; r < n; ++r) if (co.factor[r] != 0.0) { fi.push_back(r); fv.push_back(co.factor[r]); }
+        }
+        fp[q + 1] = (int) fi.size();
+    }
+    dense_rows.resize(SMALL_NDENSE, 0);
+    const size_t nf = std::max<size_t>(1, fi.size());
+    if (hipMalloc((void **) &sp.fp, sizeof(int) * (m + 1)) != hipSuccess || hipMalloc((void **) &sp.fi, sizeof(int) * nf) != hipSuccess ||
+        hipMalloc((void **) &sp.fv, sizeof(double) * nf) != hipSuccess || hipMalloc((void **) &sp.sgn, sizeof(double) * m) != hipSuccess ||
+        hipMalloc((void **) &sp.dense_of, sizeof(int) * m) != hipSuccess ||
+        hipMalloc((void **) &sp.dense_rows, sizeof(int) * SMALL_NDENSE) != hipSuccess ||
+        hipHostMalloc((void **) &sp.io_host, sizeof(double) * (7 * (size_t) m + 16), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **) &sp.io_dev, sp.io_host, 0) != hipSuccess)
+        return -1;
+    if (hdm_memcpy_h2d_sync(sp.fp, fp.data(), sizeof(int) * (m + 1)) != hipSuccess ||
+        (fi.size() && (hdm_memcpy_h2d_sync(sp.fi, fi.data(), sizeof(int) * fi.size()) != hipSuccess ||
+                       hdm_memcpy_h2d_sync(sp.fv, fv.data(), sizeof(double) * fv.size()) != hipSuccess)) ||
+        hdm_memcpy_h2d_sync(sp.sgn, sg.data(), sizeof(double) * m) != hipSuccess ||
+        hdm_memcpy_h2d_sync(sp.dense_of, dense_of.data(), sizeof(int) * m) != hipSuccess ||
+        hdm_memcpy_h2d_sync(sp.dense_rows, dense_rows.data(), sizeof(int) * SMALL_NDENSE) != hipSuccess)
+        return -1;
+    sp.ndense = 0;
+    for (int q = 0; q < m; ++q) sp.ndense += (dense_of[q] >= 0);
+    sp.state = 1;
+    return 1;
+}
+
+int HMiKKTPhaseAEligible(hdsdp_kkt *HKKT) {
+    if (!HKKT || HKKT->nCones != 1 || HKKT->isKKTSparse) return 0;
+    hdsdp_cone *hc = HKKT->cones[0];
+    if (hc->coneBuildSchur != cone_build_schur) return 0;
+    MiCone *c = (MiCone *) hc->coneData;
+    return (c->m == HKKT->nRow && small_plan(c) == 1) ? 1 : 0;
+}
+
+hdsdp_retcode HMiKKTPhaseA(hdsdp_kkt *HKKT, double barHsdTau, double *rowDual, double *rhs, double *d1, double *d2, double *d3,
+                           int *isInterior, double *logdet) {
+    StatScope stat_(ST_BUILD_M, __func__);
+    if (!HMiKKTPhaseAEligible(HKKT)) return HDSDP_RETCODE_FAILED;
+    MiCone *c = (MiCone *) HKKT->cones[0]->coneData;
+    MiCone::SmallPlan &sp = c->small;
+    MiKKTPriv *pv = priv_of(HKKT);
+    MiLin *ls = (MiLin *) c->dualFactor->chol, *lm = (MiLin *) HKKT->kktM->chol;
+    const int m = c->m, n = c->n;
+    HIP_RC(hipStreamSynchronize(g.stream));            // the mapped block is about to be rewritten
+    double *yin = sp.io_host, *bin = sp.io_host + m, *out = sp.io_host + 2 * (size_t) m;
+    for (int i = 0; i < m; ++i) { yin[i] = rowDual ? rowDual[i] : 0.0; bin[i] = rhs ? rhs[i] : 0.0; }
+    out[0] = -1.0;
+    HdmSmallArgs a = {};
+    a.n = n; a.m = m; a.C = c->Cfull; a.ldc = c->n16;
+    a.fp = sp.fp; a.fi = sp.fi; a.fv = sp.fv; a.sgn = sp.sgn; a.dense_of = sp.dense_of; a.ndense = sp.ndense; a.dense_rows = sp.dense_rows;
+    a.y = sp.io_dev; a.b = sp.io_dev + m; a.out = sp.io_dev + 2 * (size_t) m;
+    a.tau = barHsdTau; a.eye = -c->Rd + c->perturb; a.Rd = c->Rd;
+    a.Sout = c->S; a.lds = c->n16;
+    c->pS_ok = false;                                  // (the pass writes S itself)
+    a.LS = ls->ch.L; a.WS = ls->ch.Dinv; a.M = lm->Mdev; a.ldm = lm->ch.npad; a.LM = lm->ch.L; a.WM = lm->ch.Dinv;
+    if (ls->ch.npad != SMALL_P || lm->ch.npad != SMALL_P) return HDSDP_RETCODE_FAILED;
+    // (the operator's accumulators as HKKTBuildUp(KKT_TYPE_INFEASIBLE) leaves them, hdsdp_schur.c:141-165, :256-268: the
+    // kernel itself zeroes what it does not fill of the 128 x 128 device matrix)
+    RC(hdm_small_phase_a(a, g.stream));
+    if (pv->mirror)
+        HIP_RC(hipMemcpy2DAsync(HKKT->kktMatElem, sizeof(double) * m, lm->Mdev, sizeof(double) * SMALL_P, sizeof(double) * m, m,
+                                hipMemcpyDeviceToHost, g.stream));
+    HIP_RC(hipStreamSynchronize(g.stream));
+    const int infoS = (int) out[0], infoM = (int) out[1];
+    ls->ch.factored = (infoS == 0); ls->ch.have_inv = false;
+    c->dualFactor->nFactorizes += 1;
+    if (isInterior) *isInterior = (infoS == 0);
+    if (infoS != 0) return HDSDP_RETCODE_OK;           // "not positive definite" is a value, not an error
+    if (logdet) *logdet = out[2];
+    memset(HKKT->dASinvVec, 0, sizeof(double) * m); memset(HKKT->dASinvRdSinvVec, 0, sizeof(double) * m);
+    for (int i = 0; i < m; ++i) { HKKT->dASinvVec[i] = out[4 + i]; HKKT->dASinvRdSinvVec[i] = out[4 + m + i]; }
+    HKKT->dTraceSinv = (c->Rd != 0.0) ? out[3] : 0.0;
+    pv->Mdev_valid = true;
+    lm->ch.factored = (infoM == 0); lm->ch.have_inv = false;
+    lm->srcHost = nullptr; lm->srcDev = lm->Mdev; lm->srcLd = SMALL_P;
+    HKKT->kktM->nFactorizes += 1;
+    if (infoM != 0) {
+        // the Schur matrix is not numerically positive definite: the multi-launch path's way out (pivoted solver) takes over
+        fprintf(stderr, "[hdsdp_mi355x] HMiKKTPhaseA: Schur matrix is not positive definite (pivot %d); solving through HKKTFactorize\n", infoM);
+        if (HKKTFactorize(HKKT) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+        if (d1 && HKKTSolve(HKKT, rhs, d1) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+        if (d2 && HKKTSolve(HKKT, HKKT->dASinvVec, d2) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+        if (d3 && HKKTSolve(HKKT, HKKT->dASinvRdSinvVec, d3) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+        return HDSDP_RETCODE_OK;
+    }
+    HKKT->kktM->nSolves += 3;
+    if (d1) memcpy(d1, out + 4 + 2 * (size_t) m, sizeof(double) * m);
+    if (d2) memcpy(d2, out + 4 + 3 * (size_t) m, sizeof(double) * m);
+    if (d3) memcpy(d3, out + 4 + 4 * (size_t) m, sizeof(double) * m);
+    const double *stamp = out + 4 + 5 * (size_t) m;
+    for (int i = 0; i < 6; ++i) g.stage_ms[i] = (stamp[i + 1] - stamp[i]) * 1e-5;   // HMiGetStageTimes: 100 MHz ticks -> ms
+    g.stage_ms[6] = (stamp[6] > stamp[0]) ? stamp[7] / ((stamp[6] - stamp[0]) * 10.0) : 0.0;   // shader clock during the pass, GHz
+    return HDSDP_RETCODE_OK;
+}
+
+// host only (no device call): the reverse Cuthill-McKee order HKKTInit looks at for a sparse Schur pattern; lower-triangular CSC in,
+// perm[old] = new out
+int HMiRcmOrder(int m, const int *colBeg, const int *rowIdx, int *perm) {
+    if (m <= 0 || !colBeg || !rowIdx || !perm) return 1;
+    std::vector<int> beg(colBeg, colBeg + m + 1), idx(rowIdx, rowIdx + colBeg[m]);
+    const std::vector<int> p = rcm_order(m, beg, idx);
+    for (int i = 0; i < m; ++i) perm[i] = p[i];
+    return 0;
+}
+
+// how the operator's matrix will be factored: *permuted = 1 if the factor object holds P M P' (reverse Cuthill-McKee order of
+// the sparse pattern), *fraction = blocks inside the pattern's block envelope / blocks of the dense lower triangle (1 = dense)
+void HMiKKTEnvelopeInfo(hdsdp_kkt *HKKT, int *permuted, double *fraction) {
+    if (permuted) *permuted = 0;
+    if (fraction) *fraction = 1.0;
+    if (!HKKT || !HKKT->kktM) return;
+    MiLin *l = (MiLin *) HKKT->kktM->chol;
+    if (permuted) *permuted = l->perm.empty() ? 0 : 1;
+    if (fraction && !l->ch.env_colh.empty()) {
+        double in = 0.0, all = 0.0;
+        for (int k = 0; k < l->ch.nblk; ++k) { in += l->ch.env_colh[k] - k + 1; all += l->ch.nblk - k; }
+        *fraction = in / all;
+    }
+}
+
+int HMiGetCallStats(double *seconds, int64_t *calls, int n) {
+    for (int k = 0; k < n && k < ST_N; ++k) { if (seconds) seconds[k] = g_stat_sec[k]; if (calls) calls[k] = g_stat_calls[k]; }
+    return ST_N;
+}
+const char *HMiCallStatName(int k) { return (k >= 0 && k < ST_N) ? g_stat_name[k] : ""; }
+void HMiResetCallStats(void) { for (int k = 0; k < ST_N; ++k) { g_stat_sec[k] = 0.0; g_stat_calls[k] = 0; } g_stat_nfn = 0; }
+int HMiRcclSelfTest(int device) {
+    if (ensure_ctx()) return 1;
+    return rccl_self_test(device < 0 ? g_main.device : device);
+}

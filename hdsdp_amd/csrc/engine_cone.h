@@ -1,0 +1,851 @@
+// engine_cone.h -- the MI355X SDP cone: device state (MiCone), the operator's private state (MiKKTPriv) and the cone slots -- S assembly, interior checks, barrier, ratio test, norms, A X, primal recovery
+// Implementation header of engine.hip: included exactly once, there, in this order (the pieces share the anonymous namespace
+// and the engine's thread-local context `g`); split out of a 3 300-line file in round 3, nothing else changed.
+// =============================================================================================
+// MI355X SDP cone
+// =============================================================================================
+enum { PATH_GEMM = 0, PATH_R1 = 1, PATH_SPARSE = 2 };
+
+struct MiKKTPriv;
+
+struct MiCone {
+    int n = 0, m = 0;          // block dimension, global number of constraints
+    int rank = 0, world = 1;   // row sharding: constraint i is owned by rank i % world
+    int mloc = 0;              // constraints owned here
+    int n16 = 0;               // n rounded up to 16 (MFMA sub-tile)
+    int nblk = 0;              // n16 / 16
+    long npb = 0;              // p-blocks of the blocked congruence layout: nblk(nblk+1)/2 * 16
+    long npb_loc = 0;          // p-blocks per rank (K range of the local Gram part)
+    int Lr = 0;                // rows per segment of the Gram operand (local rows + 3 augmented, padded)
+    int path = PATH_GEMM;
+    bool synthetic = false;
+    MiBlockData blk;           // presolve results (empty rows for synthetic)
+    std::vector<int> own;      // global indices of the owned constraints
+    // device data
+    double *Afull = nullptr;   // mloc x (n16 x n16) constraint matrices in A_L form: strict lower + half diagonal
+    double *Cfull = nullptr;   // n16 x n16 objective, full symmetric
+    double *CL = nullptr;      // objective in A_L form (GEMM path, HSD builds)
+    double *Avec = nullptr;    // n16 x mloc16 rank-one factors (R1 path)
+    double *sgn = nullptr;     // mloc signs (R1 path)
+    int mloc16 = 0;
+    long astride = 0;          // elements per constraint matrix in Afull (skyline storage of the A_L form, hdm_common.h)
+    int *sp_rp = nullptr, *sp_ti = nullptr, *sp_tj = nullptr;  // sparse path: triplets of the owned rows
+    double *sp_tv = nullptr;
+    int *rows_seg = nullptr;   // world*Lr: segment-ordered Gram row -> global constraint (-1 pad, -2.. aug)
+    int *rows_own = nullptr;   // mloc: owned row -> global constraint
+    double *S = nullptr, *Scheck = nullptr;  // n x n (ld n16) dual matrix buffers
+    double *ydev = nullptr;
+    double *yhost = nullptr;   // pinned staging of the owned multipliers (the upload is asynchronous)
+    double *chk_host = nullptr, *chk_dev = nullptr;   // mapped pinned block of the single-launch small-block check: y[mloc], then info, log det
+    bool fac_ok = false; int fac_psd = 0;             // the dual factor object holds the factorisation of S = T(pS) (result: fac_psd)
+    double *corr = nullptr;    // sharded corrector build: this cone's 2m dot products before they join the operator's
+    hdsdp_linsys_fp *dualFactor = nullptr;
+    HdmChol *primal = nullptr; // KKT_TYPE_PRIMAL: factor object of the registered primal matrix (lazy)
+    HdmLanczos *lanczos = nullptr;  // ratio test state (lazy); dS lives in `dS`
+    double nrm[4] = {0, 0, 0, 0}; bool norms_ready = false;   // data norms (rows abs / Frobenius, objective abs / Frobenius)
+    double objScal = 1.0;           // product of the coneScal factors applied to C
+    HdmChol *checker = nullptr;     // second factor object (primal recovery works on S without the residual term)
+    double *dS = nullptr;
+    double *Xup = nullptr;          // uploaded primal matrix of the cone utilities
+    double *Pr1 = nullptr, *Pr2 = nullptr;   // primal recovery scratch (npad x npad each; Xinv / Yinv are sized per builder path)
+    double Rd = 0.0, perturb = 0.0;
+    double *trA = nullptr;     // host: tr(A_i) of all m constraints (b of the synthetic family)
+    // work space
+    int Bc = 8;                // constraints per congruence batch
+    double *T = nullptr;       // Bc x n16 x n16
+    double *AhatLoc = nullptr; // [world*npb_loc][Lr][16] congruence output of the owned rows
+    double *AhatAll = nullptr; // [world][npb_loc][Lr][16] after the transpose (== AhatLoc when world == 1)
+    bool ext_ahat = false;     // buffers supplied by the caller (torch-owned, for RCCL)
+    double *slabs = nullptr;   // nsplit x R x R
+    double *Gm = nullptr;      // R x R augmented Gram (lower valid)
+    int nsplit = 1;
+    long R = 0;                // world * Lr
+    // R1 work
+    double *U = nullptr, *V = nullptr, *Gr1 = nullptr, *Ct = nullptr, *W = nullptr, *Xinv = nullptr, *Yinv = nullptr;
+    // exchange hooks (world > 1)
+    hmi_alltoall_fn alltoall = nullptr;
+    hmi_alltoall_piece_fn a2a_start = nullptr;   // piecewise exchange overlapped with the Gram product (optional)
+    hmi_alltoall_wait_fn a2a_wait = nullptr;
+    int a2a_pieces = 1;
+    hipEvent_t piece_ev[64] = {};                // staged exchange: congruence step 2 finished the p-blocks of piece k
+    int last_pieces = 1, last_staged = 0;        // HMiConeGetExchangeStats
+    hmi_allreduce_fn allreduce = nullptr;
+    void *xctx = nullptr;
+    bool work_ready = false;
+    bool shared_ts = false;    // T and the Gram slabs are one buffer (one GPU): T's diagonal-tile uppers are re-zeroed per batch
+    // single-process multi-device mode: the shards of one block share ONE Schur operator (the caller's); only shard 0
+    // writes into it, the others stop after the all-reduce
+    bool kkt_owner = true;
+    int kkt_counted = 0;       // progress of the aggregated-pattern queries (cone_add_sym_nz)
+    // Where the dual matrix and the step matrix stand (single-device blocks): S = T(pS), dS = T(pD) for the linear map
+    // T(tau, y, eye) = tau C - sum y_i A_i + eye I.  A request for T(p) with p = pS + alpha pD is answered by S + alpha dS
+    // (one pass over n^2) instead of a sweep over all m constraint matrices (cone_assemble).
+    std::vector<double> pS, pD;          // tau, eye, then the mloc multipliers
+    bool pS_ok = false, pD_ok = false;
+    int aff_chain = 0;                   // updates of S in place since its last full assembly
+    // fused single-launch Phase-A pass of a small rank-one block (small.hip): factors as a CSR, built on first use
+    struct SmallPlan {
+        int state = 0;         // 0 = not looked at, 1 = ready, -1 = not eligible
+        int *fp = nullptr, *fi = nullptr, *dense_of = nullptr, *dense_rows = nullptr;
+        double *fv = nullptr, *sgn = nullptr;
+        int ndense = 0;
+        double *io_host = nullptr, *io_dev = nullptr;   // mapped pinned block: y[m], b[m] in; 4 + 5 m doubles out
+    } small;
+};
+
+struct MiKKTPriv {
+    int mirror = 1;
+    double *vecs = nullptr;   // device: ASinv[m], ASinvRdSinv[m], ASinvCSinv[m], scal[4]
+    double *rhs = nullptr;
+    bool Mdev_valid = false;  // device M holds the result of the last BuildUp
+    // cones of HKKT->cones[] whose coneBuildSchur is this engine's (they accumulate on the device) and the others (the
+    // reference's CPU cones: they accumulate into the host fields, hdsdp_conic_*.c)
+    int n_engine = 0, n_foreign = 0;
+    double *Mtmp = nullptr;   // pinned m x m staging buffer for the mixed case (device part added to the host part)
+    // sparse Schur operator (isKKTSparse, hdsdp_schur.c:46-139): the host matrix is the aggregated CSC pattern; its
+    // entries as (row, column) pairs on the device, plus a staging vector of nnz values
+    long nnz = 0;
+    int *sp_rows = nullptr, *sp_cols = nullptr;
+    int *sp_prow = nullptr, *sp_pcol = nullptr;   // the same entries in the factor object's (permuted, lower) coordinates, if it is permuted
+    double *sp_vals = nullptr;
+};
+
+// the kkt private state hangs off kktM->chol's MiLin (Mdev) plus a side struct keyed by the kkt pointer
+std::vector<std::pair<hdsdp_kkt *, MiKKTPriv *>> g_priv;
+MiKKTPriv *priv_of(hdsdp_kkt *k) {
+    for (auto &p : g_priv)
+        if (p.first == k) return p.second;
+    MiKKTPriv *n = new MiKKTPriv();
+    g_priv.push_back({k, n});
+    return n;
+}
+void priv_drop(hdsdp_kkt *k) {
+    for (size_t i = 0; i < g_priv.size(); ++i)
+        if (g_priv[i].first == k) {
+            if (g_priv[i].second->vecs) (void) hipFree(g_priv[i].second->vecs);
+            if (g_priv[i].second->rhs) (void) hipFree(g_priv[i].second->rhs);
+            if (g_priv[i].second->Mtmp) (void) hipHostFree(g_priv[i].second->Mtmp);
+            if (g_priv[i].second->sp_rows) (void) hipFree(g_priv[i].second->sp_rows);
+            if (g_priv[i].second->sp_prow) (void) hipFree(g_priv[i].second->sp_prow);
+            if (g_priv[i].second->sp_pcol) (void) hipFree(g_priv[i].second->sp_pcol);
+            if (g_priv[i].second->sp_cols) (void) hipFree(g_priv[i].second->sp_cols);
+            if (g_priv[i].second->sp_vals) (void) hipFree(g_priv[i].second->sp_vals);
+            delete g_priv[i].second;
+            g_priv.erase(g_priv.begin() + i);
+            return;
+        }
+}
+
+// single-process multi-device mode (group_impl.h): a group cone's slots fan out to one MiCone per device
+hdsdp_retcode gc_build_schur(void *cd, int iCone, void *kktv, int typeKKT);
+MiCone *cone_data(hdsdp_cone *cone);   // the block's device data; for a group cone that of shard 0
+int group_configure_from_env();
+bool group_wants_block(int nRow, int nCol, const int *beg, const int *idx, const double *val);
+hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *beg, const int *idx,
+                                const double *val, bool synthetic);
+
+int cone_alloc_common(MiCone *c) {
+    c->n16 = (int) hdm_roundup(c->n, 16);
+    c->astride = hdm_sky_size(c->n16);
+    c->nblk = c->n16 / 16;
+    c->npb = (long) c->nblk * (c->nblk + 1) / 2 * 16;
+    c->npb_loc = (c->npb + c->world - 1) / c->world;
+    c->own.clear();
+    // One GPU: constraints that are zero on this block (most of them in a many-block problem; the reference's
+    // "sparse SDP cone", hdsdp_conic_sdp.c:1814-1886, loops over the non-zero ones only) are left out of the device
+    // data altogether: no congruence, no Gram rows, nothing written to their rows of M.  Sharded blocks keep the plain
+    // cyclic deal (row i on rank i % world) that the exchange layout is built on.
+    const bool compact = (c->world == 1 && !c->synthetic && (int) c->blk.rows.size() == c->m);
+    for (int i = c->rank; i < c->m; i += c->world)
+        if (!compact || c->blk.rows[i].type != MI_COEFF_ZERO) c->own.push_back(i);
+    c->mloc = (int) c->own.size();
+    int maxloc = compact ? c->mloc : (c->m + c->world - 1) / c->world;
+    c->Lr = (c->world == 1) ? (int) hdm_roundup(maxloc + 3, 8) : (int) hdm_roundup(maxloc + 3, HDM_TILE);
+    c->R = (long) c->world * c->Lr;
+    const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
+    HDM_HIP_CHECK(hipMalloc((void **) &c->S, nn));
+    HDM_HIP_CHECK(hipMalloc((void **) &c->Scheck, nn));
+    HDM_HIP_CHECK(hipMalloc((void **) &c->Cfull, nn));
+    HDM_HIP_CHECK(hdm_memset_sync(c->Cfull, 0, nn));
+    HDM_HIP_CHECK(hipMalloc((void **) &c->ydev, sizeof(double) * (size_t) std::max(1, c->m)));
+    std::vector<int> rs((size_t) c->R, -1);
+    for (int gq = 0; gq < c->world; ++gq) {
+        int cnt = 0;
+        if (compact) { for (int i : c->own) rs[cnt++] = i; }
+        else for (int i = gq; i < c->m; i += c->world) rs[(size_t) gq * c->Lr + cnt++] = i;
+        if (gq == 0) { rs[cnt] = -2; rs[cnt + 1] = -3; rs[cnt + 2] = -4; }  // I, S, C rows
+    }
+    HDM_HIP_CHECK(hipMalloc((void **) &c->rows_seg, sizeof(int) * (size_t) c->R));
+    HDM_HIP_CHECK(hdm_memcpy_h2d_sync(c->rows_seg, rs.data(), sizeof(int) * (size_t) c->R));
+    HDM_HIP_CHECK(hipMalloc((void **) &c->rows_own, sizeof(int) * (size_t) std::max(1, c->mloc)));
+    HDM_HIP_CHECK(hdm_memcpy_h2d_sync(c->rows_own, c->own.data(), sizeof(int) * (size_t) c->mloc));
+    if (HFpLinsysCreate(&c->dualFactor, c->n, HDSDP_LINSYS_DENSE_DIRECT) != HDSDP_RETCODE_OK) return 1;
+    return 0;
+}
+
+int cone_alloc_gemm_work(MiCone *c) {
+    const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
+    // batch size: as many constraints per launch as 32 GiB of intermediates allow, at most 1024 (each launch pays a
+    // dispatch ramp and a tail: measured step time 400.9 / 396.8 / 393.2 / 393.2 ms at 256 / 512 / 1000 / 2000 per launch on
+    // one box).  The launches are evened out (2000 rows -> 2 x 1000, a rank's 250 rows -> one launch); the kernel's
+    // XCD-local decode pads a batch to a multiple of 8 itself.  If the allocation fails the batch is halved.
+    long tcap = 32;   // GiB of intermediates
+    if (const char *e = getenv("HDM_TCAP_GIB")) tcap = atol(e);
+    long bc = (long) (((double) tcap * (1L << 30)) / (double) nn);
+    long bcmax = 1024;
+    if (const char *e = getenv("HDM_BC")) bcmax = atol(e);
+    bc = std::max(1L, std::min(bc, bcmax));
+    const long rows = std::max(1, c->mloc);
+    for (;;) {
+        const long launches = (rows + bc - 1) / bc;
+        bc = (rows + launches - 1) / launches;
+        c->Bc = (int) bc;
+        if (hipMalloc((void **) &c->T, nn * (size_t) c->Bc + hdm_operand_pad(c->n16)) == hipSuccess) break;
+        (void) hipGetLastError();
+        c->T = nullptr;
+        if (bc <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the congruence intermediates\n"); return 1; }
+        bc /= 2;
+    }
+    HDM_HIP_CHECK(hdm_memset_sync(c->T, 0, nn * (size_t) c->Bc));  // step 1 writes lower tiles only; the rest must read as 0
+    const size_t ahat = sizeof(double) * (size_t) c->world * c->npb_loc * c->Lr * 16;
+    if (!c->AhatLoc) {
+        HDM_HIP_CHECK(hipMalloc((void **) &c->AhatLoc, ahat + sizeof(double) * HDM_OPERAND_PAD_DOUBLES));
+        HDM_HIP_CHECK(hdm_memset_sync(c->AhatLoc, 0, ahat));
+        if (c->world == 1) c->AhatAll = c->AhatLoc;
+        else {
+            HDM_HIP_CHECK(hipMalloc((void **) &c->AhatAll, ahat + sizeof(double) * HDM_OPERAND_PAD_DOUBLES));
+            HDM_HIP_CHECK(hdm_memset_sync(c->AhatAll, 0, ahat));
+        }
+    }
+    // Gram split-K: the grid is tiles x nsplit workgroups on 512 resident slots (256 CUs x 2).  The split index
+    // is the fast workgroup index, and workgroups are dealt round-robin over the 8 XCDs: with nsplit a multiple
+    // of 8 every XCD keeps to its own K ranges, so the ~64 tiles it runs concurrently share their row/column
+    // panels in that XCD's L2 (profiles/r01_a: with nsplit = 15 the Gram kernel fetched 513 GB per launch,
+    // i.e. every tile load went to the fabric).  Short K ranges (small problems): among the multiples of 8 pick the
+    // one whose last scheduling round is fullest; long K ranges are handled below.
+    const long RT = (c->R + HDM_TILE - 1) / HDM_TILE;
+    const long tiles = RT * (RT + 1) / 2;
+    const long kblocks = c->npb_loc;
+    const long slab_cap = std::max(1L, (long) ((4LL << 30) / (sizeof(double) * (double) c->R * c->R)));  // <= 4 GiB of slabs
+    const long kcap = std::max(1L, kblocks / 64);
+    long ns = 1;
+    double best = -1.0;
+    for (long cand = 1; cand <= 64 && cand <= slab_cap && cand <= kcap; ++cand) {
+        if (cand > 8 && cand % 8) continue;
+        const double rounds = (double) (tiles * cand) / 512.0;
+        double eff = rounds / std::ceil(rounds);
+        if (rounds < 2.0) eff *= 0.5 + 0.25 * rounds;  // too few workgroups to hide the tail
+        if (cand < 8 && kcap >= 8 && slab_cap >= 8) eff *= 0.5;  // prefer XCD-aligned splits when possible
+        if (eff > best + 1e-9) { best = eff; ns = cand; }
+    }
+    // Long K ranges: many SHORT splits.  Co-resident workgroups progress at slightly different rates (about 2 %), so
+    // over a long tile they drift out of the few-stage window in which the XCD's L2 still holds a neighbour's operand
+    // panel; with short tiles every round restarts aligned.  Measured Gram kernel at n = m = 2000: 129.9 / 124.6 /
+    // 121.1 / 116.6 ms at 64 / 256 / 512 / 1024 splits.  The price is nsplit x R^2 doubles of slabs (<= 40 GiB).
+    {
+        const long big_cap = (long) ((40LL << 30) / (sizeof(double) * (double) c->R * c->R));
+        const long byk = kblocks / 96;   // >= 96 k blocks (of 16) per workgroup keeps prologue + epilogue under 4 %
+        if (byk >= 128) {
+            const long big = std::min(std::min(1024L, byk), big_cap) & ~7L;
+            if (big > ns) ns = big;
+        }
+    }
+    if (const char *e = getenv("HDM_NSPLIT")) ns = std::max(1L, std::min(atol(e), kblocks / 16));   // A/B knob
+    // One GPU: the congruence intermediates T are dead by the time the Gram product writes its split-K slabs, so the two
+    // share ONE buffer (the larger of the two sizes: 33 GB instead of 32 + 33 GB at n = m = 2000).  The only thing step 2
+    // reads of T that step 1 does not write is the strict upper triangle of T's diagonal tiles: with the buffer shared
+    // it is re-zeroed before every batch (hdm_zero_diag_upper, 1 GB of stores per 1000 matrices) instead of once at
+    // allocation.  Sharded builds keep them apart: there the Gram splits of the early exchange pieces run while step 2
+    // still reads T for the later ones.  HDM_SHARE_T_SLABS=0 keeps two buffers (A/B runs).
+    bool share = (c->world == 1);
+    if (const char *e = getenv("HDM_SHARE_T_SLABS")) share = share && atoi(e) != 0;
+    if (share) {
+        const size_t tbytes = nn * (size_t) c->Bc + hdm_operand_pad(c->n16);
+        for (;;) {
+            c->nsplit = (int) ns;
+            const size_t sbytes = sizeof(double) * (size_t) c->R * c->R * c->nsplit;
+            if (sbytes <= tbytes) { c->slabs = c->T; c->shared_ts = true; break; }
+            // the slabs are the bigger of the two: one buffer of their size serves both
+            (void) hipFree(c->T);
+            c->T = nullptr;
+            if (hipMalloc((void **) &c->T, sbytes + hdm_operand_pad(c->n16)) == hipSuccess) { c->slabs = c->T; c->shared_ts = true; break; }
+            (void) hipGetLastError();
+            if (hipMalloc((void **) &c->T, tbytes) != hipSuccess) { (void) hipGetLastError(); c->T = nullptr; return 1; }
+            if (ns <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the Gram slabs\n"); return 1; }
+            ns = std::max(8L, (ns / 2) & ~7L);
+        }
+    }
+    // the slabs are the one allocation here that is a tuning choice: halve the split count until it fits
+    for (; !c->shared_ts;) {
+        c->nsplit = (int) ns;
+        if (hipMalloc((void **) &c->slabs, sizeof(double) * (size_t) c->R * c->R * c->nsplit) == hipSuccess) break;
+        (void) hipGetLastError();
+        c->slabs = nullptr;
+        if (ns <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the Gram slabs\n"); return 1; }
+        ns = std::max(8L, (ns / 2) & ~7L);
+    }
+    HDM_HIP_CHECK(hipMalloc((void **) &c->Gm, sizeof(double) * (size_t) c->R * c->R));
+    // the "S row" (At = I) never changes
+    if (c->rank == 0) {
+        if (hdm_blocked_eye(c->AhatLoc, c->Lr, c->mloc + 1, c->nblk, c->n, g.stream)) return 1;
+    }
+    return 0;
+}
+
+// --- vtable slots ---------------------------------------------------------------------------
+void cone_setstart(void *cd, double rResi) { ((MiCone *) cd)->Rd = rResi; }  // hdsdp_conic_sdp.c:1546-1550
+int cone_getdim(void *cd) { return ((MiCone *) cd)->n; }
+// rows of M this block contributes to: all m for a dense block (:1404-1405), the k rows on which the block has data for
+// a block most constraints are zero on (the reference's sparse SDP cone, :1479-1480) -- what HKKTInit weighs against
+// 0.3 m^2 when it chooses between the dense Schur matrix and the aggregated-pattern CSC
+int cone_kkt_rows(const MiCone *c) {
+    const bool compact = (c->world == 1 && !c->synthetic && (int) c->blk.rows.size() == c->m);
+    // the reference makes a block a sparse SDP cone iff at most 0.3 m of the constraints have data on it
+    // (HUserDataChooseCone, hdsdp_user_data.c:82-86; HDSDP_SPARSE_CONE_THRESHOLD); its dense cone claims all of M
+    return (compact && (double) c->mloc <= 0.3 * (double) c->m) ? c->mloc : c->m;
+}
+int64_t cone_getsymnnz(void *cd) { MiCone *c = (MiCone *) cd; const int64_t k = cone_kkt_rows(c); return k * k; }
+// the two pattern queries of HKKTAllocSparseKKT (hdsdp_schur.c:46-139), with the protocol of the reference's sparse SDP
+// cone (sdpSparseConeAddSymNnzImpl / sdpSparseConeGetSymMapping, hdsdp_conic_sdp.c:2086-2170): columns are visited in
+// order; in the column of its next row the block marks that row and all its later ones.  The positions handed back in
+// the second call are not kept: the engine's builders write a dense device matrix at global (row, column) indices and
+// the operator gathers the pattern's entries from it.
+void cone_add_sym_nz(void *cd, int iCol, int *schurMatCol) {
+    MiCone *c = (MiCone *) cd;
+    if (c->kkt_counted >= c->mloc || c->own[c->kkt_counted] != iCol) return;
+    for (int e = c->kkt_counted; e < c->mloc; ++e) schurMatCol[c->own[e]] = 1;
+}
+void cone_get_kkt_map(void *cd, int iCol, int *schurMatCol) {
+    (void) schurMatCol;
+    MiCone *c = (MiCone *) cd;
+    if (c->kkt_counted < c->mloc && c->own[c->kkt_counted] == iCol) c->kkt_counted += 1;
+}
+
+// S <- tau*C - sum y_i A_i - Rd*I (+ perturb)   hdsdp_conic_sdp.c:343-402, :1616-1633
+// Sharded: every rank sums its own rows (rank 0 also adds tau*C and the identity term), then all-reduce.
+int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, const double *eye_override = nullptr) {
+    // the upload below is asynchronous: the source is a pinned buffer of the cone, and the previous upload from it has
+    // been consumed by the time it is rewritten (every caller synchronises on the factorisation that follows)
+    if (!c->yhost) HDM_HIP_CHECK(hipHostMalloc((void **) &c->yhost, sizeof(double) * (size_t) std::max(1, c->mloc), hipHostMallocDefault));
+    HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
+    double *yo = c->yhost;
+    bool any = false;
+    for (int q = 0; q < c->mloc; ++q) { yo[q] = y_host ? y_host[c->own[q]] : 0.0; any |= (yo[q] != 0.0); }
+    const double eye_now = eye_override ? *eye_override : (-c->Rd + c->perturb);
+    // ---- shortcut (see MiCone::pS).  The reference's line searches and correctors ask for the dual matrix twice at the same
+    // point (interior check, then barrier) and at points y + alpha dy along the direction whose dS the ratio test has just
+    // assembled: each a 32 GB sweep at n = m = 2000 (6 ms), 14 % of a whole solve's device time.  The request is compared
+    // with what the buffers hold, component by component; anything else takes the sweep.
+    // 1: only the exact case -- the same point again -- is short-cut, so every number is the one a sweep would have produced.
+    // 2: also points on the line through the last ratio test's direction (S + alpha dS); the results then differ from a
+    // sweep's in the last bits (as a sweep's differ from the reference's own summation order).  0: off.
+    // Default: 2 where a sweep costs something -- 16 MiB of constraint data or more, i.e. from about n = m = 160 on; at
+    // n = m = 2000 the reference's line searches and correctors ask for 344 such points per solve, 6 ms each -- and 1 on
+    // small blocks, where the sweep is free and the end game of a badly conditioned instance can turn on the last bits
+    // (gpp100 through the reference's driver in mode 2: same dual objective, a primal estimate 3e-4 further away).
+    // HDSDP_MI355X_AFFINE_S=0/1/2 overrides.
+    static const int aff_env = [] { const char *e = getenv("HDSDP_MI355X_AFFINE_S"); return e ? atoi(e) : -1; }();
+    const long sweep_bytes = (long) c->mloc * c->n * (c->n + 1) * 4;
+    const int aff_mode = aff_env >= 0 ? aff_env : (sweep_bytes >= (16L << 20) ? 2 : 1);
+    const bool track = aff_mode > 0 && c->world == 1;
+    if (track && target != c->dS && c->pS_ok) {
+        const int np = c->mloc + 2;
+        auto comp = [&](int i) { return i == 0 ? tau : i == 1 ? eye_now : yo[i - 2]; };
+        bool same = true;
+        for (int i = 0; i < np && same; ++i) same = (comp(i) == c->pS[i]);
+        if (same && target == c->S) return 0;                                  // S already is T(p)
+        double alpha = 0.0;
+        bool hit = same;
+        if (!same && c->pD_ok && aff_mode >= 2) {
+            int kmax = 0;
+            for (int i = 1; i < np; ++i) if (fabs(c->pD[i]) > fabs(c->pD[kmax])) kmax = i;
+            if (c->pD[kmax] != 0.0) {
+                alpha = (comp(kmax) - c->pS[kmax]) / c->pD[kmax];
+                hit = std::isfinite(alpha);
+                for (int i = 0; i < np && hit; ++i) {
+                    const double d = comp(i) - c->pS[i], e = alpha * c->pD[i];
+                    hit = fabs(d - e) <= 1.8e-15 * (fabs(comp(i)) + fabs(c->pS[i]) + fabs(e));
+                }
+            }
+        }
+        if (hit && same) {                                                     // the same point into the other buffer: a copy
+            HDM_HIP_CHECK(hipMemcpyAsync(target, c->S, sizeof(double) * (size_t) c->n16 * c->n16, hipMemcpyDeviceToDevice, g.stream));
+            return 0;
+        }
+        if (hit && c->dS && (target != c->S || c->aff_chain < 16)) {
+            if (hdm_axpy_mat(target, c->S, c->dS, alpha, (long) c->n16 * c->n16, g.stream)) return 1;
+            if (target == c->S) {
+                for (int i = 0; i < np; ++i) c->pS[i] = comp(i);
+                c->aff_chain += 1;
+            }
+            return 0;
+        }
+    }
+    HDM_HIP_CHECK(hipMemcpyAsync(c->ydev, yo, sizeof(double) * c->mloc, hipMemcpyHostToDevice, g.stream));
+    if (track && (target == c->S || target == c->dS)) {
+        std::vector<double> &pp = (target == c->S) ? c->pS : c->pD;
+        pp.resize((size_t) c->mloc + 2);
+        pp[0] = tau; pp[1] = eye_now;
+        for (int q = 0; q < c->mloc; ++q) pp[2 + q] = yo[q];
+        (target == c->S ? c->pS_ok : c->pD_ok) = true;
+        if (target == c->S) c->aff_chain = 0;
+    }
+    const double lead = (c->rank == 0) ? 1.0 : 0.0;
+    if (hdm_sym_combine(c->Afull, c->astride, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
+                        lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)), target, c->n, c->n16, c->n16, g.stream)) return 1;
+    if (c->world > 1) {
+        HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
+        if (!c->allreduce || c->allreduce(c->xctx, target, (int64_t) c->n16 * c->n16)) return 1;
+    }
+    return 0;
+}
+
+hdsdp_retcode cone_factor_S(MiCone *c, int *isPsd);
+hdsdp_retcode cone_factor_check(MiCone *c, int *isPsd);
+hdsdp_retcode cone_checker(MiCone *c, HdmChol **out);
+
+// Interior check of a SMALL block (n <= 128, at most 1 MB of resident constraint data) in ONE launch and one synchronisation:
+// assembly, Cholesky with the triangular inverse, pivot information and log det S (small.hip: hdm_small_check_kernel).  The
+// same point asked for again -- the reference's line search asks "interior?" and then for the barrier at the point it has just
+// checked -- is answered from what the factor object holds, with no device work at all.
+// Returns 0 when it has answered (*isPsd set), 1 when the block is not eligible (the caller takes the call-by-call route).
+int cone_small_check(MiCone *c, double tau, const double *y_host, const double *eye_override, int whichBuffer, int *isPsd, hdsdp_retcode *rc) {
+    static const bool on = [] { const char *e = getenv("HDSDP_MI355X_SMALL_CHECK"); return !(e && atoi(e) == 0); }();
+    *rc = HDSDP_RETCODE_OK;
+    // (a single workgroup walks the resident constraint data: up to 1 MB of it in general, 4 MB for blocks of dimension <= 64,
+    // where the call-by-call assembly's few workgroups are latency-bound themselves -- theta1: 0.45 ms per check)
+    const long resident = (long) c->mloc * c->n16 * c->n16;
+    if (!on || c->world != 1 || !c->Afull || c->n16 > SMALL_P || resident > ((c->n16 <= 64) ? (1L << 19) : (1L << 17))) return 1;
+    HdmChol *ch = &((MiLin *) c->dualFactor->chol)->ch;
+    if (whichBuffer != 0) { if (cone_checker(c, &ch) != HDSDP_RETCODE_OK) return 1; }
+    if (ch->npad != SMALL_P || ch->nblk != 1) return 1;
+    const double eye_now = eye_override ? *eye_override : (-c->Rd + c->perturb);
+    const int np = c->mloc + 2;
+    if (!c->chk_host) {
+        if (hipHostMalloc((void **) &c->chk_host, sizeof(double) * (size_t) (c->mloc + 4), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **) &c->chk_dev, c->chk_host, 0) != hipSuccess) { (void) hipGetLastError(); c->chk_host = nullptr; return 1; }
+    }
+    double *yo = c->chk_host;
+    bool same = (whichBuffer == 0 && c->pS_ok && (int) c->pS.size() == np && c->pS[0] == tau && c->pS[1] == eye_now);
+    for (int q = 0; q < c->mloc; ++q) {
+        const double v = y_host ? y_host[c->own[q]] : 0.0;
+        if (same && c->pS[2 + q] != v) same = false;
+        yo[q] = v;
+    }
+    if (same && c->fac_ok) { if (isPsd) *isPsd = c->fac_psd; return 0; }      // S = T(p) and its factor are in place
+    HdmSmallCheckArgs a = {};
+    a.n = c->n; a.n16 = c->n16; a.m = c->mloc; a.A = c->Afull; a.astride = c->astride; a.C = c->Cfull;
+    a.y = c->chk_dev; a.tau = tau; a.eye = eye_now;
+    a.Sout = (whichBuffer == 0) ? c->S : c->Scheck;
+    a.L = ch->L; a.W = ch->Dinv; a.out = c->chk_dev + c->mloc;
+    yo[c->mloc] = -1.0;
+    if (hdm_small_check(a, g.stream) || hipStreamSynchronize(g.stream) != hipSuccess) { *rc = HDSDP_RETCODE_FAILED; return 0; }
+    const int info = (int) yo[c->mloc];
+    if (info < 0) { *rc = HDSDP_RETCODE_FAILED; return 0; }
+    ch->factored = (info == 0); ch->have_inv = false;
+    ch->logdet_ok = (info == 0); ch->logdet_val = yo[c->mloc + 1];
+    if (whichBuffer == 0) {
+        c->dualFactor->nFactorizes += 1;
+        c->pS.resize((size_t) np);
+        c->pS[0] = tau; c->pS[1] = eye_now;
+        for (int q = 0; q < c->mloc; ++q) c->pS[2 + q] = yo[q];
+        c->pS_ok = true; c->aff_chain = 0;
+        c->fac_ok = true; c->fac_psd = (info == 0);
+    }
+    if (isPsd) *isPsd = (info == 0);
+    return 0;
+}
+
+void cone_update(void *cd, double tau, double *y) {
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
+    ((MiCone *) cd)->fac_ok = false;          // S moves, its factor does not follow
+    cone_assemble((MiCone *) cd, tau, y, ((MiCone *) cd)->S);
+}
+
+hdsdp_retcode cone_factor_S(MiCone *c, int *isPsd) {
+    MiLin *l = (MiLin *) c->dualFactor->chol;
+    c->fac_ok = false;
+    RC(l->ch.load_device(c->S, c->n16, g.stream));
+    int info = 0;
+    RC(l->ch.factor(g.stream, &info));
+    c->dualFactor->nFactorizes += 1;
+    if (isPsd) *isPsd = (info == 0);
+    return HDSDP_RETCODE_OK;
+}
+
+// the second factor object ("dualChecker" of the reference, def_hdsdp_conic.h): trial points of the line search and the
+// primal recovery are factored here so that the factor of the current S stays valid
+hdsdp_retcode cone_checker(MiCone *c, HdmChol **out) {
+    if (!c->checker) {
+        c->checker = new HdmChol();
+        if (c->checker->init(c->n)) return HDSDP_RETCODE_MEMORY;
+    }
+    *out = c->checker;
+    return HDSDP_RETCODE_OK;
+}
+
+hdsdp_retcode cone_factor_check(MiCone *c, int *isPsd) {
+    HdmChol *ch = nullptr;
+    RC(cone_checker(c, &ch));
+    int info = 0;
+    if (ch->load_device(c->Scheck, c->n16, g.stream) || ch->factor(g.stream, &info)) return HDSDP_RETCODE_FAILED;
+    if (isPsd) *isPsd = (info == 0);
+    return HDSDP_RETCODE_OK;
+}
+
+// sdpDenseConeInteriorCheckExpert (hdsdp_conic_sdp.c:2192-2207): B = dCCoef*C + dACoefScal*sum_i dACoef_i A_i + dEyeCoef*I
+// (+ the perturbation unless the target is the step buffer, :383-385) into the chosen buffer, then the PSD check
+hdsdp_retcode cone_interior_expert(void *cd, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef,
+                                   int whichBuffer, int *isInterior) {
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
+    MiCone *c = (MiCone *) cd;
+    std::vector<double> ys(std::max(1, c->m), 0.0);
+    for (int i = 0; i < c->m; ++i) ys[i] = -dACoefScal * (dACoef ? dACoef[i] : 0.0);   // cone_assemble subtracts
+    const double eye = dEyeCoef + c->perturb;
+    double *target = (whichBuffer == 0) ? c->S : c->Scheck;
+    {
+        hdsdp_retcode rcs;
+        if (cone_small_check(c, dCCoef, ys.data(), &eye, whichBuffer, isInterior, &rcs) == 0) return rcs;
+    }
+    if (cone_assemble(c, dCCoef, ys.data(), target, &eye)) return HDSDP_RETCODE_FAILED;
+    HIP_RC(hipStreamSynchronize(g.stream));   // ys is read by an asynchronous copy
+    return (whichBuffer == 0) ? cone_factor_S(c, isInterior) : cone_factor_check(c, isInterior);
+}
+
+// sdpDenseConeAddStepToBufferAndCheck (hdsdp_conic_sdp.c:2333-2361): S + dStep*dS with the dS of the last ratio test;
+// BUFFER_DUALVAR updates S in place, BUFFER_DUALCHECK leaves S alone and factors the trial point in the checker
+hdsdp_retcode cone_axpy_check(void *cd, double dStep, int whichBuffer, int *isInterior) {
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
+    MiCone *c = (MiCone *) cd;
+    if (!c->dS) return HDSDP_RETCODE_FAILED;
+    const long cnt = (long) c->n16 * c->n16;
+    double *target = (whichBuffer == 0) ? c->S : c->Scheck;
+    if (whichBuffer == 0) { c->pS_ok = false; c->fac_ok = false; }   // S moves without a point being named: the next request assembles it
+    RC(hdm_axpy_mat(target, c->S, c->dS, dStep, cnt, g.stream));
+    return (whichBuffer == 0) ? cone_factor_S(c, isInterior) : cone_factor_check(c, isInterior);
+}
+
+void cone_reduce_resi(void *cd, double resiReduction) { ((MiCone *) cd)->Rd = resiReduction; }   // :2224-2228
+void cone_set_perturb(void *cd, double dDualPerturb) { ((MiCone *) cd)->perturb = dDualPerturb; }  // :2236-2241
+
+// hdsdp_conic_sdp.c:2172-2180
+hdsdp_retcode cone_interior(void *cd, double tau, double *y, int *isInterior) {
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
+    MiCone *c = (MiCone *) cd;
+    {
+        hdsdp_retcode rcs;
+        if (cone_small_check(c, tau, y, nullptr, 0, isInterior, &rcs) == 0) return rcs;
+    }
+    RC(cone_assemble(c, tau, y, c->S));
+    return cone_factor_S(c, isInterior);
+}
+
+// hdsdp_conic_sdp.c:2252-2291
+hdsdp_retcode cone_barrier(void *cd, double tau, double *y, int whichBuffer, double *logdet) {
+    StatScope stat_(ST_ASSEMBLE_FACTOR, __func__);
+    MiCone *c = (MiCone *) cd;
+    if (y) {   // only with BUFFER_DUALVAR (the reference asserts it)
+        int psd = 0;
+        hdsdp_retcode rcs;
+        if (cone_small_check(c, tau, y, nullptr, 0, &psd, &rcs) == 0) { if (rcs != HDSDP_RETCODE_OK || !psd) return HDSDP_RETCODE_FAILED; }
+        else {
+            RC(cone_assemble(c, tau, y, c->S));
+            if (cone_factor_S(c, &psd) != HDSDP_RETCODE_OK || !psd) return HDSDP_RETCODE_FAILED;
+        }
+    }
+    {   // a factor that came from the single-launch check brought its log det along
+        const HdmChol *fq = (whichBuffer == 0) ? &((MiLin *) c->dualFactor->chol)->ch : c->checker;
+        if (fq && fq->factored && fq->logdet_ok) { *logdet = fq->logdet_val; return HDSDP_RETCODE_OK; }
+    }
+    std::vector<double> d(c->n);
+    if (whichBuffer == 0) {
+        if (HFpLinsysGetDiag(c->dualFactor, d.data()) != HDSDP_RETCODE_OK) return HDSDP_RETCODE_FAILED;
+    } else {
+        if (!c->checker || !c->checker->factored || c->checker->get_diag(d.data(), g.stream)) return HDSDP_RETCODE_FAILED;
+    }
+    double s = 0.0;
+    for (int i = 0; i < c->n; ++i) s += log(d[i]);
+    *logdet = 2.0 * s;
+    return HDSDP_RETCODE_OK;
+}
+
+// sdpDenseConeRatioTestImpl (hdsdp_conic_sdp.c:1640-1686): dS = dTauStep*C - sum dy_i A_i + dAdaRatio*Rd*I, then the
+// largest alpha with S + alpha dS >= 0 by Lanczos on L^-1 (-dS) L^-T (lanczos.hip).  L is the factor of the chosen
+// buffer: the current S (BUFFER_DUALVAR) or the trial point factored last in the checker (BUFFER_DUALCHECK).
+hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAdaRatio, int whichBuffer, double *maxStep) {
+    StatScope stat_(ST_RATIO, __func__);
+    MiCone *c = (MiCone *) cd;
+    MiLin *l = (MiLin *) c->dualFactor->chol;
+    HdmChol *fac = (whichBuffer == 0) ? &l->ch : c->checker;   // LTarget, :1661-1665
+    if (!fac || !fac->factored) return HDSDP_RETCODE_FAILED;
+    const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
+    if (!c->dS) {
+        HIP_RC(hipMalloc((void **) &c->dS, nn));
+        HIP_RC(hdm_memset_sync(c->dS, 0, nn));
+    }
+    const double eye = dAdaRatio * c->Rd;
+    if (cone_assemble(c, dTauStep, dy, c->dS, &eye)) return HDSDP_RETCODE_FAILED;
+    if (c->n == 1) {   // :1668-1675
+        double s0 = 0.0, d0 = 0.0;
+        HIP_RC(hipMemcpyAsync(&d0, c->dS, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        HIP_RC(hipMemcpyAsync(&s0, (whichBuffer == 0) ? c->S : c->Scheck, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        HIP_RC(hipStreamSynchronize(g.stream));
+        *maxStep = (d0 > 0.0) ? INFINITY : (-s0 / d0);
+        return HDSDP_RETCODE_OK;
+    }
+    RC(hdm_mirror_lower(c->dS, c->n16, c->n, g.stream));
+    if (fac->invert_factor(g.stream)) return HDSDP_RETCODE_FAILED;
+    if (!c->lanczos) {
+        c->lanczos = new HdmLanczos();
+        if (c->lanczos->init(c->n)) return HDSDP_RETCODE_MEMORY;
+    }
+    int steps = 0;
+    static const bool dbg = [] { const char *e = getenv("HDSDP_MI355X_RATIO_DEBUG"); return e && atoi(e); }();
+    const auto t0 = std::chrono::steady_clock::now();
+    if (c->lanczos->solve(fac->Linv, fac->npad, c->dS, c->n16, g.stream, maxStep, &steps)) return HDSDP_RETCODE_FAILED;
+    if (dbg) fprintf(stderr, "[hdsdp_mi355x ratio] n %d: %d Lanczos steps, step %.6e, solve %.1f us\n", c->n, steps, *maxStep,
+                     1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return HDSDP_RETCODE_OK;
+}
+
+// ---- the remaining cone utilities of the reference's vtable (hdsdp_conic.c:137-153) ------------------------------------
+// norms of the data: |A|_abs = sum |a_ij|, |A|_F over the full symmetric matrices (hdsdp_sdpdata.c:208-309 computes the same
+// numbers per storage class); the synthetic family has no host copy, its norms come from one pass over the device data
+
+static void coeff_norms(const MiCoeff &a, int n, double *abs_, double *fro2) {
+    // raw lower-triangular entries (packed index): diagonal once, off-diagonal twice
+    double sa = 0.0, sf = 0.0;
+    long colstart = 0;
+    int col = 0;
+    for (size_t k = 0; k < a.idx.size(); ++k) {
+        const long pidx = a.idx[k];
+        while (col < n && pidx >= colstart + (n - col)) { colstart += n - col; ++col; }
+        const bool diag = (pidx == colstart);
+        const double v = a.val[k];
+        sa += diag ? fabs(v) : 2.0 * fabs(v);
+        sf += diag ? v * v : 2.0 * v * v;
+    }
+    *abs_ = sa; *fro2 = sf;
+}
+
+int cone_data_norms(MiCone *c, double *rows_abs, double *rows_fro, double *obj_abs, double *obj_fro) {
+    if (c->norms_ready) {
+        *rows_abs = c->nrm[0]; *rows_fro = c->nrm[1]; *obj_abs = c->nrm[2]; *obj_fro = c->nrm[3];
+        return 0;
+    }
+    double ra = 0.0, rf2 = 0.0, oa = 0.0, of2 = 0.0;
+    // (a block on the congruence + Gram path has its data resident in A_L form: one HBM-bound pass over it instead of a host
+    // loop over the CSC entries, which took 1.0 s of the driver's presolve at n = m = 2000)
+    const bool on_device = c->synthetic || (c->path == PATH_GEMM && c->Afull);
+    if (!on_device) {
+        for (int i = 0; i < c->m; ++i) { double a_, f_; coeff_norms(c->blk.rows[i], c->n, &a_, &f_); ra += a_; rf2 += f_; }
+        coeff_norms(c->blk.obj, c->n, &oa, &of2);
+        oa *= c->objScal; of2 *= c->objScal * c->objScal;
+    } else {
+        double *tmp = nullptr;
+        HDM_HIP_CHECK(hipMalloc((void **) &tmp, sizeof(double) * 4));
+        HDM_HIP_CHECK(hipMemsetAsync(tmp, 0, sizeof(double) * 4, g.stream));
+        if (c->mloc > 0)
+            hipLaunchKernelGGL(mi_low_norms_kernel, dim3(c->mloc), dim3(256), 0, g.stream, c->Afull, c->astride,
+                               c->n, (long) c->n16, c->mloc, 1, tmp);
+        hipLaunchKernelGGL(mi_low_norms_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, 0L, c->n, (long) c->n16, 1, 0, tmp + 2);
+        double h[4];
+        HDM_HIP_CHECK(hipMemcpyAsync(h, tmp, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+        HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
+        (void) hipFree(tmp);
+        ra = h[0]; rf2 = h[1]; oa = h[2]; of2 = h[3];
+        if (c->world > 1 && c->allreduce) {   // rows are sharded: sum the two row totals over the ranks
+            double *dv = nullptr;
+            HDM_HIP_CHECK(hipMalloc((void **) &dv, sizeof(double) * 2));
+            double two[2] = {ra, rf2};
+            HDM_HIP_CHECK(hipMemcpy(dv, two, sizeof(two), hipMemcpyHostToDevice));
+            if (c->allreduce(c->xctx, dv, 2)) return 1;
+            HDM_HIP_CHECK(hipMemcpy(two, dv, sizeof(two), hipMemcpyDeviceToHost));
+            (void) hipFree(dv);
+            ra = two[0]; rf2 = two[1];
+        }
+    }
+    c->nrm[0] = ra; c->nrm[1] = sqrt(rf2); c->nrm[2] = oa; c->nrm[3] = sqrt(of2);
+    c->norms_ready = true;
+    return cone_data_norms(c, rows_abs, rows_fro, obj_abs, obj_fro);
+}
+
+double cone_coeff_norm(void *cd, int whichNorm) {
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeGetCoeffNorm, hdsdp_conic_sdp.c:1568-1586 (ABS_NORM 1, FRO_NORM 2)
+    double v[4];
+    if (cone_data_norms((MiCone *) cd, v, v + 1, v + 2, v + 3)) return NAN;
+    return whichNorm == 1 ? v[0] : v[1];
+}
+double cone_obj_norm(void *cd, int whichNorm) {
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);     // sdpDenseConeGetObjNorm, :1558-1561
+    double v[4];
+    if (cone_data_norms((MiCone *) cd, v, v + 1, v + 2, v + 3)) return NAN;
+    return whichNorm == 1 ? v[2] : v[3];
+}
+void cone_scal(void *cd, double dScal) {
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);             // sdpDenseConeScal, :1604-1614: the objective is scaled, nothing else
+    MiCone *c = (MiCone *) cd;
+    const long cnt = (long) c->n16 * c->n16;
+    hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, g.stream, c->Cfull, cnt, dScal);
+    if (c->CL) hipLaunchKernelGGL(mi_scale_kernel, dim3((unsigned) ((c->astride + 255) / 256)), dim3(256), 0, g.stream, c->CL, c->astride, dScal);
+    c->objScal *= dScal;
+    c->norms_ready = false;
+    c->pS_ok = c->pD_ok = false;     // S and dS were assembled with the old objective: no short-cut from them (cone_assemble)
+    (void) hipStreamSynchronize(g.stream);
+}
+
+// X (host, n x n column-major, symmetric) -> the device scratch matrix Xup (ld = npad of the dual factor)
+static int cone_upload_X(MiCone *c, const double *X, long *ldx) {
+    MiLin *l = (MiLin *) c->dualFactor->chol;
+    const long ld = l->ch.npad;
+    const size_t np2 = sizeof(double) * (size_t) ld * ld;
+    if (!c->Xup) HDM_HIP_CHECK(hipMalloc((void **) &c->Xup, np2));   // (Xinv / Yinv belong to the builders, sized per path)
+    HDM_HIP_CHECK(hipMemsetAsync(c->Xup, 0, np2, g.stream));
+    HDM_HIP_CHECK(hipMemcpy2DAsync(c->Xup, sizeof(double) * ld, X, sizeof(double) * c->n, sizeof(double) * c->n, c->n,
+                                   hipMemcpyHostToDevice, g.stream));
+    *ldx = ld;
+    return 0;
+}
+
+// sdpDenseConeBuildPrimalXSXDirection (hdsdp_conic_sdp.c:2021-2040 -> fds_trimultiply, dense_opts.c:102-132), the cone's
+// coneBuildPrimalDirection slot used by the primal refinement (hdsdp_psdp.c:236,295):  XSX += X^T D X  (full symmetric
+// n x n, host), D = the dual matrix (iDualMat != 0) or the dual step dS of the last ratio test, both resident.  Two
+// plain MFMA GEMMs on the device; only X goes up and the n x n product comes back.
+void cone_build_primal_dir(void *cd, void *kktv, double *X, double *XSX, int iDualMat) {
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
+    (void) kktv;
+    MiCone *c = (MiCone *) cd;
+    const int n = c->n;
+    long ldx = 0;
+    const double *D = iDualMat ? c->S : c->dS;
+    if (!D) { fprintf(stderr, "[hdsdp_mi355x] primal direction: no dual step has been formed yet\n"); return; }
+    if (cone_upload_X(c, X, &ldx)) return;
+    const size_t np2 = sizeof(double) * (size_t) ldx * ldx;
+    if (!c->Pr1 && hipMalloc((void **) &c->Pr1, np2) != hipSuccess) return;
+    if (!c->Pr2 && hipMalloc((void **) &c->Pr2, np2) != hipSuccess) return;
+    // Pr1 <- D as a full symmetric matrix (the resident copy has its lower triangle valid), zero padded
+    if (hipMemsetAsync(c->Pr1, 0, np2, g.stream) != hipSuccess) return;
+    if (hipMemcpy2DAsync(c->Pr1, sizeof(double) * ldx, D, sizeof(double) * c->n16, sizeof(double) * n, n,
+                         hipMemcpyDeviceToDevice, g.stream) != hipSuccess) return;
+    if (hdm_mirror_lower(c->Pr1, ldx, n, g.stream)) return;
+    HdmGemmArgs q = {};
+    q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE; q.ldc = ldx;
+    // T = D X   (B operand element (j, k) = X(k, j): K-major)
+    q.A = c->Pr1; q.lda = ldx; q.a_kmajor = 0; q.B = c->Xup; q.ldb = ldx; q.b_kmajor = 1; q.C = c->Pr2;
+    if (hdm_launch_gemm(q, g.stream)) return;
+    // P = X^T T   (A operand element (i, k) = X(k, i): K-major; B operand element (j, k) = T(k, j): K-major)
+    q.A = c->Xup; q.lda = ldx; q.a_kmajor = 1; q.B = c->Pr2; q.ldb = ldx; q.b_kmajor = 1; q.C = c->Pr1;
+    if (hdm_launch_gemm(q, g.stream)) return;
+    std::vector<double> h((size_t) n * n);
+    if (hipMemcpy2DAsync(h.data(), sizeof(double) * n, c->Pr1, sizeof(double) * ldx, sizeof(double) * n, n,
+                         hipMemcpyDeviceToHost, g.stream) != hipSuccess) return;
+    if (hipStreamSynchronize(g.stream) != hipSuccess) return;
+    for (size_t e = 0; e < h.size(); ++e) XSX[e] += h[e];
+}
+
+void cone_a_times_x(void *cd, double *X, double *ATimesX) {
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeATimesX, :2470-2477: y_i += <A_i, X>
+    MiCone *c = (MiCone *) cd;
+    long ldx = 0;
+    double *out = nullptr;
+    if (cone_upload_X(c, X, &ldx)) return;
+    if (hipMalloc((void **) &out, sizeof(double) * 2 * (size_t) c->m) != hipSuccess) return;
+    (void) hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t) c->m, g.stream);
+    // A is stored in A_L form: <A, X> = 2 <A_L, X> for symmetric X
+    if (hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xup, nullptr, ldx, out, out + c->m,
+                     c->rows_own, 2.0, 0.0, g.stream) == 0) {
+        if (c->world > 1 && c->allreduce) { (void) hipStreamSynchronize(g.stream); (void) c->allreduce(c->xctx, out, c->m); }
+        std::vector<double> h(c->m);
+        if (hipMemcpyAsync(h.data(), out, sizeof(double) * c->m, hipMemcpyDeviceToHost, g.stream) == hipSuccess &&
+            hipStreamSynchronize(g.stream) == hipSuccess)
+            for (int i = 0; i < c->m; ++i) ATimesX[i] += h[i];
+    }
+    (void) hipFree(out);
+}
+
+static double cone_dot_with(MiCone *c, const double *dev, long ldd, int lower_valid, double *X) {
+    long ldx = 0;
+    double *out = nullptr, h = NAN;
+    if (cone_upload_X(c, X, &ldx)) return NAN;
+    if (hipMalloc((void **) &out, sizeof(double)) != hipSuccess) return NAN;
+    (void) hipMemsetAsync(out, 0, sizeof(double), g.stream);
+    if (lower_valid) hipLaunchKernelGGL(mi_lower_dot_kernel, dim3(1), dim3(256), 0, g.stream, dev, ldd, c->Xup, ldx, c->n, out);
+    else hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, dev, ldd, c->Xup, ldx, c->n, 0, 1.0, out);
+    if (hipMemcpyAsync(&h, out, sizeof(double), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+        hipStreamSynchronize(g.stream) != hipSuccess) h = NAN;
+    (void) hipFree(out);
+    return h;
+}
+double cone_trace_cx(void *cd, double *X) {
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeTraceCX, :2520-2523
+    MiCone *c = (MiCone *) cd;
+    return cone_dot_with(c, c->Cfull, c->n16, 0, X);
+}
+double cone_x_dot_s(void *cd, double *X) {
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);    // sdpDenseConeXDotS, :2549-2560 (S is lower-valid: fds_dot_fds, dense_opts.c:134-156)
+    MiCone *c = (MiCone *) cd;
+    return cone_dot_with(c, c->S, c->n16, 1, X);
+}
+void cone_get_dual(void *cd, double *dConeDual, double *dummy) {
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);   // sdpDenseConeGetDual, :2494-2506: S, symmetrised
+    (void) dummy;
+    MiCone *c = (MiCone *) cd;
+    const int n = c->n;
+    if (hipMemcpy2DAsync(dConeDual, sizeof(double) * n, c->S, sizeof(double) * c->n16, sizeof(double) * n, n,
+                         hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) return;
+    for (int j = 0; j < n; ++j)
+        for (int i = j + 1; i < n; ++i) dConeDual[(size_t) j + (size_t) i * n] = dConeDual[(size_t) i + (size_t) j * n];
+}
+
+// sdpDenseConeGetPrimal (hdsdp_conic_sdp.c:2393-2446), the cone's conePRecover slot:
+//     X = mu * L^-T ( sym( L^-1 dS L^-T ) + I ) L^-1,   S = C - sum y_i A_i = L L^T (no residual term),  dS = sum dy_i A_i.
+// The reference does four triangular solves with n right-hand sides on the checker factor; here S is factored into a
+// second resident factor object, inverted once, and the four products are plain MFMA GEMMs with the explicit Linv.
+// Like the reference, an S that is not positive definite prints a message and leaves the output untouched.
+void cone_precover(void *cd, double dBarrierMu, double *y, double *dy, double *X, double *aux) {
+    StatScope stat_(ST_PRIMAL_UTIL, __func__);
+    (void) aux;
+    MiCone *c = (MiCone *) cd;
+    const double zero = 0.0;
+    const int n = c->n;
+    const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
+    auto fail = [](const char *what) { fprintf(stderr, "[hdsdp_mi355x] primal recovery: %s\n", what); };
+    if (cone_assemble(c, 1.0, y, c->Scheck, &zero)) return fail("S assembly failed");
+    HdmChol *chp = nullptr;
+    if (cone_checker(c, &chp) != HDSDP_RETCODE_OK) return fail("out of memory");
+    HdmChol &ch = *chp;
+    int info = 0;
+    if (ch.load_device(c->Scheck, c->n16, g.stream) || ch.factor(g.stream, &info)) return fail("factorisation failed");
+    if (info != 0) { printf("Recovery step is infeasible\n"); return; }
+    if (!c->dS) {
+        if (hipMalloc((void **) &c->dS, nn) != hipSuccess || hdm_memset_sync(c->dS, 0, nn) != hipSuccess) return fail("out of memory");
+    }
+    std::vector<double> ndy(c->m);
+    for (int i = 0; i < c->m; ++i) ndy[i] = -dy[i];           // cone_assemble subtracts: dS = + sum dy_i A_i
+    if (cone_assemble(c, 0.0, ndy.data(), c->dS, &zero)) return fail("dS assembly failed");
+    if (hipStreamSynchronize(g.stream) != hipSuccess) return fail("stream");   // ndy is read by an async copy
+    if (hdm_mirror_lower(c->dS, c->n16, n, g.stream)) return fail("mirror");
+    if (ch.invert_factor(g.stream)) return fail("triangular inverse failed");
+    const size_t np2 = sizeof(double) * (size_t) ch.npad * ch.npad;
+    if (!c->Pr1 && hipMalloc((void **) &c->Pr1, np2) != hipSuccess) return fail("out of memory");
+    if (!c->Pr2 && hipMalloc((void **) &c->Pr2, np2) != hipSuccess) return fail("out of memory");
+    HdmGemmArgs q = {};
+    q.M = c->n16; q.N = c->n16; q.K = c->n16; q.batch = 1; q.alpha = 1.0; q.epilogue = HDM_EPI_STORE; q.ldc = ch.npad;
+    // T1 = W dS          (W = Linv)
+    q.A = ch.Linv; q.lda = ch.npad; q.a_kmajor = 0; q.B = c->dS; q.ldb = c->n16; q.b_kmajor = 0; q.C = c->Pr1;
+    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
+    // Z = T1 W^T
+    q.A = c->Pr1; q.lda = ch.npad; q.a_kmajor = 0; q.B = ch.Linv; q.ldb = ch.npad; q.b_kmajor = 0; q.C = c->Pr2;
+    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
+    if (hdm_sym_scale(c->Pr2, ch.npad, c->n16, 1.0, 1.0, g.stream)) return fail("sym");
+    // T2 = W^T Z
+    q.A = ch.Linv; q.lda = ch.npad; q.a_kmajor = 1; q.B = c->Pr2; q.ldb = ch.npad; q.b_kmajor = 0; q.C = c->Pr1;
+    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
+    // X = T2 W
+    q.A = c->Pr1; q.lda = ch.npad; q.a_kmajor = 0; q.B = ch.Linv; q.ldb = ch.npad; q.b_kmajor = 1; q.C = c->Pr2;
+    if (hdm_launch_gemm(q, g.stream)) return fail("gemm");
+    if (hdm_sym_scale(c->Pr2, ch.npad, n, 0.0, dBarrierMu, g.stream)) return fail("sym");
+    if (hipMemcpy2DAsync(X, sizeof(double) * n, c->Pr2, sizeof(double) * ch.npad, sizeof(double) * n, n,
+                         hipMemcpyDeviceToHost, g.stream) != hipSuccess) return fail("copy");
+    (void) hipStreamSynchronize(g.stream);
+}

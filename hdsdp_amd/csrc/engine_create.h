@@ -1,0 +1,182 @@
+// engine_create.h -- cone construction: upload of the constraint data, choice of the device path, the synthetic family
+// Implementation header of engine.hip: included exactly once, there, in this order (the pieces share the anonymous namespace
+// and the engine's thread-local context `g`); split out of a 3 300-line file in round 3, nothing else changed.
+int grp_sum_launch(const double *const *ptrs, int W, long lo, long cnt, double *out, hipStream_t s) {
+    MiGrpPtrs pl = {};
+    for (int q = 0; q < W && q < 16; ++q) pl.p[q] = ptrs[q];
+    hipLaunchKernelGGL(mi_grp_sum_kernel, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, s, pl, W, lo, cnt, out);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+// ---------------------------------------------------------------- cone construction
+static int upload_dense_rows(MiCone *c) {
+    // densify every owned constraint into a full symmetric n16 x n16 matrix (via packed staging)
+    const long P = (long) c->n * (c->n + 1) / 2;
+    const long nn = (long) c->n16 * c->n16;
+    HDM_HIP_CHECK(hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc) + hdm_operand_pad(c->n16)));
+    HDM_HIP_CHECK(hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc)));
+    const int chunk = (int) std::max(1L, std::min<long>(64, (256L << 20) / (P * 8)));
+    double *stage_dev = nullptr, *stage_host = nullptr;
+    HDM_HIP_CHECK(hipMalloc((void **) &stage_dev, sizeof(double) * (size_t) P * chunk));
+    HDM_HIP_CHECK(hipHostMalloc((void **) &stage_host, sizeof(double) * (size_t) P * chunk, hipHostMallocDefault));
+    for (int r0 = 0; r0 < c->mloc; r0 += chunk) {
+        int nc = std::min(chunk, c->mloc - r0);
+        memset(stage_host, 0, sizeof(double) * (size_t) P * nc);
+        for (int q = 0; q < nc; ++q) {
+            const MiCoeff &co = c->blk.rows[c->own[r0 + q]];
+            for (size_t e = 0; e < co.idx.size(); ++e) stage_host[(size_t) q * P + co.idx[e]] = co.val[e];
+        }
+        HDM_HIP_CHECK(hipMemcpyAsync(stage_dev, stage_host, sizeof(double) * (size_t) P * nc, hipMemcpyHostToDevice, g.stream));
+        if (hdm_unpack_low(stage_dev, P, c->Afull + (long) r0 * c->astride, c->astride, c->n, c->n16, nc, g.stream)) return 1;
+        HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
+    }
+    {   // objective
+        memset(stage_host, 0, sizeof(double) * (size_t) P);
+        for (size_t e = 0; e < c->blk.obj.idx.size(); ++e) stage_host[c->blk.obj.idx[e]] = c->blk.obj.val[e];
+        HDM_HIP_CHECK(hipMemcpyAsync(stage_dev, stage_host, sizeof(double) * (size_t) P, hipMemcpyHostToDevice, g.stream));
+        if (hdm_unpack_sym(stage_dev, P, c->Cfull, nn, c->n, c->n16, 1, g.stream)) return 1;
+        HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
+    }
+    (void) hipFree(stage_dev);
+    (void) hipHostFree(stage_host);
+    return 0;
+}
+
+// device path a block takes by itself: the rank-one fast path iff every non-zero constraint is rank one (the reference's
+// all-M2 plans), the sparse gather path iff all rows are short triplet lists, else congruence + Gram; sharded blocks
+// (world > 1) always take the latter
+static int natural_path(const MiBlockData &blk, int nRow, int nCol, int world) {
+    int nz = 0, r1 = 0;
+    for (int i = 0; i < nRow; ++i) {
+        int t = blk.rows[i].type;
+        if (t != MI_COEFF_ZERO) nz++;
+        if (t == MI_COEFF_SPR1 || t == MI_COEFF_DSR1) r1++;
+    }
+    int path = (nz > 0 && r1 == nz && world == 1) ? PATH_R1 : PATH_GEMM;
+    if (path == PATH_GEMM && world == 1 && nz > 0) {
+        // sparse gather path: only triplet-class rows, and the pair products are far cheaper than m congruences
+        bool all_sparse = true;
+        double tot = 0.0;
+        for (int i = 0; i < nRow; ++i) {
+            int t = blk.rows[i].type;
+            if (t == MI_COEFF_DENSE || t == MI_COEFF_DSR1) all_sparse = false;
+            tot += (double) blk.rows[i].idx.size();
+        }
+        if (all_sparse && tot * tot < 0.05 * (double) nRow * nCol * (double) nCol * nCol) path = PATH_SPARSE;
+    }
+    return path;
+}
+
+// the device data of one SDP block for rank `rank` of `world` on the calling thread's context
+static hdsdp_retcode make_sdp_cone(MiCone **out, int nRow, int nCol, const int *coneMatBeg, const int *coneMatIdx,
+                                   const double *coneMatElem, int rank, int world) {
+    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
+    MiCone *c = new MiCone();
+    c->n = nCol; c->m = nRow; c->rank = rank; c->world = world;
+    if (world > 1) hdm_gemm_reserve_cus(8);   // the exchange's collectives run beside the persistent GEMM launches
+    if (mi_block_from_csc(c->blk, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem)) { delete c; return HDSDP_RETCODE_FAILED; }
+    if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
+    c->trA = (double *) calloc(nRow, sizeof(double));
+    for (int i = 0; i < nRow; ++i) {
+        const MiCoeff &co = c->blk.rows[i];
+        long d = 0; int j = 0;  // packed index of (j,j)
+        for (size_t e = 0; e < co.idx.size(); ++e) {
+            while (j < nCol && d < co.idx[e]) { d += nCol - j; ++j; }
+            if (j < nCol && d == co.idx[e]) c->trA[i] += co.val[e];
+        }
+    }
+    c->path = natural_path(c->blk, nRow, nCol, world);
+    const char *force = getenv("HDSDP_MI355X_FORCE_GEMM");
+    if (force && atoi(force)) c->path = PATH_GEMM;
+    const char *forcesp = getenv("HDSDP_MI355X_FORCE_PATH");
+    if (forcesp && world == 1) c->path = atoi(forcesp);
+    if (c->mloc == 0) c->path = PATH_GEMM;   // no constraint touches this block: only the objective's scalars remain
+    if (upload_dense_rows(c)) return HDSDP_RETCODE_MEMORY;   // dense copies also feed the S assembly
+    if (c->path == PATH_R1) {
+        c->mloc16 = (int) hdm_roundup(std::max(1, c->mloc), 16);
+        const size_t av = sizeof(double) * (size_t) c->n16 * c->mloc16;
+        std::vector<double> hA((size_t) c->n16 * c->mloc16, 0.0), hs(c->mloc16, 0.0);
+        for (int q = 0; q < c->mloc; ++q) {
+            const MiCoeff &co = c->blk.rows[c->own[q]];
+            if (co.type == MI_COEFF_ZERO) continue;
+            for (int r = 0; r < nCol; ++r) hA[(size_t) q * c->n16 + r] = co.factor[r];
+            hs[q] = co.sign;
+        }
+        if (hipMalloc((void **) &c->Avec, av) != hipSuccess || hipMalloc((void **) &c->U, av) != hipSuccess ||
+            hipMalloc((void **) &c->V, av) != hipSuccess || hipMalloc((void **) &c->W, std::max(av, sizeof(double) * (size_t) c->n16 * c->n16)) != hipSuccess ||
+            hipMalloc((void **) &c->sgn, sizeof(double) * c->mloc16) != hipSuccess ||
+            hipMalloc((void **) &c->Gr1, sizeof(double) * (size_t) c->mloc16 * c->mloc16) != hipSuccess ||
+            hipMalloc((void **) &c->Ct, sizeof(double) * (size_t) c->n16 * c->n16) != hipSuccess ||
+            hipMalloc((void **) &c->Xinv, sizeof(double) * (size_t) c->n16 * c->n16) != hipSuccess)
+            return HDSDP_RETCODE_MEMORY;
+        if (hdm_memcpy_h2d_sync(c->Avec, hA.data(), av) != hipSuccess ||
+            hdm_memcpy_h2d_sync(c->sgn, hs.data(), sizeof(double) * c->mloc16) != hipSuccess)
+            return HDSDP_RETCODE_FAILED;
+    }
+    if (c->path == PATH_SPARSE) {
+        std::vector<int> rp(c->mloc + 1, 0), ti, tj;
+        std::vector<double> tv;
+        for (int q = 0; q < c->mloc; ++q) {
+            const MiCoeff &co = c->blk.rows[c->own[q]];
+            for (size_t e = 0; e < co.idx.size(); ++e) {
+                long pk = co.idx[e];
+                int col = 0; long start = 0;
+                while (pk >= start + (nCol - col)) { start += nCol - col; ++col; }
+                ti.push_back(col + (int) (pk - start)); tj.push_back(col); tv.push_back(co.val[e]);
+            }
+            rp[q + 1] = (int) ti.size();
+        }
+        const size_t nt = std::max<size_t>(1, ti.size());
+        const size_t nn2 = sizeof(double) * (size_t) hdm_roundup(nCol, 128) * hdm_roundup(nCol, 128);
+        if (hipMalloc((void **) &c->sp_rp, sizeof(int) * rp.size()) != hipSuccess ||
+            hipMalloc((void **) &c->sp_ti, sizeof(int) * nt) != hipSuccess ||
+            hipMalloc((void **) &c->sp_tj, sizeof(int) * nt) != hipSuccess ||
+            hipMalloc((void **) &c->sp_tv, sizeof(double) * nt) != hipSuccess ||
+            hipMalloc((void **) &c->Xinv, nn2) != hipSuccess || hipMalloc((void **) &c->Yinv, nn2) != hipSuccess ||
+            hipMalloc((void **) &c->W, nn2) != hipSuccess || hipMalloc((void **) &c->Ct, nn2) != hipSuccess)
+            return HDSDP_RETCODE_MEMORY;
+        if (hdm_memcpy_h2d_sync(c->sp_rp, rp.data(), sizeof(int) * rp.size()) != hipSuccess ||
+            (ti.size() && (hdm_memcpy_h2d_sync(c->sp_ti, ti.data(), sizeof(int) * ti.size()) != hipSuccess ||
+                           hdm_memcpy_h2d_sync(c->sp_tj, tj.data(), sizeof(int) * tj.size()) != hipSuccess ||
+                           hdm_memcpy_h2d_sync(c->sp_tv, tv.data(), sizeof(double) * tv.size()) != hipSuccess)))
+            return HDSDP_RETCODE_FAILED;
+    }
+    if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    *out = c;
+    return HDSDP_RETCODE_OK;
+}
+
+static hdsdp_retcode make_synth_cone(MiCone **out, int nCol, int nRow, int rank, int world) {
+    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
+    MiCone *c = new MiCone();
+    c->n = nCol; c->m = nRow; c->rank = rank; c->world = world; c->synthetic = true; c->path = PATH_GEMM;
+    if (world > 1) hdm_gemm_reserve_cus(8);
+    if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
+    if (hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc) + hdm_operand_pad(c->n16)) != hipSuccess) {
+        fprintf(stderr, "[hdsdp_mi355x] cannot allocate %.1f GiB for the constraint matrices\n",
+                (double) c->astride * c->mloc * 8 / (1 << 30));
+        return HDSDP_RETCODE_MEMORY;
+    }
+    if (hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc)) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    for (int q = 0; q < c->mloc; ++q)  // owned rows are strided in the global numbering
+        if (hdm_synth_fill_low(c->Afull + (long) q * c->astride, c->astride, c->n, c->n16, c->own[q], 1, g.stream)) return HDSDP_RETCODE_FAILED;
+    if (hdm_synth_obj(c->Cfull, c->n, c->n16, c->m, g.stream)) return HDSDP_RETCODE_FAILED;
+    // b_i = tr(A_i): diagonal draws only (host, m*n splitmix evaluations)
+    c->trA = (double *) calloc(nRow, sizeof(double));
+    const uint64_t P = (uint64_t) nCol * (nCol + 1) / 2, gam = 0x9E3779B97F4A7C15ULL;
+    for (int i = 0; i < nRow; ++i) {
+        double tr = 0.0;
+        uint64_t k = 0;
+        for (int j = 0; j < nCol; ++j) {
+            uint64_t z = gam + (2 * ((uint64_t) i * P + k) + 1) * gam;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z = z ^ (z >> 31);
+            tr += 2.0 * ((double) (z >> 11) / 9007199254740992.0) - 1.0;
+            k += nCol - j;
+        }
+        c->trA[i] = tr;
+    }
+    if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    *out = c;
+    return HDSDP_RETCODE_OK;
+}

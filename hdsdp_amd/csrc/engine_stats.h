@@ -1,0 +1,73 @@
+// engine_stats.h -- where a caller's wall time goes below the C ABI (HMiGetCallStats, HDSDP_MI355X_CALL_STATS / _TRACE) and the error macros
+// Implementation header of engine.hip: included exactly once, there, in this order (the pieces share the anonymous namespace
+// and the engine's thread-local context `g`); split out of a 3 300-line file in round 3, nothing else changed.
+// ---- where a caller's wall time goes inside the library (HMiGetCallStats; HDSDP_MI355X_CALL_STATS=1 prints the table at
+// exit): only the caller's thread counts, and only the outermost entry (HKKTBuildUp calls the cones' slots, the cones
+// call HFpLinsys*), so the categories add up to the time the driver spent below the C ABI
+enum { ST_BUILD_M = 0, ST_BUILD_CORR, ST_FACTORIZE, ST_SOLVE, ST_ASSEMBLE_FACTOR, ST_RATIO, ST_PRIMAL_UTIL, ST_LINSYS, ST_N };
+const char *g_stat_name[ST_N] = {"HKKTBuildUp (M-forming types)", "HKKTBuildUp (corrector)", "HKKTFactorize", "HKKTSolve",
+                                 "cone: S assembly + factor (update, interior checks, barrier, line search)",
+                                 "cone: ratio test", "cone: primal recovery + utilities", "HFpLinsys* called by CPU cones"};
+double g_stat_sec[ST_N];
+long g_stat_calls[ST_N];
+// the same time by entry point (the outermost entry's function name), printed under the categories
+struct StatFn { const char *name; int k; double sec; long calls; double mx; };
+StatFn g_stat_fn[64];
+int g_stat_nfn = 0;
+thread_local int t_stat_depth = 0;
+static bool stat_trace() { static int t = -1; if (t < 0) { const char *e = getenv("HDSDP_MI355X_TRACE"); t = (e && atoi(e)) ? 1 : 0; } return t == 1; }
+struct StatScope {
+    int k;
+    bool on = false;
+    std::chrono::steady_clock::time_point t0;
+    const char *name;
+    StatScope(int k_, const char *name_) : k(k_), name(name_) {
+        if (t_ctx) return;                       // worker threads of a device group run below an entry that is already timed
+        on = (t_stat_depth++ == 0);
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    ~StatScope() {
+        if (t_ctx) return;
+        --t_stat_depth;
+        if (on && stat_trace()) {                // HDSDP_MI355X_TRACE=1: drain the device after every entry and say which
+            const hipError_t e = hipDeviceSynchronize();
+            fprintf(stderr, "[hdsdp_mi355x trace] %s -> %s\n", name, e == hipSuccess ? "ok" : hipGetErrorName(e));
+        }
+        if (on) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            g_stat_sec[k] += dt;
+            g_stat_calls[k] += 1;
+            int f = 0;
+            while (f < g_stat_nfn && g_stat_fn[f].name != name) ++f;
+            if (f == g_stat_nfn && g_stat_nfn < 64) g_stat_fn[g_stat_nfn++] = StatFn{name, k, 0.0, 0, 0.0};
+            if (f < 64) { g_stat_fn[f].sec += dt; g_stat_fn[f].calls += 1; if (dt > g_stat_fn[f].mx) g_stat_fn[f].mx = dt; }
+        }
+    }
+};
+void stats_print_at_exit() {
+    double tot = 0.0;
+    for (int k = 0; k < ST_N; ++k) tot += g_stat_sec[k];
+    fprintf(stderr, "[hdsdp_mi355x] wall time below the C ABI: %.3f s\n", tot);
+    for (int k = 0; k < ST_N; ++k) {
+        if (!g_stat_calls[k]) continue;
+        fprintf(stderr, "[hdsdp_mi355x]   %-78s %8ld calls %10.3f s\n", g_stat_name[k], g_stat_calls[k], g_stat_sec[k]);
+        for (int f = 0; f < g_stat_nfn; ++f)
+            if (g_stat_fn[f].k == k)
+                fprintf(stderr, "[hdsdp_mi355x]       %-74s %8ld calls %10.3f s   (longest call %.1f ms)\n", g_stat_fn[f].name, g_stat_fn[f].calls,
+                        g_stat_fn[f].sec, 1e3 * g_stat_fn[f].mx);
+    }
+}
+
+#define HIP_RC(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            fprintf(stderr, "[hdsdp_mi355x] HIP error %s at %s:%d\n", hipGetErrorName(_e), __FILE__, __LINE__); \
+            return HDSDP_RETCODE_FAILED;                                                         \
+        }                                                                                        \
+    } while (0)
+
+#define RC(x)                                    \
+    do {                                         \
+        if ((x) != 0) return HDSDP_RETCODE_FAILED; \
+    } while (0)

@@ -176,7 +176,9 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     d.tiles = tl.dev;
     d.ntiles = tl.n;
     d.dbg = (g_dbg && args.role == g_dbg_role) ? g_dbg : nullptr;
+#ifdef HDM_DIAGNOSTICS
     if (d.dbg && !g_capturing && getenv("HDM_DBG_SYNC")) HDM_HIP_CHECK(hipDeviceSynchronize());   // diagnostic: isolate the stamped launch from its neighbours
+#endif
     // Kernel variants.  The shipped library carries ONE loop for the three Schur roles (variant 64: rotated, explicitly
     // interleaved K loop, persistent and one-workgroup-per-tile forms) and the masked loop of generic launches (variant 0).
     // A -DHDM_DIAGNOSTICS build (python -m hdsdp_amd.build --diagnostics) adds what the measurement tools select with HDM_VAR /

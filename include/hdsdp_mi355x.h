@@ -26,6 +26,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* Everything declared in this header is the library's exported surface and nothing else is: the library is built with
+ * -fvisibility=hidden, these declarations carry default visibility. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ---- interface/hdsdp.h:42-48 ---- */
 typedef enum { HDSDP_RETCODE_OK, HDSDP_RETCODE_FAILED, HDSDP_RETCODE_MEMORY } hdsdp_retcode;
@@ -359,6 +364,51 @@ hdsdp_retcode HMiSDPAGetBlock(const HMiSDPA *p, int iBlk, int *dim, const int **
 const double *HMiSDPAGetRHS(const HMiSDPA *p);
 void HMiSDPAFree(HMiSDPA **pp);
 
+
+/* =====================================  environment switches  =====================================
+ * Every environment variable the shipped library reads (tests/test_abi_cpu.py holds this table to the sources, both ways).
+ * "other position" tests: tests/test_gpu_switches.py runs every device path under the non-default setting in a child
+ * process and compares with the default run.  A -DHDM_DIAGNOSTICS build (python -m hdsdp_amd.build --diagnostics) reads
+ * three more -- HDM_VAR, HDM_CONG2_DIRECT, HDM_DBG_SYNC -- for stamped kernels and timing ablations; the product never does.
+ *
+ *  variable                       default   meaning                                                      covered by
+ *  -- configuration ---------------------------------------------------------------------------------------------------
+ *  LOCAL_RANK                     0         device of the caller's context (process-per-GPU mode)         test_gpu_dist.py
+ *  HDSDP_MI355X_GPUS              1         shards of the in-process device group (unchanged driver)      test_gpu_group.py::test_unchanged_driver_shards_by_environment
+ *  HDSDP_MI355X_LOOPBACK          0         shards may share devices (rehearsal)                          same
+ *  HDSDP_MI355X_SHARD_MIN_N       512       smallest block dimension that is sharded                      same
+ *  HDSDP_MI355X_TRANSPORT         copy      device group transport: copy | rccl (rccl unverified between  test_gpu_group.py::test_config5_at_size_on_eight_devices
+ *                                           devices on this pool: opt-in)                                 (needs 8 devices)
+ *  HDSDP_MI355X_A2A_PIECES        8         pieces of the sharded build's exchange                        test_gpu_switches.py
+ *  HDSDP_MI355X_STAGED_A2A        1         step 2 by packed-index range, pieces leave as they finish     test_gpu_switches.py
+ *  HDSDP_MI355X_FORCE_GEMM        0         every block takes the congruence + Gram path                  test_gpu_switches.py, test_gpu_parity.py
+ *  HDSDP_MI355X_FORCE_PATH        -         force device path 0 / 1 / 2 (tests)                           test_gpu_parity.py::test_every_device_path_gives_the_same_numbers
+ *  HDSDP_MI355X_SPARSE_KKT        1         0: always the dense Schur matrix                              test_gpu_switches.py
+ *  HDSDP_MI355X_KKT_ENVELOPE      1         block-envelope factorisation of a sparse operator             test_gpu_switches.py
+ *  HDSDP_MI355X_KKT_RCM           1         reverse Cuthill-McKee order of a sparse operator              test_gpu_switches.py
+ *  HDSDP_MI355X_AFFINE_S          by cost   0 / 1 / 2: dual matrix short-cuts (engine_cone.h)             test_gpu_switches.py
+ *  HDSDP_MI355X_SMALL_CHECK       1         one-launch interior check of small blocks                     test_gpu_switches.py
+ *  HDM_TCAP_GIB                   32        GiB of congruence intermediates per launch group              test_gpu_switches.py, test_gpu_group.py
+ *  HDM_BC                         1024      constraints per congruence launch (upper bound)               test_gpu_switches.py
+ *  HDM_NSPLIT                     by size   K splits of the Gram product                                  test_gpu_switches.py
+ *  HDM_SHARE_T_SLABS              1         intermediates and Gram slabs share one buffer (one GPU)       test_gpu_switches.py
+ *  -- fallbacks kept reachable (the default is the fast form) ----------------------------------------------------------
+ *  HDM_PERSIST                    1         persistent GEMM workgroups; 0: one workgroup per tile         test_gpu_switches.py, test_gpu_kernels.py
+ *  HDM_PERSIST_RESERVE_CUS        0 / 8     CUs a persistent launch leaves to the collectives             test_gpu_switches.py, test_gpu_kernels.py
+ *  HDM_DIAG_SWEEP                 1         register-sweep diagonal block; 0: LDS-panel kernel            test_gpu_switches.py, test_gpu_kernels.py
+ *  HDM_TRSV_FLOW                  1         single-launch substitution; 0: per-block launches             test_gpu_switches.py, test_gpu_kernels.py
+ *  HDM_TRSV_FLOW_FAIL_ONCE        0         test hook: throw the first single-launch result away          test_gpu_kernels.py::test_fallback_chains_of_the_factor_and_solve_kernels
+ *  HDM_GRAPHS                     1         0 / 1 / 2: hipGraph replay of factorisation / substitutions   test_gpu_switches.py, test_gpu_kernels.py
+ *  HDM_SYM_COMBINE_SKY            1         S assembly in storage order; 0: element-indexed kernel        test_gpu_switches.py
+ *  HDM_LANCZOS_WHOLE              1         small blocks: whole ratio test in one launch                  test_gpu_switches.py
+ *  HDM_LANCZOS_FUSED              1         small blocks: three Lanczos steps per launch                  test_gpu_switches.py
+ *  HDM_LANCZOS_GROUP              1         large blocks: steps between Ritz checks queued back to back   test_gpu_switches.py
+ *  -- output only (no code path changes) --------------------------------------------------------------------------------
+ *  HDSDP_MI355X_CALL_STATS        0         table of wall time below the C ABI at exit                    tools/small_driver_stats.sh
+ *  HDSDP_MI355X_TRACE             0         synchronise and report after every entry                      (diagnostic)
+ *  HDSDP_MI355X_RATIO_DEBUG       0         one line per ratio test: Lanczos steps, time                  (diagnostic)
+ */
+
 /* ==================================  utilities  ================================== */
 int HMiDeviceInit(int device);         /* hipSetDevice + stream; returns 0 on success */
 int HMiDeviceSynchronize(void);
@@ -395,6 +445,9 @@ double HMiMfmaPeakProbe(int iters);    /* measured fp64 MFMA TFLOP/s of a regist
 /* GEMM-shaped issue probe: mode 0 = 16 accumulators x (4+4) operand registers, 1 = one operand pair */
 double HMiMfmaIssueProbe(int mode, int wgPerCu, int iters);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -232,3 +232,43 @@ def test_bench_labels_follow_the_size_and_a_gpu_count_it_cannot_meet_is_an_error
     assert r.returncode != 0
     assert "--gpus 8 requested" in (r.stderr + r.stdout), (r.stderr + r.stdout)[-500:]
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_library_exports_nothing_but_the_declared_surface():
+    """-fvisibility=hidden: the dynamic symbol table holds the header's functions and no internal symbol (round 2's library
+    exported 197 symbols for a boundary of 25 + helpers)"""
+    from hdsdp_amd import api
+    out = subprocess.run(["nm", "-D", "--defined-only", api.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert exported == _declared_functions(), sorted(set(exported) ^ set(_declared_functions()))
+
+
+def test_every_environment_switch_is_listed_in_the_header_and_covered():
+    """the header's table of environment switches against the sources (both ways), and every switch that selects a code path
+    against the settings tests/test_gpu_switches.py runs or the test the table names"""
+    csrc = os.path.join(ROOT, "hdsdp_amd", "csrc")
+    read = set()
+    diag_only = set()
+    for f in os.listdir(csrc):
+        if not f.endswith((".hip", ".h", ".cpp")):
+            continue
+        txt = open(os.path.join(csrc, f)).read()
+        # variables read only inside #ifdef HDM_DIAGNOSTICS blocks do not exist in the product
+        parts = re.split(r"#ifdef HDM_DIAGNOSTICS(.*?)#e(?:ndif|lse)", txt, flags=re.S)
+        for k, part in enumerate(parts):
+            for v in re.findall(r'getenv\("([A-Za-z_0-9]+)"\)', part):
+                (diag_only if k % 2 == 1 else read).add(v)
+    diag_only -= read
+    table = open(HEADER).read().split("environment switches")[1].split("utilities")[0]
+    listed = set(re.findall(r"^ \*  ([A-Z][A-Z_0-9]+)\s", table, flags=re.M))
+    assert read == listed, (sorted(read - listed), sorted(listed - read))
+    assert diag_only <= {"HDM_VAR", "HDM_CONG2_DIRECT", "HDM_DBG_SYNC"}
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("switch_tests", os.path.join(ROOT, "tests", "test_gpu_switches.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    run = set(k for s in mod.SETTINGS for k in s)
+    for line in table.splitlines():
+        m = re.match(r"^ \*  ([A-Z][A-Z_0-9]+)\s", line)
+        if m and "test_gpu_switches.py" in line:
+            assert m.group(1) in run, m.group(1) + " is said to be covered by test_gpu_switches.py but no setting names it"
