@@ -38,7 +38,7 @@ EXPORTS = [
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiKKTGetRows", "HMiDeviceInit",
     "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
-    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiRcmOrder", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
+    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiKKTTileInfo", "HMiBspSolve", "HMiRcmOrder", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
 ]
 
@@ -178,6 +178,8 @@ def load_library():
         "HMiCholEnvelopeSolve": (C.c_int, [vp, C.c_int, ip, vp, vp, vp, ip]),
         "HMiCholEnvelopeProbe": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp]),
         "HMiKKTEnvelopeInfo": (None, [kp, ip, dp]),
+        "HMiKKTTileInfo": (C.c_int, [kp, ip, C.POINTER(C.c_int64), ip, C.POINTER(C.c_int64)]),
+        "HMiBspSolve": (C.c_int, [C.c_int, ip, ip, dp, dp, dp, ip, ip, dp]),
         "HMiRcmOrder": (C.c_int, [C.c_int, ip, ip, ip]),
         "HMiPresolveCSC": (C.c_int, [C.c_int, C.c_int, ip, ip, dp, ip, ip, ip, ip, ip, ip]),
         "HMiReadSDPA": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
@@ -556,6 +558,14 @@ class KKT:
         p, f = C.c_int(0), C.c_double(1.0)
         load_library().HMiKKTEnvelopeInfo(self._k, C.byref(p), C.byref(f))
         return bool(p.value), float(f.value)
+
+    def tile_info(self):
+        """None, or (tiles stored, tiles of the dense lower triangle, levels, bytes) of a sparse operator kept in tile form"""
+        t, lv = C.c_int(0), C.c_int(0)
+        dt, by = C.c_int64(0), C.c_int64(0)
+        if not load_library().HMiKKTTileInfo(self._k, C.byref(t), C.byref(dt), C.byref(lv), C.byref(by)):
+            return None
+        return t.value, dt.value, lv.value, by.value
 
     def stage_times_ms(self):
         t = np.zeros(8)

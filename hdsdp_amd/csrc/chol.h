@@ -54,6 +54,11 @@ struct HdmChol {
     int inverse_full(double *out_dev, long ldo, hipStream_t s);
 };
 
+// diagonal-tile factorisations of a block-sparse matrix (bsparse.hip): 128 x 128 tiles, 16384 doubles apart; tile
+// diag_tile[cols[b]] is factored in place (lower), its inverse goes to Winv + cols[b] * 16384; rows past m are padding
+int hdm_potrf_sweep_configure();
+int hdm_potrf_sweep_batched(double *tiles, const int *diag_tile, const int *cols, int ncols, double *Winv, int *info, int m, hipStream_t s);
+
 // several engine shards share this device: the single-launch substitution (which needs co-resident workgroups) is off
 void hdm_flow_set_shared_device(int on);
 double hdm_diag_block_probe(int variant, int reps, hipStream_t s);   // diagnostic: us per diagonal-block kernel (0: LDS panels, 1: register sweep)

@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void hdm_potrf_diag_kernel(double *__restrict_
 #define DIAG_SWEEP_LDS_DOUBLES (SMALL_P * (SMALL_P + 1) + 2 * SMALL_P)
 // nv: rows of this block that belong to the matrix (the rest is the identity padding, which needs no pivots: a 21 x 21 block
 // -- truss1's largest -- is 6 four-pivot steps instead of 32, and the reference's driver factors such blocks thousands of times)
-__global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_kernel(double *__restrict__ A, long ld, double *__restrict__ Dinv,
-                                                                    int *__restrict__ info, int col0, int nv) {
+__device__ __forceinline__ void hdm_potrf_diag_sweep_body(double *__restrict__ A, long ld, double *__restrict__ Dinv, int *__restrict__ info,
+                                                          int col0, int nv) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *img = sm;                                  // 128 x 129 staging image; its head doubles as the sweep's block images
     double *rsv = sm + SMALL_P * (SMALL_P + 1);
@@ -223,6 +223,43 @@ __global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_kernel(double *__re
     __syncthreads();
     sm_store_one<true>(SMALL_P, a, img, A, ld, ty, tx, tid);
     sm_store_one<false>(SMALL_P, rr, img, Dinv, SMALL_P, ty, tx, tid);
+}
+__global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_kernel(double *__restrict__ A, long ld, double *__restrict__ Dinv,
+                                                                    int *__restrict__ info, int col0, int nv) {
+    hdm_potrf_diag_sweep_body(A, ld, Dinv, info, col0, nv);
+}
+// the same for a list of independent diagonal tiles of a block-sparse matrix (bsparse.hip): workgroup b factors the diagonal
+// tile of block column cols[b]; a non-positive pivot is reported as the smallest failing row + 1 over the launch
+__global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_tiles_kernel(double *__restrict__ tiles, const int *__restrict__ diag_tile,
+                                                                          const int *__restrict__ cols, double *__restrict__ Winv,
+                                                                          int *__restrict__ info, int m) {
+    const int k = cols[blockIdx.x];
+    int dummy = 0;
+    (void) dummy;
+    double *A = tiles + ((long) diag_tile[k] << 14);
+    // (atomicCAS keeps the FIRST reporter; with several workgroups the smallest row is wanted: report through atomicMin on a
+    // word that starts at 0 = "none" is awkward, so a failing tile writes row + 1 only if the word is 0 or larger)
+    __shared__ int linfo;
+    if (threadIdx.x == 0) linfo = 0;
+    __syncthreads();
+    hdm_potrf_diag_sweep_body(A, SMALL_P, Winv + ((long) k << 14), &linfo, k * SMALL_P, min(SMALL_P, m - k * SMALL_P));
+    __syncthreads();
+    if (threadIdx.x == 0 && linfo) {
+        int old = atomicCAS(info, 0, linfo);
+        while (old != 0 && linfo < old) { const int seen = atomicCAS(info, old, linfo); if (seen == old) break; old = seen; }
+    }
+}
+int hdm_potrf_sweep_configure() {
+    HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_potrf_diag_sweep_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      DIAG_SWEEP_LDS_DOUBLES * (int) sizeof(double)));
+    return 0;
+}
+int hdm_potrf_sweep_batched(double *tiles, const int *diag_tile, const int *cols, int ncols, double *Winv, int *info, int m, hipStream_t s) {
+    if (ncols <= 0) return 0;
+    hipLaunchKernelGGL(hdm_potrf_diag_sweep_tiles_kernel, dim3(ncols), dim3(SM_T), DIAG_SWEEP_LDS_DOUBLES * sizeof(double), s, tiles,
+                       diag_tile, cols, Winv, info, m);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // pad region of an (npad x npad) matrix whose valid part is n x n: identity on the diagonal

@@ -20,6 +20,7 @@
 #include "lanczos.h"
 #include "lu.h"
 #include "small.h"
+#include "bsparse.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -36,15 +37,16 @@
 __global__ void mi_low_norms_kernel(const double *__restrict__ A, long astride, int n, long ld, int count, int a_l_form,
                                     double *__restrict__ out);
 __global__ void mi_scale_kernel(double *__restrict__ A, long count, double s);
-__global__ void mi_put_row_kernel(double *__restrict__ M, long ldm, int i, const double *__restrict__ v, int m);
+__global__ void mi_put_row_kernel(HdmMatView Mv, int i, const double *__restrict__ v, int m);
 __global__ void mi_lower_dot_kernel(const double *__restrict__ S, long lds_, const double *__restrict__ X, long ldx, int n,
                                     double *__restrict__ out);
 __global__ void mi_mat_dot_kernel(const double *__restrict__ X, long ldx, const double *__restrict__ Y, long ldy, int n,
                                   int diag_only, double scale, double *__restrict__ out);
-__global__ void mi_csc_gather_kernel(const double *__restrict__ M, long ld, const int *__restrict__ rows,
-                                     const int *__restrict__ cols, long nnz, double *__restrict__ vals);
-__global__ void mi_csc_scatter_kernel(double *__restrict__ M, long ld, const int *__restrict__ rows,
-                                      const int *__restrict__ cols, long nnz, const double *__restrict__ vals);
+__global__ void mi_csc_gather_kernel(HdmMatView Mv, const int *__restrict__ rows, const int *__restrict__ cols, long nnz,
+                                     double *__restrict__ vals);
+__global__ void mi_csc_scatter_kernel(HdmMatView Mv, const int *__restrict__ rows, const int *__restrict__ cols, long nnz,
+                                      const double *__restrict__ vals);
+__global__ void mi_get_row_kernel(HdmMatView Mv, int i, int m, double *__restrict__ out);
 
 namespace {
 

@@ -265,11 +265,71 @@ int HMiRcmOrder(int m, const int *colBeg, const int *rowIdx, int *perm) {
 
 // how the operator's matrix will be factored: *permuted = 1 if the factor object holds P M P' (reverse Cuthill-McKee order of
 // the sparse pattern), *fraction = blocks inside the pattern's block envelope / blocks of the dense lower triangle (1 = dense)
+int HMiKKTTileInfo(hdsdp_kkt *HKKT, int *tiles, int64_t *denseTiles, int *levels, int64_t *bytes) {
+    if (tiles) *tiles = 0;
+    if (denseTiles) *denseTiles = 0;
+    if (levels) *levels = 0;
+    if (bytes) *bytes = 0;
+    if (!HKKT || !HKKT->kktM) return 0;
+    MiLin *l = (MiLin *) HKKT->kktM->chol;
+    if (!l->bsp) return 0;
+    if (tiles) *tiles = l->bsp->ntiles;
+    if (denseTiles) *denseTiles = l->bsp->dense_tiles();
+    if (levels) *levels = l->bsp->nlevels;
+    if (bytes) *bytes = (int64_t) l->bsp->bytes();
+    return 1;
+}
+int HMiBspSolve(int m, const int *colBeg, const int *rowIdx, const double *val, const double *b, double *x, int *info, int *stats,
+                double *ms) {
+    if (ensure_ctx()) return 1;
+    HdmBsp bs;
+    int rc = 1;
+    int *rows_d = nullptr, *cols_d = nullptr;
+    double *vals_d = nullptr;
+    do {
+        if (bs.init(m, colBeg, rowIdx, 1.0)) break;
+        const long nnz = colBeg[m];
+        std::vector<int> cols((size_t) nnz);
+        for (int c = 0; c < m; ++c) for (int q = colBeg[c]; q < colBeg[c + 1]; ++q) cols[q] = c;
+        if (hipMalloc((void **) &rows_d, sizeof(int) * nnz) != hipSuccess || hipMalloc((void **) &cols_d, sizeof(int) * nnz) != hipSuccess ||
+            hipMalloc((void **) &vals_d, sizeof(double) * nnz) != hipSuccess) break;
+        if (hipMemcpy(rows_d, rowIdx, sizeof(int) * nnz, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(cols_d, cols.data(), sizeof(int) * nnz, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(vals_d, val, sizeof(double) * nnz, hipMemcpyHostToDevice) != hipSuccess) break;
+        hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((nnz + 255) / 256)), dim3(256), 0, g.stream, bs.view_M(), rows_d, cols_d, nnz, vals_d);
+        int inf = 0;
+        const int reps = ms ? 3 : 1;
+        float best = 1e30f;
+        bool bad = false;
+        for (int r = 0; r < reps && !bad; ++r) {
+            if (bs.load_M(g.stream)) { bad = true; break; }
+            (void) hipEventRecord(g.ev[6], g.stream);
+            if (bs.factor(g.stream, &inf)) { bad = true; break; }
+            (void) hipEventRecord(g.ev[7], g.stream);
+            (void) hipEventSynchronize(g.ev[7]);
+            float e = 0.f;
+            (void) hipEventElapsedTime(&e, g.ev[6], g.ev[7]);
+            best = std::min(best, e);
+        }
+        if (bad) break;
+        if (info) *info = inf;
+        if (ms) *ms = best;
+        if (stats) { stats[0] = bs.nb; stats[1] = bs.ntiles; stats[2] = bs.nlevels; }
+        if (inf == 0 && b && x && bs.solve_host(b, x, g.stream)) break;
+        rc = 0;
+    } while (0);
+    if (rows_d) (void) hipFree(rows_d);
+    if (cols_d) (void) hipFree(cols_d);
+    if (vals_d) (void) hipFree(vals_d);
+    bs.destroy();
+    return rc;
+}
 void HMiKKTEnvelopeInfo(hdsdp_kkt *HKKT, int *permuted, double *fraction) {
     if (permuted) *permuted = 0;
     if (fraction) *fraction = 1.0;
     if (!HKKT || !HKKT->kktM) return;
     MiLin *l = (MiLin *) HKKT->kktM->chol;
+    if (l->bsp) { if (permuted) *permuted = 1; if (fraction) *fraction = (double) l->bsp->ntiles / (double) l->bsp->dense_tiles(); return; }
     if (permuted) *permuted = l->perm.empty() ? 0 : 1;
     if (fraction && !l->ch.env_colh.empty()) {
         double in = 0.0, all = 0.0;

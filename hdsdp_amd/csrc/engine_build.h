@@ -168,6 +168,7 @@ hdsdp_retcode exchange_and_gram(MiCone *c, bool staged = false) {
 
 hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT, HdmChol *chOverride = nullptr);
 double *kkt_Mdev(hdsdp_kkt *kkt, long *ld);
+HdmMatView kkt_view(hdsdp_kkt *kkt);
 hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
 hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT);
 
@@ -193,7 +194,9 @@ hdsdp_retcode build_primal_general(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, con
     const size_t np2 = sizeof(double) * (size_t) ldx * ldx;
     if (!c->Pr1) HIP_RC(hipMalloc((void **) &c->Pr1, np2));
     if (!c->Pr2) HIP_RC(hipMalloc((void **) &c->Pr2, np2));
-    double *Mdev = kkt_Mdev(kkt, &ldm), *row = nullptr, *ALsq = nullptr;
+    (void) ldm;
+    const HdmMatView Mview = kkt_view(kkt);
+    double *row = nullptr, *ALsq = nullptr;
     HIP_RC(hipMalloc((void **) &row, sizeof(double) * (size_t) m));
     HIP_RC(hipMalloc((void **) &ALsq, sizeof(double) * (size_t) c->n16 * c->n16 + hdm_operand_pad(c->n16)));
     HdmGemmArgs q = {};
@@ -222,7 +225,7 @@ hdsdp_retcode build_primal_general(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, con
         if (hipMemsetAsync(row, 0, sizeof(double) * (size_t) m, g.stream) != hipSuccess ||
             hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Pr2, nullptr, ldx, row, row,
                          c->rows_own, 2.0, 0.0, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
-        hipLaunchKernelGGL(mi_put_row_kernel, dim3((m + 255) / 256), dim3(256), 0, g.stream, Mdev, ldm, c->own[qi], row, m);
+        hipLaunchKernelGGL(mi_put_row_kernel, dim3((m + 255) / 256), dim3(256), 0, g.stream, Mview, c->own[qi], row, m);
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) rc = HDSDP_RETCODE_FAILED;
     (void) hipFree(row);
@@ -277,6 +280,14 @@ hdsdp_retcode cone_build_schur_fixed(void *cd, int iCone, void *kktv, int typeKK
     return cone_build_schur(cd, iCone, kktv, typeKKT);
 }
 
+// where the builders put M: the dense device matrix, or the tile store of a sparse operator in tile form
+HdmMatView kkt_view(hdsdp_kkt *kkt) {
+    MiLin *l = (MiLin *) kkt->kktM->chol;
+    if (l->bsp) return l->bsp->view_M();
+    HdmMatView v;
+    v.base = l->Mdev; v.ld = l->ch.npad;
+    return v;
+}
 double *kkt_Mdev(hdsdp_kkt *kkt, long *ld) {
     MiLin *l = (MiLin *) kkt->kktM->chol;
     if (ld) *ld = l->ch.npad;
@@ -378,12 +389,10 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
         HIP_RC(hipStreamSynchronize(g.stream));
         if (!c->allreduce || c->allreduce(c->xctx, c->Gm, (int64_t) c->R * c->R)) return HDSDP_RETCODE_FAILED;
     }
-    long ldm = 0;
-    double *Mdev = kkt_Mdev(kkt, &ldm);
     const int hsd = (typeKKT == KKT_TYPE_HOMOGENEOUS);
     const long pI = (c->world == 1) ? c->mloc : (c->m + c->world - 1) / c->world;  // rows owned by rank 0 = position of the "I row"
     if (c->kkt_owner)
-        RC(hdm_extract(c->Gm, c->R, c->R, pI, c->rows_seg, Mdev, ldm, pv->vecs, pv->vecs + m, pv->vecs + 2 * m,
+        RC(hdm_extract(c->Gm, c->R, c->R, pI, c->rows_seg, kkt_view(kkt), pv->vecs, pv->vecs + m, pv->vecs + 2 * m,
                        pv->vecs + 3 * m, c->Rd, hsd, g.stream));
     HIP_RC(hipEventRecord(g.ev[4], g.stream));
     HIP_RC(hipEventSynchronize(g.ev[4]));

@@ -28,8 +28,6 @@ hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKK
     v.M = n16; v.N = m16; v.K = n16; v.batch = 1; v.alpha = 1.0; v.epilogue = HDM_EPI_STORE;
     RC(hdm_launch_gemm(v, g.stream));
     TRACE_STEP("r1 step 3");
-    long ldm = 0;
-    double *Mdev = kkt_Mdev(kkt, &ldm);
     if (typeKKT == KKT_TYPE_CORRECTOR) {
         // ASinv_i = s_i a_i' S^-1 a_i = s_i <u_i,u_i>; ASinvRdSinv_i = Rd s_i |v_i|^2
         hipLaunchKernelGGL(mi_col_dot_kernel, dim3((c->mloc + 3) / 4), dim3(256), 0, g.stream, c->U, c->U, (long) n16,
@@ -43,7 +41,7 @@ hdsdp_retcode build_r1_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKK
     gq.M = m16; gq.N = m16; gq.K = n16; gq.batch = 1; gq.alpha = 1.0; gq.lower_only = 1; gq.epilogue = HDM_EPI_STORE;
     RC(hdm_launch_gemm(gq, g.stream));
     TRACE_STEP("r1 step 5");
-    RC(hdm_r1_hadamard(c->Gr1, m16, c->sgn, c->rows_own, c->mloc, Mdev, ldm, pv->vecs, g.stream));
+    RC(hdm_r1_hadamard(c->Gr1, m16, c->sgn, c->rows_own, c->mloc, kkt_view(kkt), pv->vecs, g.stream));
     TRACE_STEP("r1 step 6");
     if (c->Rd != 0.0) {
         RC(hdm_r1_colnorm(c->V, n16, n16, c->sgn, c->rows_own, c->mloc, c->Rd, pv->vecs + m, g.stream));
@@ -103,8 +101,6 @@ hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int ty
     const int m = kkt->nRow;
     const long ldx = ch.npad;
     RC(ch.inverse_full(c->Xinv, ldx, g.stream));
-    long ldm = 0;
-    double *Mdev = kkt_Mdev(kkt, &ldm);
     RC(hdm_sparse_dot(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Xinv, ldx, c->mloc, c->rows_own, 1.0, pv->vecs, g.stream));
     if (c->Rd != 0.0) {
         HdmGemmArgs q = {};  // Y = X X^T = S^-2
@@ -118,7 +114,7 @@ hdsdp_retcode build_sparse_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int ty
     if (c->Rd != 0.0)
         hipLaunchKernelGGL(mi_mat_dot_kernel, dim3(1), dim3(256), 0, g.stream, c->Xinv, ldx, nullptr, 0L, c->n, 1, 1.0,
                            pv->vecs + 3 * m);
-    RC(hdm_sparse_pairs(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Xinv, ldx, c->mloc, c->rows_own, Mdev, ldm, g.stream));
+    RC(hdm_sparse_pairs(c->sp_rp, c->sp_ti, c->sp_tj, c->sp_tv, c->Xinv, ldx, c->mloc, c->rows_own, kkt_view(kkt), g.stream));
     if (typeKKT == KKT_TYPE_HOMOGENEOUS) {
         HdmGemmArgs w = {};  // W = X C,  Ct = W X = X C X
         w.A = c->Xinv; w.lda = ldx; w.B = c->Cfull; w.ldb = c->n16; w.C = c->W; w.ldc = ldx;

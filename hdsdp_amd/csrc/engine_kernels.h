@@ -2,9 +2,21 @@
 // Implementation header of engine.hip: included exactly once, there, in this order (global scope, between the anonymous-namespace pieces); split out of a 3 300-line file in round 3, nothing else changed.
 // kernels local to this file -------------------------------------------------------------------
 // row i of the lower triangle of M (column-major, ld): M[i, j] += v[j] for j <= i
-__global__ void mi_put_row_kernel(double *__restrict__ M, long ldm, int i, const double *__restrict__ v, int m) {
+__global__ void mi_put_row_kernel(HdmMatView Mv, int i, const double *__restrict__ v, int m) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < m && j <= i) M[i + (long) j * ldm] += v[j];
+    if (j < m && j <= i) *hdm_mat_at(Mv, i, j) += v[j];
+}
+// out[j] = M(i, j) of the symmetric matrix behind the view (lower triangle stored), 0 where the tile store has no tile
+__global__ void mi_get_row_kernel(HdmMatView Mv, int i, int m, double *__restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int r = i > j ? i : j, c = i > j ? j : i;
+    if (Mv.tilemap) {
+        int pr = Mv.perm[r], pc = Mv.perm[c];
+        if (pr < pc) { const int t = pr; pr = pc; pc = t; }
+        if (Mv.tilemap[(pr >> 7) + (long) (pc >> 7) * Mv.nbt] < 0) { out[j] = 0.0; return; }
+    }
+    out[j] = *hdm_mat_at(Mv, r, c);
 }
 
 __global__ void mi_col_dot_kernel(const double *__restrict__ X, const double *__restrict__ Y, long ld, int n,
@@ -97,18 +109,18 @@ __global__ void mi_lower_dot_kernel(const double *__restrict__ S, long lds_, con
 
 
 // sparse Schur operator: entry p of the aggregated CSC pattern <-> element (rows[p], cols[p]) of the dense device matrix
-__global__ void mi_csc_gather_kernel(const double *__restrict__ M, long ld, const int *__restrict__ rows,
-                                     const int *__restrict__ cols, long nnz, double *__restrict__ vals) {
+__global__ void mi_csc_gather_kernel(HdmMatView Mv, const int *__restrict__ rows, const int *__restrict__ cols, long nnz,
+                                     double *__restrict__ vals) {
     const long p = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < nnz) vals[p] = M[rows[p] + (long) cols[p] * ld];
+    if (p < nnz) vals[p] = *hdm_mat_at(Mv, rows[p], cols[p]);
 }
-__global__ void mi_csc_scatter_kernel(double *__restrict__ M, long ld, const int *__restrict__ rows,
-                                      const int *__restrict__ cols, long nnz, const double *__restrict__ vals) {
+__global__ void mi_csc_scatter_kernel(HdmMatView Mv, const int *__restrict__ rows, const int *__restrict__ cols, long nnz,
+                                      const double *__restrict__ vals) {
     const long p = (long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < nnz) M[rows[p] + (long) cols[p] * ld] = vals[p];
+    if (p < nnz) *hdm_mat_at(Mv, rows[p], cols[p]) = vals[p];
 }
 
-// device group, copy transport: out[i] = sum over the shards (in shard order) of p[q][lo + i]
+// the copy transport's all-reduce: out[i] = sum over the shards' buffers, in shard order
 struct MiGrpPtrs { const double *p[16]; };
 __global__ void mi_grp_sum_kernel(MiGrpPtrs pl, int W, long lo, long cnt, double *__restrict__ out) {
     const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;

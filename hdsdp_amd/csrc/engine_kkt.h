@@ -142,50 +142,22 @@ hdsdp_retcode HKKTCreate(hdsdp_kkt **pHKKT) {
     return HDSDP_RETCODE_OK;
 }
 
-// Reverse Cuthill-McKee order of a symmetric pattern given as its lower triangle in CSC form: perm[old] = new.  Every
-// connected component starts from a vertex of minimal degree found by a few breadth-first sweeps (pseudo-peripheral).
-static std::vector<int> rcm_order(int m, const std::vector<int> &beg, const std::vector<int> &idx) {
-    std::vector<int> deg(m, 0);
-    for (int c = 0; c < m; ++c)
-        for (int q = beg[c]; q < beg[c + 1]; ++q) if (idx[q] != c) { deg[c] += 1; deg[idx[q]] += 1; }
-    std::vector<int> ap(m + 1, 0);
-    for (int v = 0; v < m; ++v) ap[v + 1] = ap[v] + deg[v];
-    std::vector<int> adj((size_t) ap[m]), fill(ap.begin(), ap.end() - 1);
-    for (int c = 0; c < m; ++c)
-        for (int q = beg[c]; q < beg[c + 1]; ++q) if (idx[q] != c) { adj[fill[c]++] = idx[q]; adj[fill[idx[q]]++] = c; }
-    std::vector<int> order; order.reserve(m);
-    std::vector<char> seen(m, 0);
-    std::vector<int> level(m, -1), queue;
-    auto bfs = [&](int root, std::vector<int> &out) {          // breadth-first from root over the unseen part; returns the last level's vertex of minimal degree
-        out.clear(); out.push_back(root);
-        std::vector<int> touched{root};
-        level[root] = 0;
-        for (size_t h = 0; h < out.size(); ++h) {
-            const int v = out[h];
-            const size_t first_child = out.size();
-            for (int q = ap[v]; q < ap[v + 1]; ++q) {
-                const int w = adj[q];
-                if (seen[w] || level[w] >= 0) continue;
-                level[w] = level[v] + 1; out.push_back(w); touched.push_back(w);
-            }
-            std::sort(out.begin() + first_child, out.end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
-        }
-        const int last_level = level[out.back()];
-        int best = out.back();
-        for (int v : out) if (level[v] == last_level && (deg[v] < deg[best] || (deg[v] == deg[best] && v < best))) best = v;
-        for (int v : touched) level[v] = -1;
-        return best;
-    };
-    for (int s0 = 0; s0 < m; ++s0) {
-        if (seen[s0]) continue;
-        int root = s0;
-        for (int sweep = 0; sweep < 3; ++sweep) root = bfs(root, queue);
-        bfs(root, queue);
-        for (int v : queue) { seen[v] = 1; order.push_back(v); }
-    }
-    std::vector<int> perm(m);
-    for (int k = 0; k < m; ++k) perm[order[k]] = m - 1 - k;     // reversed
-    return perm;
+// (reverse Cuthill-McKee: hdm_rcm_order, bsparse.hip)
+static std::vector<int> rcm_order(int m, const std::vector<int> &beg, const std::vector<int> &idx) { return hdm_rcm_order(m, beg, idx); }
+
+// a linear-system object for a sparse Schur operator in TILE form: the same vtable, no dense factor behind it
+static hdsdp_retcode linsys_create_tiles(hdsdp_linsys_fp **pHLin, int nCol, HdmBsp *bsp) {
+    hdsdp_linsys_fp *h = (hdsdp_linsys_fp *) calloc(1, sizeof(hdsdp_linsys_fp));
+    if (!h) return HDSDP_RETCODE_MEMORY;
+    h->nCol = nCol; h->LinType = HDSDP_LINSYS_SPARSE_DIRECT;
+    h->cholCreate = lin_create; h->cholSetParam = lin_setparam; h->cholSymbolic = lin_symbolic; h->cholNumeric = lin_numeric;
+    h->cholPsdCheck = lin_psdcheck; h->cholFSolve = lin_fsolve; h->cholBSolve = lin_bsolve; h->cholSolve = lin_solve;
+    h->cholGetDiag = lin_getdiag; h->cholInvert = lin_invert; h->cholDestroy = lin_destroy;
+    MiLin *l = new MiLin();
+    l->n = nCol; l->type = HDSDP_LINSYS_SPARSE_DIRECT; l->csc_in = true; l->bsp = bsp;
+    h->chol = l;
+    *pHLin = h;
+    return HDSDP_RETCODE_OK;
 }
 
 hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones) {
@@ -248,7 +220,20 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
                 return HDSDP_RETCODE_MEMORY;
             memset(HKKT->kktMatElem, 0, sizeof(double) * nnz);
             for (int iCol = 0; iCol < nRow; ++iCol) HKKT->kktDiag[iCol] = &HKKT->kktMatElem[beg[iCol]];
-            hdsdp_retcode rcs = HFpLinsysCreate(&HKKT->kktM, nRow, HDSDP_LINSYS_SPARSE_DIRECT);
+            // Device storage of a sparse operator.  TILE form (bsparse.h) when it pays: the rows are reordered (dense rows last,
+            // reverse Cuthill-McKee for the rest), and matrix and factor exist only as the 128 x 128 tiles inside the block
+            // pattern of the Cholesky factor -- O(tiles of L) memory, a level-scheduled left-looking factorisation.  Taken when
+            // those tiles are at most half of the dense lower triangle's (HDSDP_MI355X_KKT_TILES=0: never); otherwise the dense
+            // device matrix factored on its block envelope, as in round 2.
+            HdmBsp *bsp = nullptr;
+            {
+                static const bool use_tiles = [] { const char *e = getenv("HDSDP_MI355X_KKT_TILES"); return !(e && atoi(e) == 0); }();
+                if (use_tiles && nRow > 2 * 128) {
+                    bsp = new HdmBsp();
+                    if (bsp->init(nRow, beg.data(), idx.data(), 0.5)) { bsp->destroy(); delete bsp; bsp = nullptr; }
+                }
+            }
+            hdsdp_retcode rcs = bsp ? linsys_create_tiles(&HKKT->kktM, nRow, bsp) : HFpLinsysCreate(&HKKT->kktM, nRow, HDSDP_LINSYS_SPARSE_DIRECT);
             if (rcs != HDSDP_RETCODE_OK) return rcs;
             rcs = HFpLinsysSymbolic(HKKT->kktM, HKKT->kktMatBeg, HKKT->kktMatIdx);
             if (rcs != HDSDP_RETCODE_OK) return rcs;
@@ -274,7 +259,7 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
                 static const bool use_env = [] { const char *e = getenv("HDSDP_MI355X_KKT_ENVELOPE"); return !(e && atoi(e) == 0); }();
                 static const bool use_rcm = [] { const char *e = getenv("HDSDP_MI355X_KKT_RCM"); return !(e && atoi(e) == 0); }();
                 MiLin *lm = (MiLin *) HKKT->kktM->chol;
-                if (use_env && lm && lm->ch.nblk > 1) {
+                if (use_env && lm && !lm->bsp && lm->ch.nblk > 1) {
                     const int nb = lm->ch.nblk;
                     auto envelope = [&](const std::vector<int> *perm, std::vector<int> &first) {   // returns the factorisation's cost in block products
                         first.resize(nb);
@@ -317,6 +302,9 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
                 }
             }
             printf("    Using sparse Schur complement (%d nnzs)\n", HKKT->kktMatBeg[nRow]);
+            if (bsp)
+                fprintf(stderr, "[hdsdp_mi355x] sparse Schur operator in tile form: %d of %ld tiles (%.2f GiB instead of %.2f), %d levels\n", bsp->ntiles,
+                        bsp->dense_tiles(), (double) bsp->bytes() / (1 << 30), 2.0 * 8.0 * (double) bsp->nb * 128 * bsp->nb * 128 / (1 << 30), bsp->nlevels);
         }
     }
     if (!HKKT->isKKTSparse) {
@@ -337,9 +325,11 @@ hdsdp_retcode HKKTInit(hdsdp_kkt *HKKT, int nRow, int nCones, hdsdp_cone **cones
     // indices, the blocked Cholesky factors it densely.  What the sparse form changes is the host side -- the matrix the
     // driver, the CPU cones (through kktMapping / kktDiag) and HKKTRegularize see is the nnz-long CSC, not m^2 doubles.
     MiLin *l = (MiLin *) HKKT->kktM->chol;
-    const size_t mm = sizeof(double) * (size_t) l->ch.npad * l->ch.npad;
-    if (hipMalloc((void **) &l->Mdev, mm) != hipSuccess) return HDSDP_RETCODE_MEMORY;
-    if (hdm_memset_sync(l->Mdev, 0, mm) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    if (!l->bsp) {
+        const size_t mm = sizeof(double) * (size_t) l->ch.npad * l->ch.npad;
+        if (hipMalloc((void **) &l->Mdev, mm) != hipSuccess) return HDSDP_RETCODE_MEMORY;
+        if (hdm_memset_sync(l->Mdev, 0, mm) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    }
     MiKKTPriv *pv = priv_of(HKKT);
     if (hipMalloc((void **) &pv->vecs, sizeof(double) * (3 * (size_t) nRow + 4)) != hipSuccess) return HDSDP_RETCODE_MEMORY;
     pv->n_engine = pv->n_foreign = 0;
@@ -364,7 +354,8 @@ static hdsdp_retcode kkt_clean(hdsdp_kkt *HKKT, int typeKKT) {  // hdsdp_schur.c
     if (hipMemsetAsync(pv->vecs, 0, sizeof(double) * (3 * (size_t) m + 4), g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
     if (typeKKT != KKT_TYPE_CORRECTOR) {
         MiLin *l = (MiLin *) HKKT->kktM->chol;
-        if (hipMemsetAsync(l->Mdev, 0, sizeof(double) * (size_t) l->ch.npad * l->ch.npad, g.stream) != hipSuccess)
+        if (l->bsp) { if (l->bsp->zero_M(g.stream)) return HDSDP_RETCODE_FAILED; }
+        else if (hipMemsetAsync(l->Mdev, 0, sizeof(double) * (size_t) l->ch.npad * l->ch.npad, g.stream) != hipSuccess)
             return HDSDP_RETCODE_FAILED;
         if (HKKT->isKKTSparse) memset(HKKT->kktMatElem, 0, sizeof(double) * (size_t) HKKT->kktMatBeg[m]);   // (CPU cones add into it)
         // (dense host matrix: CPU cones add into it, so it starts from zero -- but with engine cones only, kkt_pull's copy
@@ -400,7 +391,7 @@ static hdsdp_retcode kkt_pull(hdsdp_kkt *HKKT, int typeKKT) {
         if (HKKT->isKKTSparse) {
             // the pattern's entries of the dense device matrix (an engine cone only writes inside the pattern it declared)
             if (pv->nnz > 0) {
-                hipLaunchKernelGGL(mi_csc_gather_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, Mdev, ld,
+                hipLaunchKernelGGL(mi_csc_gather_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, kkt_view(HKKT),
                                    pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
                 if (hipMemcpyAsync(dst, pv->sp_vals, sizeof(double) * (size_t) pv->nnz, hipMemcpyDeviceToHost, g.stream) != hipSuccess)
                     return HDSDP_RETCODE_FAILED;
@@ -478,6 +469,8 @@ void HKKTExport(hdsdp_kkt *HKKT, double *dKKTASinvVec, double *dKKTASinvRdSinvVe
     if (dTraceSinv) *dTraceSinv = HKKT->dTraceSinv;
 }
 
+static HdmMatView dense_view(double *base, long ld) { HdmMatView v; v.base = base; v.ld = ld; return v; }
+
 hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
     StatScope stat_(ST_FACTORIZE, __func__);
     // hdsdp_schur.c:328-336.  With the host mirror on, the host matrix is authoritative (the driver and
@@ -486,6 +479,27 @@ hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
     MiLin *l = (MiLin *) HKKT->kktM->chol;
     HKKT->kktM->nFactorizes += 1;
     int info = 0;
+    if (l->bsp) {
+        // tile form: the factor store is filled from the host CSC (host mirror on: the driver and the CPU cones may have touched
+        // it) or from the accumulation store, then factored level by level (bsparse.hip)
+        if (pv->mirror) {
+            if (l->bsp->zero_L(g.stream)) return HDSDP_RETCODE_FAILED;
+            if (pv->nnz > 0) {
+                if (hipMemcpyAsync(pv->sp_vals, HKKT->kktMatElem, sizeof(double) * (size_t) pv->nnz, hipMemcpyHostToDevice, g.stream) != hipSuccess)
+                    return HDSDP_RETCODE_FAILED;
+                hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->bsp->view_L(),
+                                   pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
+            }
+        } else {
+            if (!pv->Mdev_valid || l->bsp->load_M(g.stream)) return HDSDP_RETCODE_FAILED;
+        }
+        if (l->bsp->factor(g.stream, &info)) return HDSDP_RETCODE_FAILED;
+        if (info != 0) {
+            fprintf(stderr, "[hdsdp_mi355x] HKKTFactorize: sparse Schur matrix (tile form) is not positive definite (pivot %d)\n", info);
+            return lin_switch_indefinite(HKKT->kktM);
+        }
+        return HDSDP_RETCODE_OK;
+    }
     if (pv->mirror && HKKT->isKKTSparse) {
         // the host CSC is authoritative: its values go up (nnz doubles) and are scattered over the zeroed dense device
         // matrix, which is then factored like the dense operator's
@@ -493,8 +507,8 @@ hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
         if (pv->nnz > 0) {
             if (hipMemcpyAsync(pv->sp_vals, HKKT->kktMatElem, sizeof(double) * (size_t) pv->nnz, hipMemcpyHostToDevice, g.stream) != hipSuccess)
                 return HDSDP_RETCODE_FAILED;
-            hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->Mdev,
-                               (long) l->ch.npad, pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
+            hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream,
+                               dense_view(l->Mdev, l->ch.npad), pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
         }
         pv->Mdev_valid = true;
         l->srcHost = nullptr; l->srcDev = l->Mdev; l->srcLd = l->ch.npad;
@@ -511,12 +525,12 @@ hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
         // the factor object holds P M P': the pattern's entries (already in sp_vals when they came up from the host CSC,
         // gathered from the device matrix otherwise) go to their permuted places in a zeroed image
         if (!pv->mirror && pv->nnz > 0)
-            hipLaunchKernelGGL(mi_csc_gather_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->Mdev,
-                               (long) l->ch.npad, pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
+            hipLaunchKernelGGL(mi_csc_gather_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream,
+                               dense_view(l->Mdev, l->ch.npad), pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
         if (hipMemsetAsync(l->ch.L, 0, sizeof(double) * (size_t) l->ch.npad * l->ch.npad, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
         if (pv->nnz > 0)
-            hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->ch.L,
-                               (long) l->ch.npad, pv->sp_prow, pv->sp_pcol, pv->nnz, pv->sp_vals);
+            hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream,
+                               dense_view(l->ch.L, l->ch.npad), pv->sp_prow, pv->sp_pcol, pv->nnz, pv->sp_vals);
         if (l->ch.finish_load(g.stream)) return HDSDP_RETCODE_FAILED;
     } else {
         if (l->ch.load_device(l->Mdev, l->ch.npad, g.stream)) return HDSDP_RETCODE_FAILED;
@@ -542,6 +556,27 @@ void HKKTRegularize(hdsdp_kkt *HKKT, double dKKTReg) {  // hdsdp_schur.c:348-373
         // device-resident M (HMiKKTSetHostMirror(.., 0)): same rule on the device copy; the diagonal (m doubles)
         // makes the round trip, the matrix does not
         MiLin *l = (MiLin *) HKKT->kktM->chol;
+        if (l->bsp) {
+            // tile form: the pattern's values make the round trip (nnz doubles), the rule runs on the diagonal entries (the first of
+            // every column), and they go back into the accumulation store
+            if (!pv->Mdev_valid || pv->nnz <= 0) return;
+            const int m = HKKT->nRow;
+            std::vector<double> v((size_t) pv->nnz);
+            hipLaunchKernelGGL(mi_csc_gather_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->bsp->view_M(),
+                               pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
+            if (hipMemcpyAsync(v.data(), pv->sp_vals, sizeof(double) * v.size(), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+                hipStreamSynchronize(g.stream) != hipSuccess) return;
+            double mn = INFINITY;
+            for (int i = 0; i < m; ++i) mn = std::min(mn, v[HKKT->kktMatBeg[i]]);
+            const double reg = std::min(dKKTReg * mn, 1e-05);
+            if (reg < 1e-14) return;
+            for (int i = 0; i < m; ++i) v[HKKT->kktMatBeg[i]] += reg;
+            if (hipMemcpyAsync(pv->sp_vals, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, g.stream) != hipSuccess) return;
+            hipLaunchKernelGGL(mi_csc_scatter_kernel, dim3((unsigned) ((pv->nnz + 255) / 256)), dim3(256), 0, g.stream, l->bsp->view_M(),
+                               pv->sp_rows, pv->sp_cols, pv->nnz, pv->sp_vals);
+            (void) hipStreamSynchronize(g.stream);      // v is read by an asynchronous copy
+            return;
+        }
         if (!pv->Mdev_valid || !l->Mdev) return;
         const int m = HKKT->nRow;
         const size_t pitch = sizeof(double) * ((size_t) l->ch.npad + 1);
@@ -634,20 +669,19 @@ void *HMiKKTDeviceMatrix(hdsdp_kkt *HKKT, int64_t *ld) {
     return p;
 }
 hdsdp_retcode HMiKKTGetRows(hdsdp_kkt *HKKT, int nRows, const int *rows, double *out) {
-    // full symmetric rows of the device copy of M (lower triangle valid): row i = M[i, 0..i] followed by M[i+1.., i]
+    // full symmetric rows of the device copy of M (lower triangle stored: dense matrix or tile store)
     MiKKTPriv *pv = priv_of(HKKT);
-    long ld = 0;
-    const double *Mdev = kkt_Mdev(HKKT, &ld);
     const int m = HKKT->nRow;
-    if (!Mdev || !pv->Mdev_valid) return HDSDP_RETCODE_FAILED;
-    HIP_RC(hipStreamSynchronize(g.stream));
-    for (int r = 0; r < nRows; ++r) {
-        const int i = rows[r];
-        if (i < 0 || i >= m) return HDSDP_RETCODE_FAILED;
-        double *o = out + (size_t) r * m;
-        HIP_RC(hipMemcpy2D(o, sizeof(double), Mdev + i, sizeof(double) * (size_t) ld, sizeof(double), (size_t) i + 1, hipMemcpyDeviceToHost));
-        if (i + 1 < m)
-            HIP_RC(hipMemcpy(o + i + 1, Mdev + (i + 1) + (size_t) i * ld, sizeof(double) * (size_t) (m - i - 1), hipMemcpyDeviceToHost));
+    if (!pv->Mdev_valid) return HDSDP_RETCODE_FAILED;
+    double *tmp = nullptr;
+    HIP_RC(hipMalloc((void **) &tmp, sizeof(double) * (size_t) std::max(1, m)));
+    hdsdp_retcode rc = HDSDP_RETCODE_OK;
+    for (int r = 0; r < nRows && rc == HDSDP_RETCODE_OK; ++r) {
+        if (rows[r] < 0 || rows[r] >= m) { rc = HDSDP_RETCODE_FAILED; break; }
+        hipLaunchKernelGGL(mi_get_row_kernel, dim3((m + 255) / 256), dim3(256), 0, g.stream, kkt_view(HKKT), rows[r], m, tmp);
+        if (hipMemcpyAsync(out + (size_t) r * m, tmp, sizeof(double) * (size_t) m, hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+            hipStreamSynchronize(g.stream) != hipSuccess) rc = HDSDP_RETCODE_FAILED;
     }
-    return HDSDP_RETCODE_OK;
+    (void) hipFree(tmp);
+    return rc;
 }

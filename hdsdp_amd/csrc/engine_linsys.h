@@ -13,6 +13,9 @@ struct MiLin {
     int maxIter = -1;
     // Schur systems: M lives here (device, ld = ch.npad) before factorisation
     double *Mdev = nullptr;
+    // sparse Schur operator in tile form (bsparse.h): the matrix and its factor are 128 x 128 tiles inside the block pattern of
+    // the Cholesky factor; no dense m x m array exists anywhere (ch stays uninitialised, Mdev null)
+    HdmBsp *bsp = nullptr;
     // symmetric-indefinite fallback (HFpLinsysSwitchToIndefinite, hdsdp_linsolver.c:1827-1857): once switched, every
     // later factorisation goes through the pivoted solver, like the reference's replaced vtable
     HdmLu *lu = nullptr;
@@ -87,6 +90,7 @@ hdsdp_retcode lin_factor_indef(MiLin *l) {
 // linalg/hdsdp_linsolver.c:1082-1110 (copy + dpotrf; info != 0 is a failure here)
 hdsdp_retcode lin_numeric(void *chol, int *colMatBeg, int *colMatIdx, double *colMatElem) {
     MiLin *l = (MiLin *) chol;
+    if (l->bsp) return HDSDP_RETCODE_FAILED;      // (a tile-form Schur operator is factored by HKKTFactorize, nothing else owns one)
     if (l->csc_in) {
         colMatElem = const_cast<double *>(lin_densify(l, colMatBeg, colMatIdx, colMatElem));
         if (!colMatElem) return HDSDP_RETCODE_FAILED;
@@ -101,6 +105,10 @@ hdsdp_retcode lin_numeric(void *chol, int *colMatBeg, int *colMatIdx, double *co
 // the matrix is re-read from where the failed factorisation took it
 hdsdp_retcode lin_switch_indefinite(hdsdp_linsys_fp *HLin) {
     MiLin *l = (MiLin *) HLin->chol;
+    if (l->bsp) {
+        fprintf(stderr, "[hdsdp_mi355x] the tile-form Schur operator has no pivoted way out (HDSDP_MI355X_KKT_TILES=0 keeps the dense one)\n");
+        return HDSDP_RETCODE_FAILED;
+    }
     HLin->LinType = HDSDP_LINSYS_DENSE_INDEFINITE;
     l->indef = true;
     return lin_factor_indef(l);
@@ -108,6 +116,7 @@ hdsdp_retcode lin_switch_indefinite(hdsdp_linsys_fp *HLin) {
 // linalg/hdsdp_linsolver.c:1112-1144 (info > 0 => "not PSD" is a value, not an error)
 hdsdp_retcode lin_psdcheck(void *chol, int *colMatBeg, int *colMatIdx, double *colMatElem, int *isPsd) {
     MiLin *l = (MiLin *) chol;
+    if (l->bsp) return HDSDP_RETCODE_FAILED;
     if (l->csc_in) {
         colMatElem = const_cast<double *>(lin_densify(l, colMatBeg, colMatIdx, colMatElem));
         if (!colMatElem) return HDSDP_RETCODE_FAILED;
@@ -121,7 +130,7 @@ hdsdp_retcode lin_psdcheck(void *chol, int *colMatBeg, int *colMatIdx, double *c
 // :1146-1196 dtrsm with L / L^T ; solVec == NULL => in place
 void lin_fsolve(void *chol, int nRhs, double *rhs, double *sol) {
     MiLin *l = (MiLin *) chol;
-    if (l->indef) return;                        // :1741-1759, no half solves with the pivoted factor
+    if (l->indef || l->bsp) return;                        // :1741-1759, no half solves with the pivoted factor
     // the slot returns void (hdsdp_linsolver.h:22): a device failure can only be reported, and poisons the output so that
     // the caller's next NaN check (e.g. HFpLinsysSolve, :2085-2110) sees it
     if (l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 1, g.stream)) {
@@ -131,7 +140,7 @@ void lin_fsolve(void *chol, int nRhs, double *rhs, double *sol) {
 }
 void lin_bsolve(void *chol, int nRhs, double *rhs, double *sol) {
     MiLin *l = (MiLin *) chol;
-    if (l->indef) return;
+    if (l->indef || l->bsp) return;
     if (l->ch.solve_host(rhs, sol ? sol : rhs, nRhs, 2, g.stream)) {
         fprintf(stderr, "[hdsdp_mi355x] backward substitution failed on the device\n");
         (sol ? sol : rhs)[0] = NAN;
@@ -143,6 +152,11 @@ hdsdp_retcode lin_solve(void *chol, int nRhs, double *rhs, double *sol) {
     if (l->indef) {                              // :1761-1780 dsytrs
         if (!l->lu || !l->lu->factored) return HDSDP_RETCODE_FAILED;
         RC(l->lu->solve_host(rhs, sol ? sol : rhs, nRhs, g.stream));
+        return HDSDP_RETCODE_OK;
+    }
+    if (l->bsp) {
+        for (int r = 0; r < nRhs; ++r)
+            RC(l->bsp->solve_host(rhs + (size_t) r * l->n, (sol ? sol : rhs) + (size_t) r * l->n, g.stream));
         return HDSDP_RETCODE_OK;
     }
     if (!l->ch.factored) return HDSDP_RETCODE_FAILED;
@@ -163,14 +177,14 @@ hdsdp_retcode lin_solve(void *chol, int nRhs, double *rhs, double *sol) {
 // :1227-1236
 hdsdp_retcode lin_getdiag(void *chol, double *diag) {
     MiLin *l = (MiLin *) chol;
-    if (l->indef) return HDSDP_RETCODE_FAILED;   // :1782-1788
+    if (l->indef || l->bsp) return HDSDP_RETCODE_FAILED;   // :1782-1788
     RC(l->ch.get_diag(diag, g.stream));
     return HDSDP_RETCODE_OK;
 }
 // :1238-1260 dpotri + HUtilMatSymmetrize: full symmetric inverse into dFullMatrix (n x n)
 void lin_invert(void *chol, double *dFull, double *) {
     MiLin *l = (MiLin *) chol;
-    if (l->indef) return;                        // :1790-1797
+    if (l->indef || l->bsp) return;              // :1790-1797
     HdmChol &c = l->ch;
     if (!l->work) {
         if (hipMalloc((void **) &l->work, sizeof(double) * (size_t) c.npad * c.npad) != hipSuccess) return;
@@ -187,6 +201,7 @@ void lin_destroy(void **pchol) {
     if (l->lu) { l->lu->destroy(); delete l->lu; }
     if (l->work) (void) hipFree(l->work);
     if (l->Mdev) (void) hipFree(l->Mdev);
+    if (l->bsp) { l->bsp->destroy(); delete l->bsp; }
     delete l;
     *pchol = nullptr;
 }

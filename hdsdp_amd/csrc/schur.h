@@ -1,24 +1,25 @@
 // schur.h -- launch helpers of schur.hip
 #pragma once
 #include "hdm_common.h"
+#include "bsparse.h"
 
 int hdm_unpack_sym(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s);
 int hdm_synth_fill(double *full, long fstride, int n, int ld, int c0, int batch, hipStream_t s);
 int hdm_synth_obj(double *C, int n, int ld, int m, hipStream_t s);
 int hdm_blocked_eye(double *dst, long row_stride, long row, int nblk, int n, hipStream_t s);
 int hdm_slab_reduce(const double *slabs, long slab_stride, int nsplit, double *out, long total, long R, hipStream_t s);
-int hdm_extract(const double *G, long ldg, long R, long pI, const int *rows_seg, double *M, long ldm, double *asinv,
+int hdm_extract(const double *G, long ldg, long R, long pI, const int *rows_seg, const HdmMatView &Mv, double *asinv,
                 double *asinvrd, double *asinvc, double *scal, double Rd, int hsd, hipStream_t s);
 int hdm_sym_combine(const double *A, long astride, int m, const double *y, const double *C, double tau, double eye,
                     double *S, int n, long lda, long lds_, hipStream_t s);
-int hdm_r1_hadamard(const double *Gm, long ldg, const double *sgn, const int *rows_global, int mloc, double *M,
-                    long ldm, double *asinv, hipStream_t s);
+int hdm_r1_hadamard(const double *Gm, long ldg, const double *sgn, const int *rows_global, int mloc, const HdmMatView &Mv,
+                    double *asinv, hipStream_t s);
 int hdm_r1_colnorm(const double *V, long ldv, int n, const double *sgn, const int *rows_global, int mloc, double Rd,
                    double *asinvrd, hipStream_t s);
 int hdm_sym_dot2(const double *A, long astride, int n, long lda, int count, const double *X, const double *Y, long ldx,
                  double *outx, double *outy, const int *rows_global, double sx, double sy, hipStream_t s);
 int hdm_sparse_pairs(const int *rp, const int *ti, const int *tj, const double *tv, const double *X, long ldx, int mloc,
-                     const int *rows_global, double *M, long ldm, hipStream_t s);
+                     const int *rows_global, const HdmMatView &Mv, hipStream_t s);
 int hdm_sparse_dot(const int *rp, const int *ti, const int *tj, const double *tv, const double *Y, long ldy, int mloc,
                    const int *rows_global, double scale, double *out, hipStream_t s);
 int hdm_unpack_low(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s);

@@ -12,6 +12,7 @@
 //                               (hdsdp_conic_sdp.c:687-778, hdsdp_sdpdata.c:1003-1118)
 #include "hdm_common.h"
 #include "schur.h"
+#include "bsparse.h"
 #include <algorithm>
 
 // ------------------------------------------------------------------------------------------
@@ -192,7 +193,7 @@ __device__ __forceinline__ double hdm_gsym(const double *__restrict__ G, long ld
     return a >= p ? G[a + p * ldg] : G[p + a * ldg];
 }
 __global__ void hdm_extract_kernel(const double *__restrict__ G, long ldg, long R, long pI,
-                                   const int *__restrict__ rows_seg, double *__restrict__ M, long ldm,
+                                   const int *__restrict__ rows_seg, HdmMatView Mv,
                                    double *__restrict__ asinv, double *__restrict__ asinvrd,
                                    double *__restrict__ asinvc, double *__restrict__ scal, double Rd, int hsd) {
     long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,7 +203,7 @@ __global__ void hdm_extract_kernel(const double *__restrict__ G, long ldg, long 
             int ga = rows_seg[a], gb = rows_seg[b];
             if (ga >= 0 && gb >= 0) {
                 int r = ga > gb ? ga : gb, c = ga > gb ? gb : ga;
-                M[r + (long) c * ldm] += G[a + b * ldg];
+                *hdm_mat_at(Mv, r, c) += G[a + b * ldg];
             }
         }
     }
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void hdm_sym_combine_sky_kernel(const double *
 //   M_ij = s_i s_j Gm_ij^2 ; ASinv_i = s_i Gm_ii ; ASinvRdSinv_i = Rd s_i |S^-1 a_i|^2 = Rd s_i |Linv^T u_i|^2
 // ------------------------------------------------------------------------------------------
 __global__ void hdm_r1_hadamard_kernel(const double *__restrict__ Gm, long ldg, const double *__restrict__ sgn,
-                                       const int *__restrict__ rows_global, int mloc, double *__restrict__ M, long ldm,
+                                       const int *__restrict__ rows_global, int mloc, HdmMatView Mv,
                                        double *__restrict__ asinv) {
     long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long) mloc * mloc) return;
@@ -301,7 +302,7 @@ __global__ void hdm_r1_hadamard_kernel(const double *__restrict__ Gm, long ldg, 
     double g = Gm[i + (long) j * ldg];
     int gi = rows_global[i], gj = rows_global[j];
     int r = gi > gj ? gi : gj, c = gi > gj ? gj : gi;
-    M[r + (long) c * ldm] += sgn[i] * sgn[j] * g * g;
+    *hdm_mat_at(Mv, r, c) += sgn[i] * sgn[j] * g * g;
     if (i == j) asinv[gi] += sgn[i] * g;
 }
 
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) void hdm_sparse_pair_kernel(const int *__restr
                                                                const int *__restrict__ tj, const double *__restrict__ tv,
                                                                const double *__restrict__ X, long ldx, int mloc,
                                                                const int *__restrict__ rows_global,
-                                                               double *__restrict__ M, long ldm) {
+                                                               HdmMatView Mv) {
     const int lane = threadIdx.x & 63;
     const long t = (long) blockIdx.x * 4 + (threadIdx.x >> 6);
     const long npairs = (long) mloc * (mloc + 1) / 2;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void hdm_sparse_pair_kernel(const int *__restr
     if (lane == 0 && tot > 0) {
         const int gi = rows_global[i], gj = rows_global[j];
         const int rr = gi > gj ? gi : gj, cc = gi > gj ? gj : gi;
-        M[rr + (long) cc * ldm] += acc;
+        *hdm_mat_at(Mv, rr, cc) += acc;
     }
 }
 
@@ -500,11 +501,11 @@ int hdm_slab_reduce(const double *slabs, long slab_stride, int nsplit, double *o
     return 0;
 }
 
-int hdm_extract(const double *G, long ldg, long R, long pI, const int *rows_seg, double *M, long ldm, double *asinv,
+int hdm_extract(const double *G, long ldg, long R, long pI, const int *rows_seg, const HdmMatView &Mv, double *asinv,
                 double *asinvrd, double *asinvc, double *scal, double Rd, int hsd, hipStream_t s) {
     long tot = R * R;
     hipLaunchKernelGGL(hdm_extract_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, G, ldg, R, pI,
-                       rows_seg, M, ldm, asinv, asinvrd, asinvc, scal, Rd, hsd);
+                       rows_seg, Mv, asinv, asinvrd, asinvc, scal, Rd, hsd);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -526,11 +527,11 @@ int hdm_sym_combine(const double *A, long astride, int m, const double *y, const
     return 0;
 }
 
-int hdm_r1_hadamard(const double *Gm, long ldg, const double *sgn, const int *rows_global, int mloc, double *M,
-                    long ldm, double *asinv, hipStream_t s) {
+int hdm_r1_hadamard(const double *Gm, long ldg, const double *sgn, const int *rows_global, int mloc, const HdmMatView &Mv,
+                    double *asinv, hipStream_t s) {
     long tot = (long) mloc * mloc;
     hipLaunchKernelGGL(hdm_r1_hadamard_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, Gm, ldg, sgn,
-                       rows_global, mloc, M, ldm, asinv);
+                       rows_global, mloc, Mv, asinv);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -568,11 +569,11 @@ int hdm_sym_dot2(const double *A, long astride, int n, long lda, int count, cons
 }
 
 int hdm_sparse_pairs(const int *rp, const int *ti, const int *tj, const double *tv, const double *X, long ldx, int mloc,
-                     const int *rows_global, double *M, long ldm, hipStream_t s) {
+                     const int *rows_global, const HdmMatView &Mv, hipStream_t s) {
     const long npairs = (long) mloc * (mloc + 1) / 2;
     if (npairs <= 0) return 0;
     hipLaunchKernelGGL(hdm_sparse_pair_kernel, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, s, rp, ti, tj, tv, X, ldx,
-                       mloc, rows_global, M, ldm);
+                       mloc, rows_global, Mv);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -386,6 +386,7 @@ void HMiSDPAFree(HMiSDPA **pp);
  *  HDSDP_MI355X_SPARSE_KKT        1         0: always the dense Schur matrix                              test_gpu_switches.py
  *  HDSDP_MI355X_KKT_ENVELOPE      1         block-envelope factorisation of a sparse operator             test_gpu_switches.py
  *  HDSDP_MI355X_KKT_RCM           1         reverse Cuthill-McKee order of a sparse operator              test_gpu_switches.py
+ *  HDSDP_MI355X_KKT_TILES         1         tile form of a sparse operator when it pays (bsparse.h)       test_gpu_switches.py
  *  HDSDP_MI355X_AFFINE_S          by cost   0 / 1 / 2: dual matrix short-cuts (engine_cone.h)             test_gpu_switches.py
  *  HDSDP_MI355X_SMALL_CHECK       1         one-launch interior check of small blocks                     test_gpu_switches.py
  *  HDM_TCAP_GIB                   32        GiB of congruence intermediates per launch group              test_gpu_switches.py, test_gpu_group.py
@@ -439,6 +440,17 @@ int HMiRcmOrder(int m, const int *colBeg, const int *rowIdx, int *perm);
 /* how the operator's matrix will be factored: *permuted = 1 if the factor object holds P M P' (reverse Cuthill-McKee order of the
    sparse pattern), *fraction = 128-blocks inside the pattern's block envelope / blocks of the dense lower triangle */
 void HMiKKTEnvelopeInfo(hdsdp_kkt *HKKT, int *permuted, double *fraction);
+/* A sparse Schur operator whose factor's block pattern fills at most half of the triangle is kept in TILE form on the device
+   (csrc/bsparse.h): rows reordered (dense rows last, reverse Cuthill-McKee for the rest), matrix and factor stored as the
+   128 x 128 tiles inside the block pattern of the Cholesky factor only, factored left-looking by levels of the block elimination
+   tree -- the device counterpart of the reference's sparse direct solver behind the aggregated-pattern CSC operator
+   (interface/hdsdp_schur.c:46-139, linalg/hdsdp_linsolver.c:509-809).  Returns 1 and fills the outputs when HKKT is in that
+   form: tiles stored, tiles of the dense lower triangle, levels, bytes of device memory of the tile stores. */
+int HMiKKTTileInfo(hdsdp_kkt *HKKT, int *tiles, int64_t *denseTiles, int *levels, int64_t *bytes);
+/* the tile-form factorisation and solve on a host matrix (lower-triangular CSC, diagonal entry first in every column):
+   stats[0..2] = block rows, tiles stored, levels; ms (may be NULL) = factorisation time, best of three */
+int HMiBspSolve(int m, const int *colBeg, const int *rowIdx, const double *val, const double *b, double *x, int *info, int *stats,
+                double *ms);
 int HMiCholEnvelopeProbe(int n, int band, int reps, double *ms_dense, double *ms_env);   /* factorisation time of a block-banded matrix, dense vs on its envelope */
 double HMiDiagBlockProbe(int variant, int reps);   /* us per 128 x 128 diagonal-block kernel of the Cholesky (0: LDS panels, 1: register sweep) */
 double HMiMfmaPeakProbe(int iters);    /* measured fp64 MFMA TFLOP/s of a register-only loop */

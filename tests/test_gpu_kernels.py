@@ -390,3 +390,73 @@ def test_block_envelope_cholesky_equals_the_dense_one(n, first):
     for bi in range(nb):
         if first[bi] > 0:
             assert not out["env"][1][bi * 128:min(n, bi * 128 + 128), :first[bi] * 128].any()
+
+
+def _spd_lower_csc(m, pairs, rng):
+    """a symmetric positive definite matrix with the given off-diagonal pattern: (beg, idx, val) of its lower triangle with the
+    diagonal entry first in every column, and the dense matrix"""
+    A = np.zeros((m, m))
+    for i, j in pairs:
+        if i != j:
+            v = rng.uniform(-1.0, 1.0)
+            A[max(i, j), min(i, j)] = v
+    A = A + A.T
+    A[np.arange(m), np.arange(m)] = np.sum(np.abs(A), axis=1) + 1.0 + rng.uniform(0, 1, m)
+    beg, idx, val = [0], [], []
+    for c in range(m):
+        rows = [c] + [int(r) for r in np.nonzero(A[c + 1:, c])[0] + c + 1]
+        idx += rows
+        val += [A[r, c] for r in rows]
+        beg.append(len(idx))
+    return np.array(beg, dtype=np.int32), np.array(idx, dtype=np.int32), np.array(val), A
+
+
+@pytest.mark.parametrize("kind", ["band", "arrow", "chain_arrow", "random", "block_diagonal"])
+def test_tile_form_cholesky_against_lapack(kind):
+    """csrc/bsparse.hip (the device counterpart of the reference's sparse direct solver for a sparse Schur matrix): reordering,
+    block symbolic factorisation, level-scheduled left-looking numeric factorisation on 128 x 128 tiles and the two
+    substitutions, against a dense LAPACK solve -- a band, an arrow (block diagonal plus dense linking rows: dense in every
+    envelope, two levels here), a chain with linking rows, random fill, and independent blocks; also a matrix that is not
+    positive definite"""
+    import ctypes as C
+    from hdsdp_amd import api
+    lib = api.load_library()
+    rng = np.random.RandomState(7)
+    if kind == "band":
+        m = 1100
+        pairs = [(i, j) for i in range(m) for j in range(max(0, i - 37), i)]
+    elif kind == "arrow":
+        m = 1500
+        pairs = [(i, j) for i in range(m - 40) for j in range(i - i % 12, i)] + [(i, j) for i in range(m - 40, m) for j in range(i)]
+    elif kind == "chain_arrow":
+        m = 900
+        pairs = [(i, i - 1) for i in range(1, m)] + [(i, i - 9) for i in range(9, m)] + [(m - 1 - q, j) for q in range(5) for j in range(m - 1 - q)]
+    elif kind == "random":
+        m = 700
+        pairs = [(int(rng.randint(0, m)), int(rng.randint(0, m))) for _ in range(3 * m)]
+    else:
+        m = 1000
+        pairs = [(i, j) for i in range(m) for j in range(i - i % 50, i)]
+    perm0 = rng.permutation(m)                                   # the driver's numbering is arbitrary
+    pairs = [(int(perm0[i]), int(perm0[j])) for i, j in pairs]
+    beg, idx, val, A = _spd_lower_csc(m, pairs, rng)
+    b = rng.uniform(-1, 1, m)
+    x = np.zeros(m)
+    info, stats, ms = C.c_int(-1), (C.c_int * 3)(), C.c_double(0.0)
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    rc = lib.HMiBspSolve(m, beg.ctypes.data_as(ip), idx.ctypes.data_as(ip), val.ctypes.data_as(dp), b.ctypes.data_as(dp),
+                         x.ctypes.data_as(dp), C.byref(info), stats, C.byref(ms))
+    assert rc == 0 and info.value == 0, (rc, info.value)
+    ref = np.linalg.solve(A, b)
+    assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref), np.linalg.norm(x - ref) / np.linalg.norm(ref)
+    nb, ntiles, nlevels = stats[0], stats[1], stats[2]
+    assert nb == (m + 127) // 128
+    if kind == "arrow":
+        assert ntiles <= 3 * nb and nlevels <= nb                # diagonal tiles, a neighbour where a small block straddles two tiles, the linking rows: no fill
+    if kind == "block_diagonal":
+        assert ntiles <= 2 * nb
+    # not positive definite: reported, not an error
+    val2 = val.copy()
+    val2[beg[m // 2]] = -3.0
+    rc = lib.HMiBspSolve(m, beg.ctypes.data_as(ip), idx.ctypes.data_as(ip), val2.ctypes.data_as(dp), None, None, C.byref(info), stats, None)
+    assert rc == 0 and info.value > 0

@@ -50,7 +50,12 @@ CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None), "mcp100": (-226.15735
          # driver's HKKTInit comes up with the SPARSE Schur operator (aggregated CSC pattern, 192 entries, as in the pure
          # reference), every block is one of the reference's sparse SDP cones (they stay CPU cones in both modes and write
          # through kktMapping into the engine's CSC), and the engine factors and solves what they assembled
-         "chain16": (74.932288321, 42)}
+         "chain16": (74.932288321, 42),
+         # tests/golden/arrow128.dat-s (oracle/make_arrow_sdpa.py): 128 small blocks sharing 32 linking constraints, m = 1056 -- the
+         # driver's HKKTInit comes up with the sparse operator (37 904 entries, an arrow), which the engine keeps in TILE form
+         # (csrc/bsparse.h: 17 of 45 tiles, three levels); the reference's sparse SDP cones write into the host CSC through
+         # kktMapping, HKKTFactorize scatters it into the tile store and factors it level by level
+         "arrow128": (3564.58337, 38)}
 
 
 @pytest.mark.parametrize("attach", ["0", "1"], ids=["cpu-cones+engine-operator", "engine-cones"])
@@ -109,6 +114,9 @@ def test_reference_driver_runs_on_the_engine(inst, attach, tmp_path):
         assert "Primal refinement starts" in out
     if inst == "chain16":
         assert "Using sparse Schur complement (192 nnzs)" in out
+    if inst == "arrow128":
+        assert "Using sparse Schur complement (37904 nnzs)" in out
+        assert "sparse Schur operator in tile form: 17 of 45 tiles" in out, out[-3000:]
     if ref_iters is not None:
         its = [int(m.group(1)) for m in re.finditer(r"^\s+(\d+)\s+[-+]\d\.\d+e[-+]\d+\s+[-+]\d\.\d+e[-+]\d+", out, re.M)]
         assert its and abs(max(its) - ref_iters) <= 2, (max(its) if its else None, ref_iters)
