@@ -66,8 +66,8 @@ int persist_counters(int **cnt, int *slots) {
     return 0;
 }
 
-// subset: 0 = all tiles; 1 = main tiles only (below the diagonal, all 128 rows valid: rows = the M dimension);
-// 2 = the others (diagonal and bottom-edge tiles)
+// subset: 0 = all tiles; 1 = the full diagonal tiles only (tm == tn with 8 valid sub-tile rows; rows = the M dimension);
+// 2 = all the others
 int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long colmask, TileList &out, int subset = 0, int rows = 0) {
     int dev = 0;
     HDM_HIP_CHECK(hipGetDevice(&dev));
@@ -85,8 +85,8 @@ int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long col
             if (lower_only && tm < tn) continue;
             if (colmask && !((colmask >> tn) & 1ULL)) continue;
             if (subset) {
-                const bool main_tile = (tm > tn) && ((tm + 1) * HDM_TILE <= rows);
-                if ((subset == 1) != main_tile) continue;
+                const bool full_diag = (tm == tn) && (((rows - tm * HDM_TILE + 15) >> 4) >= 8);
+                if ((subset == 1) != full_diag) continue;
             }
             long w = 1;
             if (klimit == HDM_KLIM_BY_M) w = tm + 1;
@@ -110,6 +110,8 @@ int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long col
 }
 }  // namespace
 
+static int launch_tiles(const HdmGemmArgs &args, int subset, hipStream_t stream);
+
 int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     if (args.M <= 0 || args.N <= 0 || args.batch <= 0) return 0;
     if ((args.M % 8) || (args.N % 8) || (args.K % HDM_BK)) {
@@ -121,7 +123,18 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
         fprintf(stderr, "[hdsdp_mi355x] gemm: bad k_chunk\n");
         return 1;
     }
-    const int MT = (args.M + HDM_TILE - 1) / HDM_TILE, NT = (args.N + HDM_TILE - 1) / HDM_TILE;
+    const int NT = (args.N + HDM_TILE - 1) / HDM_TILE;
+    if (args.role == HDM_ROLE_CONG2) {
+        // the role IS the SYR2K form lower(U W^T + W U^T) into the blocked layout: its full diagonal tiles compute one
+        // product and add the transpose (gemm_tile.h: symdiag), which is only that tile if the second pair mirrors the first
+        const bool mirrored = args.A2 == args.B && args.B2 == args.A && args.lda2 == args.ldb && args.ldb2 == args.lda &&
+                              args.strideA2 == args.strideB && args.strideB2 == args.strideA;
+        if (!mirrored || !args.lower_only || args.epilogue != HDM_EPI_BLOCKED || args.klimit != HDM_KLIM_BY_N ||
+            args.M != args.N || args.a_kmajor || args.b_kmajor) {
+            fprintf(stderr, "[hdsdp_mi355x] gemm role 2 is lower(A B^T + B A^T), blocked output, K cut by the column tile: launch refused\n");
+            return 1;
+        }
+    }
     if (args.role != HDM_ROLE_GENERIC) {
         // Roles 1-3 stage whole 128-row tiles WITHOUT a row mask (Stager::load_nomask): rows past the matrix edge are
         // read and thrown away.  Every such launch therefore states how many elements are readable from each operand
@@ -166,8 +179,35 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
             }
         }
     }
+    if (args.role == HDM_ROLE_CONG2) {
+        // two kernels: the full diagonal tiles as P + P^T (role HDM_ROLE_CONG2D), then everything else.  The launch's
+        // algorithmic flops are split by what the tiles hold: output element (i, j), i >= j, is 2 products x (j + 1) terms
+        double all = 0.0, diag = 0.0;
+        for (int tn = 0; tn < NT; ++tn) {
+            if (args.tile_col_mask && NT <= 64 && !((args.tile_col_mask >> tn) & 1ULL)) continue;
+            const int j0 = tn * HDM_TILE, j1 = std::min(args.N, j0 + HDM_TILE);
+            const bool full = (((args.M - j0 + 15) >> 4) >= 8);
+            for (int j = j0; j < j1; ++j) {
+                all += (double) (args.M - j) * (j + 1);
+                if (full) diag += (double) (j1 - j) * (j + 1);
+            }
+        }
+        const double share = all > 0.0 ? diag / all : 0.0;
+        HdmGemmArgs dg = args;
+        dg.role = HDM_ROLE_CONG2D; dg.A2 = nullptr; dg.B2 = nullptr; dg.flops = args.flops * share;
+        if (launch_tiles(dg, 1, stream)) return 1;
+        HdmGemmArgs mn = args;
+        mn.flops = args.flops * (1.0 - share);
+        return launch_tiles(mn, 2, stream);
+    }
+    return launch_tiles(args, 0, stream);
+}
+
+// one kernel launch over a subset of the tile list (get_tiles); args.role selects the kernel
+static int launch_tiles(const HdmGemmArgs &args, int subset, hipStream_t stream) {
+    const int MT = (args.M + HDM_TILE - 1) / HDM_TILE, NT = (args.N + HDM_TILE - 1) / HDM_TILE;
     TileList tl;
-    if (get_tiles(MT, NT, args.klimit, args.lower_only, args.tile_col_mask, tl)) return 1;
+    if (get_tiles(MT, NT, args.klimit, args.lower_only, args.tile_col_mask, tl, subset, args.M)) return 1;
     if (tl.n == 0) return 0;
     HdmGemmDev d;
     d.a = args;
@@ -242,6 +282,7 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
             case HDM_ROLE_CONG1: HDM_LAUNCH_V(false, true, HDM_ROLE_CONG1); break;   // U = Linv * A_L (A_L k-contiguous)
             case HDM_ROLE_CONG2: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG2); break;  // At = U Linv^T + Linv U^T
             case HDM_ROLE_GRAM: HDM_LAUNCH_V(true, true, HDM_ROLE_GRAM); break;      // M = Ahat Ahat^T
+            case HDM_ROLE_CONG2D: HDM_LAUNCH_V(false, false, HDM_ROLE_CONG2D); break; // step 2's full diagonal tiles: P + P^T
             default:
                 if (lay == 3) HDM_LAUNCH(true, true, HDM_ROLE_GENERIC, 0);
                 else if (lay == 2) HDM_LAUNCH(true, false, HDM_ROLE_GENERIC, 0);

@@ -22,6 +22,7 @@ bool hdm_persist_supported(bool a_kmajor, bool b_kmajor, int role, int variant) 
     if (role == HDM_ROLE_CONG1) return !a_kmajor && b_kmajor && common;
     if (role == HDM_ROLE_CONG2) return !a_kmajor && !b_kmajor && (common || cong2_extra);
     if (role == HDM_ROLE_GRAM) return a_kmajor && b_kmajor && common;
+    if (role == HDM_ROLE_CONG2D) return !a_kmajor && !b_kmajor && common;
     return false;
 }
 
@@ -40,6 +41,12 @@ int hdm_launch_persist(bool a_kmajor, bool b_kmajor, int role, int variant, dim3
         if (variant == 192) return launch_p<false, false, HDM_ROLE_CONG2, 192>(grid, block, stream, d, cnt);
         if (variant == 320) return launch_p<false, false, HDM_ROLE_CONG2, 320>(grid, block, stream, d, cnt);
         if (variant == 576) return launch_p<false, false, HDM_ROLE_CONG2, 576>(grid, block, stream, d, cnt);
+#endif
+    } else if (role == HDM_ROLE_CONG2D && !a_kmajor && !b_kmajor) {
+        if (variant == 64) return launch_p<false, false, HDM_ROLE_CONG2D, 64>(grid, block, stream, d, cnt);
+#ifdef HDM_DIAGNOSTICS
+        if (variant == 96) return launch_p<false, false, HDM_ROLE_CONG2D, 96>(grid, block, stream, d, cnt);
+        if (variant == 192) return launch_p<false, false, HDM_ROLE_CONG2D, 192>(grid, block, stream, d, cnt);
 #endif
     } else if (role == HDM_ROLE_GRAM && a_kmajor && b_kmajor) {
         if (variant == 64) return launch_p<true, true, HDM_ROLE_GRAM, 64>(grid, block, stream, d, cnt);

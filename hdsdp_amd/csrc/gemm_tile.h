@@ -501,6 +501,14 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
     }
     stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, (VAR & 128) ? 0 : m0, kt0, tid);
     stB.init(B, ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, (VAR & 128) ? 0 : n0, kt0, tid);
+    // Congruence step 2, full diagonal tiles: their own launch (role HDM_ROLE_CONG2D, hdm_launch_gemm splits role 2's tile
+    // list).  There the second product is the transpose of the first (W_t U_t^T = (U_t W_t^T)^T: the launcher holds role 2
+    // to A2 == B, B2 == A), so the tile is P + P^T with ONE product P = U_t W_t^T over all 64 cells in the main loop -- 64
+    // cell-passes where the 36-cell deal of both products ran 72, at the main loop's MFMA density, with the triangular
+    // live ranges of the last K block on BOTH operands (U and W are lower triangular: stage s keeps row and column
+    // sub-tiles >= s) -- and the transpose is added in the epilogue through LDS.  A kernel of its own because the two stage
+    // sequences in one function cost the step-2 kernel 65 spilled VGPRs (it has none without).
+    constexpr bool symdiag = (ROLE == HDM_ROLE_CONG2D);
     const int npass = (DUAL && a.A2) ? 2 : 1;
     if (DUAL && a.A2) {
         stA.chain(a.A2 + (long) z * a.strideA2, a.lda2, m0, kt0, tid, kt1 - kt0);
@@ -521,7 +529,7 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
     // buffers and the launcher verifies (hdm_launch_gemm: operand spans); a generic launch -- Cholesky updates, the small
     // products of the rank-one path on buffers of a few KB -- takes the masked loop below, whose epilogue knows about
     // diagonal tiles.  A generic diagonal tile on this path once read 16 KB past a 2 KB operand: a device fault.)
-    if (ROLE != HDM_ROLE_GENERIC && a.lower_only && tm == tn) {   // workgroup-uniform: diagonal tile, 36-cell scheme
+    if (ROLE != HDM_ROLE_GENERIC && !symdiag && a.lower_only && tm == tn) {   // workgroup-uniform: diagonal tile, 36-cell scheme
         const int nst = (kt1 - kt0) * npass;
         const int rvd = (a.M - m0 + 15) >> 4;                      // valid sub-tile rows (= columns) of this tile
         if (rvd < 8) {                                             // the last, short diagonal tile: only its needed cells
@@ -537,16 +545,18 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
             HDM_CELL_STAMP(3)
             return;
         }
-        switch (wave) {
-            case 0: cell_tile<DiagCells<0>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
-            case 1: cell_tile<DiagCells<1>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
-            case 2: cell_tile<DiagCells<2>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
-            default: cell_tile<DiagCells<3>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+        if constexpr (ROLE != HDM_ROLE_CONG2) {   // (step 2's full diagonal tiles are role HDM_ROLE_CONG2D's)
+            switch (wave) {
+                case 0: cell_tile<DiagCells<0>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+                case 1: cell_tile<DiagCells<1>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+                case 2: cell_tile<DiagCells<2>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+                default: cell_tile<DiagCells<3>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+            }
+            HDM_CELL_STAMP(1)
         }
-        HDM_CELL_STAMP(1)
         return;
     }
-    if (ROLE != HDM_ROLE_GENERIC && tm != tn && m0 + HDM_TILE > a.M && n0 + HDM_TILE <= a.N) {
+    if (ROLE != HDM_ROLE_GENERIC && !symdiag && tm != tn && m0 + HDM_TILE > a.M && n0 + HDM_TILE <= a.N) {
         // workgroup-uniform: bottom-edge tile below the diagonal, rv < 8 valid sub-tile rows
         const int nst = (kt1 - kt0) * npass;
         const int rv = (a.M - m0 + 15) >> 4;
@@ -702,6 +712,13 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
             for (int t = 0; t < nfull; ++t) HDM_RUN(0, 3, 0)
             HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0) HDM_RUN(1, 3, 0) HDM_RUN(1, 3, 0)
             HDM_RUN(2, 3, 0) HDM_RUN(2, 3, 0) HDM_RUN(3, 3, 0) HDM_END(3, 3, 0)
+        } else if constexpr (ROLE == HDM_ROLE_CONG2D) {
+            // one product; in the last K block both operands are on their diagonal: stage s keeps row and column
+            // sub-tiles >= s, i.e. the wave's own [s/2..3] x [s/2..3]: 60 of the block's 128 sub-tile products
+            const int nfull = tn * 8;
+            for (int t = 0; t < nfull; ++t) HDM_RUN(0, 3, 0)
+            HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0) HDM_RUN(1, 3, 1) HDM_RUN(1, 3, 1)
+            HDM_RUN(2, 3, 2) HDM_RUN(2, 3, 2) HDM_RUN(3, 3, 3) HDM_END(3, 3, 3)
         } else if constexpr (ROLE == HDM_ROLE_CONG1) {
             // first K block: A_L on the B side, live column sub-tiles <= s; last K block: Linv on the A side, rows >= s
             HDM_RUN(0, 0, 0) HDM_RUN(0, 0, 0) HDM_RUN(0, 1, 0) HDM_RUN(0, 1, 0)
@@ -763,6 +780,47 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
     // Sub-tile ownership is INTERLEAVED: wave (wm, wn) owns row sub-tiles 2i + wm and column sub-tiles 2j + wn (i, j = 0..3),
     // so that when a triangular operand kills the first or last few sub-tiles of a stage the live ones are still spread
     // evenly over the waves.  lane l, reg r of acc[j][i] holds C[m0 + (2i+wm)*16 + l15][n0 + (2j+wn)*16 + lq + 4r]
+    if constexpr (symdiag) {
+        // acc holds P = U_t W_t^T (all 64 sub-tiles); the tile wanted is P + P^T, lower sub-tiles only.  Every wave parks
+        // its sub-tiles on or above the diagonal TRANSPOSED in LDS (36 x 2 KiB: exactly the four stage buffers), region
+        // bj (bj + 1) / 2 + bi holding X[p][q ^ p] = P[bi, bj](q, p); the owner of the mirrored sub-tile reads its own
+        // element positions back.  The XOR keeps both sides at four lanes per 8-byte bank group -- what a 64-lane b64
+        // access costs anyway -- in unpadded 16 x 16 regions.
+        __syncthreads();                      // the last stage's fragment reads are done
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int si = 2 * i + wm, sj = 2 * j + wn;
+                if (si > sj) continue;        // wave-uniform
+                double *x = smem + (sj * (sj + 1) / 2 + si) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[(lq + 4 * r) * 16 + (l15 ^ (lq + 4 * r))] = acc[j][i][r];
+            }
+        }
+        __syncthreads();
+        const long rs16 = a.blk_row_stride * 16;
+        double *lane_base = a.C + (a.blk_row0 + z) * 16 + l15 + (long) lq * rs16;
+        const double rt2 = 1.4142135623730951;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int si = 2 * i + wm, sj = 2 * j + wn;
+                const int bi = (m0 >> 4) + si, bj = (n0 >> 4) + sj;
+                if (si < sj || bi >= a.nblk) continue;   // wave-uniform
+                const double *x = smem + (si * (si + 1) / 2 + sj) * 256;
+                const double sc = (bi == bj) ? 1.0 : rt2;
+                const long sub = (long) bj * a.nblk - (long) bj * (bj - 1) / 2 + (bi - bj);
+                double *q = lane_base + sub * 16 * rs16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    q[(long) (4 * r) * rs16] = sc * (acc[j][i][r] + x[l15 * 16 + ((lq + 4 * r) ^ l15)]);
+            }
+        }
+        stamp_end();
+        return;
+    }
     if (a.epilogue == HDM_EPI_BLOCKED) {
         // one base pointer per lane, everything else is wave-uniform 64-bit strides
         const long rs16 = a.blk_row_stride * 16;                       // elements between consecutive p-blocks

@@ -80,7 +80,9 @@ enum HdmEpilogue {
 
 // kernel roles: a distinct kernel symbol per role so that rocprofv3 --stats separates the hot-path
 // launches (congruence step 1/2, Gram) from the small Cholesky/TRTRI helper GEMMs
-enum HdmRole { HDM_ROLE_GENERIC = 0, HDM_ROLE_CONG1 = 1, HDM_ROLE_CONG2 = 2, HDM_ROLE_GRAM = 3, HDM_NROLES = 4 };
+// HDM_ROLE_CONG2D is internal to the launcher: a role-2 launch is issued as two kernels, the full diagonal tiles (computed
+// as P + P^T from one product, gemm_tile.h) and everything else; callers never ask for it
+enum HdmRole { HDM_ROLE_GENERIC = 0, HDM_ROLE_CONG1 = 1, HDM_ROLE_CONG2 = 2, HDM_ROLE_GRAM = 3, HDM_ROLE_CONG2D = 4, HDM_NROLES = 5 };
 
 struct HdmGemmArgs {
     const double *A, *B;

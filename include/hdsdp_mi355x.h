@@ -421,8 +421,9 @@ const char *HMiVersion(void);
 void HMiGetStageTimes(double *ms, int n);
 
 /* live per-kernel timing with HIP events on the engine stream (for bench.py's roofline block): roles are
- * [0] helper GEMMs (Cholesky/TRTRI), [1] congruence step 1 (T = Linv A), [2] congruence step 2, [3] Gram.
- * Each array has 4 entries: total ms, algorithmic flops and launch count since the last call. */
+ * [0] helper GEMMs (Cholesky/TRTRI), [1] congruence step 1 (T = Linv A), [2] congruence step 2 without its full diagonal
+ * tiles, [3] Gram, [4] the full diagonal tiles of congruence step 2 (a kernel of their own: P + P^T from one product).
+ * Each array has 5 entries: total ms, algorithmic flops and launch count since the last call. */
 void HMiSetKernelTiming(int on);
 int HMiGetKernelTiming(double *ms, double *flops, int64_t *launches);
 /* diagnostic builds (HDM_VAR=32): per-workgroup s_memtime stamps of launches with the given role, 8 words each */

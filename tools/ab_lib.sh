@@ -13,8 +13,9 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     k = d["roofline"]["kernels"]
-    print("%-40s %.3f ms/step  K1 %.2f  K2 %.2f  gram %.2f  checksum_ok %s  sum_d2 %.16g" % (sys.argv[2], d["ms_per_step"], k["congruence_step1"]["ms_per_step"],
-          k["congruence_step2"]["ms_per_step"], k["gram"]["ms_per_step"], d.get("checksum_ok"), d["checksum"]["sum_d2"]))
+    w = d["roofline"].get("congruence_step2_whole", {})
+    print("%-40s %.3f ms/step  K1 %.2f  K2 %.2f (diagonal tiles %.2f)  gram %.2f  checksum_ok %s  sum_d2 %.16g" % (sys.argv[2], d["ms_per_step"], k["congruence_step1"]["ms_per_step"],
+          w.get("ms_per_step", k["congruence_step2"]["ms_per_step"]), w.get("diagonal_tiles_ms_per_step", 0.0), k["gram"]["ms_per_step"], d.get("checksum_ok"), d["checksum"]["sum_d2"]))
 except Exception as e:
     print(sys.argv[2], "no result:", e)
 PY

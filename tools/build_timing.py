@@ -16,8 +16,8 @@ lib.HMiSetKernelTiming(1)
 for _ in range(2):
     kkt.build_up(0)
 lib.HMiSetKernelTiming(0)
-kms, kfl = np.zeros(4), np.zeros(4)
-kln = np.zeros(4, dtype=np.int64)
+kms, kfl = np.zeros(5), np.zeros(5)
+kln = np.zeros(5, dtype=np.int64)
 lib.HMiGetKernelTiming(kms.ctypes.data_as(C.POINTER(C.c_double)), kfl.ctypes.data_as(C.POINTER(C.c_double)),
                        kln.ctypes.data_as(C.POINTER(C.c_int64)))
-print("HDM_VAR=%s  K1 %.2f  K2 %.2f  gram %.2f ms per build" % (os.environ.get("HDM_VAR", "-"), kms[1] / 2, kms[2] / 2, kms[3] / 2))
+print("HDM_VAR=%s  K1 %.2f  K2 %.2f (+ diagonal tiles %.2f)  gram %.2f ms per build" % (os.environ.get("HDM_VAR", "-"), kms[1] / 2, kms[2] / 2, kms[4] / 2, kms[3] / 2))
