@@ -34,7 +34,7 @@ EXPORTS = [
     "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeCheckIsInteriorExpert",
     "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetCoeffNorm", "HMiConeGetObjNorm",
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
-    "HMiConeGetTraces", "HMiConeGetPath", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
+    "HMiConeGetTraces", "HMiConeGetPath", "HMiConeSweepInfo", "HMiConeUseSweepCopy", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiKKTGetRows", "HMiDeviceInit",
     "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
@@ -145,6 +145,8 @@ def load_library():
         "HMiConeGetDualMatrix": (C.c_int, [vp, dp]),
         "HMiConeGetTraces": (C.c_int, [vp, dp]),
         "HMiConeGetPath": (C.c_int, [vp]),
+        "HMiConeSweepInfo": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+        "HMiConeUseSweepCopy": (C.c_int, [vp, C.c_int]),
         "HMiKKTSetHostMirror": (None, [kp, C.c_int]),
         "HMiConeSetExchange": (None, [vp, vp, vp, vp]),
         "HMiConeSetExchangePieces": (None, [vp, vp, vp, C.c_int]),
@@ -432,6 +434,15 @@ class SDPCone:
     @property
     def path(self):
         return load_library().HMiConeGetPath(self._h)
+
+    def use_sweep_copy(self, on):
+        _check(load_library().HMiConeUseSweepCopy(self._h, int(bool(on))), "HMiConeUseSweepCopy")
+
+    def sweep_info(self):
+        """(in use, stored values, skyline positions they stand for) of the zero-suppressed copy the S / dS sweeps read"""
+        v, p = C.c_int64(0), C.c_int64(0)
+        on = load_library().HMiConeSweepInfo(self._h, C.byref(v), C.byref(p))
+        return bool(on), int(v.value), int(p.value)
 
     def destroy(self):
         if self._h:

@@ -112,6 +112,23 @@ hdsdp_retcode HMiConeGetTraces(hdsdp_cone *cone, double *trA) {
     return HDSDP_RETCODE_OK;
 }
 int HMiConeGetPath(hdsdp_cone *cone) { return cone_data(cone)->path; }
+int HMiConeUseSweepCopy(hdsdp_cone *cone, int on) {
+    MiCone *c = cone_data(cone);
+    if (ensure_ctx()) return 1;
+    c->pS_ok = c->pD_ok = false;     // the next request is assembled, not short-cut
+    if (!on) { c->zs_state = -1; return 0; }
+    if (!c->zs.val && c->Afull && c->mloc > 0 &&
+        hdm_zs_build(c->Afull, c->astride, c->mloc, c->astride, 1.0, &c->zs, g.stream)) return 1;
+    c->zs_state = c->zs.val ? 1 : -1;
+    return c->zs.val ? 0 : 1;
+}
+int HMiConeSweepInfo(hdsdp_cone *cone, int64_t *values, int64_t *positions) {
+    const MiCone *c = cone_data(cone);
+    const bool on = (c->zs_state == 1);
+    if (values) *values = on ? (int64_t) c->zs.nnz : 0;
+    if (positions) *positions = on ? (int64_t) c->zs.sky * c->zs.m : 0;
+    return on ? 1 : 0;
+}
 
 // ---------------------------------------------------------------- single-process multi-device mode (group_impl.h)
 int HMiSetDevices(int nDevices, const int *deviceIds) {

@@ -146,6 +146,7 @@ void cone_destroy_data(void **pcd) {
                       c->U, c->V, c->Gr1, c->Ct, c->W, c->Xinv, c->Yinv};
     for (double *b : bufs)
         if (b) (void) hipFree(b);
+    hdm_zs_free(&c->zs);
     if (!c->ext_ahat) {
         if (c->AhatAll && c->AhatAll != c->AhatLoc) (void) hipFree(c->AhatAll);
         if (c->AhatLoc) (void) hipFree(c->AhatLoc);

@@ -23,6 +23,7 @@ struct MiCone {
     std::vector<int> own;      // global indices of the owned constraints
     // device data
     double *Afull = nullptr;   // mloc x (n16 x n16) constraint matrices in A_L form: strict lower + half diagonal
+    HdmZs zs; int zs_state = 0; // zero-suppressed copy of Afull for the S / dS sweeps (schur.h); 0 = not looked at, 1 = in use, -1 = not built
     double *Cfull = nullptr;   // n16 x n16 objective, full symmetric
     double *CL = nullptr;      // objective in A_L form (GEMM path, HSD builds)
     double *Avec = nullptr;    // n16 x mloc16 rank-one factors (R1 path)
@@ -391,7 +392,21 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
         if (target == c->S) c->aff_chain = 0;
     }
     const double lead = (c->rank == 0) ? 1.0 : 0.0;
-    if (hdm_sym_combine(c->Afull, c->astride, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
+    // The sweep reads the zero-suppressed copy of the constraint data where one exists (schur.h: HdmZs; built at the first
+    // sweep that costs something -- 16 MiB of constraint data or more -- unless over 60 % of the stored positions are non-zero:
+    // the synthetic family's 32 GB are 13.6 GB there).  Bit-identical sums.  HDSDP_MI355X_ZS=0: never; 2: any size, any fill.
+    static const int zs_env = [] { const char *e = getenv("HDSDP_MI355X_ZS"); return e ? atoi(e) : 1; }();
+    if (any && c->zs_state == 0) {
+        c->zs_state = -1;
+        if (zs_env && (zs_env >= 2 || sweep_bytes >= (16L << 20))) {
+            if (hdm_zs_build(c->Afull, c->astride, c->mloc, c->astride, zs_env >= 2 ? 1.0 : 0.6, &c->zs, g.stream)) return 1;
+            if (c->zs.val) c->zs_state = 1;
+        }
+    }
+    if (any && c->zs_state == 1) {
+        if (hdm_sym_combine_zs(c->zs, c->ydev, c->Cfull, lead * tau, lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)),
+                               target, c->n, c->n16, c->n16, g.stream)) return 1;
+    } else if (hdm_sym_combine(c->Afull, c->astride, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
                         lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)), target, c->n, c->n16, c->n16, g.stream)) return 1;
     if (c->world > 1) {
         HDM_HIP_CHECK(hipStreamSynchronize(g.stream));

@@ -29,3 +29,24 @@ int hdm_lower_half(const double *full, double *low, int n, long ld, hipStream_t 
 int hdm_zero_diag_upper(double *T, long tstride, int n, int batch, hipStream_t s);
 // one skyline-stored A_L matrix (hdm_common.h) -> square column-major n x n
 int hdm_sky_to_square(const double *sky, double *sq, int n, hipStream_t s);
+
+// ---- zero-suppressed copy of a batch of skyline-stored A_L matrices for the HBM-bound sweeps (schur.hip) ----
+// The sweeps that assemble S and dS read every stored element of every constraint matrix (32 GB at n = m = 2000) to add
+// y_i * a to an accumulator -- also where a = 0, which is most of the storage for anything but a fully dense family (the
+// reference calls a matrix DENSE from 30 % of its entries on, hdsdp_sdpdata.c:2321-2345; the synthetic family keeps 40 %).
+// The copy stores, per chunk of 1024 consecutive skyline positions and per matrix, a 1024-bit occupancy mask with the
+// offset of each 64-bit word's first value (192 bytes) and the non-zero values only; chunk-major, so that the workgroup
+// that owns a chunk streams ONE contiguous range of memory for all matrices.  Same sums in the same order as the dense
+// sweep (the skipped terms are exact zeros): bit-identical results.
+struct HdmZs {
+    unsigned long long *meta = nullptr;   // [chunk][matrix][24]: 16 mask words, then 16 uint32 offsets relative to base[chunk]
+    double *val = nullptr;                // the non-zero values, chunk by chunk, matrix by matrix, in position order
+    unsigned long long *base = nullptr;   // [chunk]: first value of the chunk's range in val
+    long nchunk = 0, sky = 0, nnz = 0;
+    int m = 0;
+};
+// builds the copy unless more than max_fill of the positions are non-zero (then out->val stays null: not worth the memory)
+int hdm_zs_build(const double *A, long astride, int m, long sky, double max_fill, HdmZs *out, hipStream_t s);
+void hdm_zs_free(HdmZs *z);
+int hdm_sym_combine_zs(const HdmZs &z, const double *y, const double *C, double tau, double eye, double *S, int n, long lda,
+                       long lds_, hipStream_t s);

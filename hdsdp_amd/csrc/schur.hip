@@ -12,6 +12,7 @@
 //                               (hdsdp_conic_sdp.c:687-778, hdsdp_sdpdata.c:1003-1118)
 #include "hdm_common.h"
 #include "schur.h"
+#include <vector>
 #include "bsparse.h"
 #include <algorithm>
 
@@ -289,6 +290,177 @@ __global__ __launch_bounds__(256) void hdm_sym_combine_sky_kernel(const double *
 }
 
 // ------------------------------------------------------------------------------------------
+// zero-suppressed sweep format (schur.h: HdmZs).  Workgroup b owns skyline positions 1024 b .. 1024 b + 1023 = 16 mask words of
+// every matrix; bit l of word w is position 1024 b + 64 w + l.  The two builder kernels run four waves of four words each, the
+// sweep two waves of eight; a wave's mask words and offsets are wave-uniform: scalar loads.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned hdm_lanes_below(unsigned long long mask) {   // set bits of `mask` below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
+}
+
+// pass 1: non-zeros per chunk, all matrices
+__global__ __launch_bounds__(256) void hdm_zs_count_kernel(const double *__restrict__ A, long astride, int m, long sky,
+                                                            unsigned long long *__restrict__ total) {
+    __shared__ unsigned long long wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long p0 = (long) blockIdx.x * 1024 + 256 * wave + lane;
+    unsigned long long cnt = 0;
+    for (int c = 0; c < m; ++c) {
+        const double *a = A + (long) c * astride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long p = p0 + 64 * q;
+            const double v = (p < sky) ? a[p] : 0.0;
+            cnt += (unsigned long long) __popcll(__ballot(v != 0.0));
+        }
+    }
+    if (lane == 0) wsum[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) total[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// pass 2: masks, offsets and values of chunk b, matrix after matrix (the offsets run on through the chunk's range)
+__global__ __launch_bounds__(256) void hdm_zs_fill_kernel(const double *__restrict__ A, long astride, int m, long sky,
+                                                           const unsigned long long *__restrict__ base,
+                                                           unsigned long long *__restrict__ meta, double *__restrict__ val) {
+    __shared__ unsigned pc[2][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long p0 = (long) blockIdx.x * 1024 + 256 * wave + lane;
+    double *out = val + base[blockIdx.x];
+    unsigned running = 0;
+    for (int c = 0; c < m; ++c) {
+        const double *a = A + (long) c * astride;
+        double v[4];
+        unsigned long long mk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long p = p0 + 64 * q;
+            v[q] = (p < sky) ? a[p] : 0.0;
+            mk[q] = __ballot(v[q] != 0.0);
+            if (lane == 0) pc[c & 1][4 * wave + q] = (unsigned) __popcll(mk[q]);
+        }
+        __syncthreads();                     // (two buffers: the next matrix writes the other one before anyone can lag two behind)
+        unsigned before = running, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const unsigned k = pc[c & 1][w];
+            if (w < 4 * wave) before += k;
+            all += k;
+        }
+        unsigned long long *rec = meta + ((long) blockIdx.x * m + c) * 24;
+        unsigned off = before;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (lane == 0) {
+                rec[4 * wave + q] = mk[q];
+                reinterpret_cast<unsigned *>(rec + 16)[4 * wave + q] = off;
+            }
+            if ((mk[q] >> lane) & 1ULL) out[off + hdm_lanes_below(mk[q])] = v[q];
+            off += (unsigned) __popcll(mk[q]);
+        }
+        running += all;
+    }
+}
+
+// S(lower incl. diag) = tau*C - sum_i y_i A_i + eye*I from the zero-suppressed copy: the sums of hdm_sym_combine_sky_kernel
+// term by term in the same order, without the terms whose a is an exact zero.
+// Workgroup = one chunk, two waves: wave w owns mask words 8 w .. 8 w + 7 (lane l of word q = position 1024 b + 512 w + 64 q + l),
+// so a chunk row is 4160 waves at n16 = 2000 -- all resident at once (the 2080 four-wave workgroups of the dense sweep need a
+// second, nearly empty round).  Two matrices per trip: their 16 mask words, first offsets and multipliers sit in SGPRs (a word
+// is its own lane mask: the loads of a word's zeros are switched off by it, v_cndmask takes it as is; the offsets of words
+// 1..7 are running popcounts); the metadata of the NEXT trip is requested after this trip's value loads have been issued and
+// before they are waited for, so its latency hides behind theirs (scalar loads return out of order: any wait for them is a
+// wait for all, which is why the request may not come earlier).
+struct HdmZsTrip { unsigned long long mk[2][8]; unsigned off[2]; double y[2]; };
+__global__ __launch_bounds__(128) void hdm_sym_combine_zs_kernel(const unsigned long long *__restrict__ meta,
+                                                                  const double *__restrict__ val,
+                                                                  const unsigned long long *__restrict__ base, int m,
+                                                                  const double *__restrict__ y, const double *__restrict__ C,
+                                                                  double tau, double eye, double *__restrict__ S, int n, int lda,
+                                                                  long lds_, long sky) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double *v0 = val + base[blockIdx.x];
+    const unsigned long long *rec = meta + (long) blockIdx.x * m * 24 + 8 * wave;                                   // this wave's 8 mask words of matrix 0
+    const unsigned *offp = reinterpret_cast<const unsigned *>(meta + (long) blockIdx.x * m * 24 + 16) + 8 * wave;   // offset of its first word
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    auto load_trip = [&](HdmZsTrip &t, int c) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned long long *r = rec + (long) (c + u) * 24;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t.mk[u][q] = r[q];
+            t.off[u] = offp[(long) (c + u) * 48];
+            t.y[u] = y[c + u];
+        }
+    };
+    auto issue = [&](const HdmZsTrip &t, double (&a)[2][8]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            unsigned o = t.off[u];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                a[u][q] = __builtin_amdgcn_inverse_ballot_w64(t.mk[u][q]) ? v0[o + hdm_lanes_below(t.mk[u][q])] : 0.0;
+                o += (unsigned) __popcll(t.mk[u][q]);
+            }
+        }
+    };
+    auto accumulate = [&](const HdmZsTrip &t, const double (&a)[2][8]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] -= t.y[u] * a[u][q];
+    };
+    HdmZsTrip A, B;
+    double a[2][8];
+    const int mp = m & ~1;
+    int c = 0;
+    if (mp >= 2) load_trip(A, 0);
+    for (; c + 4 <= mp; c += 4) {
+        issue(A, a);
+        __builtin_amdgcn_sched_barrier(0);
+        load_trip(B, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        accumulate(A, a);
+        issue(B, a);
+        __builtin_amdgcn_sched_barrier(0);
+        load_trip(A, min(c + 4, mp - 2));
+        __builtin_amdgcn_sched_barrier(0);
+        accumulate(B, a);
+    }
+    if (c + 2 <= mp) { issue(A, a); accumulate(A, a); c += 2; }
+    if (c < m) {                                  // odd count: the last matrix alone
+        const unsigned long long *r = rec + (long) c * 24;
+        unsigned o = offp[(long) c * 48];
+        const double yc = y[c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned long long mk = r[q];
+            const double v = __builtin_amdgcn_inverse_ballot_w64(mk) ? v0[o + hdm_lanes_below(mk)] : 0.0;
+            o += (unsigned) __popcll(mk);
+            acc[q] -= yc * v;
+        }
+    }
+    const int tlast = (lda + 127) / 128 - 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const long sp = (long) blockIdx.x * 1024 + 512 * wave + 64 * q + lane;
+        if (sp >= sky) continue;
+        int t = 0;
+        while (t < tlast && hdm_sky_panel(t + 1, lda) <= sp) ++t;
+        const long local = sp - hdm_sky_panel(t, lda);
+        const int ldp = lda - 128 * t;
+        const int i = 128 * t + (int) (local % ldp), j = 128 * t + (int) (local / ldp);
+        if (i < j || i >= n || j >= n) continue;
+        double v = acc[q];
+        if (i == j) v *= 2.0;
+        v += tau * C[i + (long) j * lda];
+        if (i == j) v += eye;
+        S[i + (long) j * lds_] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // rank-one (M2) path.  U = Linv * [a_1 .. a_m] (n x m), Gm = U^T U  =>  Gm_ij = a_i' S^-1 a_j
 //   M_ij = s_i s_j Gm_ij^2 ; ASinv_i = s_i Gm_ii ; ASinvRdSinv_i = Rd s_i |S^-1 a_i|^2 = Rd s_i |Linv^T u_i|^2
 // ------------------------------------------------------------------------------------------
@@ -523,6 +695,53 @@ int hdm_sym_combine(const double *A, long astride, int m, const double *y, const
     long tot = (long) n * n;
     hipLaunchKernelGGL(hdm_sym_combine_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, A, astride, m, y,
                        C, tau, eye, S, n, lda, lds_);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_zs_build(const double *A, long astride, int m, long sky, double max_fill, HdmZs *out, hipStream_t s) {
+    *out = HdmZs();
+    if (m <= 0 || sky <= 0) return 0;
+    const long nchunk = (sky + 1023) / 1024;
+    if ((double) m * 1024.0 >= 4.0e9) return 0;           // a chunk's offsets are 32-bit
+    unsigned long long *total = nullptr;
+    HDM_HIP_CHECK(hipMalloc((void **) &total, sizeof(unsigned long long) * nchunk));
+    hipLaunchKernelGGL(hdm_zs_count_kernel, dim3((unsigned) nchunk), dim3(256), 0, s, A, astride, m, sky, total);
+    HDM_HIP_CHECK(hipGetLastError());
+    std::vector<unsigned long long> h(nchunk);
+    HDM_HIP_CHECK(hipMemcpyAsync(h.data(), total, sizeof(unsigned long long) * nchunk, hipMemcpyDeviceToHost, s));
+    HDM_HIP_CHECK(hipStreamSynchronize(s));
+    unsigned long long run = 0;
+    for (long b = 0; b < nchunk; ++b) { const unsigned long long k = h[b]; h[b] = run; run += k; }
+    if ((double) run > max_fill * (double) m * (double) sky) { (void) hipFree(total); return 0; }
+    out->base = total;                                     // reused: counts -> exclusive offsets
+    HDM_HIP_CHECK(hipMemcpyAsync(out->base, h.data(), sizeof(unsigned long long) * nchunk, hipMemcpyHostToDevice, s));
+    // (+ 64 values of slack: the lanes behind a word's last non-zero read the slot that follows)
+    if (hipMalloc((void **) &out->val, sizeof(double) * (size_t) (run + 64)) != hipSuccess ||
+        hipMalloc((void **) &out->meta, sizeof(unsigned long long) * 24 * (size_t) nchunk * m) != hipSuccess) {
+        (void) hipGetLastError();
+        hdm_zs_free(out);
+        return 0;                                          // no memory for the copy: the dense sweep stays
+    }
+    HDM_HIP_CHECK(hipMemsetAsync(out->val + run, 0, sizeof(double) * 64, s));
+    hipLaunchKernelGGL(hdm_zs_fill_kernel, dim3((unsigned) nchunk), dim3(256), 0, s, A, astride, m, sky, out->base, out->meta, out->val);
+    HDM_HIP_CHECK(hipGetLastError());
+    HDM_HIP_CHECK(hipStreamSynchronize(s));
+    out->nchunk = nchunk; out->sky = sky; out->nnz = (long) run; out->m = m;
+    return 0;
+}
+
+void hdm_zs_free(HdmZs *z) {
+    if (z->meta) (void) hipFree(z->meta);
+    if (z->val) (void) hipFree(z->val);
+    if (z->base) (void) hipFree(z->base);
+    *z = HdmZs();
+}
+
+int hdm_sym_combine_zs(const HdmZs &z, const double *y, const double *C, double tau, double eye, double *S, int n, long lda,
+                       long lds_, hipStream_t s) {
+    hipLaunchKernelGGL(hdm_sym_combine_zs_kernel, dim3((unsigned) z.nchunk), dim3(128), 0, s, z.meta, z.val, z.base, z.m, y, C, tau,
+                       eye, S, n, (int) lda, lds_, z.sky);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

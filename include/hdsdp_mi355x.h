@@ -262,6 +262,12 @@ hdsdp_retcode HMiConeGetDualMatrix(hdsdp_cone *cone, double *S);
 hdsdp_retcode HMiConeGetTraces(hdsdp_cone *cone, double *trA);
 /* which device path the cone's builder uses: 0 = dense congruence + Gram (MFMA), 1 = rank-one */
 int HMiConeGetPath(hdsdp_cone *cone);
+/* the zero-suppressed copy of the constraint data the S / dS sweeps read (csrc/schur.h: HdmZs): returns 1 and the number of
+ * stored values / of skyline positions it stands for when the cone has built one, 0 when its sweeps read the dense storage */
+int HMiConeSweepInfo(hdsdp_cone *cone, int64_t *values, int64_t *positions);
+/* on = 1: build the copy now whatever the block's size and fill, and sweep from it; on = 0: sweep from the dense storage
+ * (a copy that exists is kept).  For tests and A/B runs; the default is the rule of HDSDP_MI355X_ZS in the table below. */
+int HMiConeUseSweepCopy(hdsdp_cone *cone, int on);
 
 /* ===============================  device-resident fast path  ===============================
  * The reference boundary hands host buffers (S in, M out).  For benchmarking with inputs resident in
@@ -389,6 +395,7 @@ void HMiSDPAFree(HMiSDPA **pp);
  *  HDSDP_MI355X_KKT_TILES         1         tile form of a sparse operator when it pays (bsparse.h)       test_gpu_switches.py
  *  HDSDP_MI355X_AFFINE_S          by cost   0 / 1 / 2: dual matrix short-cuts (engine_cone.h)             test_gpu_switches.py
  *  HDSDP_MI355X_SMALL_CHECK       1         one-launch interior check of small blocks                     test_gpu_switches.py
+ *  HDSDP_MI355X_ZS                by cost   0 / 1 / 2: zero-suppressed copy for the S / dS sweeps (schur.h) test_gpu_switches.py
  *  HDM_TCAP_GIB                   32        GiB of congruence intermediates per launch group              test_gpu_switches.py, test_gpu_group.py
  *  HDM_BC                         1024      constraints per congruence launch (upper bound)               test_gpu_switches.py
  *  HDM_NSPLIT                     by size   K splits of the Gram product                                  test_gpu_switches.py

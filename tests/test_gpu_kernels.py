@@ -460,3 +460,47 @@ def test_tile_form_cholesky_against_lapack(kind):
     val2[beg[m // 2]] = -3.0
     rc = lib.HMiBspSolve(m, beg.ctypes.data_as(ip), idx.ctypes.data_as(ip), val2.ctypes.data_as(dp), None, None, C.byref(info), stats, None)
     assert rc == 0 and info.value > 0
+
+
+@pytest.mark.parametrize("case", ["syn200x37", "syn136x5", "gpp100_B", "mix40_A"])
+def test_sweeps_from_the_zero_suppressed_copy_give_the_same_bits(case):
+    """S = tau C - sum y_i A_i - Rd I and the ratio test's dS, swept from the zero-suppressed copy of the constraint data
+    (csrc/schur.h: HdmZs -- occupancy masks + the non-zero values, chunk-major) and from the dense skyline storage: the same
+    sums in the same order without the exact-zero terms, so the same bits.  Sizes with a ragged last chunk, matrix counts
+    that are not a multiple of the four the sweep takes per trip, and data that is almost all zeros (rank-one rows)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import load_golden, y_of
+    from hdsdp_amd import api
+    rng = np.random.default_rng(5)
+    if case.startswith("syn"):
+        n, m = (int(v) for v in case[3:].split("x"))
+        mk = lambda: api.SDPCone.synthetic(n, m)
+        Rd, tau, y = -10.0 * n, 1.0, 0.05 * rng.uniform(-1, 1, m)
+    else:
+        g = load_golden(case)
+        n, m = int(g["dims"][0]), int(g["dims"][1])
+        mk = lambda: api.SDPCone.from_csc(n, m, g["csc_beg"], g["csc_idx"], g["csc_val"])
+        Rd, tau, y = float(g["Rd"][0]), float(g["tau"][0]), y_of(g)
+    dy = rng.uniform(-1, 1, m)
+    got = []
+    for on in (0, 1):
+        cone = mk()
+        cone.set_start(Rd)
+        cone.use_sweep_copy(on)
+        used, vals, pos = cone.sweep_info()
+        assert used == bool(on)
+        if on:
+            assert 0 < vals <= pos
+            if case.startswith("syn"):
+                assert 0.2 < vals / pos < 0.45          # keep-probability 0.4 on the lower triangle; stored zeros above it and in the padding
+        assert cone.check_is_interior(tau, y)
+        S = cone.get_dual().copy()
+        step = cone.ratio_test(0.3, dy, 0.1)
+        ok = cone.check_is_interior(tau, y + 0.5 * min(step, 1.0) * dy)     # (a point on the line: axpy short-cut or a sweep, as the block's size says)
+        S2 = cone.get_dual().copy()
+        got.append((S, step, bool(ok), S2))
+        cone.destroy()
+    assert np.array_equal(got[0][0], got[1][0])
+    assert got[0][1] == got[1][1] and got[0][2] == got[1][2]
+    assert np.array_equal(got[0][3], got[1][3])

@@ -17,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SETTINGS = [
     {"HDSDP_MI355X_AFFINE_S": "0"}, {"HDSDP_MI355X_AFFINE_S": "2"},
     {"HDSDP_MI355X_SMALL_CHECK": "0"},
+    {"HDSDP_MI355X_ZS": "0"}, {"HDSDP_MI355X_ZS": "2"},                 # sweeps from the dense storage everywhere / from the zero-suppressed copy everywhere
     {"HDSDP_MI355X_SPARSE_KKT": "0"}, {"HDSDP_MI355X_KKT_RCM": "0"}, {"HDSDP_MI355X_KKT_ENVELOPE": "0"}, {"HDSDP_MI355X_KKT_TILES": "0"},
     {"HDSDP_MI355X_FORCE_GEMM": "1"},
     {"HDM_LANCZOS_WHOLE": "0"}, {"HDM_LANCZOS_WHOLE": "0", "HDM_LANCZOS_FUSED": "0"},
