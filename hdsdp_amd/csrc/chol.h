@@ -61,4 +61,5 @@ int hdm_potrf_sweep_batched(double *tiles, const int *diag_tile, const int *cols
 
 // several engine shards share this device: the single-launch substitution (which needs co-resident workgroups) is off
 void hdm_flow_set_shared_device(int on);
+bool hdm_flow_shared_device();   // several engine instances share one device: no kernel may count on its grid being co-resident
 double hdm_diag_block_probe(int variant, int reps, hipStream_t s);   // diagnostic: us per diagonal-block kernel (0: LDS panels, 1: register sweep)

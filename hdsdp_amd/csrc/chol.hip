@@ -785,6 +785,7 @@ int HdmChol::get_diag(double *diag_host, hipStream_t s) {
 // co-resident, which nobody can promise when other streams of the same process compete for the CUs.
 static std::atomic<int> g_flow_shared_device{0};
 void hdm_flow_set_shared_device(int on) { g_flow_shared_device.store(on); }
+bool hdm_flow_shared_device() { return g_flow_shared_device.load() != 0; }
 static bool hdm_flow_enabled() {
     static int on = -1;
     if (on < 0) { const char *e = getenv("HDM_TRSV_FLOW"); on = (e && atoi(e) == 0) ? 0 : 1; }

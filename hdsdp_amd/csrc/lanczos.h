@@ -11,6 +11,11 @@ struct HdmLanczos {
     double *bv = nullptr, *b1 = nullptr, *b2 = nullptr, *bw = nullptr, *bz = nullptr;   // n16 x 8 vector blocks (column 0 used)
     double *warm = nullptr, *tmp = nullptr, *scal = nullptr, *startd = nullptr;   // startd: device copy of `start`, zero padded
     double *part = nullptr;   // 32 x n16 partial sums of the plain matrix-vector product
+    double *LT = nullptr;     // n16 x n16 transposed copy of Linv (large blocks, hdm_lanczos_group_kernel), made per test
+    unsigned *gsync = nullptr; // its grid barrier: counter, give-up word
+    bool big_ok = true; int big_wg = 0;
+    unsigned sync_epoch = 0;   // barrier epochs handed out so far
+    double *scal_h = nullptr;  // host side of `scal` (mapped pinned memory: `scal` is its device address)
     std::vector<double> start;   // the reference's pseudo-random start vector (host)
 
     int init(int n);

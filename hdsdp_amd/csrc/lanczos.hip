@@ -14,6 +14,8 @@
 // The start vector reproduces glibc's srand()/rand() stream (TYPE_3 additive feedback generator) without touching
 // the process-wide libc state, so the device run starts from the reference's own vector.
 #include "lanczos.h"
+#include "chol.h"
+#include <algorithm>
 
 #include <cmath>
 #include <cstdio>
@@ -183,6 +185,224 @@ __global__ __launch_bounds__(1024) void hdm_lanczos_fused_kernel(const double *_
         __syncthreads();
     }
     if (tid == 0) out[2 * nsteps] = (double) done;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Large blocks (256 < n16 <= 4096): the Lanczos steps between two Ritz checks in ONE launch of LZG_WG co-resident workgroups.
+//
+// At n = 2000 a step was four dependent launches (three matrix-vector products, the recurrence) of 5-10 us of work each behind
+// 10 us of launch gap each: 0.11 ms per step, and 186 of the 243 ratio tests of a headline solve run all 30 steps.  Here a
+// step is five grid-wide barriers apart instead: workgroup b owns the columns b, b + G, ... of each product -- all three are
+// column dots (t1 = Linv^T v down the columns of Linv, t2 = -dS t1 down the columns of the symmetric dS, w = Linv t2 down the
+// columns of a transposed copy of Linv made once per test) with the operand vector in LDS and 32-64 loads in flight per
+// thread -- and of the recurrence; the two inner products of the recurrence are per-workgroup partial sums that every
+// workgroup adds up in the same fixed order.  The barrier is a monotone counter (release / acquire at agent scope, bounded
+// spin); the host launches this form only where the grid is co-resident by construction (one workgroup per CU, nothing else
+// on the device) and falls back to the launch-per-product form for the rest of the object's life if a wait ever runs out.
+// ---------------------------------------------------------------------------------------------------------------------
+#define LZG_WG 256
+struct LzgArgs {
+    const double *Linv; long ldl; const double *LinvT; long ldt; const double *dS; long ldd;
+    int n; double *V; long ldv; int k0, nsteps; double hprev;
+    double *blk, *t1, *t2, *pa, *pb, *out; unsigned *sync;   // sync: 64 + LZG_WG words, see lzg_barrier
+    unsigned epoch0;           // barrier epochs of this launch: epoch0 + 1, + 2, ... (the words are never reset)
+    double *dbg;               // diagnostic (HDSDP_MI355X_RATIO_DEBUG=2): workgroup 0 adds up the 100 MHz ticks of its 9 phases here
+};
+
+// What workgroups hand to each other inside the launch -- the product vectors, the partial sums, the new basis vector: a few
+// KB per step -- is written and read with agent-scope atomic accesses (they go past the caches that are not coherent between
+// XCDs), so the barrier needs no cache maintenance: an agent-scope fence writes back / invalidates the XCD's whole L2, and a
+// thousand waves doing that five times per Lanczos step made the first version of this kernel slower than the launches it
+// replaced (0.17 against 0.12 ms per step).  The matrices are only read and stay cached.
+__device__ __forceinline__ double lzg_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lzg_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// barrier number `epoch` (1, 2, ...) of a launch of G <= 256 workgroups, without read-modify-write atomics (an atomic addition
+// that every XCD must see is performed at the memory side, one after the other per address): every workgroup stores the epoch
+// into its OWN word once its own stores have completed, wave 0 of workgroup 0 polls the G words (four per lane) and then stores
+// the epoch into the go word, which everybody else polls.
+// sync[0]: go word; sync[1]: a wait ran out; sync[64 + b]: workgroup b's word.
+__device__ __forceinline__ bool lzg_barrier(unsigned *sync, unsigned epoch, int b, int G, int *s_ok) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's stores have completed (they are coherent by themselves)
+    __syncthreads();
+    if (threadIdx.x < 64) {                       // wave 0 (the other waves wait at the __syncthreads below)
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(sync + 64 + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        if (b == 0) {
+            for (int it = 0;; ++it) {
+                bool all = true;
+                for (int q = lane; q < G; q += 64)
+                    all = all && (__hip_atomic_load(sync + 64 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch);
+                if (__all(all)) break;
+                if (it > (1 << 21)) { ok = 0; break; }            // (wave-uniform)
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) __hip_atomic_store(ok ? sync : sync + 1, ok ? epoch : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == 0) {
+            for (int it = 0; __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch; ++it) {
+                if (it > (1 << 22) || __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok) __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) *s_ok = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return *s_ok != 0;
+}
+
+// res[c] = column (b + c G) of A . xs   for this workgroup's columns; MODE 0: all rows, 1: rows i >= j, 2: rows i <= j.
+// Four columns x TRIPS rows per thread are loaded before anything is added; sums in a fixed order.
+template <int TRIPS, int MODE>
+__device__ __forceinline__ void lzg_col_dots(const double *__restrict__ A, long ld, int n, const double *xs, int b, int G,
+                                             double *res, double (*red)[4]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c0 = 0; b + c0 * G < n; c0 += 4) {
+        double v[4][TRIPS];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int j = b + (c0 + cc) * G;
+#pragma unroll
+            for (int it = 0; it < TRIPS; ++it) {
+                const int i = tid + 256 * it;
+                const bool ok = j < n && i < n && (MODE == 0 || (MODE == 1 ? i >= j : i <= j));
+                v[cc][it] = ok ? A[i + (long) j * ld] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            double a = 0.0;
+#pragma unroll
+            for (int it = 0; it < TRIPS; ++it) a += v[cc][it] * xs[tid + 256 * it];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) red[cc][wave] = a;
+        }
+        __syncthreads();
+        if (tid < 4) res[c0 + tid] = ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3];
+        __syncthreads();
+    }
+}
+
+template <int TRIPS>
+__global__ __launch_bounds__(256) void hdm_lanczos_group_kernel(LzgArgs a) {
+    __shared__ double xs[TRIPS * 256];
+    __shared__ double res[16], red[4][4], vown[16], pown[16];
+    __shared__ double bc;
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, G = gridDim.x, n = a.n;
+    unsigned nbar = 0;
+    auto load_vec = [&](const double *x) {
+#pragma unroll
+        for (int it = 0; it < TRIPS; ++it) { const int i = tid + 256 * it; xs[i] = (i < n) ? lzg_ld(x + i) : 0.0; }
+        __syncthreads();
+    };
+    // sum of the G per-workgroup partial sums, the same order in every workgroup
+    auto total = [&](const double *p) {
+        double t = 0.0;
+        if (wave == 0) {
+            for (int q = lane; q < G; q += 64) t += lzg_ld(p + q);
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0) bc = t;
+        }
+        __syncthreads();
+        const double r = bc;
+        __syncthreads();
+        return r;
+    };
+    double hprev = a.hprev;
+    int done = 0;
+    unsigned long long tk = (a.dbg && b == 0 && tid == 0) ? __builtin_amdgcn_s_memrealtime() : 0ULL;
+    auto stamp = [&](int slot) {
+        if (a.dbg && b == 0 && tid == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            a.dbg[slot] += (double) (now - tk);
+            tk = now;
+        }
+    };
+    for (int s = 0; s < a.nsteps; ++s) {
+        const int k = a.k0 + s;
+        const double *vk = a.V + (long) k * a.ldv;
+        if (tid < 16) {                          // the owned elements of v_k and v_{k-1}, for the recurrence
+            const int j = b + tid * G;
+            vown[tid] = (j < n) ? lzg_ld(vk + j) : 0.0;
+            pown[tid] = (j < n && k > 0) ? lzg_ld(a.V + j + (long) (k - 1) * a.ldv) : 0.0;
+        }
+        load_vec(vk);
+        lzg_col_dots<TRIPS, 1>(a.Linv, a.ldl, n, xs, b, G, res, red);                 // t1 = Linv^T v
+        if (tid < 16 && b + tid * G < n) lzg_st(a.t1 + b + tid * G, res[tid]);
+        stamp(0);
+        if (!lzg_barrier(a.sync, a.epoch0 + (++nbar), b, G, &s_ok)) { if (b == 0 && tid == 0) a.out[2 * a.nsteps + 1] = 1.0; return; }
+        stamp(1);
+        load_vec(a.t1);
+        lzg_col_dots<TRIPS, 0>(a.dS, a.ldd, n, xs, b, G, res, red);                   // t2 = -dS t1
+        if (tid < 16 && b + tid * G < n) lzg_st(a.t2 + b + tid * G, -res[tid]);
+        stamp(2);
+        if (!lzg_barrier(a.sync, a.epoch0 + (++nbar), b, G, &s_ok)) { if (b == 0 && tid == 0) a.out[2 * a.nsteps + 1] = 1.0; return; }
+        stamp(3);
+        load_vec(a.t2);
+        lzg_col_dots<TRIPS, 2>(a.LinvT, a.ldt, n, xs, b, G, res, red);                // w = Linv t2
+        // the three-term recurrence on the owned elements (hdsdp_lanczos.c:199-218); thread 0 keeps the partial sums
+        if (tid == 0) {
+            double p = 0.0;
+            for (int c = 0; b + c * G < n; ++c) {
+                double x = res[c];
+                if (k > 0) x -= hprev * pown[c];
+                res[c] = x;
+                p += x * vown[c];
+            }
+            lzg_st(a.pa + b, p);
+        }
+        stamp(4);
+        if (!lzg_barrier(a.sync, a.epoch0 + (++nbar), b, G, &s_ok)) { if (b == 0 && tid == 0) a.out[2 * a.nsteps + 1] = 1.0; return; }
+        stamp(5);
+        const double alp = -total(a.pa);
+        if (tid == 0) {
+            double p = 0.0;
+            for (int c = 0; b + c * G < n; ++c) {
+                const double x = res[c] + alp * vown[c];
+                res[c] = x;
+                p += x * x;
+            }
+            lzg_st(a.pb + b, p);
+        }
+        stamp(6);
+        if (!lzg_barrier(a.sync, a.epoch0 + (++nbar), b, G, &s_ok)) { if (b == 0 && tid == 0) a.out[2 * a.nsteps + 1] = 1.0; return; }
+        stamp(7);
+        const double nrm = sqrt(total(a.pb));
+        if (b == 0 && tid == 0) { a.out[2 * s] = alp; a.out[2 * s + 1] = nrm; }
+        done = s + 1;
+        if (!(nrm > 0.0)) break;                 // (the same number in every workgroup)
+        if (tid < 16 && b + tid * G < n) {
+            const int j = b + tid * G;
+            const double xn = res[tid] * (1.0 / nrm);
+            lzg_st(a.V + j + (long) (k + 1) * a.ldv, xn);
+            a.blk[j] = xn;
+        }
+        hprev = nrm;
+        stamp(8);
+        if (!lzg_barrier(a.sync, a.epoch0 + (++nbar), b, G, &s_ok)) { if (b == 0 && tid == 0) a.out[2 * a.nsteps + 1] = 1.0; return; }
+        stamp(9);
+    }
+    if (b == 0 && tid == 0) a.out[2 * a.nsteps] = (double) done;
+}
+
+// B = A^T for an n x n column-major matrix (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void hdm_transpose_kernel(const double *__restrict__ A, long lda, double *__restrict__ B, long ldb, int n) {
+    __shared__ double t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + tx, j = j0 + r;
+        t[r][tx] = (i < n && j < n) ? A[i + (long) j * lda] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = j0 + tx, j = i0 + r;      // B(i, j) = A(j, i)
+        if (i < n && j < n) B[i + (long) j * ldb] = t[tx][r];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -488,9 +708,12 @@ __global__ __launch_bounds__(1024) void hdm_lanczos_whole_kernel(const double *_
 // z = V[:, 0..kc) * coef   (single workgroup; V column stride ldv)
 __global__ __launch_bounds__(1024) void hdm_lincomb_kernel(const double *__restrict__ V, long ldv, int kc,
                                                            const double *__restrict__ coef, double *__restrict__ z, int n) {
+    __shared__ double cf[64];              // (the coefficients come from mapped host memory: one trip each)
+    if (threadIdx.x < kc && threadIdx.x < 64) cf[threadIdx.x] = coef[threadIdx.x];
+    __syncthreads();
     for (int i = threadIdx.x; i < n; i += 1024) {
         double s = 0.0;
-        for (int c = 0; c < kc; ++c) s += V[i + (long) c * ldv] * coef[c];
+        for (int c = 0; c < kc; ++c) s += V[i + (long) c * ldv] * cf[c];
         z[i] = s;
     }
 }
@@ -506,6 +729,14 @@ __global__ __launch_bounds__(1024) void hdm_resnorm_kernel(const double *__restr
     if (lane == 0) red[wave] = s;
     __syncthreads();
     if (tid == 0) { double t = 0.0; for (int q = 0; q < 16; ++q) t += red[q]; out[0] = sqrt(t); }
+}
+
+// start vector of a test: the pseudo-random vector, or the previous test's Ritz image + 1e-3 x that vector (hdsdp_lanczos.c:166-181);
+// (product and sum rounded separately, as the host loop this replaces did)
+__global__ __launch_bounds__(1024) void hdm_warm_start_kernel(double *__restrict__ out, const double *__restrict__ warm,
+                                                              const double *__restrict__ startd, int n, int n16, int fresh) {
+    for (int i = threadIdx.x; i < n16; i += 1024)
+        out[i] = (i >= n) ? 0.0 : (fresh ? startd[i] : __dadd_rn(warm[i], __dmul_rn(1e-03, startd[i])));
 }
 
 // v <- v / |v| into the block's column 0 and into V[:, 0]   (single workgroup)
@@ -625,6 +856,65 @@ void jacobi_eig(int k, std::vector<double> A, std::vector<double> &d, std::vecto
     }
 }
 
+// The Ritz matrix of a Lanczos run is TRIDIAGONAL: implicit QL with Wilkinson shifts (the EISPACK tql2 recurrence) instead of the
+// cyclic Jacobi above, which took 1.1 ms at k = 30 and 3.7 ms over the ten checks of a 30-step test on a host core -- three
+// times the device time of those steps once they ran in one launch per group.  U: the symmetric k x k matrix (column-major; only
+// its diagonal and first subdiagonal are read).  Eigenvalues ascending in d, vectors in the columns of Y.  Returns false if an
+// eigenvalue does not converge in 60 sweeps (the caller then takes the Jacobi route).
+bool tridiag_eig(int k, const std::vector<double> &U, std::vector<double> &d, std::vector<double> &Y) {
+    std::vector<double> e(k, 0.0);
+    d.resize(k);
+    for (int i = 0; i < k; ++i) d[i] = U[(size_t) i * k + i];
+    for (int i = 0; i + 1 < k; ++i) e[i] = U[(size_t) i * k + i + 1];       // T(i + 1, i)
+    Y.assign((size_t) k * k, 0.0);
+    for (int i = 0; i < k; ++i) Y[(size_t) i * k + i] = 1.0;
+    for (int l = 0; l < k; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < k - 1; ++m) {
+                const double dd = fabs(d[m]) + fabs(d[m + 1]);
+                if (fabs(e[m]) + dd == dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 60) return false;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + copysign(r, g));
+                double sn = 1.0, cs = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = sn * e[i];
+                    const double b = cs * e[i];
+                    e[i + 1] = (r = hypot(f, g));
+                    if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+                    sn = f / r; cs = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * sn + 2.0 * cs * b;
+                    d[i + 1] = g + (p = sn * r);
+                    g = cs * r - b;
+                    double *yi = &Y[(size_t) i * k], *yi1 = &Y[(size_t) (i + 1) * k];
+                    for (int q = 0; q < k; ++q) {
+                        f = yi1[q];
+                        yi1[q] = sn * yi[q] + cs * f;
+                        yi[q] = cs * yi[q] - sn * f;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    for (int i = 0; i < k; ++i) {                 // ascending selection sort of (value, vector)
+        int mn = i;
+        for (int j = i + 1; j < k; ++j) if (d[j] < d[mn]) mn = j;
+        if (mn != i) {
+            std::swap(d[i], d[mn]);
+            for (int r = 0; r < k; ++r) std::swap(Y[(size_t) i * k + r], Y[(size_t) mn * k + r]);
+        }
+    }
+    return true;
+}
+
 }  // namespace
 
 void hdm_lanczos_start_vector(int n, double *p) {
@@ -690,7 +980,12 @@ int HdmLanczos::init(int n_) {
     HDM_HIP_CHECK(hipMalloc((void **) &bz, blk));
     HDM_HIP_CHECK(hipMalloc((void **) &warm, sizeof(double) * (size_t) n16));
     HDM_HIP_CHECK(hipMalloc((void **) &tmp, sizeof(double) * (size_t) n16));
-    HDM_HIP_CHECK(hipMalloc((void **) &scal, sizeof(double) * 64));
+    // the scalars that travel between host and device -- (alpha, beta) pairs, Ritz coefficients, residual norms -- live in one
+    // block of mapped pinned host memory: the kernels write their results straight into it and the host reads them after its
+    // synchronisation (a copy into pageable memory per group of steps cost more than the group's kernels at n = 2000)
+    HDM_HIP_CHECK(hipHostMalloc((void **) &scal_h, sizeof(double) * 128, hipHostMallocMapped));
+    memset(scal_h, 0, sizeof(double) * 128);
+    HDM_HIP_CHECK(hipHostGetDevicePointer((void **) &scal, scal_h, 0));
     HDM_HIP_CHECK(hipMalloc((void **) &part, sizeof(double) * 32 * (size_t) n16));
     for (double *b : {bv, b1, b2, bw, bz}) HDM_HIP_CHECK(hdm_memset_sync(b, 0, blk));
     HDM_HIP_CHECK(hdm_memset_sync(warm, 0, sizeof(double) * (size_t) n16));
@@ -708,9 +1003,12 @@ int HdmLanczos::init(int n_) {
 }
 
 void HdmLanczos::destroy() {
-    for (double *b : {V, bv, b1, b2, bw, bz, warm, tmp, scal, part, startd})
+    for (double *b : {V, bv, b1, b2, bw, bz, warm, tmp, part, startd, LT})
         if (b) (void) hipFree(b);
-    V = bv = b1 = b2 = bw = bz = warm = tmp = scal = part = startd = nullptr;
+    if (gsync) (void) hipFree(gsync);
+    if (scal_h) (void) hipHostFree(scal_h);
+    gsync = nullptr; scal_h = nullptr;
+    V = bv = b1 = b2 = bw = bz = warm = tmp = scal = part = startd = LT = nullptr;
 }
 
 // out (column 0 of a vector block) = Linv * ( -dS * ( Linv^T * in ) ): three HBM-bound matrix-vector products with
@@ -750,9 +1048,8 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
                                warm, nComputed == 0 ? 1 : 0, scal + 60);
         }
         HDM_HIP_CHECK(hipGetLastError());
-        double r[3] = {0.0, 0.0, 1.0};
-        HDM_HIP_CHECK(hipMemcpyAsync(r, scal + 60, sizeof(r), hipMemcpyDeviceToHost, s));
         HDM_HIP_CHECK(hipStreamSynchronize(s));
+        const double r[3] = {scal_h[60], scal_h[61], scal_h[62]};
         if (r[2] != 0.0) return 1;
         nComputed += 1;
         if (maxStep) *maxStep = r[0];
@@ -762,22 +1059,8 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
     const int md = maxdim, nh = md + 1;
     std::vector<double> H((size_t) nh * nh, 0.0);
     auto Hm = [&](int i, int j) -> double & { return H[(size_t) j * nh + i]; };
-    // starting vector: fresh, or the previous Ritz image + 1e-3 * the same pseudo-random vector (:166-181)
-    {
-        std::vector<double> v0(n16, 0.0);
-        if (nComputed == 0) {
-            for (int i = 0; i < n; ++i) v0[i] = start[i];
-            HDM_HIP_CHECK(hipMemcpyAsync(tmp, v0.data(), sizeof(double) * n16, hipMemcpyHostToDevice, s));
-            HDM_HIP_CHECK(hipStreamSynchronize(s));
-        } else {
-            HDM_HIP_CHECK(hipMemcpyAsync(v0.data(), warm, sizeof(double) * n16, hipMemcpyDeviceToHost, s));
-            HDM_HIP_CHECK(hipStreamSynchronize(s));
-            for (int i = 0; i < n; ++i) v0[i] += 1e-03 * start[i];
-            for (int i = n; i < n16; ++i) v0[i] = 0.0;
-            HDM_HIP_CHECK(hipMemcpyAsync(tmp, v0.data(), sizeof(double) * n16, hipMemcpyHostToDevice, s));
-            HDM_HIP_CHECK(hipStreamSynchronize(s));
-        }
-    }
+    // starting vector: fresh, or the previous Ritz image + 1e-3 * the same pseudo-random vector (:166-181), made on the device
+    hipLaunchKernelGGL(hdm_warm_start_kernel, dim3(1), dim3(1024), 0, s, tmp, warm, startd, n, n16, nComputed == 0 ? 1 : 0);
     HDM_HIP_CHECK(hipMemsetAsync(V, 0, sizeof(double) * (size_t) n16 * (md + 1), s));
     hipLaunchKernelGGL(hdm_normalize_kernel, dim3(1), dim3(1024), 0, s, tmp, V, bv, n16);
     HDM_HIP_CHECK(hipGetLastError());
@@ -791,6 +1074,30 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
     static const bool fuse_env = [] { const char *e = getenv("HDM_LANCZOS_FUSED"); return !(e && atoi(e) == 0); }();
     const bool fused = fuse_env && n16 <= LZ_FUSED_MAX && checkFreq >= 1;
     static const bool group_env = [] { const char *e = getenv("HDM_LANCZOS_GROUP"); return !(e && atoi(e) == 0); }();   // 0: one synchronisation per step (A/B)
+    // large blocks: the steps of a group in one launch of co-resident workgroups (hdm_lanczos_group_kernel); 0: a launch per product
+    static const bool big_env = [] { const char *e = getenv("HDM_LANCZOS_BIG"); return !(e && atoi(e) == 0); }();
+    bool big = big_env && big_ok && !fused && n16 > LZ_FUSED_MAX && n16 <= 4096 && checkFreq >= 1 && !hdm_flow_shared_device();
+    if (big) {
+        if (big_wg == 0) {
+            int dev = 0, cus = 0;
+            big_wg = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+                         ? std::min(LZG_WG, cus) : -1;
+            (void) hipGetLastError();
+        }
+        if (big_wg <= 0 || (n16 + big_wg - 1) / big_wg > 16) big = false;
+    }
+    static const bool dbg2 = [] { const char *e = getenv("HDSDP_MI355X_RATIO_DEBUG"); return e && atoi(e) >= 2; }();
+    if (big) {
+        if (dbg2) HDM_HIP_CHECK(hipMemsetAsync(bz + 4 * (size_t) n16, 0, sizeof(double) * 16, s));
+        if (!LT) HDM_HIP_CHECK(hipMalloc((void **) &LT, sizeof(double) * (size_t) n16 * n16));
+        if (!gsync) {
+            HDM_HIP_CHECK(hipMalloc((void **) &gsync, sizeof(unsigned) * (64 + LZG_WG)));
+            HDM_HIP_CHECK(hipMemsetAsync(gsync, 0, sizeof(unsigned) * (64 + LZG_WG), s));
+            sync_epoch = 0;
+        }
+        hipLaunchKernelGGL(hdm_transpose_kernel, dim3((n16 + 31) / 32, (n16 + 31) / 32), dim3(256), 0, s, Linv, ldl, LT, (long) n16, n16);
+        HDM_HIP_CHECK(hipGetLastError());
+    }
     double grp[2 * 8 + 1] = {0.0};               // (alpha, beta) of the current group of steps, fused form
     int grp_k0 = -1, grp_n = 0;
     for (k = 0; k < md; ++k) {
@@ -802,8 +1109,33 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
                 hipLaunchKernelGGL(hdm_lanczos_fused_kernel, dim3(1), dim3(1024), 0, s, Linv, ldl, dS, ldd, n16, V, (long) n16, k, grp_n,
                                    hprev, bv, scal + 44);
                 HDM_HIP_CHECK(hipGetLastError());
-                HDM_HIP_CHECK(hipMemcpyAsync(grp, scal + 44, sizeof(double) * (2 * grp_n + 1), hipMemcpyDeviceToHost, s));   // (scal + 8 .. + 39: Ritz coefficients)
                 HDM_HIP_CHECK(hipStreamSynchronize(s));
+                for (int q = 0; q < 2 * grp_n + 1; ++q) grp[q] = scal_h[44 + q];   // (scal + 8 .. + 39, + 64 .. + 95: Ritz coefficients)
+            }
+            hs[0] = grp[2 * (k - grp_k0)]; hs[1] = grp[2 * (k - grp_k0) + 1];
+        } else if (big) {
+            if (grp_k0 < 0 || k >= grp_k0 + grp_n) {
+                grp_k0 = k;
+                grp_n = std::min(std::min(checkFreq - (k % checkFreq), md - k), 8);
+                LzgArgs a = {};
+                a.epoch0 = sync_epoch; sync_epoch += 5u * (unsigned) grp_n;     // (the barrier words are never reset: epochs only grow)
+                scal_h[44 + 2 * grp_n + 1] = 0.0;                               // give-up word of this launch
+                a.Linv = Linv; a.ldl = ldl; a.LinvT = LT; a.ldt = n16; a.dS = dS; a.ldd = ldd; a.n = n16; a.V = V; a.ldv = n16;
+                a.k0 = k; a.nsteps = grp_n; a.hprev = hprev; a.blk = bv; a.t1 = b1; a.t2 = b2; a.pa = part; a.pb = part + 1024;
+                a.out = scal + 44; a.sync = gsync; a.dbg = dbg2 ? bz + 4 * (size_t) n16 : nullptr;
+                if (n16 <= 2048) hipLaunchKernelGGL(hdm_lanczos_group_kernel<8>, dim3(big_wg), dim3(256), 0, s, a);
+                else hipLaunchKernelGGL(hdm_lanczos_group_kernel<16>, dim3(big_wg), dim3(256), 0, s, a);
+                HDM_HIP_CHECK(hipGetLastError());
+                HDM_HIP_CHECK(hipStreamSynchronize(s));
+                for (int q = 0; q < 2 * grp_n + 1; ++q) grp[q] = scal_h[44 + q];
+                if (scal_h[44 + 2 * grp_n + 1] != 0.0) {
+                    HDM_HIP_CHECK(hipMemsetAsync(gsync, 0, sizeof(unsigned) * (64 + LZG_WG), s));
+                    // a grid-wide wait ran out (the workgroups were not all resident): this object goes back to a launch per
+                    // product for good, and this test starts over -- nothing of it has left the object yet
+                    fprintf(stderr, "[hdsdp_mi355x] lanczos: grid-wide wait timed out, falling back to one launch per product\n");
+                    big_ok = false;
+                    return solve(Linv, ldl, dS, ldd, s, maxStep, steps);
+                }
             }
             hs[0] = grp[2 * (k - grp_k0)]; hs[1] = grp[2 * (k - grp_k0) + 1];
         } else {
@@ -823,10 +1155,10 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
                                        V + (size_t) kk * n16, V + (size_t) (kk + 1) * n16, bv, n16, scal + 44 + 2 * q);
                 }
                 HDM_HIP_CHECK(hipGetLastError());
-                HDM_HIP_CHECK(hipMemcpyAsync(grp, scal + 44, sizeof(double) * (2 * grp_n), hipMemcpyDeviceToHost, s));
-                // the last norm of this group is the next group's hprev: keep it where the next group's first step reads it
-                HDM_HIP_CHECK(hipMemcpyAsync(scal + 43, scal + 44 + 2 * (grp_n - 1) + 1, sizeof(double), hipMemcpyDeviceToDevice, s));
                 HDM_HIP_CHECK(hipStreamSynchronize(s));
+                for (int q = 0; q < 2 * grp_n; ++q) grp[q] = scal_h[44 + q];
+                // the last norm of this group is the next group's hprev: keep it where the next group's first step reads it
+                scal_h[43] = scal_h[44 + 2 * (grp_n - 1) + 1];
             }
             hs[0] = grp[2 * (k - grp_k0)]; hs[1] = grp[2 * (k - grp_k0) + 1];
         }
@@ -839,7 +1171,7 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
             std::vector<double> U((size_t) kp * kp);
             for (int j = 0; j < kp; ++j)
                 for (int i = 0; i < kp; ++i) U[(size_t) j * kp + i] = 0.5 * (Hm(i, j) + Hm(j, i));
-            jacobi_eig(kp, U, d, Y);
+            if (!tridiag_eig(kp, U, d, Y)) jacobi_eig(kp, U, d, Y);
             const double eig1 = d[kp - 1], eig2 = kp > 1 ? d[kp - 2] : d[kp - 1];
             // (sign convention as in the single-launch form: largest-magnitude component positive)
             for (int col : {kp - 1, kp > 1 ? kp - 2 : kp - 1}) {
@@ -850,22 +1182,20 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
             const double *y1 = &Y[(size_t) (kp - 1) * kp], *y2 = kp > 1 ? &Y[(size_t) (kp - 2) * kp] : y1;
             const double resiVal = fabs(Hm(kp, k) * y1[k]);
             if (resiVal < 1e-04 || k >= md - 1) {
-                double r12[2];
                 // z1 = V y1 ; z2 = Op z1 ; warm start <- z2 ; resiVal1 = | z2 - eig1 z1 |
-                HDM_HIP_CHECK(hipMemcpyAsync(scal + 8, y1, sizeof(double) * kp, hipMemcpyHostToDevice, s));
+                // z2' = V y2 ; resiVal2 = | Op z2' - eig1 z2' |   (the reference uses eig1 here too, :262-266)
+                // (both coefficient vectors go into the mapped block, everything is queued, one synchronisation)
+                for (int r = 0; r < kp; ++r) { scal_h[8 + r] = y1[r]; scal_h[64 + r] = y2[r]; }
                 hipLaunchKernelGGL(hdm_lincomb_kernel, dim3(1), dim3(1024), 0, s, V, (long) n16, kp, scal + 8, bz, n16);
                 if (apply(Linv, ldl, dS, ldd, bz, bw, s)) return 1;
                 HDM_HIP_CHECK(hipMemcpyAsync(warm, bw, sizeof(double) * n16, hipMemcpyDeviceToDevice, s));
                 hipLaunchKernelGGL(hdm_resnorm_kernel, dim3(1), dim3(1024), 0, s, bw, bz, eig1, n16, scal + 2);
-                HDM_HIP_CHECK(hipStreamSynchronize(s));   // y1 lives in a host vector that is reused below
-                // z2' = V y2 ; resiVal2 = | Op z2' - eig1 z2' |   (the reference uses eig1 here too, :262-266)
-                HDM_HIP_CHECK(hipMemcpyAsync(scal + 8, y2, sizeof(double) * kp, hipMemcpyHostToDevice, s));
-                hipLaunchKernelGGL(hdm_lincomb_kernel, dim3(1), dim3(1024), 0, s, V, (long) n16, kp, scal + 8, bz, n16);
+                hipLaunchKernelGGL(hdm_lincomb_kernel, dim3(1), dim3(1024), 0, s, V, (long) n16, kp, scal + 64, bz, n16);
                 if (apply(Linv, ldl, dS, ldd, bz, bw, s)) return 1;
                 hipLaunchKernelGGL(hdm_resnorm_kernel, dim3(1), dim3(1024), 0, s, bw, bz, eig1, n16, scal + 3);
                 HDM_HIP_CHECK(hipGetLastError());
-                HDM_HIP_CHECK(hipMemcpyAsync(r12, scal + 2, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
                 HDM_HIP_CHECK(hipStreamSynchronize(s));
+                const double r12[2] = {scal_h[2], scal_h[3]};
                 // after the second apply() the vector block bv still holds v_{k+1}: the recurrence can continue
                 const double resiVal1 = r12[0], resiVal2 = r12[1];
                 const double resiDiff = eig1 - eig2 - resiVal2;
@@ -881,6 +1211,13 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
                 }
             }
         }
+    }
+    if (big && dbg2) {
+        double t[10];
+        HDM_HIP_CHECK(hipMemcpy(t, bz + 4 * (size_t) n16, sizeof(t), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[hdsdp_mi355x ratio] group kernel, workgroup 0, us: Linv^T v %.0f | wait %.0f | dS t1 %.0f | wait %.0f | Linv t2 + recurrence %.0f | wait %.0f | "
+                        "alpha %.0f | wait %.0f | norm %.0f | wait %.0f\n", t[0] / 100, t[1] / 100, t[2] / 100, t[3] / 100, t[4] / 100, t[5] / 100, t[6] / 100,
+                t[7] / 100, t[8] / 100, t[9] / 100);
     }
     nComputed += 1;
     if (maxStep) *maxStep = step;

@@ -411,6 +411,7 @@ void HMiSDPAFree(HMiSDPA **pp);
  *  HDM_LANCZOS_WHOLE              1         small blocks: whole ratio test in one launch                  test_gpu_switches.py
  *  HDM_LANCZOS_FUSED              1         small blocks: three Lanczos steps per launch                  test_gpu_switches.py
  *  HDM_LANCZOS_GROUP              1         large blocks: steps between Ritz checks queued back to back   test_gpu_switches.py
+ *  HDM_LANCZOS_BIG                1         large blocks: those steps in one launch of co-resident groups test_gpu_switches.py
  *  -- output only (no code path changes) --------------------------------------------------------------------------------
  *  HDSDP_MI355X_CALL_STATS        0         table of wall time below the C ABI at exit                    tools/small_driver_stats.sh
  *  HDSDP_MI355X_TRACE             0         synchronise and report after every entry                      (diagnostic)

@@ -21,7 +21,8 @@ SETTINGS = [
     {"HDSDP_MI355X_SPARSE_KKT": "0"}, {"HDSDP_MI355X_KKT_RCM": "0"}, {"HDSDP_MI355X_KKT_ENVELOPE": "0"}, {"HDSDP_MI355X_KKT_TILES": "0"},
     {"HDSDP_MI355X_FORCE_GEMM": "1"},
     {"HDM_LANCZOS_WHOLE": "0"}, {"HDM_LANCZOS_WHOLE": "0", "HDM_LANCZOS_FUSED": "0"},
-    {"HDM_LANCZOS_WHOLE": "0", "HDM_LANCZOS_FUSED": "0", "HDM_LANCZOS_GROUP": "0"},
+    {"HDM_LANCZOS_WHOLE": "0", "HDM_LANCZOS_FUSED": "0", "HDM_LANCZOS_GROUP": "0"}, {"HDM_LANCZOS_BIG": "0"},
+    {"HDM_LANCZOS_BIG": "0", "HDM_LANCZOS_GROUP": "0"},
     {"HDM_SYM_COMBINE_SKY": "0"}, {"HDM_SHARE_T_SLABS": "0"}, {"HDM_NSPLIT": "24"}, {"HDM_BC": "8"}, {"HDM_TCAP_GIB": "1"},
     {"HDM_PERSIST": "0"}, {"HDM_PERSIST_RESERVE_CUS": "200"},
     {"HDM_DIAG_SWEEP": "0"}, {"HDM_TRSV_FLOW": "0"}, {"HDM_GRAPHS": "0"},
