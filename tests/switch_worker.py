@@ -16,9 +16,13 @@ out = {}
 shards = int(os.environ.get("SWITCH_WORKER_SHARDS", "1"))
 if shards > 1:
     api.set_devices([0] * shards, shard_min_dim=32)      # (chain16's 5 x 5 blocks stay plain cones: its operator stays sparse)
-for name in ("syn100", "gpp100_B", "theta1_A", "mix40_A", "syn640x24"):
+for name in ("syn100", "gpp100_B", "theta1_A", "mix40_A", "syn640x24", "syn2304x6"):
     if name == "syn640x24":     # several 128-tiles per side: the tiled kernels, two congruence batches, many Gram splits
         n, m, Rd, tau = 640, 24, -800.0, 1.0
+        y = 0.03 * np.cos(0.9 * np.arange(m))
+        cone = api.SDPCone.synthetic(n, m)
+    elif name == "syn2304x6":   # past 2048: the sixteen-trip form of the large-block Lanczos launch, 18 tiles per side
+        n, m, Rd, tau = 2304, 6, -3000.0, 1.0
         y = 0.03 * np.cos(0.9 * np.arange(m))
         cone = api.SDPCone.synthetic(n, m)
     else:
