@@ -205,8 +205,7 @@ hdsdp_retcode build_primal_general(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, con
     q.A = c->Xup; q.lda = ldx; q.B = c->Xup; q.ldb = ldx; q.C = c->Pr2;
     hdsdp_retcode rc = HDSDP_RETCODE_OK;
     if (hdm_launch_gemm(q, g.stream) ||
-        hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xup, c->Pr2, ldx, pv->vecs, pv->vecs + m,
-                     c->rows_own, 2.0, 2.0 * c->Rd, g.stream))
+        cone_sym_dot2(c, c->Xup, c->Pr2, ldx, pv->vecs, pv->vecs + m, 2.0, 2.0 * c->Rd))
         rc = HDSDP_RETCODE_FAILED;
     for (int qi = 0; qi < c->mloc && rc == HDSDP_RETCODE_OK; ++qi) {
         // this fallback multiplies with A_L as a generic operand in both orientations: unpack the row's skyline storage
@@ -223,8 +222,7 @@ hdsdp_retcode build_primal_general(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, con
         q.A = c->Pr1; q.lda = ldx; q.B = c->Xup; q.ldb = ldx; q.b_kmajor = 1; q.C = c->Pr2; q.beta = 0.0;
         if (hdm_launch_gemm(q, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
         if (hipMemsetAsync(row, 0, sizeof(double) * (size_t) m, g.stream) != hipSuccess ||
-            hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Pr2, nullptr, ldx, row, row,
-                         c->rows_own, 2.0, 0.0, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
+            cone_sym_dot2(c, c->Pr2, nullptr, ldx, row, row, 2.0, 0.0)) { rc = HDSDP_RETCODE_FAILED; break; }
         hipLaunchKernelGGL(mi_put_row_kernel, dim3((m + 255) / 256), dim3(256), 0, g.stream, Mview, c->own[qi], row, m);
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) rc = HDSDP_RETCODE_FAILED;
@@ -310,8 +308,7 @@ hdsdp_retcode corrector_components(MiCone *c, HdmChol &ch, MiKKTPriv *pv, int m)
     }
     // A is stored in A_L form: <A, X> = 2 <A_L, X>
     if (c->world == 1) {
-        RC(hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, pv->vecs,
-                        pv->vecs + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));
+        RC(cone_sym_dot2(c, c->Xinv, Y, ch.npad, pv->vecs, pv->vecs + m, 2.0, 2.0 * c->Rd));
         return HDSDP_RETCODE_OK;
     }
     // Sharded block: pv->vecs is the accumulator of the whole operator (every engine cone adds into it), so the sum
@@ -319,8 +316,7 @@ hdsdp_retcode corrector_components(MiCone *c, HdmChol &ch, MiKKTPriv *pv, int m)
     // multiply what the cones before this one have put there by the number of ranks.
     if (!c->corr) HIP_RC(hipMalloc((void **) &c->corr, sizeof(double) * 2 * (size_t) m));
     HIP_RC(hipMemsetAsync(c->corr, 0, sizeof(double) * 2 * (size_t) m, g.stream));
-    RC(hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xinv, Y, ch.npad, c->corr,
-                    c->corr + m, c->rows_own, 2.0, 2.0 * c->Rd, g.stream));
+    RC(cone_sym_dot2(c, c->Xinv, Y, ch.npad, c->corr, c->corr + m, 2.0, 2.0 * c->Rd));
     HIP_RC(hipStreamSynchronize(g.stream));
     if (!c->allreduce || c->allreduce(c->xctx, c->corr, (int64_t) 2 * m)) return HDSDP_RETCODE_FAILED;
     if (c->kkt_owner) RC(hdm_axpy_mat(pv->vecs, pv->vecs, c->corr, 1.0, 2L * m, g.stream));

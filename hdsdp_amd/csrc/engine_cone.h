@@ -415,6 +415,13 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
     return 0;
 }
 
+// <A_i, X> (and <A_i, Y>) over the owned constraints: from the zero-suppressed copy when the cone has one, else from the dense storage
+int cone_sym_dot2(MiCone *c, const double *X, const double *Y, long ldx, double *outx, double *outy, double sx, double sy) {
+    if (c->zs_state == 1)
+        return hdm_sym_dot2_zs(c->zs, c->n16, c->n16, X, Y, ldx, outx, outy, c->rows_own, sx, sy, g.stream);
+    return hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, X, Y, ldx, outx, outy, c->rows_own, sx, sy, g.stream);
+}
+
 hdsdp_retcode cone_factor_S(MiCone *c, int *isPsd);
 hdsdp_retcode cone_factor_check(MiCone *c, int *isPsd);
 hdsdp_retcode cone_checker(MiCone *c, HdmChol **out);
@@ -767,8 +774,7 @@ void cone_a_times_x(void *cd, double *X, double *ATimesX) {
     if (hipMalloc((void **) &out, sizeof(double) * 2 * (size_t) c->m) != hipSuccess) return;
     (void) hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t) c->m, g.stream);
     // A is stored in A_L form: <A, X> = 2 <A_L, X> for symmetric X
-    if (hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, c->Xup, nullptr, ldx, out, out + c->m,
-                     c->rows_own, 2.0, 0.0, g.stream) == 0) {
+    if (cone_sym_dot2(c, c->Xup, nullptr, ldx, out, out + c->m, 2.0, 0.0) == 0) {
         if (c->world > 1 && c->allreduce) { (void) hipStreamSynchronize(g.stream); (void) c->allreduce(c->xctx, out, c->m); }
         std::vector<double> h(c->m);
         if (hipMemcpyAsync(h.data(), out, sizeof(double) * c->m, hipMemcpyDeviceToHost, g.stream) == hipSuccess &&

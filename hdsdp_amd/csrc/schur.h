@@ -48,5 +48,8 @@ struct HdmZs {
 // builds the copy unless more than max_fill of the positions are non-zero (then out->val stays null: not worth the memory)
 int hdm_zs_build(const double *A, long astride, int m, long sky, double max_fill, HdmZs *out, hipStream_t s);
 void hdm_zs_free(HdmZs *z);
+// <A_c, X>, <A_c, Y> of all matrices from the copy (what hdm_sym_dot2 computes from the dense storage; other summation order)
+int hdm_sym_dot2_zs(const HdmZs &z, int n, long lda, const double *X, const double *Y, long ldx, double *outx, double *outy,
+                    const int *rows_global, double sx, double sy, hipStream_t s);
 int hdm_sym_combine_zs(const HdmZs &z, const double *y, const double *C, double tau, double eye, double *S, int n, long lda,
                        long lds_, hipStream_t s);

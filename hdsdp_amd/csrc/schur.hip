@@ -460,6 +460,124 @@ __global__ __launch_bounds__(128) void hdm_sym_combine_zs_kernel(const unsigned 
     }
 }
 
+// <A_c, X> and <A_c, Y> for all matrices from the zero-suppressed copy (the corrector's two dot products per constraint,
+// hdsdp_conic_sdp.c:1035-1056; primal recovery): workgroup = one chunk, two waves of eight words as in the sweep above.  A lane
+// keeps the X and Y elements of its eight positions in registers for the whole pass -- X and Y are read ONCE, where the dense
+// kernel re-reads them for every group of four matrices -- and multiplies them with the values of matrix after matrix; the
+// per-lane products of 16 matrices are parked in LDS and added up across the lanes by 16 x 4 lanes at a time (two shuffles to
+// finish), so a matrix costs four LDS accesses per lane instead of a dozen cross-lane steps.  Partial sums per (chunk, wave,
+// matrix) go to `part`, folded in fixed order by the two kernels below.
+#define ZS_DB 16
+__global__ __launch_bounds__(128) void hdm_sym_dot2_zs_kernel(const unsigned long long *__restrict__ meta,
+                                                               const double *__restrict__ val,
+                                                               const unsigned long long *__restrict__ base, int m,
+                                                               const double *__restrict__ X, const double *__restrict__ Y, long ldx,
+                                                               int n, int lda, long sky, double *__restrict__ part) {
+    __shared__ double tile[2][2][ZS_DB][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double *v0 = val + base[blockIdx.x];
+    const unsigned long long *rec = meta + (long) blockIdx.x * m * 24 + 8 * wave;
+    const unsigned *offp = reinterpret_cast<const unsigned *>(meta + (long) blockIdx.x * m * 24 + 16) + 8 * wave;
+    double xv[8], yv[8];
+    const int tlast = (lda + 127) / 128 - 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const long sp = (long) blockIdx.x * 1024 + 512 * wave + 64 * q + lane;
+        xv[q] = 0.0; yv[q] = 0.0;
+        if (sp < sky) {
+            int t = 0;
+            while (t < tlast && hdm_sky_panel(t + 1, lda) <= sp) ++t;
+            const long local = sp - hdm_sky_panel(t, lda);
+            const int ldp = lda - 128 * t;
+            const int i = 128 * t + (int) (local % ldp), j = 128 * t + (int) (local / ldp);
+            if (i >= j && i < n && j < n) {
+                xv[q] = X[i + (long) j * ldx];
+                if (Y) yv[q] = Y[i + (long) j * ldx];
+            }
+        }
+    }
+    double *prow = part + ((long) (blockIdx.x * 2 + wave) * m) * 2;
+    // two matrices per trip, the next trip's metadata requested behind this trip's value loads (as in the sweep above)
+    auto load_trip = [&](HdmZsTrip &t, int c) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cc = min(c + u, m - 1);          // (an odd count repeats the last matrix; its products are not kept)
+            const unsigned long long *r = rec + (long) cc * 24;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t.mk[u][q] = r[q];
+            t.off[u] = offp[(long) cc * 48];
+        }
+    };
+    auto issue = [&](const HdmZsTrip &t, double (&a)[2][8]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            unsigned o = t.off[u];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                a[u][q] = __builtin_amdgcn_inverse_ballot_w64(t.mk[u][q]) ? v0[o + hdm_lanes_below(t.mk[u][q])] : 0.0;
+                o += (unsigned) __popcll(t.mk[u][q]);
+            }
+        }
+    };
+    auto park = [&](const double (&a)[2][8], int slot) {       // products of the trip's two matrices into tile rows slot, slot + 1
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            double px = 0.0, py = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { px += a[u][q] * xv[q]; py += a[u][q] * yv[q]; }
+            tile[wave][0][slot + u][lane] = px;
+            tile[wave][1][slot + u][lane] = py;
+        }
+    };
+    HdmZsTrip A, B;
+    double a[2][8];
+    load_trip(A, 0);
+    for (int c0 = 0; c0 < m; c0 += ZS_DB) {
+        const int nb = min(ZS_DB, m - c0);
+        // (ZS_DB / 2 = 8 trips per batch, A and B alternating; trips past the end of the data reload the last matrix and park
+        // products nobody reads -- the loop stays uniform)
+#pragma unroll
+        for (int tr = 0; tr < ZS_DB / 2; tr += 2) {
+            issue(A, a);
+            __builtin_amdgcn_sched_barrier(0);
+            load_trip(B, c0 + 2 * tr + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            park(a, 2 * tr);
+            issue(B, a);
+            __builtin_amdgcn_sched_barrier(0);
+            load_trip(A, c0 + 2 * tr + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            park(a, 2 * tr + 2);
+        }
+        __syncthreads();
+        {
+            const int u = lane & 15, qt = lane >> 4;
+            double sx = 0.0, sy = 0.0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { sx += tile[wave][0][u][qt * 16 + t]; sy += tile[wave][1][u][qt * 16 + t]; }
+            sx += __shfl_xor(sx, 16, 64); sy += __shfl_xor(sy, 16, 64);
+            sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64);
+            if (lane < nb) { prow[(long) (c0 + lane) * 2] = sx; prow[(long) (c0 + lane) * 2 + 1] = sy; }
+        }
+        __syncthreads();
+    }
+}
+
+// out[y][c][v] = sum over the rows r = y, y + nfold, ... of part[r][c][v]   (first level of the fold; the second is
+// hdm_sym_dot2_reduce_kernel over the nfold rows)
+__global__ void hdm_dot2_fold_kernel(const double *__restrict__ part, long rows, int count, int nfold, double *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (c >= count) return;
+    double tx = 0.0, ty = 0.0;
+    for (long r = y; r < rows; r += nfold) {
+        const double2 v = *reinterpret_cast<const double2 *>(part + (r * count + c) * 2);
+        tx += v.x; ty += v.y;
+    }
+    out[((long) y * count + c) * 2] = tx;
+    out[((long) y * count + c) * 2 + 1] = ty;
+}
+
 // ------------------------------------------------------------------------------------------
 // rank-one (M2) path.  U = Linv * [a_1 .. a_m] (n x m), Gm = U^T U  =>  Gm_ij = a_i' S^-1 a_j
 //   M_ij = s_i s_j Gm_ij^2 ; ASinv_i = s_i Gm_ii ; ASinvRdSinv_i = Rd s_i |S^-1 a_i|^2 = Rd s_i |Linv^T u_i|^2
@@ -742,6 +860,29 @@ int hdm_sym_combine_zs(const HdmZs &z, const double *y, const double *C, double 
                        long lds_, hipStream_t s) {
     hipLaunchKernelGGL(hdm_sym_combine_zs_kernel, dim3((unsigned) z.nchunk), dim3(128), 0, s, z.meta, z.val, z.base, z.m, y, C, tau,
                        eye, S, n, (int) lda, lds_, z.sky);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_sym_dot2_zs(const HdmZs &z, int n, long lda, const double *X, const double *Y, long ldx, double *outx, double *outy,
+                    const int *rows_global, double sx, double sy, hipStream_t s) {
+    if (z.m <= 0) return 0;
+    const int nfold = 64;
+    const long rows = 2 * z.nchunk;
+    static thread_local double *part = nullptr;       // per host thread: a thread drives one device
+    static thread_local size_t part_cap = 0;
+    const size_t need = sizeof(double) * 2 * (size_t) z.m * (size_t) (rows + nfold);
+    if (need > part_cap) {
+        if (part) (void) hipFree(part);
+        HDM_HIP_CHECK(hipMalloc((void **) &part, need));
+        part_cap = need;
+    }
+    double *folded = part + 2 * (size_t) z.m * rows;
+    hipLaunchKernelGGL(hdm_sym_dot2_zs_kernel, dim3((unsigned) z.nchunk), dim3(128), 0, s, z.meta, z.val, z.base, z.m, X, Y, ldx, n,
+                       (int) lda, z.sky, part);
+    hipLaunchKernelGGL(hdm_dot2_fold_kernel, dim3((z.m + 255) / 256, nfold), dim3(256), 0, s, part, rows, z.m, nfold, folded);
+    hipLaunchKernelGGL(hdm_sym_dot2_reduce_kernel, dim3((z.m + 255) / 256), dim3(256), 0, s, folded, z.m, nfold, Y ? 1 : 0, outx,
+                       outy, rows_global, sx, sy);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -499,8 +499,16 @@ def test_sweeps_from_the_zero_suppressed_copy_give_the_same_bits(case):
         step = cone.ratio_test(0.3, dy, 0.1)
         ok = cone.check_is_interior(tau, y + 0.5 * min(step, 1.0) * dy)     # (a point on the line: axpy short-cut or a sweep, as the block's size says)
         S2 = cone.get_dual().copy()
-        got.append((S, step, bool(ok), S2))
+        # the corrector's <A_i, S^-1>, Rd <A_i, S^-2> read the same copy (other summation order than the dense pass: not the same bits)
+        assert cone.check_is_interior(tau, y)
+        kkt = api.KKT(m, [cone])
+        kkt.build_up(api.KKT_TYPE_CORRECTOR)
+        ex = kkt.export()
+        cor = np.concatenate([np.asarray(ex["ASinv"]), np.asarray(ex["ASinvRdSinv"])])
+        kkt.destroy()
+        got.append((S, step, bool(ok), S2, cor))
         cone.destroy()
     assert np.array_equal(got[0][0], got[1][0])
     assert got[0][1] == got[1][1] and got[0][2] == got[1][2]
     assert np.array_equal(got[0][3], got[1][3])
+    assert np.max(np.abs(got[0][4] - got[1][4])) <= 1e-12 * np.max(np.abs(got[0][4]))
