@@ -292,6 +292,13 @@ def main():
             stage["chol_S"] += t1 - t; stage["buildup"] += t2 - t1; stage["factor_M"] += t3 - t2; stage["solve3"] += t4 - t3
         return d1, d2, d3
 
+    # What THIS box's matrix pipe sustains: a register-only fp64 MFMA loop on full-range operands, two workgroups per CU, long
+    # enough (about 0.3 s) for the power management to settle.  The load is power-limited (profiles/r03_f_power_clock.txt) and
+    # boxes differ by several per cent; the bench line carries the number so that a run can be read against its own box.
+    probe_tf = None
+    if rank == 0 and not os.environ.get("HDM_BENCH_NO_PROBE"):
+        probe_tf = float(lib.HMiMfmaIssueProbe(300, 2, 350000))
+        lib.HMiDeviceSynchronize()
     for _ in range(args.warmup):
         step(False)
     lib.HMiSetKernelTiming(1)
@@ -348,6 +355,10 @@ def main():
                                    "diagonal_tiles_ms_per_step": round(float(kms[4]) / args.steps, 3),
                                    "diagonal_tiles_tflops": round(float(kfl[4] / max(kms[4], 1e-9) / 1e9), 2)},
         "helper_gemms_ms_per_step": round(float(kms[0]) / args.steps, 3),
+        # this box's own ceiling (register-only fp64 MFMA loop on random operands, measured just before the timed region) and the
+        # dominant kernel against it; `frac` above stays against the vendor peak
+        "box_mfma_loop_tflops": None if probe_tf is None else round(probe_tf, 2),
+        "frac_of_box_mfma_loop": None if not probe_tf else round(achieved / probe_tf, 4),
     }
     out = {
         "metric": "IPM iterations/sec (Schur build+factor+solve), n=%d m=%d dense SDP" % (n, m),
