@@ -400,7 +400,7 @@ __global__ __launch_bounds__(128) void hdm_sym_combine_zs_kernel(const unsigned 
             unsigned o = t.off[u];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                a[u][q] = __builtin_amdgcn_inverse_ballot_w64(t.mk[u][q]) ? v0[o + hdm_lanes_below(t.mk[u][q])] : 0.0;
+                a[u][q] = v0[o + hdm_lanes_below(t.mk[u][q])];      // (unconditional: the lanes of a word's zeros read a neighbour's value and drop it below)
                 o += (unsigned) __popcll(t.mk[u][q]);
             }
         }
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(128) void hdm_sym_combine_zs_kernel(const unsigned 
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] -= t.y[u] * a[u][q];
+            for (int q = 0; q < 8; ++q) acc[q] -= t.y[u] * (__builtin_amdgcn_inverse_ballot_w64(t.mk[u][q]) ? a[u][q] : 0.0);
     };
     HdmZsTrip A, B;
     double a[2][8];
@@ -515,17 +515,20 @@ __global__ __launch_bounds__(128) void hdm_sym_dot2_zs_kernel(const unsigned lon
             unsigned o = t.off[u];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                a[u][q] = __builtin_amdgcn_inverse_ballot_w64(t.mk[u][q]) ? v0[o + hdm_lanes_below(t.mk[u][q])] : 0.0;
+                a[u][q] = v0[o + hdm_lanes_below(t.mk[u][q])];      // (unconditional, as in the sweep)
                 o += (unsigned) __popcll(t.mk[u][q]);
             }
         }
     };
-    auto park = [&](const double (&a)[2][8], int slot) {       // products of the trip's two matrices into tile rows slot, slot + 1
+    auto park = [&](const HdmZsTrip &t, const double (&a)[2][8], int slot) {   // products of the trip's two matrices into tile rows slot, slot + 1
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             double px = 0.0, py = 0.0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { px += a[u][q] * xv[q]; py += a[u][q] * yv[q]; }
+            for (int q = 0; q < 8; ++q) {
+                const double av = __builtin_amdgcn_inverse_ballot_w64(t.mk[u][q]) ? a[u][q] : 0.0;
+                px += av * xv[q]; py += av * yv[q];
+            }
             tile[wave][0][slot + u][lane] = px;
             tile[wave][1][slot + u][lane] = py;
         }
@@ -543,12 +546,12 @@ __global__ __launch_bounds__(128) void hdm_sym_dot2_zs_kernel(const unsigned lon
             __builtin_amdgcn_sched_barrier(0);
             load_trip(B, c0 + 2 * tr + 2);
             __builtin_amdgcn_sched_barrier(0);
-            park(a, 2 * tr);
+            park(A, a, 2 * tr);
             issue(B, a);
             __builtin_amdgcn_sched_barrier(0);
             load_trip(A, c0 + 2 * tr + 4);
             __builtin_amdgcn_sched_barrier(0);
-            park(a, 2 * tr + 2);
+            park(B, a, 2 * tr + 2);
         }
         __syncthreads();
         {
