@@ -186,6 +186,20 @@ int cone_alloc_common(MiCone *c) {
 
 int cone_alloc_gemm_work(MiCone *c) {
     const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
+    {   // The zero-suppressed sweep copy (cone_build_zs) was made at creation, before these work buffers: it must never be the
+        // reason they come out smaller -- every allocation below degrades quietly (smaller batches, fewer splits) when memory is
+        // short.  If what is free does not cover a generous bound of what the builders take, the copy goes (the sweeps then read
+        // the dense storage).
+        size_t fr = 0, tot = 0;
+        if (c->zs_state == 1 && hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            const double rows = (double) std::max(1, c->mloc);
+            const double want = std::min(32.0 * (1L << 30), (double) nn * rows) +
+                                sizeof(double) * (double) c->world * c->npb_loc * c->Lr * 16 * (c->world == 1 ? 1.0 : 2.0) +
+                                41.0 * (1L << 30);
+            if ((double) fr < want) { hdm_zs_free(&c->zs); c->zs_state = -1; }
+        }
+        (void) hipGetLastError();
+    }
     // batch size: as many constraints per launch as 32 GiB of intermediates allow, at most 1024 (each launch pays a
     // dispatch ramp and a tail: measured step time 400.9 / 396.8 / 393.2 / 393.2 ms at 256 / 512 / 1000 / 2000 per launch on
     // one box).  The launches are evened out (2000 rows -> 2 x 1000, a rank's 250 rows -> one launch); the kernel's
@@ -322,6 +336,22 @@ void cone_get_kkt_map(void *cd, int iCol, int *schurMatCol) {
     if (c->kkt_counted < c->mloc && c->own[c->kkt_counted] == iCol) c->kkt_counted += 1;
 }
 
+// The zero-suppressed copy of the constraint data (schur.h: HdmZs) that the S / dS sweeps and the corrector's dot products
+// read: made once, when the block's data has arrived (cone creation -- format preparation like the unpacking into A_L form; the
+// two passes and the 14 GB allocation take 0.3-0.8 s at n = m = 2000, which does not belong into the first line search),
+// for blocks whose sweep costs something -- 16 MiB of constraint data or more -- unless over 60 % of the stored positions
+// are non-zero or the memory is not there (then the sweeps read the dense storage).  HDSDP_MI355X_ZS=0: never; 2: any size, any fill.
+int cone_build_zs(MiCone *c) {
+    static const int zs_env = [] { const char *e = getenv("HDSDP_MI355X_ZS"); return e ? atoi(e) : 1; }();
+    if (c->zs_state != 0) return 0;
+    c->zs_state = -1;
+    const long sweep_bytes = (long) c->mloc * c->n * (c->n + 1) * 4;
+    if (!c->Afull || c->mloc <= 0 || !zs_env || !(zs_env >= 2 || sweep_bytes >= (16L << 20))) return 0;
+    if (hdm_zs_build(c->Afull, c->astride, c->mloc, c->astride, zs_env >= 2 ? 1.0 : 0.6, &c->zs, g.stream)) return 1;
+    if (c->zs.val) c->zs_state = 1;
+    return 0;
+}
+
 // S <- tau*C - sum y_i A_i - Rd*I (+ perturb)   hdsdp_conic_sdp.c:343-402, :1616-1633
 // Sharded: every rank sums its own rows (rank 0 also adds tau*C and the identity term), then all-reduce.
 int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, const double *eye_override = nullptr) {
@@ -392,17 +422,8 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
         if (target == c->S) c->aff_chain = 0;
     }
     const double lead = (c->rank == 0) ? 1.0 : 0.0;
-    // The sweep reads the zero-suppressed copy of the constraint data where one exists (schur.h: HdmZs; built at the first
-    // sweep that costs something -- 16 MiB of constraint data or more -- unless over 60 % of the stored positions are non-zero:
-    // the synthetic family's 32 GB are 13.6 GB there).  Bit-identical sums.  HDSDP_MI355X_ZS=0: never; 2: any size, any fill.
-    static const int zs_env = [] { const char *e = getenv("HDSDP_MI355X_ZS"); return e ? atoi(e) : 1; }();
-    if (any && c->zs_state == 0) {
-        c->zs_state = -1;
-        if (zs_env && (zs_env >= 2 || sweep_bytes >= (16L << 20))) {
-            if (hdm_zs_build(c->Afull, c->astride, c->mloc, c->astride, zs_env >= 2 ? 1.0 : 0.6, &c->zs, g.stream)) return 1;
-            if (c->zs.val) c->zs_state = 1;
-        }
-    }
+    // The sweep reads the zero-suppressed copy of the constraint data where one exists (cone_build_zs: made at creation).
+    if (any && c->zs_state == 0 && cone_build_zs(c)) return 1;
     if (any && c->zs_state == 1) {
         if (hdm_sym_combine_zs(c->zs, c->ydev, c->Cfull, lead * tau, lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)),
                                target, c->n, c->n16, c->n16, g.stream)) return 1;

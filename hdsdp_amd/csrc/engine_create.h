@@ -141,6 +141,7 @@ static hdsdp_retcode make_sdp_cone(MiCone **out, int nRow, int nCol, const int *
             return HDSDP_RETCODE_FAILED;
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    if (cone_build_zs(c)) return HDSDP_RETCODE_FAILED;
     *out = c;
     return HDSDP_RETCODE_OK;
 }
@@ -177,6 +178,7 @@ static hdsdp_retcode make_synth_cone(MiCone **out, int nCol, int nRow, int rank,
         c->trA[i] = tr;
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    if (cone_build_zs(c)) return HDSDP_RETCODE_FAILED;
     *out = c;
     return HDSDP_RETCODE_OK;
 }

@@ -93,8 +93,8 @@ class ShardPlan:
         mpad = _roundup(self.m, 128)
         parts["Schur matrix M + its factor (replicated)"] = 3 * mpad * mpad * 8
         parts["total"] = sum(parts.values())
-        # not in the total: the zero-suppressed copy of A the S / dS sweeps read (csrc/schur.h, built at the first sweep if
-        # the memory is there; data dependent -- 8 bytes per non-zero + 192 bytes per 1024 positions; 40 % fill assumed here)
+        # not in the total: the zero-suppressed copy of A the S / dS sweeps read (csrc/schur.h, made at cone creation and given
+        # back if the work buffers need the room; data dependent -- 8 bytes per non-zero + 192 bytes per 1024 positions; 40 % fill assumed here)
         parts["optional: zero-suppressed sweep copy of A at 40 % fill"] = int(mloc * sky * (0.4 * 8 + 192.0 / 1024))
         return parts
 
