@@ -8,9 +8,11 @@
 // work runs:
 //   * the operator is three dense matrix-vector products with the explicit lower-triangular Linv that the Schur
 //     build needs anyway (HBM-bound: 2 x 16 + 32 MB at n = 2000) instead of two latency-bound triangular solves,
-//   * one fused single-workgroup kernel per step does the three-term recurrence, both reductions and the
-//     normalisation, and returns (alpha_k, beta_k) -- two doubles cross PCIe per step,
-//   * the (k+1) x (k+1) Ritz problem is solved on the host by cyclic Jacobi (no LAPACK dependency).
+//   * small blocks (n16 <= 256): the whole test is ONE single-workgroup launch (hdm_lanczos_whole_kernel), Ritz problems included;
+//   * large blocks: the steps between two Ritz checks are one launch of co-resident workgroups (hdm_lanczos_group_kernel) that
+//     returns the (alpha_k, beta_k) pairs through mapped pinned memory; the tridiagonal (k+1) x (k+1) Ritz problem is solved on
+//     the host by implicit QL (tridiag_eig; no LAPACK dependency), cyclic Jacobi being the way out if it does not converge;
+//   * the launch-per-product forms behind HDM_LANCZOS_WHOLE / _FUSED / _BIG / _GROUP = 0 remain as tested fallbacks.
 // The start vector reproduces glibc's srand()/rand() stream (TYPE_3 additive feedback generator) without touching
 // the process-wide libc state, so the device run starts from the reference's own vector.
 #include "lanczos.h"
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(256) void hdm_transpose_kernel(const double *__rest
 // with the small symmetric eigenproblem solved in the kernel too: the (k+1) x (k+1) matrix is TRIDIAGONAL (alpha on the
 // diagonal, the norms beside it), so wave 0 runs the implicit QL iteration with the rotations' scalar recurrence computed
 // redundantly by every lane and lane r keeping row r of the eigenvector matrix (the reference calls dsyevr on the same
-// matrix stored densely; the multi-launch path uses a host Jacobi: eigenvalues agree to rounding).  The multi-launch form
+// matrix stored densely; the multi-launch path uses a host QL iteration: eigenvalues agree to rounding).  The multi-launch form
 // (a group of three steps per launch, Ritz checks on the host) costs 6-12 launches and as many synchronisations per ratio
 // test: 0.53 ms on a 100 x 100 block, half of what the reference's driver spends below the C ABI on mcp100 / gpp100 and
 // 40 % on truss1 (2247 ratio tests).
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(1024) void hdm_lanczos_whole_kernel(const double *_
             for (int c = 0; c < kp; ++c) if (c != i1 && td[c] > td[i2]) i2 = c;
             // sign convention: the component of largest magnitude is positive -- what LAPACK's tridiagonal eigenvector routines
             // return (dstein scales that way, dstemr's twisted factorisation puts a positive 1 at the twist index) and what the
-            // multi-launch path's Jacobi vectors have always shown on the reference's goldens.  The sign of y1 matters: the
+            // multi-launch path's host eigenvectors have always shown on the reference's goldens.  The sign of y1 matters: the
             // NEXT ratio test is warm-started from Op (V y1) + 1e-3 x the pseudo-random vector (:166-181).
             double sg1 = 1.0, sg2 = 1.0;
             {
