@@ -4,6 +4,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/headline_stats_$1
 mkdir -p $O
 export HDSDP_DROP_ATTACH=1 HDSDP_MI355X_CALL_STATS=1
+# (graph replay off: rocprofiler-sdk 7.2 segfaults inside its own HSA interception on a hipGraphLaunch late in the solve --
+# gpurun_out/s29_hs.txt; the plain run and the run with HDM_GRAPHS=0 under the profiler both complete)
+export HDM_GRAPHS=${HDM_GRAPHS:-0}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $R/oracle/_ref/headline_solve_mi355x $1 > $O/solve.log 2>&1
 python3 $R/tools/prof_summary.py $O/stats "headline_solve_mi355x $1 (kernel-trace --stats)" > $O/summary_stats.txt 2>&1
