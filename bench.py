@@ -191,6 +191,59 @@ def cpu_baseline_blas3(n, m):
         return {"value": None, "unit": "it/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
 
 
+def rccl_self_test_in_child(ids, timeout_s=240):
+    """HMiRcclGroupSelfTest over `ids` in a FRESH child process with a timeout (RCCL between these devices may never have
+    run on this machine; a hang or a crash there must not take the bench down, and a process that has touched the GPU is
+    never re-executed).  Returns (passed, reason)."""
+    code = ("import sys; sys.path.insert(0, %r); from hdsdp_amd import api; "
+            "sys.exit(api.rccl_group_self_test(%r, 120000))" % (ROOT, list(ids)))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return False, "RCCL self-test over devices %s did not finish in %d s" % (list(ids), timeout_s)
+    if r.returncode == 0:
+        return True, None
+    tail = (r.stderr or "").strip().splitlines()[-1:] or [""]
+    return False, "RCCL self-test over devices %s failed at stage %d (%s)" % (list(ids), r.returncode, tail[0][:160])
+
+
+def plan_devices(gpus, ndev, world, loopback, self_test=rccl_self_test_in_child):
+    """How `--gpus N` is driven, as data (no GPU call; tests/test_abi_cpu.py runs it for ndev in {1, 2, 8}):
+      under torchrun (world > 1)      one process per GPU, the exchange through torch.distributed (nccl = RCCL)
+      --gpus N alone, N devices there the in-process device group over RCCL if the whole-group self-test passes in a child
+                                      process, else over device copies with the reason on the bench line
+      --gpus N --loopback, fewer      shards share devices: device copies (RCCL needs one device per rank); a rehearsal
+    A request that cannot be met is {"error": ...}, never a smaller run under an N-GPU label."""
+    from hdsdp_amd import api
+    if world > 1:
+        if world != gpus:
+            return {"error": f"--gpus {gpus} but WORLD_SIZE={world}"}
+        if ndev < 1:
+            return {"error": "no MI355X visible: bench.py has no CPU fallback"}
+        return {"mode": "torchrun", "shards": world, "ids": None, "devices_used": world, "transport_request": None,
+                "transport": "torch.distributed", "transport_fallback_reason": None, "rccl_ranks_if_nccl": world}
+    if gpus > 1 and ndev < gpus and not loopback:
+        return {"error": f"--gpus {gpus} requested but {ndev} device(s) visible (use --loopback for a rehearsal on shared "
+                         f"devices, or launch with torchrun)"}
+    if ndev < 1:
+        return {"error": "no MI355X visible: bench.py has no CPU fallback"}
+    if gpus == 1:
+        return {"mode": "single", "shards": 1, "ids": [0], "devices_used": 1, "transport_request": None,
+                "transport": "none", "transport_fallback_reason": None, "rccl_ranks": 0}
+    ids = [r % ndev for r in range(gpus)]
+    plan = {"mode": "in-process device group (HMiSetDevicesEx)", "shards": gpus, "ids": ids, "devices_used": len(set(ids))}
+    if len(set(ids)) < gpus:
+        plan.update(transport_request=api.TRANSPORT_COPY, transport="device copies", rccl_ranks=0,
+                    transport_fallback_reason="shards share devices (--loopback): RCCL needs one device per rank")
+        return plan
+    ok, why = self_test(ids)
+    if ok:
+        plan.update(transport_request=api.TRANSPORT_RCCL, transport="rccl", rccl_ranks=gpus, transport_fallback_reason=None)
+    else:
+        plan.update(transport_request=api.TRANSPORT_COPY, transport="device copies", rccl_ranks=0, transport_fallback_reason=why)
+    return plan
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,24 +271,17 @@ def main():
     # (hdsdp_amd/dist.py).  `--gpus N` WITHOUT torchrun: the in-process device group behind the C ABI (HMiSetDevices: the
     # path the reference's single-threaded driver uses), N shards on N devices over RCCL.  Either way the line reports
     # the devices really used, and a request that cannot be met is an error, not a one-GPU run with an N-GPU label.
-    shards, mode, transport = world, ("torchrun" if world > 1 else "single"), None
-    ndev = torch.cuda.device_count()
-    if world == 1 and args.gpus > 1:
-        if ndev < args.gpus and not args.loopback:
-            raise SystemExit(f"--gpus {args.gpus} requested but {ndev} device(s) visible (use --loopback for a rehearsal "
-                             f"on shared devices, or launch with torchrun)")
-        ids = [r % max(1, ndev) for r in range(args.gpus)]
-        api.set_devices(ids, shard_min_dim=0)
-        gids, transport = api.device_group()
-        if len(gids) != args.gpus:
-            raise SystemExit(f"device group has {len(gids)} shards, {args.gpus} requested")
-        shards, mode = args.gpus, "in-process device group (HMiSetDevices)"
-        devices_used = len(set(gids))
-    else:
-        if lib.HMiDeviceInit(local) != 0:
-            raise SystemExit("no MI355X visible: bench.py has no CPU fallback")
-        devices_used = world
-    if ndev == 0:
+    ndev = torch.cuda.device_count()        # (does not initialise the GPU: the self-test's child process comes first)
+    plan = plan_devices(args.gpus, ndev, world, args.loopback)
+    if "error" in plan:
+        raise SystemExit(plan["error"])
+    shards, mode, devices_used = plan["shards"], plan["mode"], plan["devices_used"]
+    if mode.startswith("in-process"):
+        api.set_devices(plan["ids"], shard_min_dim=0, transport=plan["transport_request"])
+        gids, got = api.device_group()
+        if gids != plan["ids"] or got != plan["transport_request"]:
+            raise SystemExit(f"device group is {gids} over transport {got}, asked for {plan['ids']} over {plan['transport_request']}")
+    elif lib.HMiDeviceInit(local) != 0:
         raise SystemExit("no MI355X visible: bench.py has no CPU fallback")
     torch.cuda.set_device(local % ndev)
     if devices_used != args.gpus and not args.loopback:
@@ -272,11 +318,16 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    stage = {"chol_S": 0.0, "buildup": 0.0, "factor_M": 0.0, "solve3": 0.0}
+    stage = {"assemble_S+chol_S": 0.0, "buildup": 0.0, "factor_M": 0.0, "solve3": 0.0}
+    # The cone answers a request for the very point its buffer already holds from the buffer (engine_cone.h: exact short-cut),
+    # so a bench that asked for (tau, y) = (1, 0) every step would time the Cholesky alone after the first.  tau therefore
+    # alternates between 1 and 1 + 2^-52: every step really assembles S = tau C - Rd I (one pass over C at y = 0) and factors
+    # it; the LAST timed step is at tau = 1 exactly, which is the state the checksum and the fixtures belong to.
+    tau_of = lambda k: 1.0 if (k % 2 == 0) else float(np.nextafter(1.0, 2.0))
 
-    def step(timed):
+    def step(timed, k=0):
         t = time.perf_counter()
-        ok = cone.check_is_interior(1.0, y)
+        ok = cone.check_is_interior(tau_of(k), y)
         assert ok
         t1 = time.perf_counter()
         kkt.build_up(api.KKT_TYPE_INFEASIBLE)
@@ -289,7 +340,7 @@ def main():
         d3 = kkt.solve(e["ASinvRdSinv"])
         t4 = time.perf_counter()
         if timed:
-            stage["chol_S"] += t1 - t; stage["buildup"] += t2 - t1; stage["factor_M"] += t3 - t2; stage["solve3"] += t4 - t3
+            stage["assemble_S+chol_S"] += t1 - t; stage["buildup"] += t2 - t1; stage["factor_M"] += t3 - t2; stage["solve3"] += t4 - t3
         return d1, d2, d3
 
     # What THIS box's matrix pipe sustains: a register-only fp64 MFMA loop on full-range operands, two workgroups per CU, long
@@ -299,13 +350,13 @@ def main():
     if rank == 0 and not os.environ.get("HDM_BENCH_NO_PROBE"):
         probe_tf = float(lib.HMiMfmaIssueProbe(300, 2, 350000))
         lib.HMiDeviceSynchronize()
-    for _ in range(args.warmup):
-        step(False)
+    for w in range(args.warmup):
+        step(False, args.steps + args.warmup - 1 - w)
     lib.HMiSetKernelTiming(1)
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        sol = step(True)
+    for k in range(args.steps):
+        sol = step(True, args.steps - 1 - k)
     barrier()
     elapsed = time.perf_counter() - t_start
     lib.HMiSetKernelTiming(0)
@@ -370,8 +421,9 @@ def main():
                    # how the GPUs were driven and what really ran: N requested, shards of the row deal, distinct devices in
                    # use, ranks of the RCCL communicator that carried the exchange (0 = device copies or one GPU)
                    "gpus_requested": args.gpus, "shards": shards, "devices_used": devices_used, "driver": mode,
-                   "rccl_ranks": (world if (world > 1 and torch.distributed.get_backend() == "nccl") else
-                                  (shards if transport == 1 else 0)),
+                   "transport": (("torch.distributed/" + torch.distributed.get_backend()) if world > 1 else plan["transport"]),
+                   "transport_fallback_reason": plan["transport_fallback_reason"],
+                   "rccl_ranks": ((world if torch.distributed.get_backend() == "nccl" else 0) if world > 1 else plan["rccl_ranks"]),
                    "stage_ms": {k: round(v / args.steps * 1e3, 3) for k, v in stage.items()},
                    "setup_s": round(setup_s, 1),
                    "whole_step_tflops_survey_count": round(survey_flops(n, m) / (ms_per_step * 1e-3) / 1e12, 2),

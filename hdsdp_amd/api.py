@@ -36,7 +36,7 @@ EXPORTS = [
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
     "HMiConeGetTraces", "HMiConeGetPath", "HMiConeSweepInfo", "HMiConeUseSweepCopy", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiKKTGetRows", "HMiDeviceInit",
-    "HMiSetDevices", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
+    "HMiSetDevices", "HMiSetDevicesEx", "HMiRcclGroupSelfTest", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
     "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiKKTTileInfo", "HMiBspSolve", "HMiRcmOrder", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
@@ -157,6 +157,8 @@ def load_library():
         "HMiKKTDeviceMatrix": (vp, [kp, C.POINTER(C.c_int64)]),
         "HMiKKTGetRows": (C.c_int, [kp, C.c_int, ip, dp]),
         "HMiSetDevices": (C.c_int, [C.c_int, ip]),
+        "HMiSetDevicesEx": (C.c_int, [C.c_int, ip, C.c_int]),
+        "HMiRcclGroupSelfTest": (C.c_int, [C.c_int, ip, C.c_int]),
         "HMiGetDeviceGroup": (C.c_int, [ip, C.c_int, ip]),
         "HMiSetShardMinDim": (None, [C.c_int]),
         "HMiConeGetShardCount": (C.c_int, [vp]),
@@ -201,15 +203,26 @@ def load_library():
     return lib
 
 
-def set_devices(ids, shard_min_dim=None):
-    """single-process multi-device mode (include/hdsdp_mi355x.h: HMiSetDevices): cones created afterwards with rank 0 of
-    world 1 are sharded over `ids` (repeated ids = shards sharing a device, exchanged by device copies)"""
+TRANSPORT_ENV, TRANSPORT_COPY, TRANSPORT_RCCL = -1, 0, 1
+
+
+def set_devices(ids, shard_min_dim=None, transport=TRANSPORT_ENV):
+    """single-process multi-device mode (include/hdsdp_mi355x.h: HMiSetDevicesEx): cones created afterwards with rank 0 of
+    world 1 are sharded over `ids` (repeated ids = shards sharing a device, exchanged by device copies).  transport:
+    TRANSPORT_COPY / TRANSPORT_RCCL, or TRANSPORT_ENV = what HDSDP_MI355X_TRANSPORT says (default copies)"""
     lib = load_library()
     arr = (C.c_int * len(ids))(*ids)
-    if lib.HMiSetDevices(len(ids), arr) != 0:
-        raise HDSDPError("HMiSetDevices failed")
+    if lib.HMiSetDevicesEx(len(ids), arr, int(transport)) != 0:
+        raise HDSDPError("HMiSetDevicesEx failed")
     if shard_min_dim is not None:
         lib.HMiSetShardMinDim(int(shard_min_dim))
+
+
+def rccl_group_self_test(ids, timeout_ms=60000):
+    """HMiRcclGroupSelfTest over `ids` (distinct devices): 0 = passed, else the first failing stage"""
+    lib = load_library()
+    arr = (C.c_int * len(ids))(*ids)
+    return int(lib.HMiRcclGroupSelfTest(len(ids), arr, int(timeout_ms)))
 
 
 def device_group():

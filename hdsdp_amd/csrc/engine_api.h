@@ -131,13 +131,13 @@ int HMiConeSweepInfo(hdsdp_cone *cone, int64_t *values, int64_t *positions) {
 }
 
 // ---------------------------------------------------------------- single-process multi-device mode (group_impl.h)
-int HMiSetDevices(int nDevices, const int *deviceIds) {
-    if (nDevices < 1 || !deviceIds) return 1;
+int HMiSetDevicesEx(int nDevices, const int *deviceIds, int transport) {
+    if (nDevices < 1 || !deviceIds || transport < -1 || transport > GRP_RCCL) return 1;
     g_group_env_done = true;     // an explicit call overrides HDSDP_MI355X_GPUS
-    int tr = -1;
-    if (const char *t = getenv("HDSDP_MI355X_TRANSPORT")) tr = (strcmp(t, "rccl") == 0) ? GRP_RCCL : GRP_COPIES;
-    return group_setup(nDevices, deviceIds, tr);
+    // -1: the environment's choice (HDSDP_MI355X_TRANSPORT), else the default -- group_setup reads it
+    return group_setup(nDevices, deviceIds, transport);
 }
+int HMiSetDevices(int nDevices, const int *deviceIds) { return HMiSetDevicesEx(nDevices, deviceIds, -1); }
 int HMiGetDeviceGroup(int *deviceIds, int maxIds, int *transport) {
     if (!g_group) { if (transport) *transport = -1; if (deviceIds && maxIds > 0 && g_main.init) deviceIds[0] = g_main.device; return g_main.init ? 1 : 0; }
     for (int r = 0; r < g_group->W && r < maxIds; ++r) if (deviceIds) deviceIds[r] = g_group->dev[r];
@@ -363,5 +363,10 @@ const char *HMiCallStatName(int k) { return (k >= 0 && k < ST_N) ? g_stat_name[k
 void HMiResetCallStats(void) { for (int k = 0; k < ST_N; ++k) { g_stat_sec[k] = 0.0; g_stat_calls[k] = 0; } g_stat_nfn = 0; }
 int HMiRcclSelfTest(int device) {
     if (ensure_ctx()) return 1;
-    return rccl_self_test(device < 0 ? g_main.device : device);
+    const int d = device < 0 ? g_main.device : device;
+    return rccl_group_self_test(1, &d, 60000);
+}
+int HMiRcclGroupSelfTest(int nDevices, const int *deviceIds, int timeoutMs) {
+    if (nDevices < 1 || !deviceIds) return 1;
+    return rccl_group_self_test(nDevices, deviceIds, timeoutMs);
 }

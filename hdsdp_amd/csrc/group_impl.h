@@ -587,36 +587,104 @@ hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCo
     return HDSDP_RETCODE_OK;
 }
 
-// one-rank RCCL self-test on `device` (a 1-GPU box cannot form a real group): communicator, all-reduce, and the grouped
-// send/receive the piecewise all-to-all is made of, each checked for its result.  0 = passed.
-int rccl_self_test(int device) {
-    if (hipSetDevice(device) != hipSuccess) return 1;
-    ncclComm_t comm = nullptr;
-    int dev = device;
-    if (ncclCommInitAll(&comm, 1, &dev) != ncclSuccess) return 2;
-    hipStream_t s = nullptr;
-    double *a = nullptr, *b = nullptr;
-    const int cnt = 4096;
-    int rc = 0;
-    std::vector<double> h(cnt), out(cnt);
-    for (int i = 0; i < cnt; ++i) h[i] = 0.25 * i - 7.0;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **) &a, 8 * cnt) != hipSuccess ||
-        hipMalloc((void **) &b, 8 * cnt) != hipSuccess) rc = 3;
-    if (!rc && hipMemcpy(a, h.data(), 8 * cnt, hipMemcpyHostToDevice) != hipSuccess) rc = 3;
-    if (!rc && (ncclAllReduce(a, a, cnt, ncclDouble, ncclSum, comm, s) != ncclSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = 4;
-    if (!rc && hipMemcpy(out.data(), a, 8 * cnt, hipMemcpyDeviceToHost) != hipSuccess) rc = 3;
-    for (int i = 0; i < cnt && !rc; ++i) if (out[i] != h[i]) rc = 5;
-    if (!rc) {
-        if (ncclGroupStart() != ncclSuccess || ncclSend(a, cnt, ncclDouble, 0, comm, s) != ncclSuccess ||
-            ncclRecv(b, cnt, ncclDouble, 0, comm, s) != ncclSuccess || ncclGroupEnd() != ncclSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) rc = 6;
+// RCCL self-test over the WHOLE group `ids` (n distinct devices; n = 1 is the one-rank form a 1-GPU box can run):
+// communicators (ncclCommInitAll), then from one host thread per device -- the way the group's workers drive it -- an
+// all-reduce and the grouped ncclSend/ncclRecv one piece of the sharded build's exchange is made of (grp_a2a_start), each
+// checked for its values.  Every wait polls with a deadline; a rank that fails or runs out of time raises the shared flag
+// and aborts its communicator, the others see the flag and abort theirs, so that nobody blocks in a collective a peer
+// will never join.  (ncclCommInitAll itself cannot be bounded from inside: bench.py runs this test in a child process
+// with a timeout before it lets RCCL carry the exchange.)
+// 0 = passed; 1 bad arguments / device; 2 communicators; 3 allocation / copies; 4 all-reduce did not complete;
+// 5 all-reduce values; 6 send/receive did not complete; 7 send/receive values; 8 shards share a device
+int rccl_group_self_test(int n, const int *ids, int timeout_ms) {
+    if (n < 1 || n > GRP_MAX_SHARDS || !ids) return 1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return 1;
+    for (int a = 0; a < n; ++a) {
+        if (ids[a] < 0 || ids[a] >= ndev) return 1;
+        for (int b = a + 1; b < n; ++b) if (ids[a] == ids[b]) return 8;
     }
-    if (!rc && hipMemcpy(out.data(), b, 8 * cnt, hipMemcpyDeviceToHost) != hipSuccess) rc = 3;
-    for (int i = 0; i < cnt && !rc; ++i) if (out[i] != h[i]) rc = 7;
-    if (a) (void) hipFree(a);
-    if (b) (void) hipFree(b);
-    if (s) (void) hipStreamDestroy(s);
-    (void) ncclCommDestroy(comm);
+    if (timeout_ms <= 0) timeout_ms = 60000;
+    std::vector<ncclComm_t> comm(n, nullptr);
+    std::vector<int> dev(ids, ids + n);
+    if (ncclCommInitAll(comm.data(), n, dev.data()) != ncclSuccess) {
+        for (auto c : comm) if (c) (void) ncclCommAbort(c);
+        if (g_main.init) (void) hipSetDevice(g_main.device);
+        return 2;
+    }
+    const int cnt = 1 << 18;                 // doubles per peer and piece: 2 MiB, enough to leave the eager protocol
+    std::atomic<bool> failed{false};
+    std::vector<int> rcs(n, 0);
+    // the values are small multiples of 1/4 (sums exact in any order) resp. plain copies: both are compared bit for bit
+    auto ar_val = [](int r, int i) { return (double) (r + 1) * (0.25 * (double) (i % 4096) - 7.0); };
+    auto sr_val = [](int src, int dst, int i) { return 1000.0 * src + dst + 0.0009765625 * (double) (i % 1024); };
+    auto rank = [&](int r) {
+        int rc = 0;
+        hipStream_t s = nullptr;
+        hipEvent_t ev = nullptr;
+        double *a = nullptr, *snd = nullptr, *rcv = nullptr;
+        std::vector<double> h((size_t) cnt * n), out((size_t) cnt * n);
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+        auto bounded_wait = [&]() {          // 0: the event has completed
+            for (;;) {
+                const hipError_t e = hipEventQuery(ev);
+                if (e == hipSuccess) return 0;
+                if (e != hipErrorNotReady) { (void) hipGetLastError(); return 1; }
+                if (failed.load() || std::chrono::steady_clock::now() > deadline) return 1;
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        };
+        do {
+            if (hipSetDevice(dev[r]) != hipSuccess) { rc = 1; break; }
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
+                hipMalloc((void **) &a, sizeof(double) * cnt) != hipSuccess ||
+                hipMalloc((void **) &snd, sizeof(double) * (size_t) cnt * n) != hipSuccess ||
+                hipMalloc((void **) &rcv, sizeof(double) * (size_t) cnt * n) != hipSuccess) { rc = 3; break; }
+            for (int i = 0; i < cnt; ++i) h[i] = ar_val(r, i);
+            if (hipMemcpy(a, h.data(), sizeof(double) * cnt, hipMemcpyHostToDevice) != hipSuccess) { rc = 3; break; }
+            for (int d = 0; d < n; ++d) for (int i = 0; i < cnt; ++i) h[(size_t) d * cnt + i] = sr_val(r, d, i);
+            if (hipMemcpy(snd, h.data(), sizeof(double) * (size_t) cnt * n, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemset(rcv, 0, sizeof(double) * (size_t) cnt * n) != hipSuccess) { rc = 3; break; }
+            // all-reduce (grp_allreduce)
+            if (ncclAllReduce(a, a, (size_t) cnt, ncclDouble, ncclSum, comm[r], s) != ncclSuccess ||
+                hipEventRecord(ev, s) != hipSuccess || bounded_wait()) { rc = 4; break; }
+            if (hipMemcpy(out.data(), a, sizeof(double) * cnt, hipMemcpyDeviceToHost) != hipSuccess) { rc = 3; break; }
+            const double tri = 0.5 * n * (n + 1);
+            for (int i = 0; i < cnt && !rc; ++i) if (out[i] != tri * (0.25 * (double) (i % 4096) - 7.0)) rc = 5;
+            if (rc) break;
+            // one piece of the exchange (grp_a2a_start): chunk d of my send buffer to rank d, chunk d of my receive buffer from rank d
+            bool okq = (ncclGroupStart() == ncclSuccess);
+            for (int d = 0; d < n && okq; ++d)
+                okq = ncclSend(snd + (size_t) d * cnt, (size_t) cnt, ncclDouble, d, comm[r], s) == ncclSuccess &&
+                      ncclRecv(rcv + (size_t) d * cnt, (size_t) cnt, ncclDouble, d, comm[r], s) == ncclSuccess;
+            if (!okq || ncclGroupEnd() != ncclSuccess || hipEventRecord(ev, s) != hipSuccess || bounded_wait()) { rc = 6; break; }
+            if (hipMemcpy(out.data(), rcv, sizeof(double) * (size_t) cnt * n, hipMemcpyDeviceToHost) != hipSuccess) { rc = 3; break; }
+            for (int d = 0; d < n && !rc; ++d)
+                for (int i = 0; i < cnt && !rc; ++i) if (out[(size_t) d * cnt + i] != sr_val(d, r, i)) rc = 7;
+        } while (0);
+        if (rc) {                            // release whoever waits for this rank, then leave without joining anything else
+            failed.store(true);
+            if (comm[r]) { (void) ncclCommAbort(comm[r]); comm[r] = nullptr; }
+        } else if (failed.load() && comm[r]) {
+            (void) ncclCommAbort(comm[r]); comm[r] = nullptr;
+        }
+        if (a) (void) hipFree(a);
+        if (snd) (void) hipFree(snd);
+        if (rcv) (void) hipFree(rcv);
+        if (ev) (void) hipEventDestroy(ev);
+        if (s) (void) hipStreamDestroy(s);
+        (void) hipGetLastError();
+        rcs[r] = rc;
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < n; ++r) th.emplace_back(rank, r);
+    rank(0);
+    for (auto &t : th) t.join();
+    for (int r = 0; r < n; ++r) if (comm[r]) (void) (failed.load() ? ncclCommAbort(comm[r]) : ncclCommDestroy(comm[r]));
     if (g_main.init) (void) hipSetDevice(g_main.device);
-    return rc;
+    int first = 0;
+    for (int r = 0; r < n; ++r) if (rcs[r] && !first) first = rcs[r];
+    if (first) for (int r = 0; r < n; ++r) if (rcs[r]) fprintf(stderr, "[hdsdp_mi355x] RCCL self-test: rank %d (device %d) failed at stage %d\n", r, dev[r], rcs[r]);
+    return first;
 }

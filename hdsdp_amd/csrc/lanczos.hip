@@ -225,7 +225,12 @@ __device__ __forceinline__ void lzg_st(double *p, double v) { __hip_atomic_store
 // the epoch into the go word, which everybody else polls.
 // sync[0]: go word; sync[1]: a wait ran out; sync[64 + b]: workgroup b's word.
 __device__ __forceinline__ bool lzg_barrier(unsigned *sync, unsigned epoch, int b, int G, int *s_ok) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's stores have completed (they are coherent by themselves)
+    // Every wave waits for its OWN hand-over stores before the workgroup barrier, so that the epoch word below cannot
+    // overtake them: the stores are sc1 (coherent by themselves, no write-back needed), but two stores of one wave to
+    // different addresses travel to different L2 channels and may complete out of order, and a workgroup-scope release
+    // fence emits no vector-memory wait outside tgsplit mode.  (Checked in the ISA: s_waitcnt vmcnt(0) precedes s_barrier.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x < 64) {                       // wave 0 (the other waves wait at the __syncthreads below)
         const int lane = threadIdx.x;

@@ -329,6 +329,11 @@ hdsdp_retcode HMiKKTGetRows(hdsdp_kkt *HKKT, int nRows, const int *rows, double 
  * copy transport can be forced between distinct, peer-accessible devices with HDSDP_MI355X_TRANSPORT=copy.
  * The process-per-GPU mode above (HMiConeSetExchange*, torchrun) is unaffected.  All return 0 on success. */
 int HMiSetDevices(int nDevices, const int *deviceIds);
+/* the same with the transport stated by the caller: 0 = device copies (peer access), 1 = RCCL (one device per shard; with
+ * shared devices the group falls back to copies and HMiGetDeviceGroup says so), -1 = HDSDP_MI355X_TRANSPORT, else copies.
+ * tests/test_gpu_group.py::test_config5_at_size_on_eight_devices asks for each in turn; bench.py --gpus N asks for RCCL once
+ * HMiRcclGroupSelfTest has passed over the same devices in a child process. */
+int HMiSetDevicesEx(int nDevices, const int *deviceIds, int transport);
 int HMiGetDeviceGroup(int *deviceIds, int maxIds, int *transport);   /* returns the shard count (1 = no group); transport
                                                                         0 = device copies, 1 = RCCL, -1 = none */
 void HMiSetShardMinDim(int nMin);
@@ -357,6 +362,11 @@ int HMiGetCallStats(double *seconds, int64_t *calls, int n);
 const char *HMiCallStatName(int k);
 void HMiResetCallStats(void);
 int HMiRcclSelfTest(int device);   /* one-rank communicator on `device` (-1: the engine's): all-reduce + grouped send/recv, checked */
+/* the same over a whole group of distinct devices, one host thread per device as the group's workers drive it: communicators,
+ * an all-reduce, and the grouped ncclSend/ncclRecv of one piece of the sharded build's exchange, values compared bit for bit;
+ * every wait is bounded by timeoutMs (<= 0: 60 s) and a rank that fails aborts its communicator so that no peer blocks.
+ * 0 = passed, else the first failing stage (csrc/group_impl.h: rccl_group_self_test).  Touches no engine state. */
+int HMiRcclGroupSelfTest(int nDevices, const int *deviceIds, int timeoutMs);
 
 /* ================================  ingest (host only)  ================================
  * SDPA sparse format reader with the reference's semantics (interface/hdsdp_file_io.c:34-381): one CSC per
@@ -383,8 +393,8 @@ void HMiSDPAFree(HMiSDPA **pp);
  *  HDSDP_MI355X_GPUS              1         shards of the in-process device group (unchanged driver)      test_gpu_group.py::test_unchanged_driver_shards_by_environment
  *  HDSDP_MI355X_LOOPBACK          0         shards may share devices (rehearsal)                          same
  *  HDSDP_MI355X_SHARD_MIN_N       512       smallest block dimension that is sharded                      same
- *  HDSDP_MI355X_TRANSPORT         copy      device group transport: copy | rccl (rccl unverified between  test_gpu_group.py::test_config5_at_size_on_eight_devices
- *                                           devices on this pool: opt-in)                                 (needs 8 devices)
+ *  HDSDP_MI355X_TRANSPORT         copy      device group transport when the caller states none            test_gpu_group.py::test_config5_at_size_on_eight_devices[rccl|copy]
+ *                                           (HMiSetDevices, HDSDP_MI355X_GPUS): copy | rccl                (needs 8 devices), test_transport_request_is_honoured
  *  HDSDP_MI355X_A2A_PIECES        8         pieces of the sharded build's exchange                        test_gpu_switches.py
  *  HDSDP_MI355X_STAGED_A2A        1         step 2 by packed-index range, pieces leave as they finish     test_gpu_switches.py
  *  HDSDP_MI355X_FORCE_GEMM        0         every block takes the congruence + Gram path                  test_gpu_switches.py, test_gpu_parity.py

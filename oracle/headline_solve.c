@@ -18,6 +18,9 @@
 #include <string.h>
 #include <stdint.h>
 #include <time.h>
+#include <signal.h>
+#include <execinfo.h>
+#include <unistd.h>
 
 #include "interface/hdsdp.h"
 #include "interface/hdsdp_utils.h"
@@ -33,7 +36,25 @@ static double draw_at(uint64_t t) {              /* draw number t (0-based) of t
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
+/* HEADLINE_SEGV_TRACE=1: on SIGSEGV / SIGBUS / SIGABRT print the faulting thread's frames (module + offset; symbols where
+ * the module exports them) and the last lines of /proc/self/maps' module list on stderr, then die by the same signal.  Exists
+ * because round 3 recorded a segfault of this program under rocprofv3 with graph replay on and could not name the frame. */
+static void segv_trace(int sig) {
+    void *fr[64];
+    static const char msg[] = "\n[headline_solve] fatal signal; frames of the faulting thread:\n";
+    (void) !write(2, msg, sizeof(msg) - 1);
+    const int nfr = backtrace(fr, 64);
+    backtrace_symbols_fd(fr, nfr, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int main(int argc, char **argv) {
+    if (getenv("HEADLINE_SEGV_TRACE")) {
+        void *warm[4];
+        (void) backtrace(warm, 4);                  /* (loads libgcc now, not inside the handler) */
+        signal(SIGSEGV, segv_trace); signal(SIGBUS, segv_trace); signal(SIGABRT, segv_trace);
+    }
     if (argc < 2) { fprintf(stderr, "usage: %s n [m]\n", argv[0]); return 2; }
     const int n = atoi(argv[1]), m = argc > 2 ? atoi(argv[2]) : n;
     const uint64_t P = (uint64_t) n * (n + 1) / 2;

@@ -234,6 +234,49 @@ def test_bench_labels_follow_the_size_and_a_gpu_count_it_cannot_meet_is_an_error
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_device_plan_labels_and_the_gpu_tests_expectations_agree():
+    """bench.plan_devices (pure: no GPU call) for 1, 2 and 8 visible devices, with the whole-group RCCL self-test faked to
+    pass and to fail: what the bench line will say (transport, rccl_ranks, fallback reason) and what bench.py will ask
+    HMiSetDevicesEx for are one statement; and tests/test_gpu_group.py's at-size test asks for exactly the two transports
+    the header's switch table names as its coverage."""
+    import importlib.util
+    from hdsdp_amd import api
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    passed = lambda ids: (True, None)
+    failed = lambda ids: (False, "RCCL self-test over devices %s failed at stage 4 (fake)" % list(ids))
+    never = lambda ids: (_ for _ in ()).throw(AssertionError("the self-test must not run here"))
+    for ndev in (1, 2, 8):
+        one = bench.plan_devices(1, ndev, 1, False, never)
+        assert one["mode"] == "single" and one["rccl_ranks"] == 0 and one["devices_used"] == 1
+        for gpus in (2, 8):
+            if gpus > ndev:
+                assert "error" in bench.plan_devices(gpus, ndev, 1, False, never)
+                lb = bench.plan_devices(gpus, ndev, 1, True, never)      # shared devices: copies, and the line says why
+                assert lb["transport_request"] == api.TRANSPORT_COPY and lb["rccl_ranks"] == 0
+                assert lb["devices_used"] == ndev < gpus and "share devices" in lb["transport_fallback_reason"]
+                assert lb["ids"] == [r % ndev for r in range(gpus)]
+                continue
+            ok = bench.plan_devices(gpus, ndev, 1, False, passed)
+            assert ok["ids"] == list(range(gpus)) and ok["devices_used"] == gpus
+            assert (ok["transport"], ok["transport_request"], ok["rccl_ranks"], ok["transport_fallback_reason"]) == \
+                   ("rccl", api.TRANSPORT_RCCL, gpus, None)
+            bad = bench.plan_devices(gpus, ndev, 1, False, failed)
+            assert (bad["transport"], bad["transport_request"], bad["rccl_ranks"]) == ("device copies", api.TRANSPORT_COPY, 0)
+            assert "stage 4" in bad["transport_fallback_reason"]
+            tr = bench.plan_devices(gpus, ndev, gpus, False, never)      # under torchrun: torch.distributed carries it
+            assert tr["mode"] == "torchrun" and tr["rccl_ranks_if_nccl"] == gpus
+    assert "error" in bench.plan_devices(4, 8, 2, False, never)          # WORLD_SIZE disagrees with --gpus
+    assert "error" in bench.plan_devices(1, 0, 1, False, never)          # no device: no CPU fallback
+    # the at-size test states its transport (it used to assert RCCL after a call that defaulted to copies)
+    src = open(os.path.join(ROOT, "tests", "test_gpu_group.py")).read()
+    body = src.split("def test_config5_at_size_on_eight_devices")[1].split("\ndef ")[0]
+    assert 'parametrize("transport", ["rccl", "copy"])' in src and "transport=want" in body and "got == want" in body
+    table = open(HEADER).read().split("environment switches")[1]
+    assert "test_config5_at_size_on_eight_devices[rccl|copy]" in table
+
+
 def test_library_exports_nothing_but_the_declared_surface():
     """-fvisibility=hidden: the dynamic symbol table holds the header's functions and no internal symbol (round 2's library
     exported 197 symbols for a boundary of 25 + helpers)"""

@@ -269,25 +269,31 @@ def test_config5_rows_eight_shards_against_host_fp64(group, monkeypatch):
         cone.destroy()
 
 
-def test_config5_at_size_on_eight_devices():
-    """BASELINE configs[4] itself: n = 2000, m = 8000, constraint rows over 8 MI355X (in-process device group over RCCL),
-    against tests/golden/full8000_rows.npz (host fp64, oracle/row_subset_golden.py: rows [0, 64) -- eight per rank -- and
-    the tile-edge rows of M, both vectors in full, log det S, residual rows of the three solves, at the bench state and at
-    cond(S) = 1e3).  Needs eight devices (136 GB of constraint data, 130 GB of transformed rows); skipped by name on a
-    smaller box -- the one-GPU rehearsals above cover the same code with m = 8000 at n = 1000 and eight shards at
-    n = m = 2000."""
+@pytest.mark.parametrize("transport", ["rccl", "copy"])
+def test_config5_at_size_on_eight_devices(transport):
+    """BASELINE configs[4] itself: n = 2000, m = 8000, constraint rows over 8 MI355X through the in-process device group,
+    once with the exchange carried by RCCL (requested explicitly: HMiSetDevicesEx(.., 1), after the whole-group self-test
+    has passed) and once by device copies (the library's default), against tests/golden/full8000_rows.npz (host fp64,
+    oracle/row_subset_golden.py: rows [0, 64) -- eight per rank -- and the tile-edge rows of M, both vectors in full,
+    log det S, residual rows of the three solves, at the bench state and at cond(S) = 1e3).  Needs eight devices (136 GB of
+    constraint data, 130 GB of transformed rows); skipped by name on a smaller box -- the one-GPU rehearsals above cover
+    the same code with m = 8000 at n = 1000 and eight shards at n = m = 2000, test_config5_at_size_streamed_on_one_device
+    the workload itself."""
     import torch
     from hdsdp_amd import api
     from test_gpu_parity import check_row_subset_state
     ndev = torch.cuda.device_count()
     if ndev < 8:
-        pytest.skip(f"BASELINE configs[4] (n=2000, m=8000) needs 8 devices, {ndev} visible: never run at size on this pool")
+        pytest.skip(f"BASELINE configs[4] (n=2000, m=8000) over 8 devices: {ndev} visible -- never run on this pool")
     g = load_golden("full8000_rows")
     n, m = int(g["n"]), int(g["m"])
-    api.set_devices(list(range(8)), shard_min_dim=0)
+    want = api.TRANSPORT_RCCL if transport == "rccl" else api.TRANSPORT_COPY
+    if want == api.TRANSPORT_RCCL:
+        assert api.rccl_group_self_test(list(range(8)), 120000) == 0
+    api.set_devices(list(range(8)), shard_min_dim=0, transport=want)
     try:
-        ids, transport = api.device_group()
-        assert ids == list(range(8)) and transport == 1          # RCCL between distinct devices
+        ids, got = api.device_group()
+        assert ids == list(range(8)) and got == want, (ids, got, want)
         cone = api.SDPCone.synthetic(n, m)
         try:
             assert cone.shard_count() == 8
@@ -299,6 +305,26 @@ def test_config5_at_size_on_eight_devices():
             cone.destroy()
     finally:
         api.set_devices([0])
+
+
+def test_transport_request_is_honoured():
+    """HMiSetDevicesEx states the transport; HMiGetDeviceGroup reports what the group really uses.  On the one device of the
+    test box: shards that share a device cannot use RCCL (one communicator rank per device) and say so by falling back to
+    copies; a one-device "group" is no group; the whole-group self-test refuses repeated ids with its own code (8) and passes
+    on the one device there is."""
+    from hdsdp_amd import api
+    try:
+        api.set_devices([0, 0], transport=api.TRANSPORT_RCCL)
+        assert api.device_group() == ([0, 0], api.TRANSPORT_COPY)
+        api.set_devices([0, 0], transport=api.TRANSPORT_COPY)
+        assert api.device_group() == ([0, 0], api.TRANSPORT_COPY)
+        api.set_devices([0], transport=api.TRANSPORT_RCCL)
+        assert api.device_group() == ([0], -1)
+    finally:
+        api.set_devices([0])
+    assert api.rccl_group_self_test([0, 0]) == 8
+    assert api.rccl_group_self_test([0]) == 0
+    assert api.rccl_group_self_test([99]) == 1
 
 
 def test_shard_plan_predicts_what_the_engine_allocates(group):

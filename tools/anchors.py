@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Un-extrapolated anchors of the CPU baseline: FULL builds of the metric's unit of work
 [chol(S) -> HKKTBuildUp(INFEASIBLE) -> HKKTFactorize -> 3 x HKKTSolve] at n = m in {200, 400} on both sides --
 the compiled reference on one host core (oracle/_ref/ref_dump bench; falls back to the plain-C port) and the device

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Write a small, strictly primal-dual feasible multi-block SDP in SDPA sparse format: three SDP blocks (21 / 34 / 9) on
 which most constraints are zero -- sparse rows on the first, dense rows on the second, single-diagonal-entry (rank-one) rows
 on the third -- and, optionally, an LP block of 5 variables.  Feasible by construction like the SURVEY.md 8(d) family:

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """per-role kernel time of ONE HKKTBuildUp at n=m=2000 (no factorisation: usable with the timing-only kernel
 ablations selected by HDM_VAR, whose results are wrong)"""
 import ctypes as C, os, sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Time HFpLinsysPsdCheck (upload + blocked Cholesky) and one solve at a few sizes through the C ABI."""
 import os, sys, time
 import numpy as np

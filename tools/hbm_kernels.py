@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """achieved HBM rate of the two memory-bound passes over the resident constraint data at n=m=2000:
 S assembly with y != 0 (hdm_sym_combine_kernel) and the corrector's <A_i, S^-1>, <A_i, S^-2> (hdm_sym_dot2_kernel)"""
 import os, sys, time

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Time the Schur system's symmetric-indefinite fallback (lu.hip) next to the regular Cholesky path, through the C ABI
 (host matrix in, host solution out, like HFpLinsysNumeric / HFpLinsysSolve)."""
 import os, sys, time

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """step time at n=m=2000 with and without the reference boundary's host round trip of M (kktMatElem mirror)"""
 import os, sys, time
 import numpy as np

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """tile-form Cholesky (csrc/bsparse.hip) on big sparse patterns: a band at m = 200 000 (a dense m x m device matrix would be 320 GB)
 and an arrow at m = 100 000; factorisation time, tiles, levels, residual of the solve"""
 import ctypes as C

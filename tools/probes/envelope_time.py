@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """factorisation of a block-banded Schur matrix: dense vs on its block envelope (HdmChol::set_envelope)"""
 import os, sys
 import numpy as np

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """wall time of HMiPotrf (device matrix in, factor out, one synchronisation) at a few sizes; HDM_DIAG_SWEEP=0/1 for A/B"""
 import os, sys, time
 import numpy as np

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """diagnostic: the ratio tests of a golden instance (fresh, warm-started, from the checker buffer), printed to full precision;
 run under HDM_LANCZOS_WHOLE=0 / 1 to compare the multi-launch and the single-launch forms"""
 import os, sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """diagnostic: wall time per ratio test / interior check / barrier on the small goldens (run under rocprofv3 --kernel-trace --stats
 for the kernel breakdown)"""
 import os, sys, time

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """where the first 0.25 s of a process go: library load, device context, first launch, first cone"""
 import os, sys, time
 t0 = time.perf_counter()

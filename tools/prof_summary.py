@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Condense rocprofv3 CSV output (kernel-trace --stats and --pmc runs) into a small text summary.
 
     python tools/prof_summary.py <rocprof output dir> [<label>]

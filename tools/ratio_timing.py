@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """wall time of the device ratio test (Lanczos) and of one interior check at n = 2000 (set HDSDP_MI355X_RATIO_DEBUG=1 for the step counts)"""
 import os, sys, time
 import numpy as np

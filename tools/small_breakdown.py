@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-call wall time of one Phase-A pass on the small BASELINE configs (launch-latency bound)."""
 import os, sys, time
 import numpy as np

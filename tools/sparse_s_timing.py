@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Sparse dual matrix (hdsdp_linsolver.c:509-809): what the engine's choice -- accept the CSC, scatter it into a
 dense device matrix, blocked MFMA Cholesky, dense inverse -- costs at sparse-cone sizes, beside a sparse direct solver on the
 host (scipy's SuperLU as a stand-in for the reference's QDLDL: factor once, then n solves for the dense inverse the

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """stage split of one step at n=m=2000 (HMiGetStageTimes + wall clock of the replicated parts)"""
 import os, sys, time
 import numpy as np

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Write the SURVEY.md 8(d) synthetic dense SDP (n, m) as an SDPA sparse file (F0 = -C, F_i = A_i, c = b), so that a
 driver reading it through its SDPA reader (C = -F0, b = c) works on exactly the generator's (C, A_i, b).
 usage: tools/synth_sdpa.py n m out.dat-s"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """diagnostic (HDM_VAR=96: stamps on the default loop): per-workgroup timeline of the last launch of one role"""
 import os, sys
 import numpy as np

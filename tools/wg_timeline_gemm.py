@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """diagnostic (HDM_VAR=32): workgroup residency of ONE stand-alone GEMM launch (role 0) in global time"""
 import os, sys
 import numpy as np
