@@ -94,13 +94,15 @@ def survey_equiv(n, m, world, kms, kln, steps):
                      "tflops": round(0.5 * m * (m + 1) / world * n * (n + 1) / max(gram_ms, 1e-9) / 1e9, 2)}}
 
 
-def workload_label(n, m):
+def workload_label(n, m, shards=8):
     """BASELINE.json's configs by (n, m): nothing else may call itself configs[3] or configs[4]"""
     fam = "synthetic dense SDP n=%d m=%d (SURVEY 8(d) splitmix64 family, state y=0 tau=1 Rd=-10n), one Phase-A pass per step" % (n, m)
     if (n, m) == (2000, 2000):
         return "configs[3]: " + fam
     if (n, m) == (2000, 8000):
-        return "configs[4]: " + fam + ", constraint rows sharded over the GPUs"
+        if shards > 1:
+            return "configs[4]: " + fam + ", constraint rows sharded over %d GPUs" % shards
+        return "configs[4]: " + fam + ", all 8000 rows on ONE device (constraint data streamed: regenerated per congruence batch)"
     return "custom (not a BASELINE config): " + fam
 
 
@@ -416,7 +418,7 @@ def main():
         "value": round(value, 4), "unit": "it/s", "n_gpus": devices_used, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload_label(n, m),
+        "config": {"workload": workload_label(n, m, shards),
                    "n": n, "m": m, "parallelism": "rows%d" % shards,
                    # how the GPUs were driven and what really ran: N requested, shards of the row deal, distinct devices in
                    # use, ranks of the RCCL communicator that carried the exchange (0 = device copies or one GPU)
@@ -425,6 +427,7 @@ def main():
                    "transport_fallback_reason": plan["transport_fallback_reason"],
                    "rccl_ranks": ((world if torch.distributed.get_backend() == "nccl" else 0) if world > 1 else plan["rccl_ranks"]),
                    "stage_ms": {k: round(v / args.steps * 1e3, 3) for k, v in stage.items()},
+                   "constraint_data": ("streamed: regenerated %d rows at a time" % cone.streaming()[1]) if cone.streaming()[0] else "resident",
                    "setup_s": round(setup_s, 1),
                    "whole_step_tflops_survey_count": round(survey_flops(n, m) / (ms_per_step * 1e-3) / 1e12, 2),
                    "whole_step_tflops_executed": round(executed_flops(n, m) / (ms_per_step * 1e-3) / 1e12, 2)},

@@ -34,7 +34,7 @@ EXPORTS = [
     "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeCheckIsInteriorExpert",
     "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetCoeffNorm", "HMiConeGetObjNorm",
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
-    "HMiConeGetTraces", "HMiConeGetPath", "HMiConeSweepInfo", "HMiConeUseSweepCopy", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
+    "HMiConeGetTraces", "HMiConeGetPath", "HMiConeSweepInfo", "HMiConeGetStreaming", "HMiConeUseSweepCopy", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiKKTGetRows", "HMiDeviceInit",
     "HMiSetDevices", "HMiSetDevicesEx", "HMiRcclGroupSelfTest", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
@@ -146,6 +146,7 @@ def load_library():
         "HMiConeGetTraces": (C.c_int, [vp, dp]),
         "HMiConeGetPath": (C.c_int, [vp]),
         "HMiConeSweepInfo": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+        "HMiConeGetStreaming": (C.c_int, [vp, ip]),
         "HMiConeUseSweepCopy": (C.c_int, [vp, C.c_int]),
         "HMiKKTSetHostMirror": (None, [kp, C.c_int]),
         "HMiConeSetExchange": (None, [vp, vp, vp, vp]),
@@ -450,6 +451,12 @@ class SDPCone:
 
     def use_sweep_copy(self, on):
         _check(load_library().HMiConeUseSweepCopy(self._h, int(bool(on))), "HMiConeUseSweepCopy")
+
+    def streaming(self):
+        """(streamed?, rows per regenerated batch): include/hdsdp_mi355x.h: HMiConeGetStreaming"""
+        b = C.c_int(0)
+        on = load_library().HMiConeGetStreaming(self._h, C.byref(b))
+        return bool(on), int(b.value)
 
     def sweep_info(self):
         """(in use, stored values, skyline positions they stand for) of the zero-suppressed copy the S / dS sweeps read"""

@@ -117,10 +117,16 @@ int HMiConeUseSweepCopy(hdsdp_cone *cone, int on) {
     if (ensure_ctx()) return 1;
     c->pS_ok = c->pD_ok = false;     // the next request is assembled, not short-cut
     if (!on) { c->zs_state = -1; return 0; }
-    if (!c->zs.val && c->Afull && c->mloc > 0 &&
-        hdm_zs_build(c->Afull, c->astride, c->mloc, c->astride, 1.0, &c->zs, g.stream)) return 1;
+    if (!c->zs.val && cone_has_rows(c) && c->mloc > 0 &&
+        hdm_zs_build_from([&](int q0, int nb) { return cone_rows(c, q0, nb); }, cone_batch(c), c->astride, c->mloc, c->astride, 1.0,
+                          &c->zs, g.stream)) return 1;
     c->zs_state = c->zs.val ? 1 : -1;
     return c->zs.val ? 0 : 1;
+}
+int HMiConeGetStreaming(hdsdp_cone *cone, int *batchRows) {
+    const MiCone *c = cone_data(cone);
+    if (batchRows) *batchRows = c->streamed ? c->Bs : 0;
+    return c->streamed ? 1 : 0;
 }
 int HMiConeSweepInfo(hdsdp_cone *cone, int64_t *values, int64_t *positions) {
     const MiCone *c = cone_data(cone);

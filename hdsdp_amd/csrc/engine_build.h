@@ -210,7 +210,8 @@ hdsdp_retcode build_primal_general(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, con
     for (int qi = 0; qi < c->mloc && rc == HDSDP_RETCODE_OK; ++qi) {
         // this fallback multiplies with A_L as a generic operand in both orientations: unpack the row's skyline storage
         // into a square scratch matrix first
-        if (hdm_sky_to_square(c->Afull + (long) qi * c->astride, ALsq, c->n16, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
+        const double *Arow = cone_rows(c, qi, 1);
+        if (!Arow || hdm_sky_to_square(Arow, ALsq, c->n16, g.stream)) { rc = HDSDP_RETCODE_FAILED; break; }
         const double *AL = ALsq;
         // Pr1 = X A_L            (B operand element (j, k) = A_L(k, j): K-major)
         q.A = c->Xup; q.lda = ldx; q.a_kmajor = 0; q.B = AL; q.ldb = c->n16; q.b_kmajor = 1; q.C = c->Pr1; q.beta = 0.0;
@@ -347,7 +348,17 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     bool staged = c->world > 1 && P > 1 && P <= 64 && c->mloc <= c->Bc && NT <= 64;
     if (const char *e = getenv("HDSDP_MI355X_STAGED_A2A")) staged = staged && atoi(e) != 0;
     c->last_pieces = P; c->last_staged = 0;
-    if (!staged) RC(congruence_rows(c, ch, c->Afull, c->astride, afull_span, c->mloc, 0));
+    if (c->streamed) {
+        // constraint data not resident: a batch is regenerated, transformed, and its buffer reused (stream order keeps the
+        // generator of batch k + 1 behind step 1 of batch k, the only reader)
+        staged = false;
+        for (int q0 = 0; q0 < c->mloc; q0 += c->Bs) {
+            const int nb = std::min(c->Bs, c->mloc - q0);
+            const double *A = cone_rows(c, q0, nb);
+            if (!A) return HDSDP_RETCODE_FAILED;
+            RC(congruence_rows(c, ch, A, c->astride, c->astride * (long) c->Bs + opad, nb, q0));
+        }
+    } else if (!staged) RC(congruence_rows(c, ch, c->Afull, c->astride, afull_span, c->mloc, 0));
     if (c->rank == 0) {
         // "I row": A = I => T = Linv, At = Linv Linv^T.  Reuse step 2 with T := Linv.
         HdmGemmArgs k2 = {};

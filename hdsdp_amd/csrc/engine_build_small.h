@@ -142,7 +142,7 @@ void cone_destroy_data(void **pcd) {
     if (!pcd || !*pcd) return;
     MiCone *c = (MiCone *) *pcd;
     if (c->shared_ts) c->slabs = nullptr;      // one buffer, freed as T
-    double *bufs[] = {c->Afull, c->Cfull, c->CL, c->Avec, c->sgn, c->S, c->Scheck, c->ydev, c->T, c->slabs, c->Gm,
+    double *bufs[] = {c->Afull, c->Abatch, c->Cfull, c->CL, c->Avec, c->sgn, c->S, c->Scheck, c->ydev, c->T, c->slabs, c->Gm,
                       c->U, c->V, c->Gr1, c->Ct, c->W, c->Xinv, c->Yinv};
     for (double *b : bufs)
         if (b) (void) hipFree(b);

@@ -24,6 +24,13 @@ struct MiCone {
     // device data
     double *Afull = nullptr;   // mloc x (n16 x n16) constraint matrices in A_L form: strict lower + half diagonal
     HdmZs zs; int zs_state = 0; // zero-suppressed copy of Afull for the S / dS sweeps (schur.h); 0 = not looked at, 1 = in use, -1 = not built
+    // STREAMED constraint data (synthetic family only): the A_L forms are not resident -- BASELINE configs[4] on one
+    // device is 136 GB of them beside 130 GB of transformed rows -- and every consumer walks them batch by batch through
+    // cone_rows(), which regenerates a batch into Abatch (counter-based generator: any range of matrices, any number of times,
+    // bit-identical).  The sweeps read the zero-suppressed copy when it fits (built the same way, in two passes).
+    bool streamed = false;
+    double *Abatch = nullptr;  // regeneration buffer, Bs matrices
+    int Bs = 0;
     double *Cfull = nullptr;   // n16 x n16 objective, full symmetric
     double *CL = nullptr;      // objective in A_L form (GEMM path, HSD builds)
     double *Avec = nullptr;    // n16 x mloc16 rank-one factors (R1 path)
@@ -209,6 +216,7 @@ int cone_alloc_gemm_work(MiCone *c) {
     long bc = (long) (((double) tcap * (1L << 30)) / (double) nn);
     long bcmax = 1024;
     if (const char *e = getenv("HDM_BC")) bcmax = atol(e);
+    if (c->streamed) bcmax = std::min<long>(bcmax, c->Bs);     // one congruence launch per regenerated batch
     bc = std::max(1L, std::min(bc, bcmax));
     const long rows = std::max(1, c->mloc);
     for (;;) {
@@ -336,6 +344,23 @@ void cone_get_kkt_map(void *cd, int iCol, int *schurMatCol) {
     if (c->kkt_counted < c->mloc && c->own[c->kkt_counted] == iCol) c->kkt_counted += 1;
 }
 
+// The A_L forms of the owned rows q0 .. q0 + count - 1 on the device (stride c->astride): the resident storage, or -- streamed
+// cone -- the batch buffer after regenerating them into it (count <= c->Bs; valid until the next call; ordered on the engine
+// stream behind whatever still reads the previous batch).
+const double *cone_rows(MiCone *c, int q0, int count) {
+    if (!c->streamed) return c->Afull ? c->Afull + (long) q0 * c->astride : nullptr;
+    if (!c->Abatch || count > c->Bs || q0 < 0 || q0 + count > c->mloc) return nullptr;
+    if (c->world == 1) {                       // owned rows are consecutive in the global numbering
+        if (hdm_synth_fill_low(c->Abatch, c->astride, c->n, c->n16, c->own[q0], count, g.stream)) return nullptr;
+    } else {
+        for (int q = 0; q < count; ++q)
+            if (hdm_synth_fill_low(c->Abatch + (long) q * c->astride, c->astride, c->n, c->n16, c->own[q0 + q], 1, g.stream)) return nullptr;
+    }
+    return c->Abatch;
+}
+int cone_batch(const MiCone *c) { return c->streamed ? std::max(1, c->Bs) : std::max(1, c->mloc); }
+bool cone_has_rows(const MiCone *c) { return c->streamed ? c->Abatch != nullptr : c->Afull != nullptr; }
+
 // The zero-suppressed copy of the constraint data (schur.h: HdmZs) that the S / dS sweeps and the corrector's dot products
 // read: made once, when the block's data has arrived (cone creation -- format preparation like the unpacking into A_L form; the
 // two passes and the 14 GB allocation take 0.3-0.8 s at n = m = 2000, which does not belong into the first line search),
@@ -346,8 +371,9 @@ int cone_build_zs(MiCone *c) {
     if (c->zs_state != 0) return 0;
     c->zs_state = -1;
     const long sweep_bytes = (long) c->mloc * c->n * (c->n + 1) * 4;
-    if (!c->Afull || c->mloc <= 0 || !zs_env || !(zs_env >= 2 || sweep_bytes >= (16L << 20))) return 0;
-    if (hdm_zs_build(c->Afull, c->astride, c->mloc, c->astride, zs_env >= 2 ? 1.0 : 0.6, &c->zs, g.stream)) return 1;
+    if (!cone_has_rows(c) || c->mloc <= 0 || !zs_env || !(zs_env >= 2 || sweep_bytes >= (16L << 20))) return 0;
+    if (hdm_zs_build_from([&](int q0, int nb) { return cone_rows(c, q0, nb); }, cone_batch(c), c->astride, c->mloc, c->astride,
+                          zs_env >= 2 ? 1.0 : 0.6, &c->zs, g.stream)) return 1;
     if (c->zs.val) c->zs_state = 1;
     return 0;
 }
@@ -427,8 +453,21 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
     if (any && c->zs_state == 1) {
         if (hdm_sym_combine_zs(c->zs, c->ydev, c->Cfull, lead * tau, lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)),
                                target, c->n, c->n16, c->n16, g.stream)) return 1;
-    } else if (hdm_sym_combine(c->Afull, c->astride, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
-                        lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)), target, c->n, c->n16, c->n16, g.stream)) return 1;
+    } else if (!c->streamed || !any) {
+        if (hdm_sym_combine(c->Afull, c->astride, any ? c->mloc : 0, c->ydev, c->Cfull, lead * tau,
+                            lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)), target, c->n, c->n16, c->n16, g.stream)) return 1;
+    } else {
+        // streamed data without a sweep copy: batch after batch, the later ones on top of what the earlier ones left in the
+        // target (tau' = 1, no identity term; each element is read and rewritten by the one thread that owns it)
+        for (int q0 = 0; q0 < c->mloc; q0 += c->Bs) {
+            const int nb = std::min(c->Bs, c->mloc - q0);
+            const double *A = cone_rows(c, q0, nb);
+            if (!A) return 1;
+            if (hdm_sym_combine(A, c->astride, nb, c->ydev + q0, q0 == 0 ? c->Cfull : target, q0 == 0 ? lead * tau : 1.0,
+                                q0 == 0 ? lead * (eye_override ? *eye_override : (-c->Rd + c->perturb)) : 0.0, target, c->n, c->n16,
+                                c->n16, g.stream)) return 1;
+        }
+    }
     if (c->world > 1) {
         HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
         if (!c->allreduce || c->allreduce(c->xctx, target, (int64_t) c->n16 * c->n16)) return 1;
@@ -440,7 +479,12 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
 int cone_sym_dot2(MiCone *c, const double *X, const double *Y, long ldx, double *outx, double *outy, double sx, double sy) {
     if (c->zs_state == 1)
         return hdm_sym_dot2_zs(c->zs, c->n16, c->n16, X, Y, ldx, outx, outy, c->rows_own, sx, sy, g.stream);
-    return hdm_sym_dot2(c->Afull, c->astride, c->n16, c->n16, c->mloc, X, Y, ldx, outx, outy, c->rows_own, sx, sy, g.stream);
+    for (int q0 = 0, B = cone_batch(c); q0 < c->mloc; q0 += B) {     // (one batch = everything when the data is resident)
+        const int nb = std::min(B, c->mloc - q0);
+        const double *A = cone_rows(c, q0, nb);
+        if (!A || hdm_sym_dot2(A, c->astride, c->n16, c->n16, nb, X, Y, ldx, outx, outy, c->rows_own + q0, sx, sy, g.stream)) return 1;
+    }
+    return 0;
 }
 
 hdsdp_retcode cone_factor_S(MiCone *c, int *isPsd);
@@ -679,7 +723,7 @@ int cone_data_norms(MiCone *c, double *rows_abs, double *rows_fro, double *obj_a
     double ra = 0.0, rf2 = 0.0, oa = 0.0, of2 = 0.0;
     // (a block on the congruence + Gram path has its data resident in A_L form: one HBM-bound pass over it instead of a host
     // loop over the CSC entries, which took 1.0 s of the driver's presolve at n = m = 2000)
-    const bool on_device = c->synthetic || (c->path == PATH_GEMM && c->Afull);
+    const bool on_device = c->synthetic || (c->path == PATH_GEMM && c->Afull);   // (a streamed cone is synthetic)
     if (!on_device) {
         for (int i = 0; i < c->m; ++i) { double a_, f_; coeff_norms(c->blk.rows[i], c->n, &a_, &f_); ra += a_; rf2 += f_; }
         coeff_norms(c->blk.obj, c->n, &oa, &of2);
@@ -688,9 +732,12 @@ int cone_data_norms(MiCone *c, double *rows_abs, double *rows_fro, double *obj_a
         double *tmp = nullptr;
         HDM_HIP_CHECK(hipMalloc((void **) &tmp, sizeof(double) * 4));
         HDM_HIP_CHECK(hipMemsetAsync(tmp, 0, sizeof(double) * 4, g.stream));
-        if (c->mloc > 0)
-            hipLaunchKernelGGL(mi_low_norms_kernel, dim3(c->mloc), dim3(256), 0, g.stream, c->Afull, c->astride,
-                               c->n, (long) c->n16, c->mloc, 1, tmp);
+        for (int q0 = 0, B = cone_batch(c); q0 < c->mloc; q0 += B) {
+            const int nb = std::min(B, c->mloc - q0);
+            const double *A = cone_rows(c, q0, nb);
+            if (!A) { (void) hipFree(tmp); return 1; }
+            hipLaunchKernelGGL(mi_low_norms_kernel, dim3(nb), dim3(256), 0, g.stream, A, c->astride, c->n, (long) c->n16, nb, 1, tmp);
+        }
         hipLaunchKernelGGL(mi_low_norms_kernel, dim3(1), dim3(256), 0, g.stream, c->Cfull, 0L, c->n, (long) c->n16, 1, 0, tmp + 2);
         double h[4];
         HDM_HIP_CHECK(hipMemcpyAsync(h, tmp, sizeof(h), hipMemcpyDeviceToHost, g.stream));

@@ -152,14 +152,47 @@ static hdsdp_retcode make_synth_cone(MiCone **out, int nCol, int nRow, int rank,
     c->n = nCol; c->m = nRow; c->rank = rank; c->world = world; c->synthetic = true; c->path = PATH_GEMM;
     if (world > 1) hdm_gemm_reserve_cus(8);
     if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
-    if (hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc) + hdm_operand_pad(c->n16)) != hipSuccess) {
-        fprintf(stderr, "[hdsdp_mi355x] cannot allocate %.1f GiB for the constraint matrices\n",
-                (double) c->astride * c->mloc * 8 / (1 << 30));
-        return HDSDP_RETCODE_MEMORY;
+    // Resident or streamed constraint data (MiCone::streamed)?  Resident needs the skyline storage of all owned rows NEXT TO
+    // what a build takes -- the transformed rows, intermediates / Gram slabs (up to 41 GiB), the Schur matrix with its factor
+    // and some slack; if the device does not have that, the rows are regenerated per batch instead.  HDSDP_MI355X_STREAM_A=1
+    // forces streaming (tests run small blocks both ways), 0 forbids it.
+    {
+        const double rows = (double) std::max(1, c->mloc);
+        const double afull = 8.0 * (double) c->astride * rows;
+        const double ahat = 8.0 * (double) c->world * c->npb_loc * c->Lr * 16 * (c->world == 1 ? 1.0 : 2.0);
+        const double work = std::min(41.0 * (1L << 30), std::max(8.0 * (double) c->n16 * c->n16 * std::min(rows, 1024.0),
+                                                                 8.0 * (double) c->R * c->R * 8.0));
+        const double schur = 3.0 * 8.0 * (double) c->m * c->m + (6.0 * (1L << 30));
+        size_t fr = 0, tot = 0;
+        bool stream = false;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) stream = (afull + ahat + work + schur > (double) fr);
+        (void) hipGetLastError();
+        if (const char *e = getenv("HDSDP_MI355X_STREAM_A")) stream = (atoi(e) != 0);
+        c->streamed = stream && c->mloc > 0;
     }
-    if (hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc)) != hipSuccess) return HDSDP_RETCODE_FAILED;
-    for (int q = 0; q < c->mloc; ++q)  // owned rows are strided in the global numbering
-        if (hdm_synth_fill_low(c->Afull + (long) q * c->astride, c->astride, c->n, c->n16, c->own[q], 1, g.stream)) return HDSDP_RETCODE_FAILED;
+    if (c->streamed) {
+        // batch = what one congruence launch takes (cone_alloc_gemm_work evens its launches out the same way)
+        long bmax = 1024;
+        if (const char *e = getenv("HDM_BC")) bmax = std::max(1L, atol(e));
+        const long launches = (c->mloc + bmax - 1) / bmax;
+        c->Bs = (int) ((c->mloc + launches - 1) / launches);
+        if (hipMalloc((void **) &c->Abatch, sizeof(double) * (size_t) c->astride * c->Bs + hdm_operand_pad(c->n16)) != hipSuccess) {
+            fprintf(stderr, "[hdsdp_mi355x] cannot allocate %.1f GiB for a batch of constraint matrices\n", (double) c->astride * c->Bs * 8 / (1 << 30));
+            return HDSDP_RETCODE_MEMORY;
+        }
+        if (hdm_memset_sync(c->Abatch, 0, sizeof(double) * (size_t) c->astride * c->Bs) != hipSuccess) return HDSDP_RETCODE_FAILED;
+        fprintf(stderr, "[hdsdp_mi355x] block n = %d, m = %d: %.1f GiB of constraint data are streamed (regenerated %d matrices at a time), not resident\n",
+                c->n, c->mloc, (double) c->astride * c->mloc * 8 / (1 << 30), c->Bs);
+    } else {
+        if (hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc) + hdm_operand_pad(c->n16)) != hipSuccess) {
+            fprintf(stderr, "[hdsdp_mi355x] cannot allocate %.1f GiB for the constraint matrices\n",
+                    (double) c->astride * c->mloc * 8 / (1 << 30));
+            return HDSDP_RETCODE_MEMORY;
+        }
+        if (hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc)) != hipSuccess) return HDSDP_RETCODE_FAILED;
+        for (int q = 0; q < c->mloc; ++q)  // owned rows are strided in the global numbering
+            if (hdm_synth_fill_low(c->Afull + (long) q * c->astride, c->astride, c->n, c->n16, c->own[q], 1, g.stream)) return HDSDP_RETCODE_FAILED;
+    }
     if (hdm_synth_obj(c->Cfull, c->n, c->n16, c->m, g.stream)) return HDSDP_RETCODE_FAILED;
     // b_i = tr(A_i): diagonal draws only (host, m*n splitmix evaluations)
     c->trA = (double *) calloc(nRow, sizeof(double));

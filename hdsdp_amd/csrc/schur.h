@@ -2,6 +2,7 @@
 #pragma once
 #include "hdm_common.h"
 #include "bsparse.h"
+#include <functional>
 
 int hdm_unpack_sym(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s);
 int hdm_synth_fill(double *full, long fstride, int n, int ld, int c0, int batch, hipStream_t s);
@@ -47,6 +48,11 @@ struct HdmZs {
 };
 // builds the copy unless more than max_fill of the positions are non-zero (then out->val stays null: not worth the memory)
 int hdm_zs_build(const double *A, long astride, int m, long sky, double max_fill, HdmZs *out, hipStream_t s);
+// the same from data that is NOT resident: source(c0, count) returns the device pointer of matrices c0 .. c0 + count - 1 (stride
+// astride; count <= batch), valid until its next call -- a streamed cone regenerates them into its batch buffer.  Two passes
+// (counts, then values), both in matrix order, so the copy is the one hdm_zs_build makes of the resident data, bit for bit.
+int hdm_zs_build_from(const std::function<const double *(int, int)> &source, int batch, long astride, int m, long sky,
+                      double max_fill, HdmZs *out, hipStream_t s);
 void hdm_zs_free(HdmZs *z);
 // <A_c, X>, <A_c, Y> of all matrices from the copy (what hdm_sym_dot2 computes from the dense storage; other summation order)
 int hdm_sym_dot2_zs(const HdmZs &z, int n, long lda, const double *X, const double *Y, long ldx, double *outx, double *outy,

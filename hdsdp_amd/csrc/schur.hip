@@ -13,6 +13,7 @@
 #include "hdm_common.h"
 #include "schur.h"
 #include <vector>
+#include <map>
 #include "bsparse.h"
 #include <algorithm>
 
@@ -298,7 +299,7 @@ __device__ __forceinline__ unsigned hdm_lanes_below(unsigned long long mask) {  
     return __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
 }
 
-// pass 1: non-zeros per chunk, all matrices
+// pass 1: non-zeros per chunk of the m matrices at A, ADDED to total[] (the builder walks the data batch by batch)
 __global__ __launch_bounds__(256) void hdm_zs_count_kernel(const double *__restrict__ A, long astride, int m, long sky,
                                                             unsigned long long *__restrict__ total) {
     __shared__ unsigned long long wsum[4];
@@ -316,18 +317,20 @@ __global__ __launch_bounds__(256) void hdm_zs_count_kernel(const double *__restr
     }
     if (lane == 0) wsum[wave] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) total[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) total[blockIdx.x] += wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// pass 2: masks, offsets and values of chunk b, matrix after matrix (the offsets run on through the chunk's range)
+// pass 2: masks, offsets and values of chunk b, matrix after matrix (the offsets run on through the chunk's range).  The m
+// matrices at A are matrices c0 .. c0 + m - 1 of mtot; run[b] carries the chunk's fill from one batch to the next.
 __global__ __launch_bounds__(256) void hdm_zs_fill_kernel(const double *__restrict__ A, long astride, int m, long sky,
                                                            const unsigned long long *__restrict__ base,
-                                                           unsigned long long *__restrict__ meta, double *__restrict__ val) {
+                                                           unsigned long long *__restrict__ meta, double *__restrict__ val,
+                                                           int c0, int mtot, unsigned *__restrict__ run) {
     __shared__ unsigned pc[2][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long p0 = (long) blockIdx.x * 1024 + 256 * wave + lane;
     double *out = val + base[blockIdx.x];
-    unsigned running = 0;
+    unsigned running = run[blockIdx.x];
     for (int c = 0; c < m; ++c) {
         const double *a = A + (long) c * astride;
         double v[4];
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256) void hdm_zs_fill_kernel(const double *__restri
             if (w < 4 * wave) before += k;
             all += k;
         }
-        unsigned long long *rec = meta + ((long) blockIdx.x * m + c) * 24;
+        unsigned long long *rec = meta + ((long) blockIdx.x * mtot + c0 + c) * 24;
         unsigned off = before;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -360,6 +363,8 @@ __global__ __launch_bounds__(256) void hdm_zs_fill_kernel(const double *__restri
         }
         running += all;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) run[blockIdx.x] = running;
 }
 
 // S(lower incl. diag) = tau*C - sum_i y_i A_i + eye*I from the zero-suppressed copy: the sums of hdm_sym_combine_sky_kernel
@@ -820,36 +825,56 @@ int hdm_sym_combine(const double *A, long astride, int m, const double *y, const
     return 0;
 }
 
-int hdm_zs_build(const double *A, long astride, int m, long sky, double max_fill, HdmZs *out, hipStream_t s) {
+int hdm_zs_build_from(const std::function<const double *(int, int)> &source, int batch, long astride, int m, long sky,
+                      double max_fill, HdmZs *out, hipStream_t s) {
     *out = HdmZs();
-    if (m <= 0 || sky <= 0) return 0;
+    if (m <= 0 || sky <= 0 || batch <= 0) return 0;
     const long nchunk = (sky + 1023) / 1024;
     if ((double) m * 1024.0 >= 4.0e9) return 0;           // a chunk's offsets are 32-bit
     unsigned long long *total = nullptr;
-    HDM_HIP_CHECK(hipMalloc((void **) &total, sizeof(unsigned long long) * nchunk));
-    hipLaunchKernelGGL(hdm_zs_count_kernel, dim3((unsigned) nchunk), dim3(256), 0, s, A, astride, m, sky, total);
-    HDM_HIP_CHECK(hipGetLastError());
+    unsigned *run_dev = nullptr;
+    // every way out below leaves nothing behind but what `out` owns (hdm_zs_free)
+    auto fail = [&](int rc) { if (total && total != out->base) (void) hipFree(total); if (run_dev) (void) hipFree(run_dev); (void) hipGetLastError(); hdm_zs_free(out); return rc; };
+    if (hipMalloc((void **) &total, sizeof(unsigned long long) * nchunk) != hipSuccess) return fail(1);
+    if (hipMemsetAsync(total, 0, sizeof(unsigned long long) * nchunk, s) != hipSuccess) return fail(1);
+    for (int c0 = 0; c0 < m; c0 += batch) {
+        const int nb = std::min(batch, m - c0);
+        const double *A = source(c0, nb);
+        if (!A) return fail(1);
+        hipLaunchKernelGGL(hdm_zs_count_kernel, dim3((unsigned) nchunk), dim3(256), 0, s, A, astride, nb, sky, total);
+        if (hipGetLastError() != hipSuccess) return fail(1);
+    }
     std::vector<unsigned long long> h(nchunk);
-    HDM_HIP_CHECK(hipMemcpyAsync(h.data(), total, sizeof(unsigned long long) * nchunk, hipMemcpyDeviceToHost, s));
-    HDM_HIP_CHECK(hipStreamSynchronize(s));
+    if (hipMemcpyAsync(h.data(), total, sizeof(unsigned long long) * nchunk, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) return fail(1);
     unsigned long long run = 0;
     for (long b = 0; b < nchunk; ++b) { const unsigned long long k = h[b]; h[b] = run; run += k; }
-    if ((double) run > max_fill * (double) m * (double) sky) { (void) hipFree(total); return 0; }
+    if ((double) run > max_fill * (double) m * (double) sky) return fail(0);   // not worth the memory
     out->base = total;                                     // reused: counts -> exclusive offsets
-    HDM_HIP_CHECK(hipMemcpyAsync(out->base, h.data(), sizeof(unsigned long long) * nchunk, hipMemcpyHostToDevice, s));
+    if (hipMemcpyAsync(out->base, h.data(), sizeof(unsigned long long) * nchunk, hipMemcpyHostToDevice, s) != hipSuccess) return fail(1);
     // (+ 64 values of slack: the lanes behind a word's last non-zero read the slot that follows)
     if (hipMalloc((void **) &out->val, sizeof(double) * (size_t) (run + 64)) != hipSuccess ||
-        hipMalloc((void **) &out->meta, sizeof(unsigned long long) * 24 * (size_t) nchunk * m) != hipSuccess) {
-        (void) hipGetLastError();
-        hdm_zs_free(out);
-        return 0;                                          // no memory for the copy: the dense sweep stays
+        hipMalloc((void **) &out->meta, sizeof(unsigned long long) * 24 * (size_t) nchunk * m) != hipSuccess ||
+        hipMalloc((void **) &run_dev, sizeof(unsigned) * nchunk) != hipSuccess)
+        return fail(0);                                    // no memory for the copy: the dense sweep stays
+    if (hipMemsetAsync(out->val + run, 0, sizeof(double) * 64, s) != hipSuccess ||
+        hipMemsetAsync(run_dev, 0, sizeof(unsigned) * nchunk, s) != hipSuccess) return fail(1);
+    for (int c0 = 0; c0 < m; c0 += batch) {
+        const int nb = std::min(batch, m - c0);
+        const double *A = source(c0, nb);
+        if (!A) return fail(1);
+        hipLaunchKernelGGL(hdm_zs_fill_kernel, dim3((unsigned) nchunk), dim3(256), 0, s, A, astride, nb, sky, out->base, out->meta, out->val,
+                           c0, m, run_dev);
+        if (hipGetLastError() != hipSuccess) return fail(1);
     }
-    HDM_HIP_CHECK(hipMemsetAsync(out->val + run, 0, sizeof(double) * 64, s));
-    hipLaunchKernelGGL(hdm_zs_fill_kernel, dim3((unsigned) nchunk), dim3(256), 0, s, A, astride, m, sky, out->base, out->meta, out->val);
-    HDM_HIP_CHECK(hipGetLastError());
-    HDM_HIP_CHECK(hipStreamSynchronize(s));
+    if (hipStreamSynchronize(s) != hipSuccess) return fail(1);
+    (void) hipFree(run_dev);
     out->nchunk = nchunk; out->sky = sky; out->nnz = (long) run; out->m = m;
     return 0;
+}
+
+int hdm_zs_build(const double *A, long astride, int m, long sky, double max_fill, HdmZs *out, hipStream_t s) {
+    return hdm_zs_build_from([&](int c0, int) { return A + (long) c0 * astride; }, std::max(1, m), astride, m, sky, max_fill, out, s);
 }
 
 void hdm_zs_free(HdmZs *z) {
@@ -867,19 +892,32 @@ int hdm_sym_combine_zs(const HdmZs &z, const double *y, const double *C, double 
     return 0;
 }
 
+// partial-sum scratch of the two dot-product sweeps: one buffer per host thread AND device (a host thread normally drives one
+// device -- the caller's, or one shard of a device group -- but the caller's thread may move to another one over its life:
+// HMiDeviceInit on another id, HMiSetDevices followed by plain cones; a buffer bound to the device of the first call would then
+// be read by a kernel on the other).  Kept until the process ends.
+static double *dot2_scratch(size_t need) {
+    struct Buf { double *p = nullptr; size_t cap = 0; };
+    static thread_local std::map<int, Buf> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    Buf &b = bufs[dev];
+    if (need > b.cap) {
+        if (b.p) (void) hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
+        if (hipMalloc((void **) &b.p, need) != hipSuccess) { (void) hipGetLastError(); b.p = nullptr; return nullptr; }
+        b.cap = need;
+    }
+    return b.p;
+}
+
 int hdm_sym_dot2_zs(const HdmZs &z, int n, long lda, const double *X, const double *Y, long ldx, double *outx, double *outy,
                     const int *rows_global, double sx, double sy, hipStream_t s) {
     if (z.m <= 0) return 0;
     const int nfold = 64;
     const long rows = 2 * z.nchunk;
-    static thread_local double *part = nullptr;       // per host thread: a thread drives one device
-    static thread_local size_t part_cap = 0;
-    const size_t need = sizeof(double) * 2 * (size_t) z.m * (size_t) (rows + nfold);
-    if (need > part_cap) {
-        if (part) (void) hipFree(part);
-        HDM_HIP_CHECK(hipMalloc((void **) &part, need));
-        part_cap = need;
-    }
+    double *part = dot2_scratch(sizeof(double) * 2 * (size_t) z.m * (size_t) (rows + nfold));
+    if (!part) return 1;
     double *folded = part + 2 * (size_t) z.m * rows;
     hipLaunchKernelGGL(hdm_sym_dot2_zs_kernel, dim3((unsigned) z.nchunk), dim3(128), 0, s, z.meta, z.val, z.base, z.m, X, Y, ldx, n,
                        (int) lda, z.sky, part);
@@ -914,15 +952,8 @@ int hdm_sym_dot2(const double *A, long astride, int n, long lda, int count, cons
     const int groups = (count + DOT2_G - 1) / DOT2_G;
     int nchunk = std::max(1, std::min(64, 4096 / std::max(1, groups)));
     nchunk = std::min(nchunk, std::max(1, n / 16));
-    // per host thread: a thread drives one device (the caller's, or one shard of a device group)
-    static thread_local double *part = nullptr;
-    static thread_local size_t part_cap = 0;
-    const size_t need = sizeof(double) * 2 * (size_t) nchunk * count;
-    if (need > part_cap) {
-        if (part) (void) hipFree(part);
-        HDM_HIP_CHECK(hipMalloc((void **) &part, need));
-        part_cap = need;
-    }
+    double *part = dot2_scratch(sizeof(double) * 2 * (size_t) nchunk * count);
+    if (!part) return 1;
     hipLaunchKernelGGL(hdm_sym_dot2_kernel, dim3(groups, nchunk), dim3(256), 0, s, A, astride, n, lda, count, X, Y, ldx,
                        nchunk, part);
     hipLaunchKernelGGL(hdm_sym_dot2_reduce_kernel, dim3((count + 255) / 256), dim3(256), 0, s, part, count, nchunk,

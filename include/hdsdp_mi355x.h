@@ -265,6 +265,13 @@ int HMiConeGetPath(hdsdp_cone *cone);
 /* the zero-suppressed copy of the constraint data the S / dS sweeps read (csrc/schur.h: HdmZs): returns 1 and the number of
  * stored values / of skyline positions it stands for when the cone has built one, 0 when its sweeps read the dense storage */
 int HMiConeSweepInfo(hdsdp_cone *cone, int64_t *values, int64_t *positions);
+/* Streamed constraint data (synthetic family, csrc/engine_cone.h: MiCone::streamed): when the A_L forms of all owned rows do
+ * not fit next to what a build needs -- BASELINE configs[4], n = 2000, m = 8000, on ONE device: 136 GB of them beside 130 GB of
+ * transformed rows -- HMiConeCreateSynthetic keeps none of them: every consumer (congruence batches, S / dS sweeps without a
+ * sweep copy, corrector dots, norms, A X) regenerates the rows it needs into a batch buffer from the counter-based generator,
+ * same bits every time.  Returns 1 and the batch size in rows for such a cone, 0 for resident data.  HDSDP_MI355X_STREAM_A
+ * forces either way. */
+int HMiConeGetStreaming(hdsdp_cone *cone, int *batchRows);
 /* on = 1: build the copy now whatever the block's size and fill, and sweep from it; on = 0: sweep from the dense storage
  * (a copy that exists is kept).  For tests and A/B runs; the default is the rule of HDSDP_MI355X_ZS in the table below. */
 int HMiConeUseSweepCopy(hdsdp_cone *cone, int on);
@@ -406,6 +413,8 @@ void HMiSDPAFree(HMiSDPA **pp);
  *  HDSDP_MI355X_AFFINE_S          by cost   0 / 1 / 2: dual matrix short-cuts (engine_cone.h)             test_gpu_switches.py
  *  HDSDP_MI355X_SMALL_CHECK       1         one-launch interior check of small blocks                     test_gpu_switches.py
  *  HDSDP_MI355X_ZS                by cost   0 / 1 / 2: zero-suppressed copy for the S / dS sweeps (schur.h) test_gpu_switches.py
+ *  HDSDP_MI355X_STREAM_A          by memory 0 / 1: synthetic constraint data resident / regenerated per     test_gpu_streamed.py
+ *                                           batch (MiCone::streamed)
  *  HDM_TCAP_GIB                   32        GiB of congruence intermediates per launch group              test_gpu_switches.py, test_gpu_group.py
  *  HDM_BC                         1024      constraints per congruence launch (upper bound)               test_gpu_switches.py
  *  HDM_NSPLIT                     by size   K splits of the Gram product                                  test_gpu_switches.py
