@@ -94,7 +94,7 @@ def survey_equiv(n, m, world, kms, kln, steps):
                      "tflops": round(0.5 * m * (m + 1) / world * n * (n + 1) / max(gram_ms, 1e-9) / 1e9, 2)}}
 
 
-def workload_label(n, m, shards=8):
+def workload_label(n, m, shards=8, streamed=False):
     """BASELINE.json's configs by (n, m): nothing else may call itself configs[3] or configs[4]"""
     fam = "synthetic dense SDP n=%d m=%d (SURVEY 8(d) splitmix64 family, state y=0 tau=1 Rd=-10n), one Phase-A pass per step" % (n, m)
     if (n, m) == (2000, 2000):
@@ -102,7 +102,8 @@ def workload_label(n, m, shards=8):
     if (n, m) == (2000, 8000):
         if shards > 1:
             return "configs[4]: " + fam + ", constraint rows sharded over %d GPUs" % shards
-        return "configs[4]: " + fam + ", all 8000 rows on ONE device (constraint data streamed: regenerated per congruence batch)"
+        return "configs[4]: " + fam + ", all 8000 rows on ONE device (constraint data %s)" % (
+            "streamed: regenerated per congruence batch" if streamed else "resident")
     return "custom (not a BASELINE config): " + fam
 
 
@@ -418,7 +419,7 @@ def main():
         "value": round(value, 4), "unit": "it/s", "n_gpus": devices_used, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload_label(n, m, shards),
+        "config": {"workload": workload_label(n, m, shards, cone.streaming()[0]),
                    "n": n, "m": m, "parallelism": "rows%d" % shards,
                    # how the GPUs were driven and what really ran: N requested, shards of the row deal, distinct devices in
                    # use, ranks of the RCCL communicator that carried the exchange (0 = device copies or one GPU)

@@ -30,7 +30,7 @@ EXPORTS = [
     "HFpLinsysCreate", "HFpLinsysSetParam", "HFpLinsysSymbolic", "HFpLinsysNumeric", "HFpLinsysSwitchToBackUp",
     "HFpLinsysPsdCheck", "HFpLinsysFSolve", "HFpLinsysBSolve", "HFpLinsysSolve", "HFpLinsysGetDiag",
     "HFpLinsysInvert", "HFpLinsysClear", "HFpLinsysDestroy",
-    "HMiConeCreateSDP", "HMiConeCreateSynthetic", "HMiConeDestroy", "HMiConeSetStart", "HMiConeUpdate",
+    "HMiConeCreateSDP", "HMiConeCreateSDP64", "HMiConeBuilderBegin", "HMiConeBuilderAddColumn", "HMiConeBuilderStored", "HMiConeBuilderFinish", "HMiConeBuilderAbort", "HMiConeCreateSynthetic", "HMiConeDestroy", "HMiConeSetStart", "HMiConeUpdate",
     "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeCheckIsInteriorExpert",
     "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetCoeffNorm", "HMiConeGetObjNorm",
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
@@ -39,7 +39,7 @@ EXPORTS = [
     "HMiSetDevices", "HMiSetDevicesEx", "HMiRcclGroupSelfTest", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
     "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiKKTTileInfo", "HMiBspSolve", "HMiRcmOrder", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
-    "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetRHS", "HMiSDPAFree",
+    "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetBlock64", "HMiSDPAGetRHS", "HMiSDPAFree",
 ]
 
 
@@ -190,7 +190,14 @@ def load_library():
         "HMiReadSDPA": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
         "HMiSDPAGetDims": (None, [vp, ip, ip, ip]),
         "HMiSDPAGetBlock": (C.c_int, [vp, C.c_int, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp)]),
+        "HMiSDPAGetBlock64": (C.c_int, [vp, C.c_int, ip, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(ip), C.POINTER(dp)]),
         "HMiSDPAGetRHS": (dp, [vp]),
+        "HMiConeCreateSDP64": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), ip, dp, C.c_int, C.c_int]),
+        "HMiConeBuilderBegin": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "HMiConeBuilderAddColumn": (C.c_int, [vp, C.c_int, C.c_int64, ip, dp]),
+        "HMiConeBuilderStored": (C.c_int64, [vp]),
+        "HMiConeBuilderFinish": (C.c_int, [C.POINTER(vp), C.POINTER(vp)]),
+        "HMiConeBuilderAbort": (None, [C.POINTER(vp)]),
         "HMiSDPAFree": (None, [C.POINTER(vp)]),
         "HMiMfmaIssueProbe": (C.c_double, [C.c_int, C.c_int, C.c_int]),
         "HMiSetDebugBuffer": (None, [vp, C.c_int]),
@@ -310,6 +317,42 @@ class SDPCone:
         _check(lib.HMiConeCreateSDP(C.byref(h), iCone, m, n, _iptr(beg), _iptr(idx), _dptr(val), rank, world),
                "HMiConeCreateSDP")
         return cls(h, n, m, rank, world)
+
+    @classmethod
+    def from_csc64(cls, n, m, beg, idx, val, iCone=0, rank=0, world=1):
+        """the same CSC with 64-bit column pointers (HMiConeCreateSDP64): a block may hold more than 2^31 - 1 entries"""
+        lib = load_library()
+        beg = np.ascontiguousarray(beg, dtype=np.int64)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        assert beg.shape[0] == m + 2
+        h = C.c_void_p()
+        _check(lib.HMiConeCreateSDP64(C.byref(h), iCone, m, n, beg.ctypes.data_as(C.POINTER(C.c_int64)), _iptr(idx), _dptr(val),
+                                      rank, world), "HMiConeCreateSDP64")
+        return cls(h, n, m, rank, world)
+
+    @classmethod
+    def from_columns(cls, n, m, columns, iCone=0, rank=0, world=1):
+        """column-by-column ingest (HMiConeBuilder*): `columns` yields (iCol, packed_idx, values), iCol 0 = the objective,
+        i = A_i, in any order; nothing but the column in hand has to exist on the caller's side"""
+        lib = load_library()
+        b = C.c_void_p()
+        _check(lib.HMiConeBuilderBegin(C.byref(b), iCone, m, n, rank, world), "HMiConeBuilderBegin")
+        try:
+            for iCol, idx, val in columns:
+                idx = np.ascontiguousarray(idx, dtype=np.int32)
+                val = np.ascontiguousarray(val, dtype=np.float64)
+                assert idx.shape == val.shape
+                _check(lib.HMiConeBuilderAddColumn(b, int(iCol), int(idx.shape[0]), _iptr(idx), _dptr(val)), "HMiConeBuilderAddColumn")
+            stored = int(lib.HMiConeBuilderStored(b))
+            h = C.c_void_p()
+            _check(lib.HMiConeBuilderFinish(C.byref(b), C.byref(h)), "HMiConeBuilderFinish")
+        finally:
+            if b:
+                lib.HMiConeBuilderAbort(C.byref(b))
+        cone = cls(h, n, m, rank, world)
+        cone.stored_entries = stored
+        return cone
 
     @classmethod
     def synthetic(cls, n, m, iCone=0, rank=0, world=1):

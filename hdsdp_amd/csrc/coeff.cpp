@@ -1,182 +1,234 @@
-// coeff.cpp -- presolve of one SDP block on the host (see coeff.h for the reference map).
+// coeff.cpp -- presolve of one SDP block on the host: classes, rank-one forms, order and plan (specification and reference
+// map: coeff.h).  Written against that specification; where the reference's behaviour has corners the goldens pin (which
+// storage positions the dense rank-one probe reads, where its quicksort leaves ties, which comparisons are strict) the
+// corner is stated where it is implemented.
 #include "coeff.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <utility>
 
 namespace {
 
-inline long pack_nnz(long n) { return n * (n + 1) / 2; }
+constexpr double kRankOneTol = 1e-10;      // 1-norm residual of the rank-one probe, and the cut below which a factor entry is dropped
+constexpr double kDenseShare = 0.3;        // more than this share of the P packed positions: DENSE
+constexpr double kDenseFactorShare = 0.5;  // more than this share of the n factor entries: DSR1
 
-// packed index -> (row, col), row >= col   (sparse_opts.c:427-441 walks the columns the same way)
-inline void unpack_index(int n, long p, int &i, int &j) {
-    j = 0;
-    long start = 0;
-    while (p >= start + (n - j)) { start += n - j; ++j; }
-    i = j + (int) (p - start);
+// the packed lower triangle, column by column: column j holds rows j .. n-1
+struct PackedIndex {
+    long n;
+    long columns_before(long j) const { return j * (2 * n - j + 1) / 2; }   // first position of column j
+    long size() const { return n * (n + 1) / 2; }
+};
+
+// (row, col) of packed positions given in ascending order: one walk over the columns for the whole list
+void rows_and_cols(int n, const std::vector<int> &pos, std::vector<int> &row, std::vector<int> &col) {
+    const PackedIndex px{n};
+    row.resize(pos.size());
+    col.resize(pos.size());
+    long j = 0, first = 0, next = n;                 // column j occupies [first, next)
+    for (size_t e = 0; e < pos.size(); ++e) {
+        while (pos[e] >= next) { ++j; first = next; next += n - j; }
+        col[e] = (int) j;
+        row[e] = (int) (j + (pos[e] - first));
+    }
+    (void) px;
 }
 
-// Rank-one test for a triplet matrix sorted by packed index: first entry must be a diagonal (i,i);
-// the entries of column i give a = A[:,i]/sqrt|A_ii|; the support must be a full anz x anz lower
-// block and reproduce every entry to 1e-10 in the 1-norm (sparse_opts.c:453-516).
-bool sparse_rank_one(int n, const std::vector<int> &ri, const std::vector<int> &ci, const std::vector<double> &x,
-                     double &sgn, std::vector<double> &a) {
-    const int nnz = (int) x.size();
-    int i = ri[0], j = ci[0];
-    double v = x[0];
-    if (i != j) return false;
-    if (nnz == 1) { sgn = x[0]; a[i] = 1.0; return true; }
-    double s = (v > 0) ? 1.0 : -1.0;
-    v = std::sqrt(std::fabs(v));
-    int k = 0, anz = 0;
-    for (k = 0; k < nnz; ++k) {
-        if (ci[k] > i) break;
-        a[ri[k]] = x[k] / v;
-        anz += 1;
-    }
-    if (nnz != (int) (anz * (anz + 1) / 2)) return false;
-    if (k == n) return false;
-    double eps = 0.0;
-    for (k = 0; k < nnz; ++k) eps += std::fabs(x[k] - s * a[ri[k]] * a[ci[k]]);
-    if (eps > 1e-10) return false;
-    sgn = s;
+// Rank-one probe of a SPARSE-class matrix (entries sorted by packed position).  The candidate factor is the column of the
+// FIRST stored entry, which therefore has to be a diagonal one; the support must be exactly the k(k+1)/2 lower positions of
+// a k x k principal block, k = entries of that column; the factor has to reproduce every stored entry, 1e-10 in the 1-norm.
+// Corners kept as the reference has them: a single (diagonal) entry is rank one with an unnormalised factor e_i and the
+// whole value as its sign; a candidate column with n entries is refused (such a matrix is not SPARSE-class anyway unless
+// n is tiny); the sign of a zero pivot counts as negative.
+bool probe_rank_one_sparse(int n, const std::vector<int> &row, const std::vector<int> &col, const std::vector<double> &v,
+                           double &sign, std::vector<double> &a) {
+    const size_t cnt = v.size();
+    if (row[0] != col[0]) return false;
+    const int pc = col[0];
+    if (cnt == 1) { sign = v[0]; a[pc] = 1.0; return true; }
+    const double s = (v[0] > 0) ? 1.0 : -1.0;
+    const double scale = std::sqrt(std::fabs(v[0]));
+    size_t k = 0;
+    while (k < cnt && col[k] <= pc) { a[row[k]] = v[k] / scale; ++k; }
+    if (cnt != k * (k + 1) / 2 || k == (size_t) n) return false;
+    double resid = 0.0;
+    for (size_t e = 0; e < cnt; ++e) resid += std::fabs(v[e] - s * a[row[e]] * a[col[e]]);
+    if (resid > kRankOneTol) return false;
+    sign = s;
     return true;
 }
 
-// Same test on a packed dense matrix (dense_opts.c:233-285)
-bool dense_rank_one(int n, const std::vector<double> &A, double &sgn, std::vector<double> &a) {
-    int i = 0;
-    long k = 0;
-    for (i = 0; i < n; ++i) {
-        if (A[k] != 0) break;
-        k += n - i;
-    }
-    if (i == n) return false;
-    double s = (A[k] > 0) ? 1.0 : -1.0;
-    double v = std::sqrt(std::fabs(A[k]));
-    const long coli = (long) (2 * n - i - 1) * i / 2;
-    for (int r = 0; r < n; ++r) a[r] = A[coli + r] / v;
-    double eps = 0.0;
-    long id = 0;
+// Rank-one probe of a DENSE-class matrix in packed storage: the candidate is the column of the first diagonal entry that is
+// not exactly zero.  The reference reads the n candidate entries from the n storage positions that END with that column's
+// (columns_before(i) - i + r for r = 0 .. n-1): for r >= i that is A(r, i); for r < i it is whatever the tail of the
+// columns before holds -- zero for a matrix that really is a a' with a_r = 0 there, and for anything else the residual test
+// decides.  The same positions are read here, so that accept / reject agree in every case.  The residual is summed column
+// by column and the probe gives up after the first column that takes it past the tolerance.
+bool probe_rank_one_dense(int n, const std::vector<double> &A, double &sign, std::vector<double> &a) {
+    const PackedIndex px{n};
+    int pc = 0;
+    while (pc < n && A[px.columns_before(pc)] == 0) ++pc;
+    if (pc == n) return false;
+    const double d = A[px.columns_before(pc)];
+    const double s = (d > 0) ? 1.0 : -1.0, scale = std::sqrt(std::fabs(d));
+    const long origin = px.columns_before(pc) - pc;
+    for (int r = 0; r < n; ++r) a[r] = A[origin + r] / scale;
+    double resid = 0.0;
+    long at = 0;
     for (int c = 0; c < n; ++c) {
-        for (int r = 0; r < n - c; ++r) eps += std::fabs(A[id + r] - s * a[c] * a[c + r]);
-        id += n - c;
-        if (eps > 1e-10) return false;
+        const long h = n - c;
+        for (long r = 0; r < h; ++r) resid += std::fabs(A[at + r] - s * a[c] * a[c + r]);
+        at += h;
+        if (resid > kRankOneTol) return false;
     }
-    sgn = s;
+    sign = s;
     return true;
 }
 
-void build_coeff(MiCoeff &c, int n, int nnz, const int *idx, const double *val) {
-    c.idx.assign(idx, idx + nnz);
-    c.val.assign(val, val + nnz);
-    if (!std::is_sorted(c.idx.begin(), c.idx.end())) {
-        std::vector<int> o(nnz);
-        for (int k = 0; k < nnz; ++k) o[k] = k;
-        std::stable_sort(o.begin(), o.end(), [&](int x, int y) { return idx[x] < idx[y]; });
-        for (int k = 0; k < nnz; ++k) { c.idx[k] = idx[o[k]]; c.val[k] = val[o[k]]; }
-    }
-    const long P = pack_nnz(n);
-    if (nnz == 0) { c.type = MI_COEFF_ZERO; c.nnz = 0; c.rank = 0; return; }
-    std::vector<double> a(n, 0.0);
-    double sgn = 0.0;
-    bool r1 = false;
-    if (nnz > 0.3 * P) {
-        c.type = MI_COEFF_DENSE;
-        std::vector<double> pk(P, 0.0);
-        for (int k = 0; k < nnz; ++k) pk[c.idx[k]] = c.val[k];
-        r1 = dense_rank_one(n, pk, sgn, a);
-        c.nnz = (int) P;
-    } else {
-        c.type = MI_COEFF_SPARSE;
-        std::vector<int> ri(nnz), ci(nnz);
-        for (int k = 0; k < nnz; ++k) unpack_index(n, c.idx[k], ri[k], ci[k]);
-        r1 = sparse_rank_one(n, ri, ci, c.val, sgn, a);
-        c.nnz = nnz;
-    }
-    c.rank = n;
-    if (!r1) return;
-    int fn = 0;
-    for (int r = 0; r < n; ++r) fn += (std::fabs(a[r]) > 1e-10);
-    double nrm = 0.0;
-    if (fn > 0.5 * n) {
-        c.type = MI_COEFF_DSR1;
-        for (int r = 0; r < n; ++r) nrm += a[r] * a[r];
-        c.nnz = (int) P;
-    } else {
-        c.type = MI_COEFF_SPR1;
-        for (int r = 0; r < n; ++r) {
-            if (std::fabs(a[r]) > 1e-10) nrm += a[r] * a[r]; else a[r] = 0.0;
+// Descending order by key with the reference's tie behaviour: its quicksort takes the first element of a range as the pivot,
+// closes in from both ends (from the right past keys <= pivot, from the left past keys >= pivot), exchanges, and finally
+// puts the pivot where the ends met; keys and indices move together.  Ties therefore end up in an order of their own, which
+// the plan -- and the goldens -- depend on.  Ranges are kept on an explicit stack (a block with 1e5 equal rows must not
+// recurse 1e5 deep), and a range whose keys are all equal is left alone: every level of the scheme would return it unchanged.
+void order_descending(std::vector<int> &ind, std::vector<int> &key) {
+    std::vector<std::pair<int, int>> todo;
+    if (!key.empty()) todo.push_back({0, (int) key.size() - 1});
+    while (!todo.empty()) {
+        const int lo = todo.back().first, hi = todo.back().second;
+        todo.pop_back();
+        if (lo >= hi) continue;
+        bool flat = true;
+        for (int t = lo + 1; t <= hi && flat; ++t) flat = (key[t] == key[lo]);
+        if (flat) continue;
+        const int pivot = key[lo];
+        int l = lo, h = hi;
+        while (l < h) {
+            while (l < h && key[h] <= pivot) --h;
+            while (l < h && key[l] >= pivot) ++l;
+            if (l < h) { std::swap(key[l], key[h]); std::swap(ind[l], ind[h]); }
         }
-        c.nnz = (int) pack_nnz(fn);
+        std::swap(key[l], key[lo]);
+        std::swap(ind[l], ind[lo]);
+        // (the reference finishes the left part first; the two parts are disjoint, so the order of work does not matter)
+        todo.push_back({l + 1, hi});
+        todo.push_back({lo, l - 1});
     }
-    nrm = std::sqrt(nrm);
-    c.sign = sgn * nrm * nrm;  // scale goes into the sign (hdsdp_sdpdata.c:880-899)
-    for (int r = 0; r < n; ++r) a[r] /= nrm;
-    c.factor = a;
-    c.factor_nnz = fn;
-    c.rank = 1;
-}
-
-// quicksort partition used by the reference for the descending nnz ordering; ties end up where
-// this exact scheme leaves them (hdsdp_utils.c:93-112)
-int partition_desc(std::vector<int> &ind, std::vector<int> &val, int l, int h) {
-    int tmp = l, p = val[l];
-    while (l < h) {
-        while (l < h && val[h] <= p) --h;
-        while (l < h && val[l] >= p) ++l;
-        if (l < h) { std::swap(val[l], val[h]); std::swap(ind[l], ind[h]); }
-    }
-    std::swap(val[l], val[tmp]);
-    std::swap(ind[l], ind[tmp]);
-    return l;
-}
-void sort_desc(std::vector<int> &ind, std::vector<int> &val, int low, int up) {
-    if (low < up) {
-        int p = partition_desc(ind, val, low, up);
-        sort_desc(ind, val, low, p - 1);
-        sort_desc(ind, val, p + 1, up);
-    }
-}
-
-int choose_strategy(const std::vector<int> &ranks, const std::vector<int> &sparsity, const std::vector<int> &perm,
-                    int nRow, int nCol, int iPerm) {
-    const double kappa = 1.5;  // SPARSE_EFFICIENCY
-    int best = 0;
-    double bestScore = INFINITY;
-    const int rowRank = ranks[perm[iPerm]];
-    const double n3 = (double) nCol * nCol * nCol;
-    double after = 0.0;
-    for (int i = iPerm; i < nRow; ++i) after += sparsity[i];
-    const double f = sparsity[iPerm];
-    const double s2 = rowRank * (f * nCol + 3 * kappa * after);
-    const double s3 = (double) nCol * kappa * f + n3 + kappa * after + n3 / nRow;
-    const double s4 = (double) nCol * kappa * f + kappa * (nCol + 1) * after + n3 / nRow;
-    const double s5 = kappa * (2.0 * kappa * f + 1) * after + n3 / nRow;
-    if (s2 <= bestScore) { best = 1; bestScore = s2; }
-    if (s3 < bestScore) { best = 2; bestScore = s3; }
-    if (s4 < bestScore) { best = 3; bestScore = s4; }
-    if (s5 < bestScore) { best = 4; bestScore = s5; }
-    return best;
 }
 
 }  // namespace
 
-int mi_block_from_csc(MiBlockData &blk, int m, int n, const int *beg, const int *idx, const double *val) {
+int mi_coeff_build(MiCoeff &c, int n, long nnz, const int *idx, const double *val) {
+    const PackedIndex px{n};
+    const long P = px.size();
+    c = MiCoeff();
+    c.stored = nnz;
+    if (nnz <= 0) return 0;                                  // ZERO
+    if (nnz > P) return 1;
+    c.idx.assign(idx, idx + nnz);
+    c.val.assign(val, val + nnz);
+    if (!std::is_sorted(c.idx.begin(), c.idx.end())) {       // entries in file order: bring them to packed order, stably
+        std::vector<long> o((size_t) nnz);
+        for (long k = 0; k < nnz; ++k) o[k] = k;
+        std::stable_sort(o.begin(), o.end(), [&](long x, long y) { return idx[x] < idx[y]; });
+        for (long k = 0; k < nnz; ++k) { c.idx[k] = idx[o[k]]; c.val[k] = val[o[k]]; }
+    }
+    if (c.idx.front() < 0 || c.idx.back() >= P) return 1;
+    {   // trace: the diagonal positions are the column starts
+        long j = 0, first = 0;
+        for (long k = 0; k < nnz; ++k) {
+            while (j < n && first < c.idx[k]) { first += n - j; ++j; }
+            if (j < n && first == c.idx[k]) c.trace += c.val[k];
+        }
+    }
+    std::vector<double> a((size_t) n, 0.0);
+    double sgn = 0.0;
+    bool one = false;
+    if ((double) nnz > kDenseShare * (double) P) {
+        c.type = MI_COEFF_DENSE;
+        c.nnz = (int) P;
+        std::vector<double> full((size_t) P, 0.0);
+        for (long k = 0; k < nnz; ++k) full[c.idx[k]] = c.val[k];
+        one = probe_rank_one_dense(n, full, sgn, a);
+    } else {
+        c.type = MI_COEFF_SPARSE;
+        c.nnz = (int) nnz;
+        std::vector<int> row, col;
+        rows_and_cols(n, c.idx, row, col);
+        one = probe_rank_one_sparse(n, row, col, c.val, sgn, a);
+    }
+    c.rank = n;
+    if (!one) return 0;
+    // rank one: dense or sparse factor, normalised, the scale folded into the sign
+    int kept = 0;
+    for (int r = 0; r < n; ++r) kept += (std::fabs(a[r]) > kRankOneTol);
+    double norm2 = 0.0;
+    if ((double) kept > kDenseFactorShare * (double) n) {
+        c.type = MI_COEFF_DSR1;
+        c.nnz = (int) P;
+        for (int r = 0; r < n; ++r) norm2 += a[r] * a[r];
+    } else {
+        c.type = MI_COEFF_SPR1;
+        c.nnz = (int) ((long) kept * (kept + 1) / 2);
+        for (int r = 0; r < n; ++r) {
+            if (std::fabs(a[r]) > kRankOneTol) norm2 += a[r] * a[r];
+            else a[r] = 0.0;
+        }
+    }
+    const double norm = std::sqrt(norm2);
+    c.sign = sgn * norm * norm;
+    for (int r = 0; r < n; ++r) a[r] /= norm;
+    c.factor.swap(a);
+    c.factor_nnz = kept;
+    c.rank = 1;
+    return 0;
+}
+
+void mi_block_plan(MiBlockData &blk) {
+    const int m = blk.m, n = blk.n;
+    for (int t = 0; t < 5; ++t) blk.counts[t] = 0;
+    blk.stored = blk.obj.stored;
+    for (int i = 0; i < m; ++i) { blk.counts[blk.rows[i].type] += 1; blk.stored += blk.rows[i].stored; }
+    std::vector<int> key((size_t) m);
+    blk.perm.resize((size_t) m);
+    for (int i = 0; i < m; ++i) { blk.perm[i] = i; key[i] = blk.rows[i].nnz; }
+    order_descending(blk.perm, key);
+    // Cost model per position p of the order (r = rank of the row there, f = its nnz, z = nnz of this and all later rows,
+    // kappa = 1.5): M2 r (f n + 3 kappa z); M3 n kappa f + n^3 + kappa z + n^3/m; M4 n kappa f + kappa (n + 1) z + n^3/m;
+    // M5 kappa (2 kappa f + 1) z + n^3/m.  M2 is taken on a tie with "nothing yet", every later candidate has to be strictly
+    // cheaper.  z is an exact integer sum (below 2^53), whichever end it is accumulated from.
+    std::vector<double> tail((size_t) m + 1, 0.0);
+    for (int p = m - 1; p >= 0; --p) tail[p] = tail[p + 1] + (double) key[p];
+    blk.strategy.resize((size_t) m);
+    const double kappa = 1.5, n3 = (double) n * n * n;
+    for (int p = 0; p < m; ++p) {
+        const double r = blk.rows[blk.perm[p]].rank, f = key[p], z = tail[p];
+        const double cost[4] = {r * (f * n + 3 * kappa * z),
+                                (double) n * kappa * f + n3 + kappa * z + n3 / m,
+                                (double) n * kappa * f + kappa * (n + 1) * z + n3 / m,
+                                kappa * (2.0 * kappa * f + 1) * z + n3 / m};
+        int pick = 0;
+        double best = INFINITY;
+        for (int q = 0; q < 4; ++q)
+            if (q == 0 ? cost[q] <= best : cost[q] < best) { best = cost[q]; pick = q + 1; }
+        blk.strategy[p] = pick;
+    }
+}
+
+template <class Off> static int block_from_csc(MiBlockData &blk, int m, int n, const Off *beg, const int *idx, const double *val) {
+    blk = MiBlockData();
     blk.n = n;
     blk.m = m;
-    blk.rows.assign(m, MiCoeff());
-    for (int t = 0; t < 5; ++t) blk.counts[t] = 0;
-    build_coeff(blk.obj, n, beg[1] - beg[0], idx + beg[0], val + beg[0]);
-    for (int i = 0; i < m; ++i) {
-        build_coeff(blk.rows[i], n, beg[i + 2] - beg[i + 1], idx + beg[i + 1], val + beg[i + 1]);
-        blk.counts[blk.rows[i].type] += 1;
-    }
-    std::vector<int> ranks(m), sparsity(m);
-    blk.perm.resize(m);
-    blk.strategy.resize(m);
-    for (int i = 0; i < m; ++i) { blk.perm[i] = i; ranks[i] = blk.rows[i].rank; sparsity[i] = blk.rows[i].nnz; }
-    sort_desc(blk.perm, sparsity, 0, m - 1);
-    for (int p = 0; p < m; ++p) blk.strategy[p] = choose_strategy(ranks, sparsity, blk.perm, m, n, p);
+    blk.rows.assign((size_t) m, MiCoeff());
+    if (mi_coeff_build(blk.obj, n, (long) (beg[1] - beg[0]), idx + beg[0], val + beg[0])) return 1;
+    for (int i = 0; i < m; ++i)
+        if (mi_coeff_build(blk.rows[i], n, (long) (beg[i + 2] - beg[i + 1]), idx + beg[i + 1], val + beg[i + 1])) return 1;
+    mi_block_plan(blk);
     return 0;
+}
+int mi_block_from_csc(MiBlockData &blk, int m, int n, const int *beg, const int *idx, const double *val) {
+    return block_from_csc(blk, m, n, beg, idx, val);
+}
+int mi_block_from_csc(MiBlockData &blk, int m, int n, const int64_t *beg, const int *idx, const double *val) {
+    return block_from_csc(blk, m, n, beg, idx, val);
 }

@@ -3,24 +3,61 @@
 
 hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *coneMatBeg,
                                const int *coneMatIdx, const double *coneMatElem, int rank, int world) {
-    if (!pCone || nRow < 1 || nCol < 1 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
-    if (group_configure_from_env()) return HDSDP_RETCODE_FAILED;
-    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
-    if (rank == 0 && world == 1 && group_wants_block(nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem))
-        return group_create_cone(pCone, iCone, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem, false);
-    MiCone *c = nullptr;
-    hdsdp_retcode rc = make_sdp_cone(&c, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem, rank, world);
-    if (rc != HDSDP_RETCODE_OK) return rc;
-    *pCone = new_cone_shell(c, iCone);
+    return cone_create_csc(pCone, iCone, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem, rank, world);
+}
+hdsdp_retcode HMiConeCreateSDP64(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int64_t *coneMatBeg,
+                                 const int *coneMatIdx, const double *coneMatElem, int rank, int world) {
+    return cone_create_csc(pCone, iCone, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem, rank, world);
+}
+
+// ---------------------------------------------------------------- column-by-column ingest (64-bit totals)
+struct HMiConeBuilder_s : MiConeBuilder {};
+hdsdp_retcode HMiConeBuilderBegin(HMiConeBuilder **pBuilder, int iCone, int nRow, int nCol, int rank, int world) {
+    if (!pBuilder || nRow < 1 || nCol < 1 || nCol > 65535 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
+    HMiConeBuilder_s *b = new HMiConeBuilder_s();
+    b->iCone = iCone; b->rank = rank; b->world = world;
+    b->blk.n = nCol; b->blk.m = nRow;
+    b->blk.rows.assign((size_t) nRow, MiCoeff());
+    b->seen.assign((size_t) nRow + 1, 0);
+    *pBuilder = b;
     return HDSDP_RETCODE_OK;
+}
+hdsdp_retcode HMiConeBuilderAddColumn(HMiConeBuilder *b, int iCol, int64_t nnz, const int *packedIdx, const double *val) {
+    if (!b || iCol < 0 || iCol > b->blk.m || nnz < 0 || (nnz > 0 && (!packedIdx || !val))) return HDSDP_RETCODE_FAILED;
+    if (b->seen[iCol]) { fprintf(stderr, "[hdsdp_mi355x] HMiConeBuilderAddColumn: column %d was given before\n", iCol); return HDSDP_RETCODE_FAILED; }
+    MiCoeff &dst = (iCol == 0) ? b->blk.obj : b->blk.rows[iCol - 1];
+    if (mi_coeff_build(dst, b->blk.n, (long) nnz, packedIdx, val)) {
+        fprintf(stderr, "[hdsdp_mi355x] HMiConeBuilderAddColumn: column %d has a packed index outside [0, n(n+1)/2) or too many entries\n", iCol);
+        return HDSDP_RETCODE_FAILED;
+    }
+    b->seen[iCol] = 1;
+    return HDSDP_RETCODE_OK;
+}
+int64_t HMiConeBuilderStored(const HMiConeBuilder *b) {
+    if (!b) return 0;
+    int64_t t = b->blk.obj.stored;
+    for (const MiCoeff &c : b->blk.rows) t += c.stored;
+    return t;
+}
+hdsdp_retcode HMiConeBuilderFinish(HMiConeBuilder **pBuilder, hdsdp_cone **pCone) {
+    if (!pBuilder || !*pBuilder || !pCone) return HDSDP_RETCODE_FAILED;
+    HMiConeBuilder_s *b = *pBuilder;
+    mi_block_plan(b->blk);                       // (columns never given are zero matrices)
+    const hdsdp_retcode rc = cone_from_block(pCone, b->iCone, b->blk, b->rank, b->world);
+    delete b;
+    *pBuilder = nullptr;
+    return rc;
+}
+void HMiConeBuilderAbort(HMiConeBuilder **pBuilder) {
+    if (pBuilder && *pBuilder) { delete *pBuilder; *pBuilder = nullptr; }
 }
 
 hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, int nRow, int rank, int world) {
     if (!pCone || nRow < 1 || nCol < 1 || world < 1 || rank < 0 || rank >= world) return HDSDP_RETCODE_FAILED;
     if (group_configure_from_env()) return HDSDP_RETCODE_FAILED;
     if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
-    if (rank == 0 && world == 1 && group_wants_block(nRow, nCol, nullptr, nullptr, nullptr))
-        return group_create_cone(pCone, iCone, nRow, nCol, nullptr, nullptr, nullptr, true);
+    if (rank == 0 && world == 1 && group_wants_synthetic(nRow, nCol))
+        return group_create_cone(pCone, iCone, nRow, nCol, nullptr, true);
     MiCone *c = nullptr;
     hdsdp_retcode rc = make_synth_cone(&c, nCol, nRow, rank, world);
     if (rc != HDSDP_RETCODE_OK) return rc;

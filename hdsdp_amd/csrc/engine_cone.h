@@ -148,9 +148,9 @@ void priv_drop(hdsdp_kkt *k) {
 hdsdp_retcode gc_build_schur(void *cd, int iCone, void *kktv, int typeKKT);
 MiCone *cone_data(hdsdp_cone *cone);   // the block's device data; for a group cone that of shard 0
 int group_configure_from_env();
-bool group_wants_block(int nRow, int nCol, const int *beg, const int *idx, const double *val);
-hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *beg, const int *idx,
-                                const double *val, bool synthetic);
+bool group_wants_block(const MiBlockData &blk);
+bool group_wants_synthetic(int nRow, int nCol);
+hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCol, MiBlockData *blk, bool synthetic);
 
 int cone_alloc_common(MiCone *c) {
     c->n16 = (int) hdm_roundup(c->n, 16);

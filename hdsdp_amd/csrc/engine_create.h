@@ -59,31 +59,39 @@ static int natural_path(const MiBlockData &blk, int nRow, int nCol, int world) {
         for (int i = 0; i < nRow; ++i) {
             int t = blk.rows[i].type;
             if (t == MI_COEFF_DENSE || t == MI_COEFF_DSR1) all_sparse = false;
-            tot += (double) blk.rows[i].idx.size();
+            tot += (double) blk.rows[i].stored;
         }
         if (all_sparse && tot * tot < 0.05 * (double) nRow * nCol * (double) nCol * nCol) path = PATH_SPARSE;
     }
     return path;
 }
 
-// the device data of one SDP block for rank `rank` of `world` on the calling thread's context
-static hdsdp_retcode make_sdp_cone(MiCone **out, int nRow, int nCol, const int *coneMatBeg, const int *coneMatIdx,
-                                   const double *coneMatElem, int rank, int world) {
+// the device data of one SDP block for rank `rank` of `world` on the calling thread's context, from the block's presolved
+// host data.  A shard of a sharded block (world > 1) copies the entries of its own rows only (the others keep class, counts
+// and trace): W shards of one block together hold one more copy of the data, not W.  With `take` the source is moved from.
+static hdsdp_retcode make_sdp_cone_from_block(MiCone **out, MiBlockData &src, bool take, int rank, int world) {
     if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
+    const int nRow = src.m, nCol = src.n;
     MiCone *c = new MiCone();
     c->n = nCol; c->m = nRow; c->rank = rank; c->world = world;
     if (world > 1) hdm_gemm_reserve_cus(8);   // the exchange's collectives run beside the persistent GEMM launches
-    if (mi_block_from_csc(c->blk, nRow, nCol, coneMatBeg, coneMatIdx, coneMatElem)) { delete c; return HDSDP_RETCODE_FAILED; }
-    if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
-    c->trA = (double *) calloc(nRow, sizeof(double));
-    for (int i = 0; i < nRow; ++i) {
-        const MiCoeff &co = c->blk.rows[i];
-        long d = 0; int j = 0;  // packed index of (j,j)
-        for (size_t e = 0; e < co.idx.size(); ++e) {
-            while (j < nCol && d < co.idx[e]) { d += nCol - j; ++j; }
-            if (j < nCol && d == co.idx[e]) c->trA[i] += co.val[e];
+    if (take) c->blk = std::move(src);
+    else if (world == 1) c->blk = src;
+    else {
+        c->blk.n = src.n; c->blk.m = src.m; c->blk.perm = src.perm; c->blk.strategy = src.strategy; c->blk.stored = src.stored;
+        for (int t = 0; t < 5; ++t) c->blk.counts[t] = src.counts[t];
+        c->blk.obj = src.obj;
+        c->blk.rows.resize((size_t) nRow);
+        for (int i = 0; i < nRow; ++i) {
+            if (i % world == rank) { c->blk.rows[i] = src.rows[i]; continue; }
+            MiCoeff &d = c->blk.rows[i];
+            const MiCoeff &o = src.rows[i];
+            d.type = o.type; d.nnz = o.nnz; d.rank = o.rank; d.stored = o.stored; d.trace = o.trace; d.sign = o.sign; d.factor_nnz = o.factor_nnz;
         }
     }
+    if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
+    c->trA = (double *) calloc(nRow, sizeof(double));
+    for (int i = 0; i < nRow; ++i) c->trA[i] = c->blk.rows[i].trace;
     c->path = natural_path(c->blk, nRow, nCol, world);
     const char *force = getenv("HDSDP_MI355X_FORCE_GEMM");
     if (force && atoi(force)) c->path = PATH_GEMM;
@@ -141,6 +149,10 @@ static hdsdp_retcode make_sdp_cone(MiCone **out, int nRow, int nCol, const int *
             return HDSDP_RETCODE_FAILED;
     }
     if (hipStreamSynchronize(g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
+    // On the congruence + Gram path everything downstream reads the device copy (A_L forms, the sweep copy): the host copy of
+    // the entries -- 19 GB at n = m = 2000, 40 %-filled -- goes back now.  The rank-one and gather paths keep theirs (small,
+    // and their host-side norms and plans read them).
+    if (c->path == PATH_GEMM) { for (MiCoeff &co : c->blk.rows) co.release(); c->blk.obj.release(); }
     if (cone_build_zs(c)) return HDSDP_RETCODE_FAILED;
     *out = c;
     return HDSDP_RETCODE_OK;

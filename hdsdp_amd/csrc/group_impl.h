@@ -272,15 +272,14 @@ int group_configure_from_env() {
     return group_setup(n, ids, -1);
 }
 
-bool group_wants_block(int nRow, int nCol, const int *beg, const int *idx, const double *val) {
+bool group_wants_synthetic(int nRow, int nCol) {
     MiGroup *G = g_group;
-    if (!G || G->W < 2) return false;
-    if (nCol < G->min_n || nRow < G->W) return false;
-    if (!beg) return true;   // synthetic dense family
-    MiBlockData blk;
-    if (mi_block_from_csc(blk, nRow, nCol, beg, idx, val)) return false;
+    return G && G->W >= 2 && nCol >= G->min_n && nRow >= G->W;
+}
+bool group_wants_block(const MiBlockData &blk) {
+    if (!group_wants_synthetic(blk.m, blk.n)) return false;
     if (const char *f = getenv("HDSDP_MI355X_FORCE_GEMM")) if (atoi(f)) return true;
-    return natural_path(blk, nRow, nCol, 1) == PATH_GEMM;
+    return natural_path(blk, blk.m, blk.n, 1) == PATH_GEMM;
 }
 
 // ------------------------------------------------------------------------------------------------ collectives
@@ -522,8 +521,7 @@ MiCone *cone_data(hdsdp_cone *cone) {
     return (MiCone *) cone->coneData;
 }
 
-hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *beg, const int *idx,
-                                const double *val, bool synthetic) {
+hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCol, MiBlockData *blk, bool synthetic) {
     MiGroup *G = g_group;
     MiConeGroup *cg = new MiConeGroup();
     cg->G = G; cg->n = nCol; cg->m = nRow;
@@ -535,7 +533,7 @@ hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCo
     std::vector<hdsdp_retcode> rcs(G->W, HDSDP_RETCODE_OK);
     (void) grun(cg, [&](int r, MiCone *) {
         rcs[r] = synthetic ? make_synth_cone(&cg->shard[r], nCol, nRow, r, G->W)
-                           : make_sdp_cone(&cg->shard[r], nRow, nCol, beg, idx, val, r, G->W);
+                           : make_sdp_cone_from_block(&cg->shard[r], *blk, false, r, G->W);   // (each shard copies its own rows)
         return 0; });
     for (int r = 0; r < G->W; ++r)
         if (rcs[r] != HDSDP_RETCODE_OK || !cg->shard[r]) {
@@ -586,6 +584,34 @@ hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCo
     *pCone = h;
     return HDSDP_RETCODE_OK;
 }
+
+// a presolved block becomes a cone: a group cone if a device group is configured and wants it, else a plain one
+static hdsdp_retcode cone_from_block(hdsdp_cone **pCone, int iCone, MiBlockData &blk, int rank, int world) {
+    if (group_configure_from_env()) return HDSDP_RETCODE_FAILED;
+    if (ensure_ctx()) return HDSDP_RETCODE_FAILED;
+    if (rank == 0 && world == 1 && group_wants_block(blk)) return group_create_cone(pCone, iCone, blk.m, blk.n, &blk, false);
+    MiCone *c = nullptr;
+    hdsdp_retcode rc = make_sdp_cone_from_block(&c, blk, true, rank, world);
+    if (rc != HDSDP_RETCODE_OK) return rc;
+    *pCone = new_cone_shell(c, iCone);
+    return HDSDP_RETCODE_OK;
+}
+template <class Off> static hdsdp_retcode cone_create_csc(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const Off *beg,
+                                                          const int *idx, const double *val, int rank, int world) {
+    if (!pCone || nRow < 1 || nCol < 1 || nCol > 65535 || world < 1 || rank < 0 || rank >= world || !beg) return HDSDP_RETCODE_FAILED;
+    MiBlockData blk;
+    if (mi_block_from_csc(blk, nRow, nCol, beg, idx, val)) {
+        fprintf(stderr, "[hdsdp_mi355x] cone data: a packed index lies outside [0, n(n+1)/2)\n");
+        return HDSDP_RETCODE_FAILED;
+    }
+    return cone_from_block(pCone, iCone, blk, rank, world);
+}
+// column-by-column ingest (engine_api.h: HMiConeBuilder*): the block's presolved columns as they arrive
+struct MiConeBuilder {
+    int iCone = 0, rank = 0, world = 1;
+    MiBlockData blk;
+    std::vector<char> seen;
+};
 
 // RCCL self-test over the WHOLE group `ids` (n distinct devices; n = 1 is the one-rank form a 1-GPU box can run):
 // communicators (ncclCommInitAll), then from one host thread per device -- the way the group's workers drive it -- an

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -16,9 +17,14 @@ struct HMiSDPA_s {
     int m = 0, nblk = 0, nlp = 0;
     std::vector<int> dims;
     std::vector<double> rhs;
-    std::vector<std::vector<int>> beg, idx;
+    // column pointers are 64-bit: a block's columns may hold more than 2^31 - 1 entries together (the reference's reader
+    // and user data cannot: hdsdp_file_io.c / def_hdsdp_user_data.h:22-32 use int); beg32 is made on demand for callers of
+    // the reference-shaped accessor and only where the block fits it
+    std::vector<std::vector<int64_t>> beg;
+    std::vector<std::vector<int>> beg32, idx;
     std::vector<std::vector<double>> val;
-    std::vector<int> lpBeg, lpIdx;
+    std::vector<int64_t> lpBeg;
+    std::vector<int> lpIdx;
     std::vector<double> lpVal;
 };
 
@@ -39,13 +45,13 @@ void soften(std::string &s) {
     for (char &c : s)
         if (c == '{' || c == '}' || c == '(' || c == ')' || c == ',' || c == '\'') c = ' ';
 }
-void bucket(int ncol, std::vector<Trip> &t, std::vector<int> &beg, std::vector<int> &idx, std::vector<double> &val) {
-    beg.assign(ncol + 1, 0);
+void bucket(int ncol, std::vector<Trip> &t, std::vector<int64_t> &beg, std::vector<int> &idx, std::vector<double> &val) {
+    beg.assign((size_t) ncol + 1, 0);
     for (auto &e : t) beg[e.col + 1]++;
     for (int c = 0; c < ncol; ++c) beg[c + 1] += beg[c];
     idx.resize(t.size());
     val.resize(t.size());
-    std::vector<int> pos(beg.begin(), beg.end() - 1);
+    std::vector<int64_t> pos(beg.begin(), beg.end() - 1);
     for (auto &e : t) { idx[pos[e.col]] = e.row; val[pos[e.col]++] = e.v; }  // stable: file order inside a column
 }
 }  // namespace
@@ -106,13 +112,14 @@ hdsdp_retcode HMiReadSDPA(const char *fname, HMiSDPA **out) {
         }
         if (blk < 0 || blk >= p->nblk) return fail("block index out of range");
         const int n = p->dims[blk];
+        if (n > 65535) return fail("block dimension above 65535: the packed index would not fit 32 bits");
         if (i < 0 || j < 0 || i >= n || j >= n) return fail("entry index out of range");
         if (i > j) { int t = i; i = j; j = t; }               // (i <= j) -> packed lower (row j, col i)
         const long pk = (long) (2 * n - i - 1) * i / 2 + j;
         trips[blk].push_back({mat, (int) pk, v});
     }
     fclose(f);
-    p->beg.resize(p->nblk); p->idx.resize(p->nblk); p->val.resize(p->nblk);
+    p->beg.resize(p->nblk); p->beg32.resize(p->nblk); p->idx.resize(p->nblk); p->val.resize(p->nblk);
     for (int b = 0; b < p->nblk; ++b) bucket(p->m + 1, trips[b], p->beg[b], p->idx[b], p->val[b]);
     if (p->nlp > 0) bucket(p->m + 1, lpt, p->lpBeg, p->lpIdx, p->lpVal);
     *out = p;
@@ -124,10 +131,25 @@ void HMiSDPAGetDims(const HMiSDPA *p, int *nConstrs, int *nBlks, int *nLpCols) {
     if (nBlks) *nBlks = p->nblk;
     if (nLpCols) *nLpCols = p->nlp;
 }
-hdsdp_retcode HMiSDPAGetBlock(const HMiSDPA *p, int iBlk, int *dim, const int **beg, const int **idx, const double **val) {
+hdsdp_retcode HMiSDPAGetBlock64(const HMiSDPA *p, int iBlk, int *dim, const int64_t **beg, const int **idx, const double **val) {
     if (iBlk < 0 || iBlk >= p->nblk) return HDSDP_RETCODE_FAILED;
     if (dim) *dim = p->dims[iBlk];
     if (beg) *beg = p->beg[iBlk].data();
+    if (idx) *idx = p->idx[iBlk].data();
+    if (val) *val = p->val[iBlk].data();
+    return HDSDP_RETCODE_OK;
+}
+hdsdp_retcode HMiSDPAGetBlock(const HMiSDPA *cp, int iBlk, int *dim, const int **beg, const int **idx, const double **val) {
+    HMiSDPA *p = const_cast<HMiSDPA *>(cp);          // (the 32-bit pointers are a cache filled on first use)
+    if (iBlk < 0 || iBlk >= p->nblk) return HDSDP_RETCODE_FAILED;
+    if (p->beg[iBlk].back() > 2147483647LL) {
+        fprintf(stderr, "[hdsdp_mi355x] block %d holds %lld entries: beyond the reference's int column pointers, use HMiSDPAGetBlock64\n",
+                iBlk, (long long) p->beg[iBlk].back());
+        return HDSDP_RETCODE_FAILED;
+    }
+    if (p->beg32[iBlk].empty()) p->beg32[iBlk].assign(p->beg[iBlk].begin(), p->beg[iBlk].end());
+    if (dim) *dim = p->dims[iBlk];
+    if (beg) *beg = p->beg32[iBlk].data();
     if (idx) *idx = p->idx[iBlk].data();
     if (val) *val = p->val[iBlk].data();
     return HDSDP_RETCODE_OK;

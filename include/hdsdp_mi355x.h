@@ -208,6 +208,27 @@ void HFpLinsysDestroy(hdsdp_linsys_fp **HLin);                                  
 hdsdp_retcode HMiConeCreateSDP(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int *coneMatBeg,
                                const int *coneMatIdx, const double *coneMatElem, int rank, int world);
 hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, int nRow, int rank, int world);
+/* 64-bit ingest (SURVEY finding 6, row f3).  The reference's user data is ONE CSC with `int` column pointers
+ * (interface/def_hdsdp_user_data.h:22-32): a block whose columns hold more than 2^31 - 1 entries together -- fully dense
+ * n = m = 2000 is 4.0e9 -- cannot be expressed in it.  Two ways in that can:
+ *   HMiConeCreateSDP64   the same CSC with 64-bit column pointers (row indices stay `int`: a packed index is below
+ *                        n(n+1)/2 < 2^31 for n <= 65535, the largest block dimension accepted);
+ *   HMiConeBuilder*      column by column: Begin, then AddColumn once per non-zero column in any order (iCol 0 = the objective
+ *                        C, iCol i = A_i; entries = packed lower index + value, any order, at most n(n+1)/2 of them), then
+ *                        Finish, which returns the cone (columns never given are zero matrices).  A column is classified as it
+ *                        arrives and the caller's arrays are not kept, so the caller may generate, hand over and free one
+ *                        column at a time and never holds a 2^31-entry array; the library's own host copy goes back as soon as
+ *                        the block's device layout is written (blocks on the congruence + Gram path).
+ * Both give the device data HMiConeCreateSDP gives on the same entries (tests/test_gpu_ingest.py: bit-identical dual matrix and
+ * Schur matrix on every CSC golden). */
+hdsdp_retcode HMiConeCreateSDP64(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int64_t *coneMatBeg,
+                                 const int *coneMatIdx, const double *coneMatElem, int rank, int world);
+typedef struct HMiConeBuilder_s HMiConeBuilder;
+hdsdp_retcode HMiConeBuilderBegin(HMiConeBuilder **pBuilder, int iCone, int nRow, int nCol, int rank, int world);
+hdsdp_retcode HMiConeBuilderAddColumn(HMiConeBuilder *builder, int iCol, int64_t nnz, const int *packedIdx, const double *val);
+int64_t HMiConeBuilderStored(const HMiConeBuilder *builder);          /* entries handed in so far */
+hdsdp_retcode HMiConeBuilderFinish(HMiConeBuilder **pBuilder, hdsdp_cone **pCone);   /* frees the builder either way */
+void HMiConeBuilderAbort(HMiConeBuilder **pBuilder);
 void HMiConeDestroy(hdsdp_cone **pCone);
 void HMiConeSetStart(hdsdp_cone *cone, double dConeStartVal);                   /* HConeSetStart  hdsdp_conic.c:222 */
 void HMiConeUpdate(hdsdp_cone *cone, double barHsdTau, double *rowDual);        /* HConeUpdate    :228 */
@@ -384,6 +405,10 @@ hdsdp_retcode HMiReadSDPA(const char *fname, HMiSDPA **out);
 void HMiSDPAGetDims(const HMiSDPA *p, int *nConstrs, int *nBlks, int *nLpCols);
 hdsdp_retcode HMiSDPAGetBlock(const HMiSDPA *p, int iBlk, int *dim, const int **beg, const int **idx,
                               const double **val);
+/* the same with the 64-bit column pointers the reader keeps (a block may hold more than 2^31 - 1 entries; HMiSDPAGetBlock
+ * refuses such a block): feeds HMiConeCreateSDP64 */
+hdsdp_retcode HMiSDPAGetBlock64(const HMiSDPA *p, int iBlk, int *dim, const int64_t **beg, const int **idx,
+                                const double **val);
 const double *HMiSDPAGetRHS(const HMiSDPA *p);
 void HMiSDPAFree(HMiSDPA **pp);
 

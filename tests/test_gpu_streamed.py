@@ -61,27 +61,35 @@ def test_the_sweep_copy_of_streamed_rows_is_the_copy_of_resident_rows(monkeypatc
     assert np.array_equal(got[0][1], got[1][1])
 
 
-def test_config5_at_size_streamed_on_one_device():
+@pytest.mark.parametrize("mode", ["auto", "streamed"])
+def test_config5_at_size_on_one_device(mode, monkeypatch, capfd):
     """BASELINE configs[4] itself -- n = 2000, m = 8000 -- on ONE device against tests/golden/full8000_rows.npz (host fp64,
     oracle/row_subset_golden.py: 72 complete rows of M incl. the tile-edge rows, both vectors in full, log det S, tr S^-1,
     residual rows of the three Phase-A solves; bench state and a cond(S) = 1e3 state with y != 0, whose S assembly sweeps all
-    8000 constraint matrices).  The cone must have chosen streaming by itself (nothing forces it here)."""
+    8000 constraint matrices).  "auto": whatever the cone chooses from the memory it finds (resident if 136 GB of constraint
+    data fit next to 130 GB of transformed rows and the work buffers, else streamed); "streamed": regeneration forced, which
+    is also what leaves room for the zero-suppressed sweep copy."""
     import torch
     from hdsdp_amd import api
     from test_gpu_parity import check_row_subset_state
     free, total = torch.cuda.mem_get_info()
     if free < 250 * (1 << 30):
         pytest.skip(f"BASELINE configs[4] on one device needs about 250 GiB of free HBM, {free >> 30} GiB free")
+    if mode == "streamed":
+        monkeypatch.setenv("HDSDP_MI355X_STREAM_A", "1")
     g = load_golden("full8000_rows")
     n, m = int(g["n"]), int(g["m"])
     cone = api.SDPCone.synthetic(n, m)
     try:
         on, rows = cone.streaming()
-        assert on and rows == 1000, (on, rows)
+        if mode == "streamed":
+            assert on and rows == 1000, (on, rows)
         assert cone.shard_count() == 1
         kkt = api.KKT(m, [cone], host_mirror=False)
         check_row_subset_state(cone, kkt, g, "bench")
         check_row_subset_state(cone, kkt, g, "hard")
+        print(f"configs[4] on one device [{mode}]: free HBM before {free / 2**30:.1f} of {total / 2**30:.1f} GiB, streamed={on}, "
+              f"sweep copy in use={cone.sweep_info()[0]}, after the builds {torch.cuda.mem_get_info()[0] / 2**30:.1f} GiB free")
         kkt.destroy()
     finally:
         cone.destroy()
