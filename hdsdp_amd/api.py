@@ -38,7 +38,7 @@ EXPORTS = [
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiKKTGetRows", "HMiDeviceInit",
     "HMiSetDevices", "HMiSetDevicesEx", "HMiRcclGroupSelfTest", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
-    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiKKTTileInfo", "HMiBspSolve", "HMiRcmOrder", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
+    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiKKTTileInfo", "HMiKKTNegativePivots", "HMiBspSolve", "HMiRcmOrder", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetBlock64", "HMiSDPAGetRHS", "HMiSDPAFree",
 ]
 
@@ -184,6 +184,7 @@ def load_library():
         "HMiCholEnvelopeProbe": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp]),
         "HMiKKTEnvelopeInfo": (None, [kp, ip, dp]),
         "HMiKKTTileInfo": (C.c_int, [kp, ip, C.POINTER(C.c_int64), ip, C.POINTER(C.c_int64)]),
+        "HMiKKTNegativePivots": (C.c_int, [kp]),
         "HMiBspSolve": (C.c_int, [C.c_int, ip, ip, dp, dp, dp, ip, ip, dp]),
         "HMiRcmOrder": (C.c_int, [C.c_int, ip, ip, ip]),
         "HMiPresolveCSC": (C.c_int, [C.c_int, C.c_int, ip, ip, dp, ip, ip, ip, ip, ip, ip]),
@@ -640,6 +641,10 @@ class KKT:
         if not load_library().HMiKKTTileInfo(self._k, C.byref(t), C.byref(dt), C.byref(lv), C.byref(by)):
             return None
         return t.value, dt.value, lv.value, by.value
+
+    def negative_pivots(self):
+        """negative pivots of the tile-form operator's last LDL' factorisation (-1: not tile form / not factored)"""
+        return int(load_library().HMiKKTNegativePivots(self._k))
 
     def stage_times_ms(self):
         t = np.zeros(8)

@@ -5,7 +5,7 @@
 // 128 x 128 TILES: the rows are reordered (rows that touch a large share of the matrix last, reverse Cuthill-McKee for the
 // rest), cut into blocks of 128, and only the tiles inside the block pattern of the Cholesky factor (a symbolic
 // factorisation of the block quotient graph) exist -- memory O(tiles of L), nothing of the m x m square.  The numeric
-// factorisation is left-looking by levels of the block elimination tree: all block columns of a level are independent, so a
+// factorisation -- an LDL' in signed-Cholesky form, see HdmBsp::factor -- is left-looking by levels of the block elimination tree: all block columns of a level are independent, so a
 // level is three launches whatever its width (tile updates on the fp64 MFMA, diagonal-block sweeps, panel products), and a
 // block-diagonal matrix with a few linking rows -- many small SDP blocks that share a handful of constraints -- is three
 // levels, not m / 128 dependent steps.
@@ -48,8 +48,11 @@ struct HdmBsp {
     int *diag_tile = nullptr;
     double *vec = nullptr;            // nb * 128 solve vector
     double *hvec = nullptr;           // pinned host staging of the same size
-    int *info_dev = nullptr;
+    int *info_dev = nullptr;          // two words: first zero pivot + 1, negative pivots
+    double *sgn = nullptr;            // nb * 128 pivot signs of the last factorisation (+1 in the padding)
+    int *src_col = nullptr;           // block column of every source pair (whose signs the update applies)
     bool factored = false;
+    int negative = 0;                 // negative pivots of the last factorisation (0: the matrix is positive definite)
     long dense_tiles() const { return (long) nb * (nb + 1) / 2; }
     size_t bytes() const { return sizeof(double) * 16384 * ((size_t) 2 * (ntiles + 1) + nb); }
 
@@ -62,7 +65,11 @@ struct HdmBsp {
     int zero_M(hipStream_t s);
     int zero_L(hipStream_t s);
     int load_M(hipStream_t s);        // L store <- M store
-    int factor(hipStream_t s, int *info);   // in the L store; info = 0, or first non-positive pivot + 1 (in the renumbered order)
+    // In the L store, as M = L~ S L~' with S = diag(+-1) the pivots' signs and L~ = L |D|^1/2 -- the reference's sparse direct
+    // solver is an LDL' without pivoting (external/qdldl.c: an indefinite matrix factors, only a pivot that is exactly zero
+    // fails, linalg/hdsdp_linsolver.c:596-626), and so is this; for a positive definite matrix it IS the Cholesky factorisation,
+    // bit for bit.  info = 0, or first zero / non-finite pivot + 1 (renumbered order); nneg = negative pivots.
+    int factor(hipStream_t s, int *info, int *nneg = nullptr);
     int solve_host(const double *rhs, double *sol, hipStream_t s);   // driver's numbering in and out
 };
 

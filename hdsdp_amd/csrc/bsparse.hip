@@ -1,4 +1,4 @@
-// bsparse.hip -- block-sparse (128 x 128 tiles) storage and left-looking level-scheduled Cholesky of a sparse Schur matrix.
+// bsparse.hip -- block-sparse (128 x 128 tiles) storage and left-looking level-scheduled LDL' (signed Cholesky) of a sparse Schur matrix.
 // See bsparse.h for the design.  Reference counterpart: the aggregated-pattern CSC operator with its sparse direct solver,
 // interface/hdsdp_schur.c:46-139 and linalg/hdsdp_linsolver.c:509-809 (QDLDL: elimination tree, symbolic and numeric LDL').
 #include "bsparse.h"
@@ -64,13 +64,16 @@ std::vector<int> hdm_rcm_order(int m, const std::vector<int> &beg, const std::ve
 typedef double bs_d4 __attribute__((ext_vector_type(4)));
 
 // One workgroup (4 waves, 64 x 64 quadrants, sixteen 16 x 16 fp64 MFMA accumulators each) per tile operation.
-//   MODE 0 (update):  C <- C - sum_s A_s B_s^T   over the target's source list
-//   MODE 1 (panel):   C <- C W_k^T               in place (every load of C has passed the last barrier before the first store)
+//   MODE 0 (update):  C <- C - sum_s A_s S_j B_s^T   over the target's source list (j = the sources' block column)
+//   MODE 1 (panel):   C <- C W_k^T S_k               in place (every load of C has passed the last barrier before the first store)
+// S = diag(sgn) are the pivot signs of the LDL' form M = L~ S L~' (bsparse.h); all +1 for a positive definite matrix, where
+// this is the Cholesky factorisation, bit for bit.
 // Tiles are 128 x 128 column-major: a 16-deep k slab of an operand is 2048 consecutive doubles.
 template <int MODE>
 __global__ __launch_bounds__(256) void bs_tile_kernel(double *__restrict__ L, const double *__restrict__ Winv, const int *__restrict__ tgt_tile,
                                                       const int *__restrict__ tgt_src_ptr, const int2 *__restrict__ src,
-                                                      const int2 *__restrict__ pan, int first) {
+                                                      const int2 *__restrict__ pan, int first, const double *__restrict__ sgn,
+                                                      const int *__restrict__ src_col) {
     __shared__ __attribute__((aligned(16))) double sA[16 * BS_LD], sB[16 * BS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -87,13 +90,18 @@ __global__ __launch_bounds__(256) void bs_tile_kernel(double *__restrict__ L, co
         for (int i = 0; i < 4; ++i) acc[j][i] = (bs_d4){0.0, 0.0, 0.0, 0.0};
     const int sk = tid >> 4, si = (tid & 15) * 8;          // staging: k row of the slab, first of 8 consecutive elements
     for (int s = s0; s < s1; ++s) {
-        const double *A, *B;
-        if (MODE == 0) { const int2 ab = src[s]; A = L + ((long) ab.x << 14); B = L + ((long) ab.y << 14); }
+        const double *A, *B, *sg = nullptr;
+        if (MODE == 0) { const int2 ab = src[s]; A = L + ((long) ab.x << 14); B = L + ((long) ab.y << 14); sg = sgn + (long) src_col[s] * BT; }
         else { A = C; B = Wk; }
         for (int k0 = 0; k0 < BT; k0 += 16) {
             const double2 *pa = reinterpret_cast<const double2 *>(A + (long) (k0 + sk) * BT + si);
             const double2 *pb = reinterpret_cast<const double2 *>(B + (long) (k0 + sk) * BT + si);
-            const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
+            const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
+            double2 b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
+            if (MODE == 0) {                                 // column k of the source tiles carries the sign of pivot k of their block column
+                const double g = sg[k0 + sk];
+                b0.x *= g; b0.y *= g; b1.x *= g; b1.y *= g; b2.x *= g; b2.y *= g; b3.x *= g; b3.y *= g;
+            }
             __syncthreads();                                 // the previous slab has been consumed
             double2 *da = reinterpret_cast<double2 *>(sA + sk * BS_LD + si), *db = reinterpret_cast<double2 *>(sB + sk * BS_LD + si);
             da[0] = a0; da[1] = a1; da[2] = a2; da[3] = a3; db[0] = b0; db[1] = b1; db[2] = b2; db[3] = b3;
@@ -119,9 +127,10 @@ __global__ __launch_bounds__(256) void bs_tile_kernel(double *__restrict__ L, co
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double *q = C + (wm * 64 + i * 16 + l15) + (long) (wn * 64 + j * 16 + lq + 4 * r) * BT;
+                const int cc = wn * 64 + j * 16 + lq + 4 * r;
+                double *q = C + (wm * 64 + i * 16 + l15) + (long) cc * BT;
                 if (MODE == 0) *q -= acc[j][i][r];
-                else *q = acc[j][i][r];
+                else *q = acc[j][i][r] * sgn[(long) pan[op].y * BT + cc];
             }
 }
 
@@ -149,9 +158,11 @@ __global__ __launch_bounds__(256) void bs_fwd_kernel(const double *__restrict__ 
 }
 
 // backward substitution, one level (levels walked downwards): x_k = W_k^T (y_k - sum_{i > k} L(i, k)^T x_i)
+// (v_k still holds the forward result y_k when its level is reached: the signs S_k of L~ S L~' x = b are applied here)
 __global__ __launch_bounds__(256) void bs_bwd_kernel(const double *__restrict__ L, const double *__restrict__ Winv, const int *__restrict__ cols,
                                                      const int *__restrict__ col_ptr, const int *__restrict__ col_row,
-                                                     const int *__restrict__ col_tile, double *__restrict__ v, int first) {
+                                                     const int *__restrict__ col_tile, double *__restrict__ v, int first,
+                                                     const double *__restrict__ sgn) {
     __shared__ double part[2][BT], t[BT];
     const int k = cols[first + blockIdx.x], tid = threadIdx.x, c = tid & 127, h = tid >> 7;
     double acc = 0.0;
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256) void bs_bwd_kernel(const double *__restrict__ 
     }
     part[h][c] = acc;
     __syncthreads();
-    if (tid < BT) t[tid] = v[(long) k * BT + tid] - (part[0][tid] + part[1][tid]);
+    if (tid < BT) t[tid] = sgn[(long) k * BT + tid] * v[(long) k * BT + tid] - (part[0][tid] + part[1][tid]);
     __syncthreads();
     const double *W = Winv + ((long) k << 14) + (long) c * BT;
     acc = 0.0;
@@ -263,8 +274,10 @@ int HdmBsp::init(int m_, const int *beg, const int *idx, double max_fraction) {
                 if (t < 0) return 1;                          // cannot happen: the symbolic factorisation closed the pattern
                 srcs[t].push_back(make_int2(qa, qb));
             }
-    std::vector<int> h_tgt, h_tsp{0};
+    std::vector<int> h_tgt, h_tsp{0}, h_scol;
     std::vector<int2> h_src, h_pan;
+    std::vector<int> tile_col((size_t) ntiles);
+    for (int k = 0; k < nb; ++k) for (int q = bptr[k]; q < bptr[k + 1]; ++q) tile_col[q] = k;
     lvl_tgt_ptr.assign(nlevels + 1, 0);
     lvl_pan_ptr.assign(nlevels + 1, 0);
     for (int l = 0; l < nlevels; ++l) {
@@ -274,6 +287,7 @@ int HdmBsp::init(int m_, const int *beg, const int *idx, double max_fraction) {
                 if (!srcs[q].empty()) {
                     h_tgt.push_back(q);
                     h_src.insert(h_src.end(), srcs[q].begin(), srcs[q].end());
+                    for (const int2 &ab : srcs[q]) h_scol.push_back(tile_col[ab.x]);
                     h_tsp.push_back((int) h_src.size());
                 }
                 if (q > bptr[k]) h_pan.push_back(make_int2(q, k));
@@ -299,7 +313,7 @@ int HdmBsp::init(int m_, const int *beg, const int *idx, double max_fraction) {
     }
     // ---- device side
     if (bs_upload(&perm_dev, perm) || bs_upload(&tilemap, tmap) || bs_upload(&lvl_cols, cols_by_level) || bs_upload(&tgt_tile, h_tgt) ||
-        bs_upload(&tgt_src_ptr, h_tsp) || bs_upload(&src, h_src) || bs_upload(&pan, h_pan) || bs_upload(&row_ptr, rp) ||
+        bs_upload(&tgt_src_ptr, h_tsp) || bs_upload(&src, h_src) || bs_upload(&src_col, h_scol) || bs_upload(&pan, h_pan) || bs_upload(&row_ptr, rp) ||
         bs_upload(&row_col, rc) || bs_upload(&row_tile, rt) || bs_upload(&col_ptr, cp) || bs_upload(&col_row, cr) ||
         bs_upload(&col_tile, ct) || bs_upload(&diag_tile, diag))
         return 1;
@@ -308,7 +322,8 @@ int HdmBsp::init(int m_, const int *beg, const int *idx, double max_fraction) {
         hipMalloc((void **) &Winv, sizeof(double) * BTT * (size_t) nb) != hipSuccess ||
         hipMalloc((void **) &vec, sizeof(double) * BT * (size_t) nb) != hipSuccess ||
         hipHostMalloc((void **) &hvec, sizeof(double) * BT * (size_t) nb, hipHostMallocDefault) != hipSuccess ||
-        hipMalloc((void **) &info_dev, sizeof(int)) != hipSuccess) {
+        hipMalloc((void **) &sgn, sizeof(double) * BT * (size_t) nb) != hipSuccess ||
+        hipMalloc((void **) &info_dev, 2 * sizeof(int)) != hipSuccess) {
         (void) hipGetLastError();
         fprintf(stderr, "[hdsdp_mi355x] block-sparse Schur matrix: out of device memory (%.1f GiB of tiles)\n", (double) bytes() / (1 << 30));
         return 1;
@@ -323,11 +338,12 @@ int HdmBsp::init(int m_, const int *beg, const int *idx, double max_fraction) {
 void HdmBsp::destroy() {
     for (void *p : {(void *) perm_dev, (void *) tilemap, (void *) Mval, (void *) Lval, (void *) Winv, (void *) lvl_cols, (void *) tgt_tile,
                     (void *) tgt_src_ptr, (void *) src, (void *) pan, (void *) row_ptr, (void *) row_col, (void *) row_tile, (void *) col_ptr,
-                    (void *) col_row, (void *) col_tile, (void *) diag_tile, (void *) vec, (void *) info_dev})
+                    (void *) col_row, (void *) col_tile, (void *) diag_tile, (void *) vec, (void *) info_dev, (void *) sgn, (void *) src_col})
         if (p) (void) hipFree(p);
     if (hvec) (void) hipHostFree(hvec);
     perm_dev = tilemap = lvl_cols = tgt_tile = tgt_src_ptr = row_ptr = row_col = row_tile = col_ptr = col_row = col_tile = diag_tile = info_dev = nullptr;
-    Mval = Lval = Winv = vec = hvec = nullptr;
+    Mval = Lval = Winv = vec = hvec = sgn = nullptr;
+    src_col = nullptr;
     src = pan = nullptr;
 }
 
@@ -344,24 +360,26 @@ int HdmBsp::load_M(hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------------
 // numeric factorisation and substitutions
 // ---------------------------------------------------------------------------------------------------------------------
-int HdmBsp::factor(hipStream_t s, int *info_host) {
-    HDM_HIP_CHECK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+int HdmBsp::factor(hipStream_t s, int *info_host, int *nneg_host) {
+    HDM_HIP_CHECK(hipMemsetAsync(info_dev, 0, 2 * sizeof(int), s));
     if (m % BT) hipLaunchKernelGGL(bs_pad_diag_kernel, dim3(1), dim3(BT), 0, s, Lval, diag_tile, nb, m);
     for (int l = 0; l < nlevels; ++l) {
         const int nt = lvl_tgt_ptr[l + 1] - lvl_tgt_ptr[l], nc = lvl_ptr[l + 1] - lvl_ptr[l], np = lvl_pan_ptr[l + 1] - lvl_pan_ptr[l];
         if (nt > 0)
-            hipLaunchKernelGGL(bs_tile_kernel<0>, dim3(nt), dim3(256), 0, s, Lval, Winv, tgt_tile, tgt_src_ptr, src, pan, lvl_tgt_ptr[l]);
-        if (hdm_potrf_sweep_batched(Lval, diag_tile, lvl_cols + lvl_ptr[l], nc, Winv, info_dev, m, s)) return 1;
+            hipLaunchKernelGGL(bs_tile_kernel<0>, dim3(nt), dim3(256), 0, s, Lval, Winv, tgt_tile, tgt_src_ptr, src, pan, lvl_tgt_ptr[l], sgn, src_col);
+        if (hdm_potrf_sweep_batched(Lval, diag_tile, lvl_cols + lvl_ptr[l], nc, Winv, info_dev, m, s, sgn)) return 1;
         if (np > 0)
-            hipLaunchKernelGGL(bs_tile_kernel<1>, dim3(np), dim3(256), 0, s, Lval, Winv, tgt_tile, tgt_src_ptr, src, pan, lvl_pan_ptr[l]);
+            hipLaunchKernelGGL(bs_tile_kernel<1>, dim3(np), dim3(256), 0, s, Lval, Winv, tgt_tile, tgt_src_ptr, src, pan, lvl_pan_ptr[l], sgn, src_col);
     }
     HDM_HIP_CHECK(hipGetLastError());
-    int info = 0;
-    HDM_HIP_CHECK(hipMemcpyAsync(&info, info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    int info[2] = {0, 0};
+    HDM_HIP_CHECK(hipMemcpyAsync(info, info_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HDM_HIP_CHECK(hipStreamSynchronize(s));
-    if (info > m) info = 0;
-    if (info_host) *info_host = info;
-    factored = (info == 0);
+    if (info[0] > m) info[0] = 0;
+    if (info_host) *info_host = info[0];
+    if (nneg_host) *nneg_host = info[1];
+    negative = info[1];
+    factored = (info[0] == 0);
     return 0;
 }
 
@@ -376,7 +394,7 @@ int HdmBsp::solve_host(const double *rhs, double *sol, hipStream_t s) {
                            vec, lvl_ptr[l]);
     for (int l = nlevels - 1; l >= 0; --l)
         hipLaunchKernelGGL(bs_bwd_kernel, dim3(lvl_ptr[l + 1] - lvl_ptr[l]), dim3(256), 0, s, Lval, Winv, lvl_cols, col_ptr, col_row, col_tile,
-                           vec, lvl_ptr[l]);
+                           vec, lvl_ptr[l], sgn);
     HDM_HIP_CHECK(hipGetLastError());
     HDM_HIP_CHECK(hipMemcpyAsync(hvec, vec, sizeof(double) * BT * (size_t) nb, hipMemcpyDeviceToHost, s));
     HDM_HIP_CHECK(hipStreamSynchronize(s));

@@ -57,7 +57,10 @@ struct HdmChol {
 // diagonal-tile factorisations of a block-sparse matrix (bsparse.hip): 128 x 128 tiles, 16384 doubles apart; tile
 // diag_tile[cols[b]] is factored in place (lower), its inverse goes to Winv + cols[b] * 16384; rows past m are padding
 int hdm_potrf_sweep_configure();
-int hdm_potrf_sweep_batched(double *tiles, const int *diag_tile, const int *cols, int ncols, double *Winv, int *info, int m, hipStream_t s);
+// sgn == nullptr: Cholesky sweeps (info[0] = first non-positive pivot + 1).  sgn != nullptr: the signed LDL' sweep of sweep128.h --
+// sgn[128 k ..] <- pivot signs of block column k, info[0] = first zero / non-finite pivot + 1, info[1] += negative pivots
+int hdm_potrf_sweep_batched(double *tiles, const int *diag_tile, const int *cols, int ncols, double *Winv, int *info, int m, hipStream_t s,
+                            double *sgn = nullptr);
 
 // several engine shards share this device: the single-launch substitution (which needs co-resident workgroups) is off
 void hdm_flow_set_shared_device(int on);

@@ -200,8 +200,12 @@ __global__ __launch_bounds__(256) void hdm_potrf_diag_kernel(double *__restrict_
 #define DIAG_SWEEP_LDS_DOUBLES (SMALL_P * (SMALL_P + 1) + 2 * SMALL_P)
 // nv: rows of this block that belong to the matrix (the rest is the identity padding, which needs no pivots: a 21 x 21 block
 // -- truss1's largest -- is 6 four-pivot steps instead of 32, and the reference's driver factors such blocks thousands of times)
+// SIGNED: the LDL' flavour of the sweep (sweep128.h) -- sgn_out[0 .. 127] receives the pivots' signs (+1 in the padding), *nneg_out
+// the number of negative ones (added atomically), and only an exactly zero / non-finite pivot is reported through `info`
+template <bool SIGNED = false>
 __device__ __forceinline__ void hdm_potrf_diag_sweep_body(double *__restrict__ A, long ld, double *__restrict__ Dinv, int *__restrict__ info,
-                                                          int col0, int nv) {
+                                                          int col0, int nv, double *__restrict__ sgn_out = nullptr,
+                                                          int *__restrict__ nneg_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *img = sm;                                  // 128 x 129 staging image; its head doubles as the sweep's block images
     double *rsv = sm + SMALL_P * (SMALL_P + 1);
@@ -218,8 +222,13 @@ __device__ __forceinline__ void hdm_potrf_diag_sweep_body(double *__restrict__ A
         for (int c = 0; c < SM_NC; ++c) a[r][c] = img[(ty + 16 * r) + (tx + 32 * c) * ldi];
     __syncthreads();
     double unused;
-    const int bad = sm_sweep<false>(nv, a, rr, img, rsv, ty, tx, &unused);
+    int nneg = 0;
+    const int bad = sm_sweep<false, SIGNED>(nv, a, rr, img, rsv, ty, tx, &unused, &nneg);
     if (bad && tid == 0) atomicCAS(info, 0, col0 + bad);
+    if (SIGNED) {
+        if (tid < SMALL_P && sgn_out) sgn_out[tid] = (tid < nv && rsv[tid] < 0.0) ? -1.0 : 1.0;
+        if (tid == 0 && nneg_out && nneg) atomicAdd(nneg_out, nneg);
+    }
     __syncthreads();
     sm_store_one<true>(SMALL_P, a, img, A, ld, ty, tx, tid);
     sm_store_one<false>(SMALL_P, rr, img, Dinv, SMALL_P, ty, tx, tid);
@@ -230,9 +239,11 @@ __global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_kernel(double *__re
 }
 // the same for a list of independent diagonal tiles of a block-sparse matrix (bsparse.hip): workgroup b factors the diagonal
 // tile of block column cols[b]; a non-positive pivot is reported as the smallest failing row + 1 over the launch
+// sgn != nullptr: the signed (LDL') sweep; sgn[128 k ..] receives block column k's pivot signs, info[1] counts negative pivots
+template <bool SIGNED>
 __global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_tiles_kernel(double *__restrict__ tiles, const int *__restrict__ diag_tile,
                                                                           const int *__restrict__ cols, double *__restrict__ Winv,
-                                                                          int *__restrict__ info, int m) {
+                                                                          int *__restrict__ info, int m, double *__restrict__ sgn) {
     const int k = cols[blockIdx.x];
     int dummy = 0;
     (void) dummy;
@@ -242,7 +253,8 @@ __global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_tiles_kernel(double
     __shared__ int linfo;
     if (threadIdx.x == 0) linfo = 0;
     __syncthreads();
-    hdm_potrf_diag_sweep_body(A, SMALL_P, Winv + ((long) k << 14), &linfo, k * SMALL_P, min(SMALL_P, m - k * SMALL_P));
+    hdm_potrf_diag_sweep_body<SIGNED>(A, SMALL_P, Winv + ((long) k << 14), &linfo, k * SMALL_P, min(SMALL_P, m - k * SMALL_P),
+                                      SIGNED ? sgn + (long) k * SMALL_P : nullptr, SIGNED ? info + 1 : nullptr);
     __syncthreads();
     if (threadIdx.x == 0 && linfo) {
         int old = atomicCAS(info, 0, linfo);
@@ -250,14 +262,22 @@ __global__ __launch_bounds__(SM_T) void hdm_potrf_diag_sweep_tiles_kernel(double
     }
 }
 int hdm_potrf_sweep_configure() {
-    HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_potrf_diag_sweep_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_potrf_diag_sweep_tiles_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      DIAG_SWEEP_LDS_DOUBLES * (int) sizeof(double)));
+    HDM_HIP_CHECK(hipFuncSetAttribute((const void *) hdm_potrf_diag_sweep_tiles_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       DIAG_SWEEP_LDS_DOUBLES * (int) sizeof(double)));
     return 0;
 }
-int hdm_potrf_sweep_batched(double *tiles, const int *diag_tile, const int *cols, int ncols, double *Winv, int *info, int m, hipStream_t s) {
+// info: two words -- [0] first failing pivot + 1 (Cholesky: not positive; LDL': exactly zero or not a number), [1] negative pivots (LDL')
+int hdm_potrf_sweep_batched(double *tiles, const int *diag_tile, const int *cols, int ncols, double *Winv, int *info, int m, hipStream_t s,
+                            double *sgn) {
     if (ncols <= 0) return 0;
-    hipLaunchKernelGGL(hdm_potrf_diag_sweep_tiles_kernel, dim3(ncols), dim3(SM_T), DIAG_SWEEP_LDS_DOUBLES * sizeof(double), s, tiles,
-                       diag_tile, cols, Winv, info, m);
+    if (sgn)
+        hipLaunchKernelGGL(hdm_potrf_diag_sweep_tiles_kernel<true>, dim3(ncols), dim3(SM_T), DIAG_SWEEP_LDS_DOUBLES * sizeof(double), s, tiles,
+                           diag_tile, cols, Winv, info, m, sgn);
+    else
+        hipLaunchKernelGGL(hdm_potrf_diag_sweep_tiles_kernel<false>, dim3(ncols), dim3(SM_T), DIAG_SWEEP_LDS_DOUBLES * sizeof(double), s, tiles,
+                           diag_tile, cols, Winv, info, m, sgn);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -339,6 +339,11 @@ int HMiKKTTileInfo(hdsdp_kkt *HKKT, int *tiles, int64_t *denseTiles, int *levels
     if (bytes) *bytes = (int64_t) l->bsp->bytes();
     return 1;
 }
+int HMiKKTNegativePivots(hdsdp_kkt *HKKT) {
+    if (!HKKT || !HKKT->kktM) return -1;
+    MiLin *l = (MiLin *) HKKT->kktM->chol;
+    return (l->bsp && l->bsp->factored) ? l->bsp->negative : -1;
+}
 int HMiBspSolve(int m, const int *colBeg, const int *rowIdx, const double *val, const double *b, double *x, int *info, int *stats,
                 double *ms) {
     if (ensure_ctx()) return 1;
@@ -374,7 +379,7 @@ int HMiBspSolve(int m, const int *colBeg, const int *rowIdx, const double *val, 
         if (bad) break;
         if (info) *info = inf;
         if (ms) *ms = best;
-        if (stats) { stats[0] = bs.nb; stats[1] = bs.ntiles; stats[2] = bs.nlevels; }
+        if (stats) { stats[0] = bs.nb; stats[1] = bs.ntiles; stats[2] = bs.nlevels; stats[3] = bs.negative; }
         if (inf == 0 && b && x && bs.solve_host(b, x, g.stream)) break;
         rc = 0;
     } while (0);

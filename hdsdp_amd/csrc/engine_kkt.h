@@ -493,10 +493,13 @@ hdsdp_retcode HKKTFactorize(hdsdp_kkt *HKKT) {
         } else {
             if (!pv->Mdev_valid || l->bsp->load_M(g.stream)) return HDSDP_RETCODE_FAILED;
         }
-        if (l->bsp->factor(g.stream, &info)) return HDSDP_RETCODE_FAILED;
+        // LDL' like the reference's sparse direct solver (linalg/hdsdp_linsolver.c:596-626 over external/qdldl.c): an indefinite
+        // matrix factors and the solves go on with the signed factor; only a pivot that is exactly zero is a failure
+        int nneg = 0;
+        if (l->bsp->factor(g.stream, &info, &nneg)) return HDSDP_RETCODE_FAILED;
         if (info != 0) {
-            fprintf(stderr, "[hdsdp_mi355x] HKKTFactorize: sparse Schur matrix (tile form) is not positive definite (pivot %d)\n", info);
-            return lin_switch_indefinite(HKKT->kktM);
+            fprintf(stderr, "[hdsdp_mi355x] HKKTFactorize: sparse Schur matrix (tile form): zero pivot at row %d of the reordered matrix\n", info);
+            return HDSDP_RETCODE_FAILED;
         }
         return HDSDP_RETCODE_OK;
     }

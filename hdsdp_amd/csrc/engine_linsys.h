@@ -105,10 +105,7 @@ hdsdp_retcode lin_numeric(void *chol, int *colMatBeg, int *colMatIdx, double *co
 // the matrix is re-read from where the failed factorisation took it
 hdsdp_retcode lin_switch_indefinite(hdsdp_linsys_fp *HLin) {
     MiLin *l = (MiLin *) HLin->chol;
-    if (l->bsp) {
-        fprintf(stderr, "[hdsdp_mi355x] the tile-form Schur operator has no pivoted way out (HDSDP_MI355X_KKT_TILES=0 keeps the dense one)\n");
-        return HDSDP_RETCODE_FAILED;
-    }
+    if (l->bsp) return HDSDP_RETCODE_OK;      // the tile form's factorisation is an LDL' already (bsparse.h): nothing to switch to
     HLin->LinType = HDSDP_LINSYS_DENSE_INDEFINITE;
     l->indef = true;
     return lin_factor_indef(l);

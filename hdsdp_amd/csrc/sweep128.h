@@ -42,9 +42,16 @@ __device__ __forceinline__ double sm_rsqrt(double p) {
 
 #define SM_BLK 1024        // doubles per block image: [128][4] columns, then [128][4] rows of R
 
-template <int KR>
+// SIGNED (the tile-form LDL' of a sparse Schur matrix, bsparse.hip): the same sweep as A = L~ S L~', S = diag(+-1) the signs of
+// the pivots, L~ = L |D|^1/2 -- an LDL' without pivoting in Cholesky clothing.  Pivot q contributes u u' sigma_q with
+// u = column / sqrt|pivot|, so the corrections of the COLUMN panels carry sigma (w = sigma u below) while the forward
+// substitution on the identity, which builds W = L~^-1 = S U^-1, runs on u alone and takes its sign with the final scale:
+// rsv[k] = sigma_k / sqrt|pivot_k| is what both deferred scalings multiply by.  Only a pivot that is exactly zero (or not a
+// number) stops the sweep, as in the reference's sparse direct solver (external/qdldl.c:109, :212); *nneg counts the negative
+// ones.  With all pivots positive every sigma is +1.0 and the arithmetic is the unsigned sweep's, bit for bit.
+template <int KR, bool SIGNED = false>
 __device__ __forceinline__ int sm_sweep_chunk(int n, double (&a)[SM_NR][SM_NC], double (&rr)[SM_NR][SM_NC],
-                                              double *blk, double *rsv, int ty, int tx) {
+                                              double *blk, double *rsv, int ty, int tx, int *nneg = nullptr) {
     constexpr int KC = KR / 2;
     const int kend = min(n, 16 * KR + 16);
     int info = 0;
@@ -79,22 +86,36 @@ __device__ __forceinline__ int sm_sweep_chunk(int n, double (&a)[SM_NR][SM_NC], 
         // round trips and four reciprocal square roots in a row before the panel reads were even issued.  A pivot that is
         // not positive turns everything after it into NaNs, harmlessly; the first such pivot is remembered in `info`.
         const double p0 = d[0][0];
-        const double rs0 = sm_rsqrt(p0);
+        const double g0 = (SIGNED && p0 < 0.0) ? -1.0 : 1.0;
+        const double rs0 = sm_rsqrt(SIGNED ? fabs(p0) : p0);
         const double l10 = d[1][0] * rs0, l20 = d[2][0] * rs0, l30 = d[3][0] * rs0;
-        const double p1 = d[1][1] - l10 * l10;
-        const double rs1 = sm_rsqrt(p1);
-        const double l21 = (d[2][1] - l20 * l10) * rs1, l31 = (d[3][1] - l30 * l10) * rs1;
-        const double p2 = (d[2][2] - l20 * l20) - l21 * l21;
-        const double rs2 = sm_rsqrt(p2);
-        const double l32 = ((d[3][2] - l30 * l20) - l31 * l21) * rs2;
-        const double p3 = ((d[3][3] - l30 * l30) - l31 * l31) - l32 * l32;
-        const double rs3 = sm_rsqrt(p3);
-        const int bad = !(p0 > 0.0) ? 1 : !(p1 > 0.0) ? 2 : !(p2 > 0.0) ? 3 : !(p3 > 0.0) ? 4 : 0;
+        const double w10 = SIGNED ? g0 * l10 : l10, w20 = SIGNED ? g0 * l20 : l20, w30 = SIGNED ? g0 * l30 : l30;
+        const double p1 = d[1][1] - l10 * w10;
+        const double g1 = (SIGNED && p1 < 0.0) ? -1.0 : 1.0;
+        const double rs1 = sm_rsqrt(SIGNED ? fabs(p1) : p1);
+        const double l21 = (d[2][1] - l20 * w10) * rs1, l31 = (d[3][1] - l30 * w10) * rs1;
+        const double w21 = SIGNED ? g1 * l21 : l21, w31 = SIGNED ? g1 * l31 : l31;
+        const double p2 = (d[2][2] - l20 * w20) - l21 * w21;
+        const double g2 = (SIGNED && p2 < 0.0) ? -1.0 : 1.0;
+        const double rs2 = sm_rsqrt(SIGNED ? fabs(p2) : p2);
+        const double l32 = ((d[3][2] - l30 * w20) - l31 * w21) * rs2;
+        const double w32 = SIGNED ? g2 * l32 : l32;
+        const double p3 = ((d[3][3] - l30 * w30) - l31 * w31) - l32 * w32;
+        const double g3 = (SIGNED && p3 < 0.0) ? -1.0 : 1.0;
+        const double rs3 = sm_rsqrt(SIGNED ? fabs(p3) : p3);
+        const int bad = SIGNED ? (!(fabs(p0) > 0.0) ? 1 : !(fabs(p1) > 0.0) ? 2 : !(fabs(p2) > 0.0) ? 3 : !(fabs(p3) > 0.0) ? 4 : 0)
+                               : (!(p0 > 0.0) ? 1 : !(p1 > 0.0) ? 2 : !(p2 > 0.0) ? 3 : !(p3 > 0.0) ? 4 : 0);
         info = (info == 0 && bad != 0) ? k0 + bad : info;
-        if (ty == 0 && tx < 4) rsv[k0 + tx] = tx == 0 ? rs0 : tx == 1 ? rs1 : tx == 2 ? rs2 : rs3;
+        if (SIGNED && nneg) *nneg += (p0 < 0.0) + (p1 < 0.0) + (p2 < 0.0) + (p3 < 0.0);
+        if (ty == 0 && tx < 4) rsv[k0 + tx] = tx == 0 ? g0 * rs0 : tx == 1 ? g1 * rs1 : tx == 2 ? g2 * rs2 : g3 * rs3;
         // this thread's rows and columns of the panel: entry q is corrected by the pivots before it, then scaled.
-        // (x, y, z, w) in: the published values; out: L[., k0 + q] resp. W[k0 + q, .]
+        // (x, y, z, w) in: the published values; out: L[., k0 + q] resp. W[k0 + q, .] (up to the deferred sign, SIGNED)
 #define SM_PANEL(V)                                                          \
+        V[0] = V[0] * rs0;                                                   \
+        V[1] = (V[1] - V[0] * w10) * rs1;                                    \
+        V[2] = ((V[2] - V[0] * w20) - V[1] * w21) * rs2;                     \
+        V[3] = (((V[3] - V[0] * w30) - V[1] * w31) - V[2] * w32) * rs3;
+#define SM_PANEL_R(V)                                                        \
         V[0] = V[0] * rs0;                                                   \
         V[1] = (V[1] - V[0] * l10) * rs1;                                    \
         V[2] = ((V[2] - V[0] * l20) - V[1] * l21) * rs2;                     \
@@ -117,12 +138,14 @@ __device__ __forceinline__ int sm_sweep_chunk(int n, double (&a)[SM_NR][SM_NC], 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) cj[c][q] = (j > k0 + q) ? cj[c][q] : 0.0;
                 }
+                if (SIGNED) { cj[c][0] *= g0; cj[c][1] *= g1; cj[c][2] *= g2; cj[c][3] *= g3; }   // the update is - sigma u u'
             }
             if (c <= KC) {                       // rows of W: zero right of their diagonal by construction
-                SM_PANEL(rj[c])
+                SM_PANEL_R(rj[c])
             }
         }
 #undef SM_PANEL
+#undef SM_PANEL_R
 #pragma unroll
         for (int r = KR; r < SM_NR; ++r) {       // rows that can lie below k0
 #pragma unroll
@@ -140,22 +163,22 @@ __device__ __forceinline__ int sm_sweep_chunk(int n, double (&a)[SM_NR][SM_NC], 
     return info;
 }
 
-template <bool LOGDET = true>
+template <bool LOGDET = true, bool SIGNED = false>
 __device__ __forceinline__ int sm_sweep(int n, double (&a)[SM_NR][SM_NC], double (&rr)[SM_NR][SM_NC],
-                                        double *blk, double *rsv, int ty, int tx, double *logdet) {
+                                        double *blk, double *rsv, int ty, int tx, double *logdet, int *nneg = nullptr) {
 #pragma unroll
     for (int r = 0; r < SM_NR; ++r)
 #pragma unroll
         for (int c = 0; c < SM_NC; ++c) rr[r][c] = (ty + 16 * r == tx + 32 * c) ? 1.0 : 0.0;
     int info = 0;
-    if (!info && n > 0) info = sm_sweep_chunk<0>(n, a, rr, blk, rsv, ty, tx);
-    if (!info && n > 16) info = sm_sweep_chunk<1>(n, a, rr, blk, rsv, ty, tx);
-    if (!info && n > 32) info = sm_sweep_chunk<2>(n, a, rr, blk, rsv, ty, tx);
-    if (!info && n > 48) info = sm_sweep_chunk<3>(n, a, rr, blk, rsv, ty, tx);
-    if (!info && n > 64) info = sm_sweep_chunk<4>(n, a, rr, blk, rsv, ty, tx);
-    if (!info && n > 80) info = sm_sweep_chunk<5>(n, a, rr, blk, rsv, ty, tx);
-    if (!info && n > 96) info = sm_sweep_chunk<6>(n, a, rr, blk, rsv, ty, tx);
-    if (!info && n > 112) info = sm_sweep_chunk<7>(n, a, rr, blk, rsv, ty, tx);
+    if (!info && n > 0) info = sm_sweep_chunk<0, SIGNED>(n, a, rr, blk, rsv, ty, tx, nneg);
+    if (!info && n > 16) info = sm_sweep_chunk<1, SIGNED>(n, a, rr, blk, rsv, ty, tx, nneg);
+    if (!info && n > 32) info = sm_sweep_chunk<2, SIGNED>(n, a, rr, blk, rsv, ty, tx, nneg);
+    if (!info && n > 48) info = sm_sweep_chunk<3, SIGNED>(n, a, rr, blk, rsv, ty, tx, nneg);
+    if (!info && n > 64) info = sm_sweep_chunk<4, SIGNED>(n, a, rr, blk, rsv, ty, tx, nneg);
+    if (!info && n > 80) info = sm_sweep_chunk<5, SIGNED>(n, a, rr, blk, rsv, ty, tx, nneg);
+    if (!info && n > 96) info = sm_sweep_chunk<6, SIGNED>(n, a, rr, blk, rsv, ty, tx, nneg);
+    if (!info && n > 112) info = sm_sweep_chunk<7, SIGNED>(n, a, rr, blk, rsv, ty, tx, nneg);
     __syncthreads();
     double ld = 0.0;
     if (!info) {
@@ -178,7 +201,7 @@ __device__ __forceinline__ int sm_sweep(int n, double (&a)[SM_NR][SM_NC], double
         // by the caller).  (Taking it from the diagonal elements where they live ran the long f64 log routine up to 32
         // times per wave under divergent masks: 8 us.)
         const int t = ty * 32 + tx;
-        if (LOGDET && t < SMALL_P) blk[t] = (t < n) ? -2.0 * log(rsv[t]) : 0.0;      // (the block images are free again)
+        if (LOGDET && t < SMALL_P) blk[t] = (t < n) ? -2.0 * log(SIGNED ? fabs(rsv[t]) : rsv[t]) : 0.0;      // (the block images are free again)
     }
     if (!LOGDET) { *logdet = 0.0; return info; }
     __syncthreads();

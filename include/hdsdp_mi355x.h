@@ -500,8 +500,15 @@ void HMiKKTEnvelopeInfo(hdsdp_kkt *HKKT, int *permuted, double *fraction);
    (interface/hdsdp_schur.c:46-139, linalg/hdsdp_linsolver.c:509-809).  Returns 1 and fills the outputs when HKKT is in that
    form: tiles stored, tiles of the dense lower triangle, levels, bytes of device memory of the tile stores. */
 int HMiKKTTileInfo(hdsdp_kkt *HKKT, int *tiles, int64_t *denseTiles, int *levels, int64_t *bytes);
+/* The tile-form factorisation is an LDL' WITHOUT pivoting in signed-Cholesky form, M = L~ S L~' with S = diag(+-1) -- what the
+   reference's sparse direct solver does (external/qdldl.c; linalg/hdsdp_linsolver.c:596-626): an indefinite matrix factors and
+   solves, only an exactly zero pivot fails HKKTFactorize, and a positive definite matrix gets its Cholesky factor bit for bit.
+   Negative pivots of the operator's last factorisation (= negative eigenvalues of M, by inertia); -1 if HKKT is not in tile form
+   or not factored. */
+int HMiKKTNegativePivots(hdsdp_kkt *HKKT);
 /* the tile-form factorisation and solve on a host matrix (lower-triangular CSC, diagonal entry first in every column):
-   stats[0..2] = block rows, tiles stored, levels; ms (may be NULL) = factorisation time, best of three */
+   *info = 0 or first zero pivot + 1; stats[0..3] = block rows, tiles stored, levels, negative pivots; ms (may be NULL) =
+   factorisation time, best of three */
 int HMiBspSolve(int m, const int *colBeg, const int *rowIdx, const double *val, const double *b, double *x, int *info, int *stats,
                 double *ms);
 int HMiCholEnvelopeProbe(int n, int band, int reps, double *ms_dense, double *ms_env);   /* factorisation time of a block-banded matrix, dense vs on its envelope */

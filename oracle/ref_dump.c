@@ -276,6 +276,22 @@ int main(int argc, char **argv) {
         double *so = calloc(mm, sizeof(double));
         HDSDP_CALL(HKKTFactorize(kk));
         HDSDP_CALL(HKKTSolve(kk, rowRHS, so)); dump_d("sol_b", so, mm);
+        if (kk->isKKTSparse && argc > 7) {
+            /* the SPARSE operator on a matrix that is not positive definite: the diagonal is lowered through kktDiag (how the
+               bound cone and HKKTRegularize write into it) until some eigenvalues are negative; the reference's sparse direct
+               solver is an LDL' without pivoting (linalg/hdsdp_linsolver.c:596-626 over external/qdldl.c): it factors, solves,
+               and only its PSD check says "not positive definite" */
+            const double shift = atof(argv[7]);
+            for (int i = 0; i < mm; ++i) *kk->kktDiag[i] -= shift;
+            int codes[3] = {-1, -1, -1};
+            codes[0] = (int) HKKTFactorize(kk);
+            codes[1] = (int) HKKTSolve(kk, rowRHS, so);
+            dump_d("indef_sol", so, mm);
+            (void) HFpLinsysPsdCheck(kk->kktM, kk->kktMatBeg, kk->kktMatIdx, kk->kktMatElem, &codes[2]);
+            dump_i("indef_codes", codes, 3);
+            dump_s("indef_shift", shift);
+            printf("indefinite round: shift %g, factorize rc %d, solve rc %d, isPsd %d\n", shift, codes[0], codes[1], codes[2]);
+        }
         printf("ref_dump ok: blocks=%d m=%d logdet=%.12e\n", nBlks, mm, ldsum);
         return 0;
     }

@@ -442,7 +442,7 @@ def test_tile_form_cholesky_against_lapack(kind):
     beg, idx, val, A = _spd_lower_csc(m, pairs, rng)
     b = rng.uniform(-1, 1, m)
     x = np.zeros(m)
-    info, stats, ms = C.c_int(-1), (C.c_int * 3)(), C.c_double(0.0)
+    info, stats, ms = C.c_int(-1), (C.c_int * 4)(), C.c_double(0.0)
     ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
     rc = lib.HMiBspSolve(m, beg.ctypes.data_as(ip), idx.ctypes.data_as(ip), val.ctypes.data_as(dp), b.ctypes.data_as(dp),
                          x.ctypes.data_as(dp), C.byref(info), stats, C.byref(ms))
@@ -455,10 +455,25 @@ def test_tile_form_cholesky_against_lapack(kind):
         assert ntiles <= 3 * nb and nlevels <= nb                # diagonal tiles, a neighbour where a small block straddles two tiles, the linking rows: no fill
     if kind == "block_diagonal":
         assert ntiles <= 2 * nb
-    # not positive definite: reported, not an error
+    assert stats[3] == 0                                         # positive definite: no negative pivot
+    # not positive definite: the factorisation is an LDL' without pivoting like the reference's sparse direct solver
+    # (external/qdldl.c) -- it goes through, counts the negative pivots (= negative eigenvalues, by inertia) and solves
     val2 = val.copy()
-    val2[beg[m // 2]] = -3.0
-    rc = lib.HMiBspSolve(m, beg.ctypes.data_as(ip), idx.ctypes.data_as(ip), val2.ctypes.data_as(dp), None, None, C.byref(info), stats, None)
+    for c in (m // 2, m // 3, m - 1):
+        val2[beg[c]] = -3.0
+    A2 = A.copy()
+    for c in (m // 2, m // 3, m - 1):
+        A2[c, c] = -3.0
+    x2 = np.zeros(m)
+    rc = lib.HMiBspSolve(m, beg.ctypes.data_as(ip), idx.ctypes.data_as(ip), val2.ctypes.data_as(dp), b.ctypes.data_as(dp),
+                         x2.ctypes.data_as(dp), C.byref(info), stats, None)
+    assert rc == 0 and info.value == 0, (rc, info.value)
+    assert stats[3] == int(np.sum(np.linalg.eigvalsh(A2) < 0)) >= 3, stats[3]
+    ref2 = np.linalg.solve(A2, b)
+    assert np.linalg.norm(x2 - ref2) <= 1e-9 * np.linalg.norm(ref2), np.linalg.norm(x2 - ref2) / np.linalg.norm(ref2)
+    # an exactly zero pivot is the one thing that fails (qdldl.c:109, :212)
+    val3 = np.zeros_like(val)
+    rc = lib.HMiBspSolve(m, beg.ctypes.data_as(ip), idx.ctypes.data_as(ip), val3.ctypes.data_as(dp), None, None, C.byref(info), stats, None)
     assert rc == 0 and info.value > 0
 
 

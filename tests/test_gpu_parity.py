@@ -705,6 +705,50 @@ def test_regularize_follows_the_reference_rule():
         cone.destroy()
 
 
+def test_tile_form_operator_factors_an_indefinite_matrix_like_the_reference():
+    """arrow128's sparse Schur operator (tile form on the device) with its diagonal lowered -- through kktDiag, how the bound
+    cone and HKKTRegularize write into it -- until FIVE eigenvalues are negative.  The reference's sparse operator is factored
+    by an LDL' without pivoting (linalg/hdsdp_linsolver.c:596-626 over external/qdldl.c): HKKTFactorize and HKKTSolve go
+    through (indef_codes of the golden: 0 0) and only the PSD check says no.  Round 3's tile form stopped at the first
+    non-positive pivot.  Now: same solution as the compiled reference's, five negative pivots (inertia), and the operator is
+    positive definite again after the diagonal is restored."""
+    import os
+    from hdsdp_amd import api
+    g = load_golden("arrow128_A")
+    assert list(g["indef_codes"]) == [0, 0, 0]                 # reference: factorize ok, solve ok, isPsd = 0
+    nb, m = int(g["mb_dims"][0]), int(g["mb_dims"][1])
+    Rd, tau, y, shift = float(g["Rd"][0]), float(g["tau"][0]), y_of(g), float(g["indef_shift"])
+    prob = api.read_sdpa(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arrow128.dat-s"))
+    cones = [api.SDPCone.from_csc(blk["n"], m, blk["beg"], blk["idx"], blk["val"], iCone=k) for k, blk in enumerate(prob["blocks"])]
+    try:
+        for c in cones:
+            c.set_start(Rd)
+            assert c.check_is_interior(tau, y)
+        kkt = api.KKT(m, cones)
+        assert kkt.is_sparse and kkt.tile_info() is not None
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        kkt.factorize()
+        assert kkt.negative_pivots() == 0
+        x0 = kkt.solve(g["b"])
+        kkt.add_to_diag(-shift)
+        A = np.triu(kkt.M) + np.triu(kkt.M, 1).T
+        assert int(np.sum(np.linalg.eigvalsh(A) < 0)) == 5
+        kkt.factorize()                                         # (raised in round 3: "not positive definite")
+        assert kkt.negative_pivots() == 5
+        x = kkt.solve(g["b"])
+        assert np.linalg.norm(x - g["indef_sol"]) <= 1e-8 * np.linalg.norm(g["indef_sol"])
+        assert np.linalg.norm(A @ x - g["b"]) <= 1e-10 * np.linalg.norm(g["b"])
+        kkt.add_to_diag(shift)
+        kkt.factorize()
+        assert kkt.negative_pivots() == 0
+        x1 = kkt.solve(g["b"])
+        assert np.linalg.norm(x1 - x0) <= 1e-9 * np.linalg.norm(x0)
+        kkt.destroy()
+    finally:
+        for c in cones:
+            c.destroy()
+
+
 @pytest.mark.parametrize("name,fname", [("truss1_A", "truss1.dat-s"), ("blocks3_A", "blocks3.dat-s"), ("chain16_A", "chain16.dat-s"),
                                         ("arrow128_A", "arrow128.dat-s")])
 def test_multi_block_instance_against_reference(name, fname):

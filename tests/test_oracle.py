@@ -282,3 +282,18 @@ def test_config5_row_fixture_is_what_the_definition_says():
             assert abs(float(np.sum(Aj * B)) - g["bench_M_rows"][q, j]) <= 1e-10 * scale, (i, j)
             assert abs(float(np.sum(Aj * Sinv)) - g["bench_ASinv"][j]) <= 1e-10 * np.max(np.abs(g["bench_ASinv"]))
             assert abs(float(np.trace(Aj)) - g["bench_b"][j]) <= 1e-12 * n
+
+
+def test_the_sparse_operators_indefinite_round_is_what_the_golden_says():
+    """arrow128_A's indefinite round (oracle/ref_dump.c, sdpam mode: the compiled reference's SPARSE Schur operator with its
+    diagonal lowered by indef_shift, factored and solved by its LDL' without pivoting): the dumped solution solves
+    (M_inf - shift I) x = b for the dumped M_inf, five eigenvalues of that matrix are negative, and the reference's own codes
+    say "factorised, solved, not positive definite" -- what tests/test_gpu_parity.py holds the tile form to."""
+    import scipy.sparse as sp
+    g = load_golden("arrow128_A")
+    m = int(g["mb_dims"][1])
+    A = sp.csc_matrix((g["M_inf"], g["kkt_idx"], g["kkt_beg"]), shape=(m, m)).toarray()
+    A = A + np.tril(A, -1).T - float(g["indef_shift"]) * np.eye(m)
+    assert int(np.sum(np.linalg.eigvalsh(A) < 0)) == 5
+    assert list(g["indef_codes"]) == [0, 0, 0]
+    assert np.linalg.norm(A @ g["indef_sol"] - g["b"]) <= 1e-12 * np.linalg.norm(g["b"])

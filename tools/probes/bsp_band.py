@@ -18,7 +18,7 @@ def run(name, A):
     assert np.all(idx[beg[:-1]] == np.arange(m))          # diagonal first
     b = np.cos(0.01 * np.arange(m))
     x = np.zeros(m)
-    info, stats, ms = C.c_int(-1), (C.c_int * 3)(), C.c_double(0.0)
+    info, stats, ms = C.c_int(-1), (C.c_int * 4)(), C.c_double(0.0)
     t0 = time.time()
     rc = lib.HMiBspSolve(m, beg.ctypes.data_as(ip), idx.ctypes.data_as(ip), val.ctypes.data_as(dp), b.ctypes.data_as(dp), x.ctypes.data_as(dp),
                          C.byref(info), stats, C.byref(ms))
