@@ -17,7 +17,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libhdsdp_mi355x.so")
-SOURCES = ["gemm_f64.hip", "gemm_persist.hip", "chol.hip", "schur.hip", "lanczos.hip", "lu.hip", "small.hip", "bsparse.hip", "engine.hip", "probes.hip", "coeff.cpp", "sdpa.cpp"]
+SOURCES = ["gemm_f64.hip", "gemm_persist.hip", "chol.hip", "schur.hip", "lanczos.hip", "lu.hip", "small.hip", "bsparse.hip", "engine.hip", "probes.hip", "coeff.cpp", "sdpa.cpp", "alloc.cpp"]
 # every header under csrc/ is a dependency of every object (a header missing from a hand-kept list once left a stale
 # library in place after an edit)
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "hdsdp_mi355x.h")]

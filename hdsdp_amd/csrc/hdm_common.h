@@ -13,6 +13,15 @@ static inline size_t hdm_operand_pad(long ld) { return (size_t) 128 * (size_t) (
 #include <cstdio>
 #include <cstdlib>
 
+// Every device allocation of the engine goes through hdm_malloc: plain hipMalloc, and -- with HDM_POISON=1 in the environment,
+// a diagnostic -- the new memory filled with 0xFF bytes (NaN as a double, -1 as an int), so that a kernel that reads what
+// nobody has written shows up as NaNs in the results instead of as whatever the allocator recycled (round 4: one run of the
+// ingest test read an earlier cone's data out of a fresh buffer and nothing said so).
+hipError_t hdm_malloc(void **p, size_t bytes);   // alloc.cpp
+#ifndef HDM_MALLOC_IMPL
+#define hipMalloc(p, bytes) hdm_malloc((void **) (p), (bytes))
+#endif
+
 #define HDM_TILE 128          // workgroup tile edge of the fp64 MFMA GEMM family
 #define HDM_BK 16             // k-depth of one LDS stage
 #define HDM_SUB 16            // MFMA sub-tile edge (v_mfma_f64_16x16x4_f64)
@@ -112,14 +121,24 @@ struct HdmGemmArgs {
     int role;         // HdmRole
     double flops;     // algorithmic flops of this launch (valid data only), for the live roofline
     // BLOCKED epilogue: destination chunk layout  dst[((blk*16 + c_local) * rowStride + row) * 16 + r_local]
-    long blk_row_stride;  // = m_pad (number of constraint rows per 16-wide p-block)
+    long blk_row_stride;  // constraint rows per 16-wide p-block (= rows of one row segment)
     long blk_row0;        // constraint row of batch entry 0
+    // row segments (0 = one segment): rows [s * blk_seg_rows, (s + 1) * blk_seg_rows) live blk_seg_stride elements after the
+    // segment before -- the layout [segment][p-block][row in segment][16] (engine_cone.h: MiCone::seg)
+    long blk_seg_rows, blk_seg_stride;
     int nblk;             // n/16: sub-blocks per matrix edge
     // SLAB epilogue / split-K
     long k_chunk;         // K range per split (multiple of HDM_BK)
     long k_base;          // first k of split 0 (a launch may cover a sub-range of the splits; C then points at its first slab)
     long slab_stride;     // elements between slabs
 };
+
+// element offset of constraint row `row` in the BLOCKED layout (without the p-block term)
+__host__ __device__ inline long hdm_blk_row_off(const HdmGemmArgs &a, long row) {
+    if (!a.blk_seg_rows) return row * 16;
+    const long sg = row / a.blk_seg_rows;
+    return (row - sg * a.blk_seg_rows) * 16 + sg * a.blk_seg_stride;
+}
 
 int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream);
 // while a stream capture is recording the launches (chol.hip), the launcher must not record timing events

@@ -43,10 +43,11 @@ __device__ __forceinline__ double sm_rsqrt(double p) {
 #define SM_BLK 1024        // doubles per block image: [128][4] columns, then [128][4] rows of R
 
 // SIGNED (the tile-form LDL' of a sparse Schur matrix, bsparse.hip): the same sweep as A = L~ S L~', S = diag(+-1) the signs of
-// the pivots, L~ = L |D|^1/2 -- an LDL' without pivoting in Cholesky clothing.  Pivot q contributes u u' sigma_q with
-// u = column / sqrt|pivot|, so the corrections of the COLUMN panels carry sigma (w = sigma u below) while the forward
-// substitution on the identity, which builds W = L~^-1 = S U^-1, runs on u alone and takes its sign with the final scale:
-// rsv[k] = sigma_k / sqrt|pivot_k| is what both deferred scalings multiply by.  Only a pivot that is exactly zero (or not a
+// the pivots, L~ = L |D|^1/2 -- an LDL' without pivoting in Cholesky clothing.  Pivot q contributes sigma_q u u' with
+// u = column / sqrt|pivot| (so L~ = U S, and U's diagonal is sigma sqrt|pivot|): the corrections of the COLUMN panels carry
+// sigma (w = sigma u below), and the deferred column scale is rsv[k] = sigma_k / sqrt|pivot_k|.  The forward substitution on the
+// identity builds Y = U^-1 row by row -- row q is (e_q - sum u_qt Y_t) / u_qq, i.e. scaled by the SIGNED rsv[q] wherever a
+// finished row enters a later one -- and what is wanted is W = L~^-1 = S Y: the rows leave with the UNSIGNED scale |rsv|.  Only a pivot that is exactly zero (or not a
 // number) stops the sweep, as in the reference's sparse direct solver (external/qdldl.c:109, :212); *nneg counts the negative
 // ones.  With all pivots positive every sigma is +1.0 and the arithmetic is the unsigned sweep's, bit for bit.
 template <int KR, bool SIGNED = false>
@@ -107,7 +108,9 @@ __device__ __forceinline__ int sm_sweep_chunk(int n, double (&a)[SM_NR][SM_NC], 
                                : (!(p0 > 0.0) ? 1 : !(p1 > 0.0) ? 2 : !(p2 > 0.0) ? 3 : !(p3 > 0.0) ? 4 : 0);
         info = (info == 0 && bad != 0) ? k0 + bad : info;
         if (SIGNED && nneg) *nneg += (p0 < 0.0) + (p1 < 0.0) + (p2 < 0.0) + (p3 < 0.0);
-        if (ty == 0 && tx < 4) rsv[k0 + tx] = tx == 0 ? g0 * rs0 : tx == 1 ? g1 * rs1 : tx == 2 ? g2 * rs2 : g3 * rs3;
+        // signed scales: what a finished column of the trailing matrix (and, inside this block, a finished row of R) is multiplied by
+        const double q0 = SIGNED ? g0 * rs0 : rs0, q1 = SIGNED ? g1 * rs1 : rs1, q2 = SIGNED ? g2 * rs2 : rs2, q3 = SIGNED ? g3 * rs3 : rs3;
+        if (ty == 0 && tx < 4) rsv[k0 + tx] = tx == 0 ? q0 : tx == 1 ? q1 : tx == 2 ? q2 : q3;
         // this thread's rows and columns of the panel: entry q is corrected by the pivots before it, then scaled.
         // (x, y, z, w) in: the published values; out: L[., k0 + q] resp. W[k0 + q, .] (up to the deferred sign, SIGNED)
 #define SM_PANEL(V)                                                          \
@@ -116,10 +119,10 @@ __device__ __forceinline__ int sm_sweep_chunk(int n, double (&a)[SM_NR][SM_NC], 
         V[2] = ((V[2] - V[0] * w20) - V[1] * w21) * rs2;                     \
         V[3] = (((V[3] - V[0] * w30) - V[1] * w31) - V[2] * w32) * rs3;
 #define SM_PANEL_R(V)                                                        \
-        V[0] = V[0] * rs0;                                                   \
-        V[1] = (V[1] - V[0] * l10) * rs1;                                    \
-        V[2] = ((V[2] - V[0] * l20) - V[1] * l21) * rs2;                     \
-        V[3] = (((V[3] - V[0] * l30) - V[1] * l31) - V[2] * l32) * rs3;
+        V[0] = V[0] * q0;                                                    \
+        V[1] = (V[1] - V[0] * l10) * q1;                                     \
+        V[2] = ((V[2] - V[0] * l20) - V[1] * l21) * q2;                      \
+        V[3] = (((V[3] - V[0] * l30) - V[1] * l31) - V[2] * l32) * q3;
 #pragma unroll
         for (int r = KR; r < SM_NR; ++r) {
             SM_PANEL(ci[r])
@@ -193,7 +196,7 @@ __device__ __forceinline__ int sm_sweep(int n, double (&a)[SM_NR][SM_NC], double
 #pragma unroll
         for (int r = 0; r < SM_NR; ++r) {
             const int i = ty + 16 * r;
-            const double si = (i < n) ? rsv[i] : 1.0;
+            const double si = (i < n) ? (SIGNED ? fabs(rsv[i]) : rsv[i]) : 1.0;
 #pragma unroll
             for (int c = 0; c < SM_NC; ++c) rr[r][c] *= si;
         }

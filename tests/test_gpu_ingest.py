@@ -68,7 +68,18 @@ def test_the_three_ways_in_give_the_same_bits(name):
             syn = _state(api, cone, m, g)
         finally:
             cone.destroy()
-        assert np.array_equal(syn["S"][lower_mask(n)], got[0]["S"][lower_mask(n)]) and np.array_equal(syn["traces"], got[0]["traces"])
+        # (the constraint matrices are the same bits; the objective C = I + sum y0_c A_c is summed with fused multiply-adds by
+        # the device generator and without by the host restatement: equal to rounding, not to the bit)
+        a, b = syn["S"][lower_mask(n)], got[0]["S"][lower_mask(n)]
+        assert np.max(np.abs(a - b)) <= 1e-13 * np.max(np.abs(b))
+        assert np.max(np.abs(syn["traces"] - got[0]["traces"])) <= 1e-13 * np.max(np.abs(got[0]["traces"]))
+        assert np.max(np.abs(syn["M"][lower_mask(m)] - got[0]["M"][lower_mask(m)])) <= 1e-11 * np.max(np.abs(got[0]["M"][lower_mask(m)]))
+    if "M_inf" in g and "csc_beg" in g:      # every way in gives the compiled reference's numbers, not just each other's
+        from util import check_close
+        for st in got:
+            check_close(st["M"][lower_mask(m)], g["M_inf"][lower_mask(m)], name + " M")
+            check_close(st["ASinv"], g["ASinv_inf"], name + " ASinv")
+            check_close(st["ASinvRdSinv"], g["ASinvRdSinv_inf"], name + " ASinvRdSinv")
     for other in got[1:]:
         msk = {"M": lower_mask(m), "S": lower_mask(n)}
         for k in ("S", "M", "ASinv", "ASinvRdSinv", "traces"):

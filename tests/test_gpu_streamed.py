@@ -57,8 +57,9 @@ def test_the_sweep_copy_of_streamed_rows_is_the_copy_of_resident_rows(monkeypatc
             got.append((cone.sweep_info(), cone.dual_matrix().copy()))
         finally:
             cone.destroy()
+    from util import lower_mask
     assert got[0][0] == got[1][0]
-    assert np.array_equal(got[0][1], got[1][1])
+    assert np.array_equal(got[0][1][lower_mask(n)], got[1][1][lower_mask(n)])      # (S is lower-valid: nothing writes the other half)
 
 
 @pytest.mark.parametrize("mode", ["auto", "streamed"])
