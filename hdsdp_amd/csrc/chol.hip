@@ -700,8 +700,12 @@ int HdmChol::factor(hipStream_t s, int *info_host) {
     return 0;
 }
 
+__global__ void hdm_zero_word_kernel(int *p) { *p = 0; }
+
 int HdmChol::enqueue_factor(hipStream_t s) {
-    HDM_HIP_CHECK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    // (a kernel, not hipMemsetAsync: this chain is captured into a hipGraph, and under HDM_POISON a replay of the captured
+    // MEMSET node was seen to leave 0xFFFFFFFF in the word -- profiles/r04_c_poison.txt; a kernel node behaves like its neighbours)
+    hipLaunchKernelGGL(hdm_zero_word_kernel, dim3(1), dim3(1), 0, s, info_dev);
     const long ld = npad;
     const size_t shm = (NB * NB + LDW * PB) * sizeof(double);
     static const bool diag_sweep = [] { const char *e = getenv("HDM_DIAG_SWEEP"); return !(e && atoi(e) == 0); }();

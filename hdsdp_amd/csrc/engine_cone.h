@@ -914,22 +914,16 @@ void cone_precover(void *cd, double dBarrierMu, double *y, double *dy, double *X
     const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
     auto fail = [](const char *what) { fprintf(stderr, "[hdsdp_mi355x] primal recovery: %s\n", what); };
     if (cone_assemble(c, 1.0, y, c->Scheck, &zero)) return fail("S assembly failed");
-    if (stat_trace()) {      // diagnostic: is the assembled lower triangle finite?
-        double *tmp = nullptr, h[2] = {0, 0};
-        if (hipMalloc((void **) &tmp, 16) == hipSuccess && hipMemsetAsync(tmp, 0, 16, g.stream) == hipSuccess) {
-            hipLaunchKernelGGL(mi_low_norms_kernel, dim3(1), dim3(256), 0, g.stream, c->Scheck, 0L, c->n, (long) c->n16, 1, 0, tmp);
-            (void) hipMemcpyAsync(h, tmp, 16, hipMemcpyDeviceToHost, g.stream);
-            (void) hipStreamSynchronize(g.stream);
-            fprintf(stderr, "[hdsdp_mi355x trace]     primal recovery: |S|_1 = %g, |S|_F^2 = %g (pS_ok %d pD_ok %d zs %d)\n", h[0], h[1], (int) c->pS_ok, (int) c->pD_ok, c->zs_state);
-            (void) hipFree(tmp);
-        }
-    }
     HdmChol *chp = nullptr;
     if (cone_checker(c, &chp) != HDSDP_RETCODE_OK) return fail("out of memory");
     HdmChol &ch = *chp;
     int info = 0;
     if (ch.load_device(c->Scheck, c->n16, g.stream) || ch.factor(g.stream, &info)) return fail("factorisation failed");
-    if (info != 0) { printf("Recovery step is infeasible\n"); return; }
+    if (info != 0) {
+        if (stat_trace()) fprintf(stderr, "[hdsdp_mi355x trace]     primal recovery: factorisation stopped at pivot %d (runs %d, graph %d)\n", info, ch.factor_runs, ch.factor_graph ? 1 : 0);
+        printf("Recovery step is infeasible\n");
+        return;
+    }
     if (!c->dS) {
         if (hipMalloc((void **) &c->dS, nn) != hipSuccess || hdm_memset_sync(c->dS, 0, nn) != hipSuccess) return fail("out of memory");
     }

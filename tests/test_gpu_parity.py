@@ -717,7 +717,7 @@ def test_tile_form_operator_factors_an_indefinite_matrix_like_the_reference():
     g = load_golden("arrow128_A")
     assert list(g["indef_codes"]) == [0, 0, 0]                 # reference: factorize ok, solve ok, isPsd = 0
     nb, m = int(g["mb_dims"][0]), int(g["mb_dims"][1])
-    Rd, tau, y, shift = float(g["Rd"][0]), float(g["tau"][0]), y_of(g), float(g["indef_shift"])
+    Rd, tau, y, shift = float(g["Rd"][0]), float(g["tau"][0]), y_of(g), float(np.asarray(g["indef_shift"]).ravel()[0])
     prob = api.read_sdpa(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arrow128.dat-s"))
     cones = [api.SDPCone.from_csc(blk["n"], m, blk["beg"], blk["idx"], blk["val"], iCone=k) for k, blk in enumerate(prob["blocks"])]
     try:
