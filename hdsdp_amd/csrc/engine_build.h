@@ -50,7 +50,6 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, lo
         k2.C = c->AhatLoc; k2.M = c->n16; k2.N = c->n16; k2.K = c->n16; k2.batch = nb; k2.alpha = 1.0;
         k2.klimit = HDM_KLIM_BY_N; k2.lower_only = 1; k2.epilogue = HDM_EPI_BLOCKED;
         k2.blk_row_stride = c->Lr; k2.blk_row0 = row0 + b0; k2.nblk = c->nblk; k2.role = HDM_ROLE_CONG2;
-        if (c->world == 1) { k2.blk_row_stride = c->seg; k2.blk_seg_rows = c->seg; k2.blk_seg_stride = c->npb_loc * (long) c->seg * 16; }
         k2.tile_col_mask = colmask;
         k2.spanA = t_span; k2.spanB = linv_span; k2.spanA2 = linv_span; k2.spanB2 = t_span;
         k2.flops = (double) nb * n3 * 2.0 / 3.0 * cong2_mask_share((c->n16 + HDM_TILE - 1) / HDM_TILE, colmask);
@@ -63,14 +62,14 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, lo
 int gram_splits(MiCone *c, int z0, int nz) {
     HdmGemmArgs gq = {};
     gq.A = c->AhatAll; gq.B = c->AhatAll; gq.a_kmajor = 1; gq.b_kmajor = 1;
-    gq.lda = 16; gq.ldb = 16; gq.a_kblk = (long) c->seg * 16; gq.b_kblk = (long) c->seg * 16;
-    if (c->nseg > 1) { gq.seg_rows = c->seg; gq.seg_extra = c->npb_loc * c->seg * 16 - (long) c->seg * 16; }
+    gq.lda = 16; gq.ldb = 16; gq.a_kblk = (long) c->Lr * 16; gq.b_kblk = (long) c->Lr * 16;
+    if (c->world > 1) { gq.seg_rows = c->Lr; gq.seg_extra = c->npb_loc * c->Lr * 16 - (long) c->Lr * 16; }
     gq.ldc = c->R; gq.M = (int) c->R; gq.N = (int) c->R; gq.K = (int) (c->npb_loc * 16);
     gq.lower_only = 1; gq.epilogue = HDM_EPI_SLAB; gq.batch = nz;
     const long chunk = (c->npb_loc + c->nsplit - 1) / c->nsplit;
     gq.k_chunk = chunk * 16; gq.slab_stride = c->R * c->R; gq.alpha = 1.0; gq.role = HDM_ROLE_GRAM;
     gq.k_base = (long) z0 * gq.k_chunk;
-    gq.spanA = gq.spanB = c->ahat_doubles() + HDM_OPERAND_PAD_DOUBLES;
+    gq.spanA = gq.spanB = (long) c->world * c->npb_loc * c->Lr * 16 + HDM_OPERAND_PAD_DOUBLES;
     gq.C = c->slabs + (long) z0 * gq.slab_stride;
     {   // (m+3)(m+4)/2 inner products of length n(n+1)/2 (this rank's share), 2 flops each
         const double rows = (double) c->m + 3.0;
@@ -367,7 +366,6 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
         k2.M = c->n16; k2.N = c->n16; k2.K = c->n16; k2.batch = 1; k2.alpha = 1.0;
         k2.klimit = HDM_KLIM_BY_N; k2.lower_only = 1; k2.epilogue = HDM_EPI_BLOCKED;
         k2.blk_row_stride = c->Lr; k2.blk_row0 = c->mloc; k2.nblk = c->nblk;
-        if (c->world == 1) { k2.blk_row_stride = c->seg; k2.blk_seg_rows = c->seg; k2.blk_seg_stride = c->npb_loc * (long) c->seg * 16; }
         RC(hdm_launch_gemm(k2, g.stream));
         if (typeKKT == KKT_TYPE_HOMOGENEOUS) {
             if (!c->CL) {

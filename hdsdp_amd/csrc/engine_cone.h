@@ -16,15 +16,7 @@ struct MiCone {
     int nblk = 0;              // n16 / 16
     long npb = 0;              // p-blocks of the blocked congruence layout: nblk(nblk+1)/2 * 16
     long npb_loc = 0;          // p-blocks per rank (K range of the local Gram part)
-    int Lr = 0;                // Gram rows per rank (local rows + 3 augmented, padded); R = world * Lr
-    // The transformed rows live in ROW SEGMENTS: [segment][p-block][row in segment][16].  Sharded (world > 1) a segment is one
-    // rank's Lr rows (the exchange layout).  One GPU: segments of 128 rows = one Gram tile (round 4) -- a Gram tile's K loop
-    // walks ONE contiguous range (16 KiB per p-block, back to back) and a congruence tile's 1024 p-block stores land 16 KiB
-    // apart, where the single-segment form [p-block][all rows][16] put them 257 KB apart (every store of an epilogue in
-    // another page).
-    int seg = 0, nseg = 0;
-    long ahat_doubles() const { return (long) nseg * npb_loc * seg * 16; }
-    long ahat_row_off(long row) const { const long sg = row / seg; return (row - sg * seg) * 16 + sg * (npb_loc * (long) seg * 16); }
+    int Lr = 0;                // rows per segment of the Gram operand (local rows + 3 augmented, padded)
     int path = PATH_GEMM;
     bool synthetic = false;
     MiBlockData blk;           // presolve results (empty rows for synthetic)
@@ -69,8 +61,8 @@ struct MiCone {
     // work space
     int Bc = 8;                // constraints per congruence batch
     double *T = nullptr;       // Bc x n16 x n16
-    double *AhatLoc = nullptr; // congruence output of the owned rows: world > 1 [world*npb_loc][Lr][16]; one GPU [nseg][npb][seg][16]
-    double *AhatAll = nullptr; // [nseg][npb_loc][seg][16]: after the transpose (world > 1), == AhatLoc when world == 1
+    double *AhatLoc = nullptr; // [world*npb_loc][Lr][16] congruence output of the owned rows
+    double *AhatAll = nullptr; // [world][npb_loc][Lr][16] after the transpose (== AhatLoc when world == 1)
     bool ext_ahat = false;     // buffers supplied by the caller (torch-owned, for RCCL)
     double *slabs = nullptr;   // nsplit x R x R
     double *Gm = nullptr;      // R x R augmented Gram (lower valid)
@@ -178,11 +170,6 @@ int cone_alloc_common(MiCone *c) {
     int maxloc = compact ? c->mloc : (c->m + c->world - 1) / c->world;
     c->Lr = (c->world == 1) ? (int) hdm_roundup(maxloc + 3, 8) : (int) hdm_roundup(maxloc + 3, HDM_TILE);
     c->R = (long) c->world * c->Lr;
-    {
-        static const int seg_env = [] { const char *e = getenv("HDM_AHAT_SEG"); return e ? atoi(e) : 128; }();
-        if (c->world > 1 || seg_env <= 0) { c->seg = c->Lr; c->nseg = c->world; }
-        else { c->seg = HDM_TILE; c->nseg = (c->Lr + HDM_TILE - 1) / HDM_TILE; }
-    }
     const size_t nn = sizeof(double) * (size_t) c->n16 * c->n16;
     HDM_HIP_CHECK(hipMalloc((void **) &c->S, nn));
     HDM_HIP_CHECK(hipMalloc((void **) &c->Scheck, nn));
@@ -214,7 +201,7 @@ int cone_alloc_gemm_work(MiCone *c) {
         if (c->zs_state == 1 && hipMemGetInfo(&fr, &tot) == hipSuccess) {
             const double rows = (double) std::max(1, c->mloc);
             const double want = std::min(32.0 * (1L << 30), (double) nn * rows) +
-                                sizeof(double) * (double) c->ahat_doubles() * (c->world == 1 ? 1.0 : 2.0) +
+                                sizeof(double) * (double) c->world * c->npb_loc * c->Lr * 16 * (c->world == 1 ? 1.0 : 2.0) +
                                 41.0 * (1L << 30);
             if ((double) fr < want) { hdm_zs_free(&c->zs); c->zs_state = -1; }
         }
@@ -243,7 +230,7 @@ int cone_alloc_gemm_work(MiCone *c) {
         bc /= 2;
     }
     HDM_HIP_CHECK(hdm_memset_sync(c->T, 0, nn * (size_t) c->Bc));  // step 1 writes lower tiles only; the rest must read as 0
-    const size_t ahat = sizeof(double) * (size_t) c->ahat_doubles();
+    const size_t ahat = sizeof(double) * (size_t) c->world * c->npb_loc * c->Lr * 16;
     if (!c->AhatLoc) {
         HDM_HIP_CHECK(hipMalloc((void **) &c->AhatLoc, ahat + sizeof(double) * HDM_OPERAND_PAD_DOUBLES));
         HDM_HIP_CHECK(hdm_memset_sync(c->AhatLoc, 0, ahat));
@@ -323,8 +310,7 @@ int cone_alloc_gemm_work(MiCone *c) {
     HDM_HIP_CHECK(hipMalloc((void **) &c->Gm, sizeof(double) * (size_t) c->R * c->R));
     // the "S row" (At = I) never changes
     if (c->rank == 0) {
-        if (hdm_blocked_eye(c->AhatLoc, c->world == 1 ? c->seg : c->Lr, c->world == 1 ? c->ahat_row_off(c->mloc + 1) : (long) (c->mloc + 1) * 16,
-                            c->nblk, c->n, g.stream)) return 1;
+        if (hdm_blocked_eye(c->AhatLoc, c->Lr, c->mloc + 1, c->nblk, c->n, g.stream)) return 1;
     }
     return 0;
 }

@@ -171,7 +171,7 @@ static hdsdp_retcode make_synth_cone(MiCone **out, int nCol, int nRow, int rank,
     {
         const double rows = (double) std::max(1, c->mloc);
         const double afull = 8.0 * (double) c->astride * rows;
-        const double ahat = 8.0 * (double) c->ahat_doubles() * (c->world == 1 ? 1.0 : 2.0);
+        const double ahat = 8.0 * (double) c->world * c->npb_loc * c->Lr * 16 * (c->world == 1 ? 1.0 : 2.0);
         const double work = std::min(41.0 * (1L << 30), std::max(8.0 * (double) c->n16 * c->n16 * std::min(rows, 1024.0),
                                                                  8.0 * (double) c->R * c->R * 8.0));
         const double schur = 3.0 * 8.0 * (double) c->m * c->m + (6.0 * (1L << 30));

@@ -660,7 +660,7 @@ hdsdp_retcode HMiConeSetExchangeBuffers(hdsdp_cone *cone, void *sendBuf, void *r
     c->AhatLoc = (double *) sendBuf;
     c->AhatAll = (c->world == 1) ? c->AhatLoc : (double *) recvBuf;
     c->ext_ahat = true;
-    const size_t ahat = sizeof(double) * (size_t) c->ahat_doubles();
+    const size_t ahat = sizeof(double) * (size_t) c->world * c->npb_loc * c->Lr * 16;
     if (hipMemsetAsync(c->AhatLoc, 0, ahat, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
     if (c->AhatAll != c->AhatLoc && hipMemsetAsync(c->AhatAll, 0, ahat, g.stream) != hipSuccess) return HDSDP_RETCODE_FAILED;
     return HDSDP_RETCODE_OK;

@@ -5,12 +5,10 @@
 // whose RESULTS ARE WRONG (192: every tile stages the same rows; 576: step 2 without its stores) and the LDS-free step-2
 // body (320), for tools/wg_timeline.py, tools/build_timing.py and tools/ab_env.sh.
 #include "gemm_persist.h"
-#include <cstdlib>
 
 template <bool AK, bool BK, int R, int V>
 static int launch_p(dim3 grid, dim3 block, hipStream_t stream, const HdmGemmDev &d, int *cnt) {
-    static const int ahead = [] { const char *e = getenv("HDM_PERSIST_AHEAD"); return (e && atoi(e) == 0) ? 0 : 1; }();
-    hipLaunchKernelGGL((hdm_gemm_persist_kernel<AK, BK, R, V>), grid, block, 0, stream, d, cnt, ahead);
+    hipLaunchKernelGGL((hdm_gemm_persist_kernel<AK, BK, R, V>), grid, block, 0, stream, d, cnt);
     return 0;
 }
 

@@ -194,7 +194,7 @@ __device__ __forceinline__ void cell_epilogue(const HdmGemmArgs &a, int z, int m
                                               const hdm_d4 (&acc)[4][4]) {
     if (a.epilogue == HDM_EPI_BLOCKED) {
         const long rs16 = a.blk_row_stride * 16;
-        double *lane_base = a.C + hdm_blk_row_off(a, a.blk_row0 + z) + l15 + (long) lq * rs16;
+        double *lane_base = a.C + (a.blk_row0 + z) * 16 + l15 + (long) lq * rs16;
 #pragma unroll
         for (int c = 0; c < T::NC; ++c) {
             const int bi = (m0 >> 4) + T::si[c], bj = (n0 >> 4) + T::sj[c];
@@ -428,7 +428,7 @@ __device__ __forceinline__ void cong2_direct_body(const HdmGemmArgs &a, int z, i
 #undef CD_LOAD
     // epilogue: the 16x16-blocked, sqrt(2)-weighted layout of the congruence output (same as the LDS kernel's)
     const long rs16 = a.blk_row_stride * 16;
-    double *lane_base = a.C + hdm_blk_row_off(a, a.blk_row0 + z) + l15 + (long) lq * rs16;
+    double *lane_base = a.C + (a.blk_row0 + z) * 16 + l15 + (long) lq * rs16;
     const double rt2 = 1.4142135623730951;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -800,7 +800,7 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
         }
         __syncthreads();
         const long rs16 = a.blk_row_stride * 16;
-        double *lane_base = a.C + hdm_blk_row_off(a, a.blk_row0 + z) + l15 + (long) lq * rs16;
+        double *lane_base = a.C + (a.blk_row0 + z) * 16 + l15 + (long) lq * rs16;
         const double rt2 = 1.4142135623730951;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -824,7 +824,7 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
     if (a.epilogue == HDM_EPI_BLOCKED) {
         // one base pointer per lane, everything else is wave-uniform 64-bit strides
         const long rs16 = a.blk_row_stride * 16;                       // elements between consecutive p-blocks
-        double *lane_base = a.C + hdm_blk_row_off(a, a.blk_row0 + z) + l15 + (long) lq * rs16;
+        double *lane_base = a.C + (a.blk_row0 + z) * 16 + l15 + (long) lq * rs16;
         const double rt2 = 1.4142135623730951;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -936,31 +936,23 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_kernel(HdmGemmDev p) {
 // above -- batch entries x, x+8, ..., the tile list inside an entry in order -- so the L2 sharing is the same.  When its own
 // queue is dry an XCD's workgroups go on to the next XCD's queue (stealing at tile granularity: the XCDs' clocks differ by
 // 2 %, and a partition that shows fewer XCDs still processes every queue).  No workgroup ever waits for another one.
-//
-// Drawing AHEAD (round 4).  The draw is an atomic round trip to the L2 (1-2 us) with two barriers around it, and it sat between a
-// tile's last store and the next tile's first load: part of the 6.5 K cycles of hand-over per tile during which the co-resident
-// workgroup has one wave per SIMD.  Now thread 0 draws the NEXT index as soon as the current one is known and keeps it in a
-// register; the round trip hides behind the tile's prologue loads.  Price: a workgroup holds one index it has not started
-// (at a queue's end that is one light tile -- the lists are sorted heaviest first -- started a little later than it could be).
-// `ahead == 0` (HDM_PERSIST_AHEAD=0) draws at the hand-over as before.
 template <bool AKM, bool BKM, int ROLE, int VAR>
-__global__ __launch_bounds__(256, 2) void hdm_gemm_persist_kernel(HdmGemmDev p, int *__restrict__ cnt, int ahead) {
+__global__ __launch_bounds__(256, 2) void hdm_gemm_persist_kernel(HdmGemmDev p, int *__restrict__ cnt) {
     __shared__ int s_idx;
     const int nb = p.a.batch, ntiles = p.ntiles;
     const int x = (int) __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;   // HW_REG_XCC_ID[3:0]
     for (int dx = 0; dx < 8; ++dx) {
         const int xq = (x + dx) & 7;
-        int drawn = 0;
-        if (ahead && threadIdx.x == 0) drawn = atomicAdd(&cnt[xq], 1);
         while (true) {
             __syncthreads();                 // the previous tile's LDS images and s_idx are done with
-            if (threadIdx.x == 0) s_idx = ahead ? drawn : atomicAdd(&cnt[xq], 1);
+            if (threadIdx.x == 0) s_idx = atomicAdd(&cnt[xq], 1);
             __syncthreads();
             const int idx = __builtin_amdgcn_readfirstlane(s_idx);
             const int z = xq + 8 * (idx / ntiles);
             if (z >= nb) break;
-            if (ahead && threadIdx.x == 0) drawn = atomicAdd(&cnt[xq], 1);
             hdm_gemm_tile<AKM, BKM, ROLE, VAR>(p, z, idx % ntiles, (long) z * ntiles + idx % ntiles);
         }
     }
 }
+
+

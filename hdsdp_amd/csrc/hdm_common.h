@@ -121,24 +121,14 @@ struct HdmGemmArgs {
     int role;         // HdmRole
     double flops;     // algorithmic flops of this launch (valid data only), for the live roofline
     // BLOCKED epilogue: destination chunk layout  dst[((blk*16 + c_local) * rowStride + row) * 16 + r_local]
-    long blk_row_stride;  // constraint rows per 16-wide p-block (= rows of one row segment)
+    long blk_row_stride;  // = m_pad (number of constraint rows per 16-wide p-block)
     long blk_row0;        // constraint row of batch entry 0
-    // row segments (0 = one segment): rows [s * blk_seg_rows, (s + 1) * blk_seg_rows) live blk_seg_stride elements after the
-    // segment before -- the layout [segment][p-block][row in segment][16] (engine_cone.h: MiCone::seg)
-    long blk_seg_rows, blk_seg_stride;
     int nblk;             // n/16: sub-blocks per matrix edge
     // SLAB epilogue / split-K
     long k_chunk;         // K range per split (multiple of HDM_BK)
     long k_base;          // first k of split 0 (a launch may cover a sub-range of the splits; C then points at its first slab)
     long slab_stride;     // elements between slabs
 };
-
-// element offset of constraint row `row` in the BLOCKED layout (without the p-block term)
-__host__ __device__ inline long hdm_blk_row_off(const HdmGemmArgs &a, long row) {
-    if (!a.blk_seg_rows) return row * 16;
-    const long sg = row / a.blk_seg_rows;
-    return (row - sg * a.blk_seg_rows) * 16 + sg * a.blk_seg_stride;
-}
 
 int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream);
 // while a stream capture is recording the launches (chol.hip), the launcher must not record timing events

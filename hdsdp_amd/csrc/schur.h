@@ -7,7 +7,7 @@
 int hdm_unpack_sym(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s);
 int hdm_synth_fill(double *full, long fstride, int n, int ld, int c0, int batch, hipStream_t s);
 int hdm_synth_obj(double *C, int n, int ld, int m, hipStream_t s);
-int hdm_blocked_eye(double *dst, long row_stride, long row_off, int nblk, int n, hipStream_t s);
+int hdm_blocked_eye(double *dst, long row_stride, long row, int nblk, int n, hipStream_t s);
 int hdm_slab_reduce(const double *slabs, long slab_stride, int nsplit, double *out, long total, long R, hipStream_t s);
 int hdm_extract(const double *G, long ldg, long R, long pI, const int *rows_seg, const HdmMatView &Mv, double *asinv,
                 double *asinvrd, double *asinvc, double *scal, double Rd, int hsd, hipStream_t s);

@@ -159,14 +159,14 @@ __global__ void hdm_synth_obj_kernel(double *__restrict__ C, int n, int ld, int 
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ void hdm_blocked_eye_kernel(double *__restrict__ dst, long row_stride, long row_off, int nblk, int n) {
+__global__ void hdm_blocked_eye_kernel(double *__restrict__ dst, long row_stride, long row, int nblk, int n) {
     // diagonal sub-blocks (bj == bi) of the "S row": At = L^-1 S L^-T = I (zero in the padding)
     int b = blockIdx.x;  // sub-block index along the diagonal
     int c = threadIdx.x >> 4, r = threadIdx.x & 15;
     long sub = (long) b * nblk - (long) b * (b - 1) / 2;
     long pb = sub * 16 + c;
     int g = b * 16 + c;
-    dst[pb * row_stride * 16 + row_off + r] = (r == c && g < n) ? 1.0 : 0.0;
+    dst[(pb * row_stride + row) * 16 + r] = (r == c && g < n) ? 1.0 : 0.0;
 }
 
 // out = sum over the split-K slabs, in slab order (deterministic).  The Gram launch writes lower 128-tiles only, so
@@ -786,9 +786,8 @@ int hdm_synth_obj(double *C, int n, int ld, int m, hipStream_t s) {
     return 0;
 }
 
-// row_stride: rows per p-block (of one row segment); row_off: element offset of the row inside its p-block, segment included
-int hdm_blocked_eye(double *dst, long row_stride, long row_off, int nblk, int n, hipStream_t s) {
-    hipLaunchKernelGGL(hdm_blocked_eye_kernel, dim3(nblk), dim3(256), 0, s, dst, row_stride, row_off, nblk, n);
+int hdm_blocked_eye(double *dst, long row_stride, long row, int nblk, int n, hipStream_t s) {
+    hipLaunchKernelGGL(hdm_blocked_eye_kernel, dim3(nblk), dim3(256), 0, s, dst, row_stride, row, nblk, n);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

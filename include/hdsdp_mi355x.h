@@ -444,12 +444,9 @@ void HMiSDPAFree(HMiSDPA **pp);
  *  HDM_BC                         1024      constraints per congruence launch (upper bound)               test_gpu_switches.py
  *  HDM_NSPLIT                     by size   K splits of the Gram product                                  test_gpu_switches.py
  *  HDM_SHARE_T_SLABS              1         intermediates and Gram slabs share one buffer (one GPU)       test_gpu_switches.py
- *  HDM_AHAT_SEG                   128       one GPU: transformed rows in segments of 128 (one Gram tile);  test_gpu_switches.py
- *                                           0: one segment, [p-block][all rows][16]
  *  -- fallbacks kept reachable (the default is the fast form) ----------------------------------------------------------
  *  HDM_PERSIST                    1         persistent GEMM workgroups; 0: one workgroup per tile         test_gpu_switches.py, test_gpu_kernels.py
  *  HDM_PERSIST_RESERVE_CUS        0 / 8     CUs a persistent launch leaves to the collectives             test_gpu_switches.py, test_gpu_kernels.py
- *  HDM_PERSIST_AHEAD              1         persistent workgroups draw their next tile one tile ahead     test_gpu_switches.py
  *  HDM_DIAG_SWEEP                 1         register-sweep diagonal block; 0: LDS-panel kernel            test_gpu_switches.py, test_gpu_kernels.py
  *  HDM_TRSV_FLOW                  1         single-launch substitution; 0: per-block launches             test_gpu_switches.py, test_gpu_kernels.py
  *  HDM_TRSV_FLOW_FAIL_ONCE        0         test hook: throw the first single-launch result away          test_gpu_kernels.py::test_fallback_chains_of_the_factor_and_solve_kernels
