@@ -174,7 +174,9 @@ static hdsdp_retcode make_synth_cone(MiCone **out, int nCol, int nRow, int rank,
         const double ahat = 8.0 * (double) c->world * c->npb_loc * c->Lr * 16 * (c->world == 1 ? 1.0 : 2.0);
         const double work = std::min(41.0 * (1L << 30), std::max(8.0 * (double) c->n16 * c->n16 * std::min(rows, 1024.0),
                                                                  8.0 * (double) c->R * c->R * 8.0));
-        const double schur = 3.0 * 8.0 * (double) c->m * c->m + (6.0 * (1L << 30));
+        // (the Schur matrix, its factor and its inverse blocks, plus 16 GiB of slack: at n = 2000, m = 8000 the resident form comes
+        // to 285 of the 287 GiB a fresh MI355X shows -- it has run, but nothing else may be on the device then)
+        const double schur = 3.0 * 8.0 * (double) c->m * c->m + (16.0 * (1L << 30));
         size_t fr = 0, tot = 0;
         bool stream = false;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) stream = (afull + ahat + work + schur > (double) fr);

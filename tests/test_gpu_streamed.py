@@ -62,35 +62,45 @@ def test_the_sweep_copy_of_streamed_rows_is_the_copy_of_resident_rows(monkeypatc
     assert np.array_equal(got[0][1][lower_mask(n)], got[1][1][lower_mask(n)])      # (S is lower-valid: nothing writes the other half)
 
 
-@pytest.mark.parametrize("mode", ["auto", "streamed"])
-def test_config5_at_size_on_one_device(mode, monkeypatch, capfd):
+@pytest.mark.parametrize("mode", ["auto", "resident"])
+def test_config5_at_size_on_one_device(mode, monkeypatch):
     """BASELINE configs[4] itself -- n = 2000, m = 8000 -- on ONE device against tests/golden/full8000_rows.npz (host fp64,
     oracle/row_subset_golden.py: 72 complete rows of M incl. the tile-edge rows, both vectors in full, log det S, tr S^-1,
     residual rows of the three Phase-A solves; bench state and a cond(S) = 1e3 state with y != 0, whose S assembly sweeps all
-    8000 constraint matrices).  "auto": whatever the cone chooses from the memory it finds (resident if 136 GB of constraint
-    data fit next to 130 GB of transformed rows and the work buffers, else streamed); "streamed": regeneration forced, which
-    is also what leaves room for the zero-suppressed sweep copy."""
+    8000 constraint matrices).  "auto": the cone decides from the memory it finds -- 136 GB of constraint data beside 130 GB
+    of transformed rows and 33 GB of work buffers leave no slack on a 288 GiB device, so it streams (regenerates the rows per
+    congruence batch) and the sweeps read the zero-suppressed copy, for which there is room then; "resident": streaming
+    forbidden (HDSDP_MI355X_STREAM_A=0) -- it fits when nothing else is on the device (285 of 287 GiB), skipped when not."""
     import torch
     from hdsdp_amd import api
     from test_gpu_parity import check_row_subset_state
     free, total = torch.cuda.mem_get_info()
     if free < 250 * (1 << 30):
         pytest.skip(f"BASELINE configs[4] on one device needs about 250 GiB of free HBM, {free >> 30} GiB free")
-    if mode == "streamed":
-        monkeypatch.setenv("HDSDP_MI355X_STREAM_A", "1")
+    if mode == "resident":
+        monkeypatch.setenv("HDSDP_MI355X_STREAM_A", "0")
     g = load_golden("full8000_rows")
     n, m = int(g["n"]), int(g["m"])
-    cone = api.SDPCone.synthetic(n, m)
+    try:
+        cone = api.SDPCone.synthetic(n, m)
+    except api.HDSDPError:
+        if mode == "resident":
+            pytest.skip("136 GB of resident constraint data do not fit next to the rest on this device today")
+        raise
     try:
         on, rows = cone.streaming()
-        if mode == "streamed":
-            assert on and rows == 1000, (on, rows)
+        assert (on, rows) == ((True, 1000) if mode == "auto" else (False, 0)), (mode, on, rows)
         assert cone.shard_count() == 1
         kkt = api.KKT(m, [cone], host_mirror=False)
-        check_row_subset_state(cone, kkt, g, "bench")
+        try:
+            check_row_subset_state(cone, kkt, g, "bench")
+        except api.HDSDPError:
+            if mode == "resident":
+                pytest.skip("the resident form ran out of device memory in its first build (285 of 287 GiB needed)")
+            raise
         check_row_subset_state(cone, kkt, g, "hard")
-        print(f"configs[4] on one device [{mode}]: free HBM before {free / 2**30:.1f} of {total / 2**30:.1f} GiB, streamed={on}, "
-              f"sweep copy in use={cone.sweep_info()[0]}, after the builds {torch.cuda.mem_get_info()[0] / 2**30:.1f} GiB free")
+        if mode == "auto":
+            assert cone.sweep_info()[0], "room for the zero-suppressed sweep copy is what streaming buys"
         kkt.destroy()
     finally:
         cone.destroy()
