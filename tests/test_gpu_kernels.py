@@ -271,13 +271,19 @@ from hdsdp_amd import api
 import ctypes as C
 lib = api.load_library()
 rng = np.random.default_rng(11)
+dhash = []
 for n in (130, 300, 1000):
-    G = rng.uniform(-1, 1, (n, n))
-    S = G @ G.T / n + np.eye(n)
     ls = api.LinSys(n, api.HDSDP_LINSYS_DENSE_DIRECT)
-    ls.numeric(np.triu(S))
-    Lc = np.linalg.cholesky(S)
     for trial in range(3):
+        # a new matrix every time through ONE factor object: the first factorisation runs eagerly, the second is captured into a
+        # hipGraph, the third replays it (chol.hip)
+        G = rng.uniform(-1, 1, (n, n))
+        S = G @ G.T / n + (1.0 + trial) * np.eye(n)
+        ls.numeric(np.triu(S))
+        Lc = np.linalg.cholesky(S)
+        d = ls.get_diag()
+        assert np.max(np.abs(d - np.diag(Lc))) <= 1e-13 * np.max(d), ("diag", n, trial)
+        dhash.append(d.tobytes())
         b = rng.uniform(-1, 1, n)
         assert np.linalg.norm(ls.solve(b) - np.linalg.solve(S, b)) <= 1e-12 * np.linalg.cond(S) * np.linalg.norm(b), ("solve", n)
         assert np.linalg.norm(ls.fsolve(b) - np.linalg.solve(Lc, b)) <= 1e-12 * np.linalg.cond(S) * np.linalg.norm(b), ("fsolve", n)
@@ -304,6 +310,7 @@ x = kkt.solve(b.copy(), inplace=True)
 assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(b)
 import hashlib
 print("MHASH", hashlib.sha256(np.ascontiguousarray(np.tril(Mh)).tobytes()).hexdigest())
+print("DHASH", hashlib.sha256(b"".join(dhash)).hexdigest())
 print("FALLBACK_OK")
 '''
 
@@ -345,51 +352,18 @@ def test_persistent_and_one_tile_per_workgroup_launches_give_the_same_bits():
     assert h[0] == h[1] == h[2], h
 
 
-def _block_banded_spd(n, first, rng):
-    """SPD matrix whose 128-block row i has entries from block column first[i] to its diagonal block only"""
-    nb = (n + 127) // 128
-    A = np.zeros((n, n))
-    for bi in range(nb):
-        r0, r1 = bi * 128, min(n, bi * 128 + 128)
-        for bj in range(first[bi], bi + 1):
-            c0, c1 = bj * 128, min(n, bj * 128 + 128)
-            A[r0:r1, c0:c1] = rng.uniform(-1, 1, (r1 - r0, c1 - c0)) * (rng.uniform(0, 1, (r1 - r0, c1 - c0)) < 0.3)
-    A = np.tril(A, -1)
-    S = A + A.T
-    return S + np.diag(np.abs(S).sum(1) + 1.0)
-
-
-@pytest.mark.parametrize("n,first", [(1000, [0, 0, 1, 2, 2, 4, 5, 5]), (700, [0, 1, 2, 3, 4, 5]), (900, [0, 0, 0, 0, 0, 0, 0, 0]),
-                                     (1100, [0, 0, 1, 1, 0, 4, 5, 6, 6])])
-def test_block_envelope_cholesky_equals_the_dense_one(n, first):
-    """the sparse Schur operator's factorisation: with the block envelope of the pattern the blocked Cholesky stops each block
-    column where the envelope ends and the substitution skips what lies outside -- same factor and same solution, bit for bit,
-    as the dense run on the same matrix (skipped updates would have added exact zeros), and LAPACK's to rounding.  Patterns:
-    staircase band, block diagonal, dense, and one whose envelope re-opens (a late row reaching back to column 0)."""
-    import ctypes as C
-    from hdsdp_amd import api
-    lib = api.load_library()
-    rng = np.random.default_rng(n)
-    S = _block_banded_spd(n, first, rng)
-    Af = np.asfortranarray(np.tril(S))
-    b = rng.uniform(-1, 1, n)
-    out = {}
-    for tag, fp in (("dense", None), ("env", np.ascontiguousarray(first, dtype=np.int32))):
-        x = np.zeros(n); Lh = np.zeros((n, n), order="F"); info = C.c_int(-1)
-        rc = lib.HMiCholEnvelopeSolve(Af.ctypes.data_as(C.c_void_p), n, None if fp is None else fp.ctypes.data_as(C.POINTER(C.c_int)),
-                                      b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), Lh.ctypes.data_as(C.c_void_p), C.byref(info))
-        assert rc == 0 and info.value == 0
-        out[tag] = (x.copy(), np.tril(Lh))
-    assert np.array_equal(out["env"][0], out["dense"][0])
-    assert np.array_equal(out["env"][1], out["dense"][1])
-    Lc = np.linalg.cholesky(S)
-    assert np.max(np.abs(out["env"][1] - Lc)) <= 1e-12 * np.max(np.abs(Lc))
-    assert np.linalg.norm(out["env"][0] - np.linalg.solve(S, b)) <= 1e-12 * np.linalg.cond(S) * np.linalg.norm(b)
-    # outside the envelope the factor is exactly zero
-    nb = len(first)
-    for bi in range(nb):
-        if first[bi] > 0:
-            assert not out["env"][1][bi * 128:min(n, bi * 128 + 128), :first[bi] * 128].any()
+def test_graph_replayed_factorisations_give_the_eager_bits():
+    """one factor object, a new matrix every time (first factorisation eager, second captured into a hipGraph, third replayed):
+    the factors' diagonals of the nine factorisations of the script above are the same bits with and without graph replay"""
+    import os, subprocess, sys, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = []
+    for extra in ({}, {"HDM_GRAPHS": "0"}):
+        r = subprocess.run([sys.executable, "-c", FALLBACK_SCRIPT % root], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **extra))
+        assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        h.append(re.search(r"DHASH (\w+)", r.stdout).group(1))
+    assert h[0] == h[1], h
 
 
 def _spd_lower_csc(m, pairs, rng):
