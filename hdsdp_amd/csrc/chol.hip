@@ -673,12 +673,16 @@ template <class F> static hipGraphExec_t hdm_capture(hipStream_t s, F body) {
     (void) hipGraphDestroy(graph);
     return exec;
 }
-// HDM_GRAPHS: 0 = never, 1 (default) = the factorisation chain when it is long enough to pay (>= 4 diagonal blocks:
-// measured 2.86 -> 2.71 ms at n = 2000), 2 = also the block substitutions (measured: no gain at 16 blocks, +8 us per
-// solve at one block -- a graph launch costs more than two or three plain launches)
+// HDM_GRAPHS: 0 (default since round 4) = never; 1 = the factorisation chain when it is long enough (>= 4 diagonal blocks);
+// 2 = also the block substitutions.  When replay was introduced (round 1) the chain at n = 2000 went 2.86 -> 2.71 ms; since the
+// diagonal-block kernel halved (round 2) the chain is sixteen dependent 56 us sweeps plus launch-to-launch latency and replay
+// buys nothing (1.859 ms replayed, 1.855 ms eager, n = 4000: 4.006 / 3.975 -- profiles/r04_e_cholesky.txt), the substitutions
+// never gained (no gain at 16 blocks, +8 us per solve at one block), and replay has cost twice: a replayed MEMSET node that wrote
+// stale bytes (profiles/r04_c_poison.txt) and rocprofiler-sdk 7.2 dying in its queue interceptor on multi-packet submissions
+// (profiles/r04_a_headline_segv.txt).  The paths stay (tests run levels 1 and 2).
 static int hdm_graph_level() {
     static int lvl = -1;
-    if (lvl < 0) { const char *e = getenv("HDM_GRAPHS"); lvl = e ? atoi(e) : 1; }
+    if (lvl < 0) { const char *e = getenv("HDM_GRAPHS"); lvl = e ? atoi(e) : 0; }
     return lvl;
 }
 

@@ -450,7 +450,7 @@ void HMiSDPAFree(HMiSDPA **pp);
  *  HDM_DIAG_SWEEP                 1         register-sweep diagonal block; 0: LDS-panel kernel            test_gpu_switches.py, test_gpu_kernels.py
  *  HDM_TRSV_FLOW                  1         single-launch substitution; 0: per-block launches             test_gpu_switches.py, test_gpu_kernels.py
  *  HDM_TRSV_FLOW_FAIL_ONCE        0         test hook: throw the first single-launch result away          test_gpu_kernels.py::test_fallback_chains_of_the_factor_and_solve_kernels
- *  HDM_GRAPHS                     1         0 / 1 / 2: hipGraph replay of factorisation / substitutions   test_gpu_switches.py, test_gpu_kernels.py
+ *  HDM_GRAPHS                     0         0 / 1 / 2: hipGraph replay of factorisation / substitutions   test_gpu_switches.py, test_gpu_kernels.py
  *  HDM_SYM_COMBINE_SKY            1         S assembly in storage order; 0: element-indexed kernel        test_gpu_switches.py
  *  HDM_LANCZOS_WHOLE              1         small blocks: whole ratio test in one launch                  test_gpu_switches.py
  *  HDM_LANCZOS_FUSED              1         small blocks: three Lanczos steps per launch                  test_gpu_switches.py

@@ -315,15 +315,15 @@ print("FALLBACK_OK")
 '''
 
 
-@pytest.mark.parametrize("env", [{"HDM_TRSV_FLOW": "0"}, {"HDM_GRAPHS": "0"}, {"HDM_GRAPHS": "2", "HDM_TRSV_FLOW": "0"},
+@pytest.mark.parametrize("env", [{"HDM_TRSV_FLOW": "0"}, {"HDM_GRAPHS": "1"}, {"HDM_GRAPHS": "2", "HDM_TRSV_FLOW": "0"},
                                  {"HDM_TRSV_FLOW_FAIL_ONCE": "1"}, {"HDM_DIAG_SWEEP": "0"}, {"HDM_PERSIST": "0"}],
-                         ids=["per-block-substitution", "no-graphs", "graph-replayed-substitution", "flow-gives-up-once",
+                         ids=["per-block-substitution", "graph-replayed-factorisation", "graph-replayed-substitution", "flow-gives-up-once",
                               "lds-panel-diagonal-block", "one-tile-per-workgroup"])
 def test_fallback_chains_of_the_factor_and_solve_kernels(env):
     """the paths behind the defaults stay covered: the per-block substitution launches (HDM_TRSV_FLOW=0, also what a
     timed-out single-launch substitution falls back to), the LDS-panel diagonal-block kernel (HDM_DIAG_SWEEP=0), the
-    one-tile-per-workgroup GEMM launches (HDM_PERSIST=0), eager instead of graph-replayed factorisation chains
-    (HDM_GRAPHS=0), graph-replayed substitutions (HDM_GRAPHS=2), and the give-up path itself (HDM_TRSV_FLOW_FAIL_ONCE=1
+    one-tile-per-workgroup GEMM launches (HDM_PERSIST=0), graph-replayed instead of eager factorisation chains
+    (HDM_GRAPHS=1), graph-replayed substitutions (HDM_GRAPHS=2), and the give-up path itself (HDM_TRSV_FLOW_FAIL_ONCE=1
     throws the first single-launch result away): in-place solves included -- a retry must start from the caller's
     untouched right-hand side -- all against LAPACK.  Child process: the switches are read once per process."""
     import os, subprocess, sys
@@ -358,7 +358,7 @@ def test_graph_replayed_factorisations_give_the_eager_bits():
     import os, subprocess, sys, re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = []
-    for extra in ({}, {"HDM_GRAPHS": "0"}):
+    for extra in ({}, {"HDM_GRAPHS": "1"}):
         r = subprocess.run([sys.executable, "-c", FALLBACK_SCRIPT % root], capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, **extra))
         assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
