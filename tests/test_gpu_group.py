@@ -110,6 +110,32 @@ def test_in_process_shards_match_one_device(n, m, world, group):
         cone.destroy()
 
 
+def test_streamed_shards_match_one_resident_device(group, monkeypatch):
+    """streamed constraint data (MiCone::streamed) under sharding: every shard regenerates ITS rows (cyclic deal: one launch of the
+    generator per row) batch by batch; three shards with batches of 8 rows against one device with resident data"""
+    from hdsdp_amd import api
+    n, m, world = 200, 70, 3
+    Rd = -2.5 * n
+    y = 0.02 * np.sin(1.3 * np.arange(m) + 0.4)
+    cone = api.SDPCone.synthetic(n, m)
+    kkt = api.KKT(m, [cone])
+    ref = _phase_a(api, cone, kkt, Rd, y)
+    assert cone.streaming() == (False, 0)
+    kkt.destroy(); cone.destroy()
+    group(world)
+    monkeypatch.setenv("HDSDP_MI355X_STREAM_A", "1")
+    monkeypatch.setenv("HDM_BC", "8")
+    cone = api.SDPCone.synthetic(n, m)
+    try:
+        assert cone.shard_count() == world and cone.streaming() == (True, 8)
+        kkt = api.KKT(m, [cone])
+        got = _phase_a(api, cone, kkt, Rd, y)
+        _compare(ref, got, m)
+        kkt.destroy()
+    finally:
+        cone.destroy()
+
+
 def test_config5_shape_world8(group):
     """BASELINE configs[4] in shape: m = 8000 constraint rows dealt over world = 8 shards (1000 rows each, as on the
     8-GPU node), at n = 256 so that eight shards fit the one GPU of the test box; equal to world = 1 to 1e-11"""
