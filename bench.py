@@ -82,6 +82,19 @@ def executed_flops(n, m):
     return m * 1.0 * n ** 3 + 0.5 * (m + 3) * (m + 4) * n * (n + 1) + n ** 3 + m ** 3 / 3.0 + 6.0 * m * m
 
 
+def algorithmic_bytes(role, n, m, world, kln, steps):
+    """least HBM bytes of ONE launch of a GEMM role: operands read once, results written once"""
+    rows = (m + world - 1) // world
+    per_launch = rows / max(1, int(kln[role]) // max(1, steps)) if role in (1, 2) else rows
+    low = n * (n + 1) / 2 * 8.0                       # one lower triangle
+    if role == 1:                                     # A_L in (skyline ~ lower triangle), U's lower tiles out
+        return per_launch * 2 * low
+    if role == 2:                                     # U in, blocked lower triangle out
+        return per_launch * 2 * low
+    R = m + 3                                         # Gram: the operand once (this rank's share of the packed index) + the lower triangle of the result
+    return R * low / world + 0.5 * R * R * 8.0        # (its split-K slabs -- 1024 x 16 MB at n = m = 2000 -- are traffic, not algorithm)
+
+
 def survey_equiv(n, m, world, kms, kln, steps):
     """achieved TFLOP/s if the work is priced with the reference's operation count; can exceed the
     MFMA peak because the triangular-factor congruence executes n^3, not 3 n^3, flops per constraint"""
@@ -192,6 +205,50 @@ def cpu_baseline_blas3(n, m):
         return json.loads(line[-1])
     except Exception as e:
         return {"value": None, "unit": "it/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
+
+
+class PowerClockSampler:
+    """rocm-smi (power, shader clock) sampled in a background thread while the timed region runs: the fp64 matrix pipe at this
+    density is power-limited (profiles/r03_f_power_clock.txt), so the line carries what the board drew and clocked at.  Reading
+    needs no privileges; no rocm-smi, no samples."""
+
+    def __init__(self):
+        import shutil
+        import threading
+        self.exe = shutil.which("rocm-smi")
+        self.samples = []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True) if self.exe else None
+
+    def _run(self):
+        import re
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run([self.exe, "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                return
+            rows = [l for l in out.splitlines() if l.startswith("card0")]
+            if rows:
+                mhz = re.findall(r"\((\d+)Mhz\)", rows[0])
+                try:
+                    self.samples.append((float(rows[0].rstrip(", ").split(",")[-1]), float(mhz[2]) if len(mhz) > 2 else float("nan")))
+                except ValueError:
+                    pass
+
+    def start(self):
+        if self._th:
+            self._th.start()
+
+    def stop(self):
+        if not self._th:
+            return None
+        self._stop.set()
+        self._th.join(timeout=15)
+        if not self.samples:
+            return None
+        w, f = np.array([x[0] for x in self.samples]), np.array([x[1] for x in self.samples])
+        return {"samples": len(self.samples), "board_power_w": [float(w.min()), float(w.mean()), float(w.max())],
+                "shader_clock_mhz": [float(np.nanmin(f)), float(np.nanmean(f)), float(np.nanmax(f))], "source": "rocm-smi card0, [min, mean, max] over the timed region"}
 
 
 def rccl_self_test_in_child(ids, timeout_s=240):
@@ -356,12 +413,16 @@ def main():
     for w in range(args.warmup):
         step(False, args.steps + args.warmup - 1 - w)
     lib.HMiSetKernelTiming(1)
+    sampler = PowerClockSampler() if (rank == 0 and world == 1 and shards == 1) else None
     barrier()
+    if sampler:
+        sampler.start()
     t_start = time.perf_counter()
     for k in range(args.steps):
         sol = step(True, args.steps - 1 - k)
     barrier()
     elapsed = time.perf_counter() - t_start
+    power_clock = sampler.stop() if sampler else None
     lib.HMiSetKernelTiming(0)
     import ctypes as C
     kms, kfl = np.zeros(5), np.zeros(5)      # roles 0-3 + [4] = the full diagonal tiles of congruence step 2 (their own kernel)
@@ -395,6 +456,13 @@ def main():
         "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
         "traffic": traffic[0], "traffic_source": traffic[1],
+        # what one launch has to move at the least: step 1 reads A_L (skyline, 8.5 n^2/2... per constraint) and writes
+        # U's lower tiles; step 2 reads U and writes the blocked lower triangle; the Gram product reads its operand once and writes its
+        # slabs.  traffic / algorithmic is the re-read factor: operand panels are re-read per tile and only partly served by L2 --
+        # energy, not time (the L2-resident ablation bounds its cost at 0.7-2.3 %)
+        "algorithmic_bytes_per_launch": float(algorithmic_bytes(dom, n, m, world, kln, args.steps)),
+        "traffic_over_algorithmic": (None if not traffic[0] else round(traffic[0] / algorithmic_bytes(dom, n, m, world, kln, args.steps), 2)),
+        "power_clock": power_clock,
         "avg_launch_ms": round(float(dom_ms), 4), "launches": int(kln[dom]),
         "flops_per_launch": float(kfl[dom] / max(1, kln[dom])),
         # the same launch priced with SURVEY 8(d)'s per-unit figure (the reference's M3 count: 3 n^3 per constraint
