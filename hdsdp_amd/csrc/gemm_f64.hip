@@ -136,7 +136,16 @@ int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
         }
     }
     if (args.role != HDM_ROLE_GENERIC) {
-        // Roles 1-3 stage whole 128-row tiles WITHOUT a row mask (Stager::load_nomask): rows past the matrix edge are
+        // Roles 1-3 fetch their tiles with buffer loads whose offsets -- lane part + chunk part, 32 bits -- must stay below the
+        // 2 GiB the buffer spans from the k block's scalar base (gemm_tile.h: SStager): 127 rows of a K-major operand, 12 k rows
+        // of an M-major one
+        const long lds_[4] = {args.lda, args.ldb, args.A2 ? args.lda2 : 0, args.B2 ? args.ldb2 : 0};
+        for (long ld : lds_)
+            if (ld < 0 || ld > (1L << 20)) {
+                fprintf(stderr, "[hdsdp_mi355x] gemm role %d: leading dimension %ld is beyond what the scalar stager addresses: launch refused\n", args.role, ld);
+                return 1;
+            }
+        // Roles 1-3 stage whole 128-row tiles WITHOUT a row mask (SStager::load_nomask): rows past the matrix edge are
         // read and thrown away.  Every such launch therefore states how many elements are readable from each operand
         // pointer, and the launch is refused unless the farthest element an unmasked load can touch lies inside.
         auto farthest = [&](bool kmajor, long ld, long kblk, long stride, int rows, bool seg) {

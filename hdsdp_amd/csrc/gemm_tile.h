@@ -85,22 +85,6 @@ struct Stager {
         p += kstep;
         if (DUAL) { if (--left == 0) { p = p2; qstride = qstride2; kstep = kstep2; } }
     }
-    // No row mask: rows past the matrix edge read whatever follows (the engine's operand buffers carry
-    // HDM_OPERAND_PAD bytes of slack, hdm_common.h).  Sound because output element (i, j) depends only on row i of
-    // one operand and row j of the other, and every epilogue masks rows/columns past the edge; it removes the eight
-    // exec-mask branches per stage, so the stage body is one basic block the scheduler can interleave.
-    __device__ __forceinline__ void load_nomask(double2 &r0, double2 &r1, double2 &r2, double2 &r3) {
-        r0 = *reinterpret_cast<const double2 *>(p);
-        r1 = *reinterpret_cast<const double2 *>(p + qstride);
-        r2 = *reinterpret_cast<const double2 *>(p + 2 * qstride);
-        r3 = *reinterpret_cast<const double2 *>(p + 3 * qstride);
-        // `remain` = k blocks not yet loaded: the pointer never moves past the last one, so a look-ahead load issued
-        // beyond the end of the K loop re-reads valid memory instead of running off the matrix (branch-free)
-        remain -= 1;
-        p += (remain > 0) ? kstep : 0;
-        if (DUAL) { if (--left == 0) { p = p2; qstride = qstride2; kstep = kstep2; } }
-    }
-    int remain = 1 << 30;
 };
 
 template <bool KM>
@@ -120,27 +104,129 @@ __device__ __forceinline__ void r2s(double *__restrict__ s, int tid, const doubl
 }
 
 template <bool KM>
-__device__ __forceinline__ void r2s4(double *__restrict__ s, int tid, const double2 &r0, const double2 &r1, const double2 &r2,
-                                     const double2 &r3) {
-    if (KM) {
-        double *dst = s + (tid >> 3) * LDK + (tid & 7) * 2;
-        *reinterpret_cast<double2 *>(dst) = r0;
-        *reinterpret_cast<double2 *>(dst + 32 * LDK) = r1;
-        *reinterpret_cast<double2 *>(dst + 64 * LDK) = r2;
-        *reinterpret_cast<double2 *>(dst + 96 * LDK) = r3;
-    } else {
-        double *dst = s + (tid >> 6) * LDM + (tid & 63) * 2;
-        *reinterpret_cast<double2 *>(dst) = r0;
-        *reinterpret_cast<double2 *>(dst + 4 * LDM) = r1;
-        *reinterpret_cast<double2 *>(dst + 8 * LDM) = r2;
-        *reinterpret_cast<double2 *>(dst + 12 * LDM) = r3;
-    }
-}
-
-template <bool KM>
 __device__ __forceinline__ double frag(const double *__restrict__ s, int x, int k) {
     return KM ? s[x * LDK + k] : s[k * LDM + x];
 }
+
+// ---------------------------------------------------------------------------------------------
+// Roles 1-3: a stage body WITHOUT vector ALU instructions.
+//
+// What the fp64 matrix pipe loses in these kernels is not waiting.  tools/probes/issue_mix_probe.hip (profiles/r04_h_issue_mix.txt)
+// puts N instructions of one class between the 16 MFMAs of a register-only loop: LDS reads and writes, buffer loads, scalar ALU
+// work and barriers at the K loop's rates leave the pipe at 0.99 of its peak, with one or two waves per SIMD alike -- and EVERY
+// vector ALU instruction (a 32-bit add as much as a 64-bit one, a v_cndmask, a v_mul_lo) takes about 11 cycles of matrix-pipe
+// time: the fp64 MFMA runs on the vector ALU's multipliers, and nothing issues to them while an address is being added up.  The
+// K loop of round 3 carried 28 such instructions per stage of 64 MFMAs -- LDS addresses rebuilt from a run-time buffer index,
+// eight 64-bit global pointers, the selects of the operand switch --: 7.5 % of the pipe, which IS the 92.6 % MFMA-busy figure.
+// So the stage body's addressing is arranged to need none:
+//   * the LDS buffer index is a compile-time constant (stages come in pairs), every fragment read is ONE per-lane base register
+//     plus a 16-bit instruction offset.  The reads are volatile so that the load/store optimiser leaves them alone: merging two
+//     into a ds_read2_b64 (8-bit offsets) costs a new base per pair -- a v_add per stage, or sixteen more live registers;
+//   * global memory is read with buffer loads: the k block's address lives in scalar registers (wave-uniform: an M-major
+//     operand's row k + wave, a K-major operand's tile row), the lane's part is one 32-bit offset register that never changes,
+//     the four chunks of a lane are scalar offsets; stepping to the next k block, clamping at the end of the range and the
+//     switch to the second operand pair (step 2) are scalar adds and selects.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) char hdm_lchar;
+typedef unsigned hdm_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double lds_ld(const hdm_lchar *p) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) volatile double *>(p);
+}
+__device__ __forceinline__ void lds_st(hdm_lchar *p, const hdm_u4 &v) {
+    *reinterpret_cast<__attribute__((address_space(3))) volatile hdm_u4 *>(p) = v;
+}
+// byte offset of fragment element (row 16 * sub, k = kk) in stage buffer cb, relative to a lane base that holds the lane's
+// (row & 15 [+ 16 * wave part], k & 3) share
+template <bool KM>
+__device__ __forceinline__ constexpr int rd_off(int cb, int sub, int kk) {
+    return cb * STAGE_DOUBLES * 8 + (KM ? (sub * 16 * LDK + kk) : (kk * LDM + sub * 16)) * 8;
+}
+// per-lane read base inside an operand's region (w16: the wave's first row, 0 or 16 for the interleaved quadrants, 0 for cells)
+template <bool KM>
+__device__ __forceinline__ int rd_lane(int w16, int l15, int lq) {
+    return (KM ? ((w16 + l15) * LDK + lq) : (lq * LDM + w16 + l15)) * 8;
+}
+// per-lane base of the staging writes (chunk q of a lane: + 4608 q bytes in both layouts: 32 rows x LDK = 4 k x LDM)
+template <bool KM>
+__device__ __forceinline__ int wr_lane(int tid) {
+    return (KM ? ((tid >> 3) * LDK + (tid & 7) * 2) : ((tid >> 6) * LDM + (tid & 63) * 2)) * 8;
+}
+__device__ __forceinline__ void st4(hdm_lchar *w, int cb, const hdm_u4 &r0, const hdm_u4 &r1, const hdm_u4 &r2, const hdm_u4 &r3) {
+    lds_st(w + cb * STAGE_DOUBLES * 8, r0);
+    lds_st(w + cb * STAGE_DOUBLES * 8 + 4608, r1);
+    lds_st(w + cb * STAGE_DOUBLES * 8 + 9216, r2);
+    lds_st(w + cb * STAGE_DOUBLES * 8 + 13824, r3);
+}
+
+// Scalar stager: the same chunks as Stager (thread t moves chunks t, t + 256, t + 512, t + 768 of a 128 x 16 tile), fetched
+// with buffer loads whose address is (scalar base of the k block) + (scalar chunk offset) + (lane offset).  No row mask:
+// rows past the matrix edge read whatever follows (the engine's operand buffers carry HDM_OPERAND_PAD bytes of slack,
+// hdm_common.h).  Sound because output element (i, j) depends only on row i of one operand and row j of the other, and every
+// epilogue masks rows/columns past the edge; it removes the eight exec-mask branches per stage, so the stage body is one basic
+// block the scheduler can interleave.  DUAL (M-major only: congruence step 2): after `left` loads the stream continues on a second operand.
+template <bool KM, bool DUAL>
+struct SStager {
+    static_assert(!(KM && DUAL), "the dual-product stream exists for M-major operands only");
+    const char *g;            // wave-uniform: this wave's chunk 0 of the current k block, lane part excluded
+    unsigned voff;            // the lane's byte offset (never changes)
+    unsigned so1, so2, so3;   // wave-uniform byte offsets of chunks 1..3
+    long kstep;               // bytes between consecutive k blocks
+    int remain;               // k blocks not yet loaded; at <= 0 the loads return zeros (branch-free look-ahead)
+    const char *g2;           // second operand
+    unsigned t1, t2, t3;
+    long kstep2;
+    int left;
+
+    __device__ __forceinline__ void init(const double *X, long ld, long kblk, long seg_rows, long seg_extra, int x0, int kt0,
+                                         int tid, int wave) {
+        if (KM) {
+            const long segoff = seg_rows ? (x0 / seg_rows) * seg_extra : 0;
+            g = reinterpret_cast<const char *>(X + segoff + (long) kt0 * kblk + (long) x0 * ld);
+            voff = (unsigned) (((long) (tid >> 3) * ld + (tid & 7) * 2) * 8);
+            so1 = (unsigned) (32 * ld * 8); so2 = 2 * so1; so3 = 3 * so1;
+            kstep = kblk * 8;
+        } else {
+            g = reinterpret_cast<const char *>(X + ((long) kt0 * HDM_BK + wave) * ld + x0);
+            voff = (unsigned) ((tid & 63) * 16);
+            so1 = (unsigned) (4 * ld * 8); so2 = 2 * so1; so3 = 3 * so1;
+            kstep = (long) HDM_BK * ld * 8;
+        }
+        remain = 1 << 30;
+        if (DUAL) { left = -1; g2 = g; t1 = so1; t2 = so2; t3 = so3; kstep2 = kstep; }
+    }
+    __device__ __forceinline__ void chain(const double *X2, long ld2, int x0, int kt0, int wave, int nst) {
+        g2 = reinterpret_cast<const char *>(X2 + ((long) kt0 * HDM_BK + wave) * ld2 + x0);
+        t1 = (unsigned) (4 * ld2 * 8); t2 = 2 * t1; t3 = 3 * t1;
+        kstep2 = (long) HDM_BK * ld2 * 8;
+        left = nst;
+    }
+    __device__ __forceinline__ void load_nomask(hdm_u4 &r0, hdm_u4 &r1, hdm_u4 &r2, hdm_u4 &r3) {
+        // raw buffer over [g, g + 2 GiB): stride 0, 32-bit data format; offsets stay far below the range (launcher check).
+        // Past the end of the K range the buffer has NO records: every load is out of range and returns zeros without
+        // touching memory -- a look-ahead beyond the last k block needs no branch, and a stage made of such loads adds
+        // nothing to the accumulators (odd stage counts are run as pairs with one such stage at the end).
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(g), 0, (remain > 0) ? 0x7fffffff : 0, 0x00020000);
+        r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+        r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so1, 0);
+        r2 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so2, 0);
+        r3 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so3, 0);
+        remain -= 1;
+        g += kstep;
+    }
+    // DUAL: the stream continues on the second operand pair.  Congruence step 2's main tiles call this at the one place of
+    // their straight-line stage sequence where it belongs (scalar moves); a cell-dealt tile, whose stage count is a run-time
+    // value, counts down instead (load_counted).  The countdown is NOT part of load_nomask: written as a condition it becomes a
+    // branch around five moves, which cuts the stage body into scheduling regions -- the look-ahead loads then issue in a clump
+    // after the barrier instead of between the fourth k-step's MFMAs.
+    __device__ __forceinline__ void second() { g = g2; so1 = t1; so2 = t2; so3 = t3; kstep = kstep2; }
+    __device__ __forceinline__ void load_counted(hdm_u4 &r0, hdm_u4 &r1, hdm_u4 &r2, hdm_u4 &r3) {
+        load_nomask(r0, r1, r2, r3);
+        if (DUAL) { if (--left == 0) second(); }
+    }
+    static constexpr bool dual = DUAL;
+};
 
 // Diagonal tiles of a lower-only product need 36 of their 64 16x16 sub-tiles (row block >= column block).  A 2x2
 // split into 64x64 wave quadrants would leave one wave idle and give the tile the full 16-MFMA cadence; instead
@@ -272,73 +358,82 @@ template <class T> constexpr int cell_frag_count() {
 
 // whole K loop + epilogue of a cell-dealt tile (at most 16 accumulators), same rotated stage as the main loop: the
 // barrier sits before the fourth k-step, whose MFMAs cover the LDS reads of the next stage's first k-step and the issue
-// of the look-ahead global loads; unmasked branch-free staging loads (callers: roles 1-3 only).
+// of the look-ahead loads; unmasked branch-free staging (callers: roles 1-3 only); stages in pairs, so that the LDS buffer
+// index is a compile-time constant and the stage body carries no vector ALU work (SStager, above).
 template <class T, bool AKM, bool BKM, class STA, class STB>
-__device__ __forceinline__ void cell_tile(const HdmGemmArgs &a, STA &stA, STB &stB, double *sA, double *sB,
+__device__ __forceinline__ void cell_tile(const HdmGemmArgs &a, STA &stA, STB &stB, hdm_lchar *sb,
                                           int nst, int tid, int z, int m0, int n0, int l15, int lq, int rv, int tri) {
     hdm_d4 acc[4][4];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c >> 2][c & 3] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
-    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    hdm_u4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     double fr0[8], fc0[8], fr1[8], fc1[8];   // two fragment sets; only the entries this wave's cells name are ever loaded
     constexpr int NC = T::NC;                // MFMAs per k-step
-    constexpr int NF = cell_frag_count<T>(); // LDS reads per fragment set (upper bound: the compiler may pair them)
-#define HDM_CLDF(FR, FC, cA, cB, kk)                                                                        \
+    constexpr int NF = cell_frag_count<T>(); // LDS reads per fragment set
+    const hdm_lchar *rdA = sb + rd_lane<AKM>(0, l15, lq);
+    const hdm_lchar *rdB = sb + 2 * STAGE_DOUBLES * 8 + rd_lane<BKM>(0, l15, lq);
+    hdm_lchar *wrA = sb + wr_lane<AKM>(tid);
+    hdm_lchar *wrB = sb + 2 * STAGE_DOUBLES * 8 + wr_lane<BKM>(tid);
+#define HDM_CLDF(FR, FC, CB, kk)                                                                            \
     _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                         \
-        if constexpr (true) {                                                                               \
-            if (cell_uses_row<T>(q)) FR[q] = frag<AKM>(cA, q * 16 + l15, (kk) + lq);                        \
-            if (cell_uses_col<T>(q)) FC[q] = frag<BKM>(cB, q * 16 + l15, (kk) + lq);                        \
-        }                                                                                                   \
+        if (cell_uses_row<T>(q)) FR[q] = lds_ld(rdA + rd_off<AKM>(CB, q, kk));                              \
+        if (cell_uses_col<T>(q)) FC[q] = lds_ld(rdB + rd_off<BKM>(CB, q, kk));                              \
     }
 #define HDM_CMMA(FR, FC)                                                                                    \
     _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                          \
         acc[c >> 2][c & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(FC[T::sj[c]], FR[T::si[c]], acc[c >> 2][c & 3], 0, 0, 0);
+    // one stage that has a successor, on buffer CB
+#define HDM_CSTAGE(CB)                                                                                      \
+    {                                                                                                       \
+        HDM_CLDF(fr1, fc1, CB, 4)                                                                           \
+        HDM_CMMA(fr0, fc0)                                                                                  \
+        HDM_CLDF(fr0, fc0, CB, 8)                                                                           \
+        HDM_CMMA(fr1, fc1)                                                                                  \
+        HDM_CLDF(fr1, fc1, CB, 12)                                                                          \
+        st4(wrA, (CB) ^ 1, ra0, ra1, ra2, ra3); st4(wrB, (CB) ^ 1, rb0, rb1, rb2, rb3);                     \
+        HDM_CMMA(fr0, fc0)                                                                                  \
+        sgb_spread<NC, 0x100, NF>();                                                                        \
+        sgb_spread<NC, 0x100, NF>();                                                                        \
+        sgb_spread<NC / 2, 0x100, NF>();                                                                    \
+        sgb_spread<NC - NC / 2, 0x200, 8>();                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __syncthreads();                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        HDM_CLDF(fr0, fc0, (CB) ^ 1, 0)                                                                     \
+        stA.load_counted(ra0, ra1, ra2, ra3); stB.load_counted(rb0, rb1, rb2, rb3);   /* stage t+2, or zeros past the end */ \
+        HDM_CMMA(fr1, fc1)                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);                                                 \
+        sgb_spread<NC, 0x20, 8>();                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+#define HDM_CLAST(CB)                                                                                       \
+    {                                                                                                       \
+        HDM_CLDF(fr1, fc1, CB, 4)                                                                           \
+        HDM_CMMA(fr0, fc0)                                                                                  \
+        HDM_CLDF(fr0, fc0, CB, 8)                                                                           \
+        HDM_CMMA(fr1, fc1)                                                                                  \
+        HDM_CLDF(fr1, fc1, CB, 12)                                                                          \
+        HDM_CMMA(fr0, fc0)                                                                                  \
+        HDM_CMMA(fr1, fc1)                                                                                  \
+    }
     stA.remain = nst; stB.remain = nst;
     if (nst > 0) {
-        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);
-        r2s4<AKM>(sA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(sB, tid, rb0, rb1, rb2, rb3);
-        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   // stage 1, in flight
+        stA.load_counted(ra0, ra1, ra2, ra3); stB.load_counted(rb0, rb1, rb2, rb3);
+        st4(wrA, 0, ra0, ra1, ra2, ra3); st4(wrB, 0, rb0, rb1, rb2, rb3);
+        stA.load_counted(ra0, ra1, ra2, ra3); stB.load_counted(rb0, rb1, rb2, rb3);   // stage 1, in flight
     }
     __syncthreads();
-    int cur = 0;
-    if (nst > 0) { HDM_CLDF(fr0, fc0, sA, sB, 0) }
-    for (int t = 0; t + 1 < nst; ++t) {
-        const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;
-        double *nA = sA + (cur ^ 1) * STAGE_DOUBLES, *nB = sB + (cur ^ 1) * STAGE_DOUBLES;
-        HDM_CLDF(fr1, fc1, cA, cB, 4)
-        HDM_CMMA(fr0, fc0)
-        HDM_CLDF(fr0, fc0, cA, cB, 8)
-        HDM_CMMA(fr1, fc1)
-        HDM_CLDF(fr1, fc1, cA, cB, 12)
-        r2s4<AKM>(nA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(nB, tid, rb0, rb1, rb2, rb3);
-        HDM_CMMA(fr0, fc0)
-        sgb_spread<NC, 0x100, NF>();
-        sgb_spread<NC, 0x100, NF>();
-        sgb_spread<NC / 2, 0x100, NF>();
-        sgb_spread<NC - NC / 2, 0x200, 8>();
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        HDM_CLDF(fr0, fc0, nA, nB, 0)
-        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   // stage t+2, or the last one again
-        HDM_CMMA(fr1, fc1)
-        __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
-        sgb_spread<NC, 0x20, 8>();
-        __builtin_amdgcn_sched_barrier(0);
-        cur ^= 1;
-    }
     if (nst > 0) {
-        const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;
-        HDM_CLDF(fr1, fc1, cA, cB, 4)
-        HDM_CMMA(fr0, fc0)
-        HDM_CLDF(fr0, fc0, cA, cB, 8)
-        HDM_CMMA(fr1, fc1)
-        HDM_CLDF(fr1, fc1, cA, cB, 12)
-        HDM_CMMA(fr0, fc0)
-        HDM_CMMA(fr1, fc1)
+        HDM_CLDF(fr0, fc0, 0, 0)
+        // stages in pairs on buffers 0, 1; an odd count ends with a stage of zeros (SStager::load_nomask)
+        const int npairs = (nst + 1) >> 1;
+        for (int t = 0; t + 1 < npairs; ++t) { HDM_CSTAGE(0) HDM_CSTAGE(1) }
+        HDM_CSTAGE(0) HDM_CLAST(1)
     }
 #undef HDM_CLDF
 #undef HDM_CMMA
+#undef HDM_CSTAGE
+#undef HDM_CLAST
     cell_epilogue<T>(a, z, m0, n0, l15, lq, rv, tri, acc);
 }
 
@@ -455,6 +550,7 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
     __shared__ __attribute__((aligned(16))) double smem[4 * STAGE_DOUBLES];
     double *sA = smem;                      // [2][STAGE]
     double *sB = smem + 2 * STAGE_DOUBLES;  // [2][STAGE]
+    hdm_lchar *sb = (hdm_lchar *) smem;     // the same four stage buffers as LDS byte addresses (roles 1-3)
     const HdmGemmArgs &a = p.a;
     const int tm = p.tiles[t].x, tn = p.tiles[t].y;
 
@@ -487,20 +583,6 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
         for (int i = 0; i < 4; ++i) acc[j][i] = (hdm_d4){0.0, 0.0, 0.0, 0.0};
 
     const int kt0 = (int) (kbeg / HDM_BK), kt1 = (int) (kend / HDM_BK);
-    constexpr bool DUAL = (ROLE == HDM_ROLE_CONG2 || ROLE == HDM_ROLE_GENERIC);
-    Stager<AKM, DUAL> stA;
-    Stager<BKM, DUAL> stB;
-    // VAR & 128: timing-only ablation (wrong results): every tile stages rows 0..127, so all operand traffic hits in L2
-    long ldb = a.ldb;
-    if (ROLE == HDM_ROLE_CONG1 && a.b_sky) {
-        // A_L in skyline storage (hdm_common.h): tile column tn reads panel tn, a plain K-major matrix of leading dimension
-        // N - 128 tn whose element (row 128 tn, k 128 tn) sits at the panel's start -- the pointer is moved back so that
-        // the stager's absolute (row, k) arithmetic lands there
-        ldb = a.N - 128L * tn;
-        B += hdm_sky_panel(tn, a.N) - 128L * tn * (ldb + 1);
-    }
-    stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, (VAR & 128) ? 0 : m0, kt0, tid);
-    stB.init(B, ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, (VAR & 128) ? 0 : n0, kt0, tid);
     // Congruence step 2, full diagonal tiles: their own launch (role HDM_ROLE_CONG2D, hdm_launch_gemm splits role 2's tile
     // list).  There the second product is the transpose of the first (W_t U_t^T = (U_t W_t^T)^T: the launcher holds role 2
     // to A2 == B, B2 == A), so the tile is P + P^T with ONE product P = U_t W_t^T over all 64 cells in the main loop -- 64
@@ -509,11 +591,6 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
     // sub-tiles >= s) -- and the transpose is added in the epilogue through LDS.  A kernel of its own because the two stage
     // sequences in one function cost the step-2 kernel 65 spilled VGPRs (it has none without).
     constexpr bool symdiag = (ROLE == HDM_ROLE_CONG2D);
-    const int npass = (DUAL && a.A2) ? 2 : 1;
-    if (DUAL && a.A2) {
-        stA.chain(a.A2 + (long) z * a.strideA2, a.lda2, m0, kt0, tid, kt1 - kt0);
-        stB.chain(a.B2 + (long) z * a.strideB2, a.ldb2, n0, kt0, tid, kt1 - kt0);
-    }
     // diagnostic builds: the cell-dealt tiles leave a stamp too (start, end, where; d[6] = -kind), so that a timeline sees
     // every workgroup of a launch
 #define HDM_CELL_STAMP(KIND)                                                                        \
@@ -525,20 +602,45 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
         d[6] = (unsigned long long) (long long) -(KIND);                                            \
         d[7] = __builtin_amdgcn_s_memrealtime();                                                    \
     }
-    // (roles 1-3 only: the cell paths stage with UNMASKED loads, which needs the slack the engine gives those operand
-    // buffers and the launcher verifies (hdm_launch_gemm: operand spans); a generic launch -- Cholesky updates, the small
-    // products of the rank-one path on buffers of a few KB -- takes the masked loop below, whose epilogue knows about
-    // diagonal tiles.  A generic diagonal tile on this path once read 16 KB past a 2 KB operand: a device fault.)
-    if (ROLE != HDM_ROLE_GENERIC && !symdiag && a.lower_only && tm == tn) {   // workgroup-uniform: diagonal tile, 36-cell scheme
+
+    if constexpr (ROLE != HDM_ROLE_GENERIC) {
+    // ======================================================================== roles 1-3: unmasked scalar staging, rotated loop
+    constexpr bool DUAL = (ROLE == HDM_ROLE_CONG2);
+    SStager<AKM, DUAL> stA;
+    SStager<BKM, DUAL> stB;
+    // VAR & 128: timing-only ablation (wrong results): every tile stages rows 0..127, so all operand traffic hits in L2
+    long ldb = a.ldb;
+    if (ROLE == HDM_ROLE_CONG1 && a.b_sky) {
+        // A_L in skyline storage (hdm_common.h): tile column tn reads panel tn, a plain K-major matrix of leading dimension
+        // N - 128 tn whose element (row 128 tn, k 128 tn) sits at the panel's start -- the pointer is moved back so that
+        // the stager's absolute (row, k) arithmetic lands there
+        ldb = a.N - 128L * tn;
+        B += hdm_sky_panel(tn, a.N) - 128L * tn * (ldb + 1);
+    }
+    stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, (VAR & 128) ? 0 : m0, kt0, tid, wave);
+    stB.init(B, ldb, a.b_kblk, a.seg_rows, a.seg_extra, (VAR & 128) ? 0 : n0, kt0, tid, wave);
+    int npass = 1;
+    if constexpr (DUAL) {
+        if (a.A2) {
+            npass = 2;
+            stA.chain(a.A2 + (long) z * a.strideA2, a.lda2, m0, kt0, wave, kt1 - kt0);
+            stB.chain(a.B2 + (long) z * a.strideB2, a.ldb2, n0, kt0, wave, kt1 - kt0);
+        }
+    }
+    // (the cell paths stage with UNMASKED loads, which needs the slack the engine gives those operand buffers and the
+    // launcher verifies (hdm_launch_gemm: operand spans); a generic launch -- Cholesky updates, the small products of the
+    // rank-one path on buffers of a few KB -- takes the masked loop below, whose epilogue knows about diagonal tiles.  A
+    // generic diagonal tile on this path once read 16 KB past a 2 KB operand: a device fault.)
+    if (!symdiag && a.lower_only && tm == tn) {   // workgroup-uniform: diagonal tile, 36-cell scheme
         const int nst = (kt1 - kt0) * npass;
         const int rvd = (a.M - m0 + 15) >> 4;                      // valid sub-tile rows (= columns) of this tile
         if (rvd < 8) {                                             // the last, short diagonal tile: only its needed cells
 #define HDM_DEDGE(RV)                                                                                                      \
     switch (wave) {                                                                                                        \
-        case 0: cell_tile<DiagEdgeCells<0, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rvd, 1); break;  \
-        case 1: cell_tile<DiagEdgeCells<1, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rvd, 1); break;  \
-        case 2: cell_tile<DiagEdgeCells<2, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rvd, 1); break;  \
-        default: cell_tile<DiagEdgeCells<3, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rvd, 1); break; \
+        case 0: cell_tile<DiagEdgeCells<0, RV>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, rvd, 1); break;  \
+        case 1: cell_tile<DiagEdgeCells<1, RV>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, rvd, 1); break;  \
+        case 2: cell_tile<DiagEdgeCells<2, RV>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, rvd, 1); break;  \
+        default: cell_tile<DiagEdgeCells<3, RV>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, rvd, 1); break; \
     }
             if (rvd <= 4) { HDM_DEDGE(4) } else if (rvd == 5) { HDM_DEDGE(5) } else if (rvd == 6) { HDM_DEDGE(6) } else { HDM_DEDGE(7) }
 #undef HDM_DEDGE
@@ -547,25 +649,25 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
         }
         if constexpr (ROLE != HDM_ROLE_CONG2) {   // (step 2's full diagonal tiles are role HDM_ROLE_CONG2D's)
             switch (wave) {
-                case 0: cell_tile<DiagCells<0>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
-                case 1: cell_tile<DiagCells<1>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
-                case 2: cell_tile<DiagCells<2>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
-                default: cell_tile<DiagCells<3>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+                case 0: cell_tile<DiagCells<0>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+                case 1: cell_tile<DiagCells<1>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+                case 2: cell_tile<DiagCells<2>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
+                default: cell_tile<DiagCells<3>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, 8, 1); break;
             }
             HDM_CELL_STAMP(1)
         }
         return;
     }
-    if (ROLE != HDM_ROLE_GENERIC && !symdiag && tm != tn && m0 + HDM_TILE > a.M && n0 + HDM_TILE <= a.N) {
+    if (!symdiag && tm != tn && m0 + HDM_TILE > a.M && n0 + HDM_TILE <= a.N) {
         // workgroup-uniform: bottom-edge tile below the diagonal, rv < 8 valid sub-tile rows
         const int nst = (kt1 - kt0) * npass;
         const int rv = (a.M - m0 + 15) >> 4;
 #define HDM_EDGE(RV)                                                                                                     \
     switch (wave) {                                                                                                      \
-        case 0: cell_tile<EdgeCells<0, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rv, 0); break;  \
-        case 1: cell_tile<EdgeCells<1, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rv, 0); break;  \
-        case 2: cell_tile<EdgeCells<2, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rv, 0); break;  \
-        default: cell_tile<EdgeCells<3, RV>, AKM, BKM>(a, stA, stB, sA, sB, nst, tid, z, m0, n0, l15, lq, rv, 0); break; \
+        case 0: cell_tile<EdgeCells<0, RV>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, rv, 0); break;  \
+        case 1: cell_tile<EdgeCells<1, RV>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, rv, 0); break;  \
+        case 2: cell_tile<EdgeCells<2, RV>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, rv, 0); break;  \
+        default: cell_tile<EdgeCells<3, RV>, AKM, BKM>(a, stA, stB, sb, nst, tid, z, m0, n0, l15, lq, rv, 0); break; \
     }
         if (rv <= 4) { HDM_EDGE(4) } else if (rv == 5) { HDM_EDGE(5) } else if (rv == 6) { HDM_EDGE(6) } else { HDM_EDGE(7) }
 #undef HDM_EDGE
@@ -579,8 +681,155 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
         cong2_direct_body(a, z, tm, tn, wm, wn, l15, lq);
         return;
     }
+    {
+        // Rotated loop: the barrier sits between the third and the fourth k-step of a stage.  By then the wave holds
+        // the fourth k-step's fragments in registers, so after the barrier it first issues the LDS reads of the NEXT
+        // stage's first k-step and then runs the 16 MFMAs of the fourth k-step, which cover that LDS latency; the look-ahead
+        // loads (unmasked, branch-free) and the LDS writes of the next stage are spread over the first three k-steps.
+        //
+        // Triangular operands.  In the congruence kernels the K block that lies on an operand's diagonal is half
+        // zeros: for stage s (16 k's) of such a block whole 16-row sub-tiles of the operand are structurally zero
+        //   step 2 (both products, last K block, B side lower triangular): column sub-tiles < s are dead,
+        //   step 1, first K block (A_L on the B side: k >= column): column sub-tiles > s are dead,
+        //   step 1, last K block (Linv on the A side: k <= row): row sub-tiles < s are dead.
+        // The stage body exists in variants that run only the live range [JLO..JHI] x [ILO..3] of a wave's 4 x 4
+        // sub-tiles; with the interleaved ownership the live sub-tiles are spread evenly over the four waves.
+        hdm_u4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // staging registers, named so they are never an alloca
+        const int nst = (kt1 - kt0) * npass;
+        double fa0[4], fb0[4], fa1[4], fb1[4];   // two fragment sets, named (not indexed) so they stay in registers
+        // this lane's fragment bases (operand A: rows 32 i + 16 wm + l15; operand B: rows 32 j + 16 wn + l15) and staging bases
+        const hdm_lchar *rdA = sb + rd_lane<AKM>(wm * 16, l15, lq);
+        const hdm_lchar *rdB = sb + 2 * STAGE_DOUBLES * 8 + rd_lane<BKM>(wn * 16, l15, lq);
+        hdm_lchar *wrA = sb + wr_lane<AKM>(tid);
+        hdm_lchar *wrB = sb + 2 * STAGE_DOUBLES * 8 + wr_lane<BKM>(tid);
+#define HDM_LDF(FA, FB, CB, kk)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) FB[i] = lds_ld(rdA + rd_off<AKM>(CB, 2 * i, kk)); \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) FA[j] = lds_ld(rdB + rd_off<BKM>(CB, 2 * j, kk));
+#define HDM_MMA(FA, FB, JLO, JHI, ILO)                                                            \
+    _Pragma("unroll") for (int j = (JLO); j <= (JHI); ++j)                                        \
+        _Pragma("unroll") for (int i = (ILO); i < 4; ++i)                                         \
+            acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[i], acc[j][i], 0, 0, 0);
+        constexpr int NR = 8;   // LDS read instructions per fragment set (one ds_read_b64 per fragment)
+        // one stage that has a successor, on buffer CB: 48 MFMAs, barrier, next stage's first fragments + look-ahead loads, 16 MFMAs
+#define HDM_STAGE(CB, JLO, JHI, ILO, SW)                                                                             \
+    {                                                                                                                \
+        constexpr int NK = ((JHI) - (JLO) + 1) * (4 - (ILO));   /* live MFMAs per k-step */                          \
+        HDM_LDF(fa1, fb1, CB, 4)                                                                                     \
+        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                                             \
+        HDM_LDF(fa0, fb0, CB, 8)                                                                                     \
+        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                                             \
+        HDM_LDF(fa1, fb1, CB, 12)                                                                                    \
+        st4(wrA, (CB) ^ 1, ra0, ra1, ra2, ra3); st4(wrB, (CB) ^ 1, rb0, rb1, rb2, rb3);                              \
+        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                                             \
+        if constexpr (NK == 16) {                                                                                    \
+            /* 16 MFMAs with the second k-step's fragment reads, 16 with the third's, then the fourth's reads and */ \
+            /* the 8 LDS writes among the last 16 */                                                                 \
+            sgb_pairs<0x8, 2, 0x100, 1, NR>();                                                                       \
+            sgb_pairs<0x8, 2, 0x100, 1, NR>();                                                                       \
+            sgb_pairs<0x8, 1, 0x100, NR / 2, 2>();                                                                   \
+            sgb_pairs<0x8, 1, 0x200, 1, 8>();                                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                         \
+        } else {                                                                                                     \
+            sgb_spread<NK, 0x100, NR>();                                                                             \
+            sgb_spread<NK, 0x100, NR>();                                                                             \
+            sgb_spread<NK / 2, 0x100, NR>();                                                                         \
+            sgb_spread<NK - NK / 2, 0x200, 8>();                                                                     \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __syncthreads();                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        HDM_LDF(fa0, fb0, (CB) ^ 1, 0)                                                                               \
+        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   /* stage t+2, or zeros past the end */ \
+        if constexpr (SW) { stA.second(); stB.second(); }   /* that was the first pair's last k block */               \
+        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);                                                          \
+        if constexpr (NK == 16) {                                                                                    \
+            sgb_pairs<0x8, 1, 0x20, 1, 8>();                                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);                                                         \
+        } else {                                                                                                     \
+            sgb_spread<NK, 0x20, 8>();                                                                               \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+        // the last stage: nothing left to stage
+#define HDM_LAST(CB, JLO, JHI, ILO)                                                               \
+    {                                                                                             \
+        HDM_LDF(fa1, fb1, CB, 4)                                                                  \
+        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                          \
+        HDM_LDF(fa0, fb0, CB, 8)                                                                  \
+        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                          \
+        HDM_LDF(fa1, fb1, CB, 12)                                                                 \
+        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                          \
+        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                          \
+    }
+        stA.remain = nst; stB.remain = nst;
+        if (nst > 0) {
+            stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);
+            st4(wrA, 0, ra0, ra1, ra2, ra3); st4(wrB, 0, rb0, rb1, rb2, rb3);
+            stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   // stage 1, in flight
+        }
+        __syncthreads();
+        if ((VAR & 32) && p.dbg) t_pro = __builtin_amdgcn_s_memtime();
+        if (nst > 0) { HDM_LDF(fa0, fb0, 0, 0) }
+        // Stages come in PAIRS on buffers 0, 1 (HDM_RUN2): every K block is eight stages, so every stage sequence of the
+        // congruence roles is even and the buffer index of a stage is a compile-time constant.
+#define HDM_RUN2(JLO, JHI, ILO) { HDM_STAGE(0, JLO, JHI, ILO, false) HDM_STAGE(1, JLO, JHI, ILO, false) }
+#define HDM_END2(JLO, JHI, ILO) { HDM_STAGE(0, JLO, JHI, ILO, false) HDM_LAST(1, JLO, JHI, ILO) }
+#define HDM_RUN2SW(JLO, JHI, ILO) { HDM_STAGE(0, JLO, JHI, ILO, false) HDM_STAGE(1, JLO, JHI, ILO, true) }
+        // The stage sequence of a tile is straight-line: plain loops over the full stages, and the eight stages of a
+        // diagonal K block unrolled with compile-time live ranges (stage s of such a block keeps sub-tiles s/2.. or
+        // ..s/2 of the wave's four: with the interleaved ownership that bound is the same for every wave).  A
+        // run-time switch between stage bodies INSIDE the loop is not an option: two copies of the body under a branch
+        // make the register allocator spill 350-480 VGPRs.
+        if constexpr (ROLE == HDM_ROLE_CONG2) {
+            // (tm > tn, full 128-row tile: diagonal and bottom-edge tiles left through the cell paths above)
+            const int nfull = tn * 4;                       // stage PAIRS before the B operand's diagonal block, per product
+            // (stage s issues the loads of stage s + 2: the first pair's last k block is requested in the sixth stage of its
+            // diagonal block, and the stagers move on to the second pair right there)
+            for (int t = 0; t < nfull; ++t) HDM_RUN2(0, 3, 0)
+            HDM_RUN2(0, 3, 0) HDM_RUN2(1, 3, 0) HDM_RUN2SW(2, 3, 0) HDM_RUN2(3, 3, 0)
+            for (int t = 0; t < nfull; ++t) HDM_RUN2(0, 3, 0)
+            HDM_RUN2(0, 3, 0) HDM_RUN2(1, 3, 0) HDM_RUN2(2, 3, 0) HDM_END2(3, 3, 0)
+        } else if constexpr (ROLE == HDM_ROLE_CONG2D) {
+            // one product; in the last K block both operands are on their diagonal: stage s keeps row and column
+            // sub-tiles >= s, i.e. the wave's own [s/2..3] x [s/2..3]: 60 of the block's 128 sub-tile products
+            const int nfull = tn * 4;
+            for (int t = 0; t < nfull; ++t) HDM_RUN2(0, 3, 0)
+            HDM_RUN2(0, 3, 0) HDM_RUN2(1, 3, 1) HDM_RUN2(2, 3, 2) HDM_END2(3, 3, 3)
+        } else if constexpr (ROLE == HDM_ROLE_CONG1) {
+            // first K block: A_L on the B side, live column sub-tiles <= s; last K block: Linv on the A side, rows >= s
+            HDM_RUN2(0, 0, 0) HDM_RUN2(0, 1, 0) HDM_RUN2(0, 2, 0) HDM_RUN2(0, 3, 0)
+            const int nmid = (tm - tn - 1) * 4;
+            for (int t = 0; t < nmid; ++t) HDM_RUN2(0, 3, 0)
+            HDM_RUN2(0, 3, 0) HDM_RUN2(0, 3, 1) HDM_RUN2(0, 3, 2) HDM_END2(0, 3, 3)
+        } else {
+            // any stage count (the Gram role's K splits): an odd count ends with a stage of zeros (SStager::load_nomask)
+            if (nst > 0) {
+                const int npairs = (nst + 1) >> 1;
+                for (int t = 0; t + 1 < npairs; ++t) HDM_RUN2(0, 3, 0)
+                HDM_END2(0, 3, 0)
+            }
+        }
+#undef HDM_RUN2
+#undef HDM_RUN2SW
+#undef HDM_END2
+#undef HDM_LAST
+#undef HDM_STAGE
+#undef HDM_LDF
+#undef HDM_MMA
+    }
+    } else {
+    // ======================================================================== generic launches: masked staging, plain loop
+    Stager<AKM, true> stA;
+    Stager<BKM, true> stB;
+    stA.init(A, a.lda, a.a_kblk, a.seg_rows, a.seg_extra, a.M, m0, kt0, tid);
+    stB.init(B, a.ldb, a.b_kblk, a.seg_rows, a.seg_extra, a.N, n0, kt0, tid);
+    const int npass = a.A2 ? 2 : 1;
+    if (a.A2) {
+        stA.chain(a.A2 + (long) z * a.strideA2, a.lda2, m0, kt0, tid, kt1 - kt0);
+        stB.chain(a.B2 + (long) z * a.strideB2, a.ldb2, n0, kt0, tid, kt1 - kt0);
+    }
     auto compute = [&](const double *cA, const double *cB) {
-
 #pragma unroll
         for (int kk = 0; kk < HDM_BK; kk += 4) {
             double fb[4], fa[4];
@@ -595,149 +844,7 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
                     acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[i], acc[j][i], 0, 0, 0);
         }
     };
-
-    if (VAR & 64) {
-        // Rotated loop: the barrier sits between the third and the fourth k-step of a stage.  By then the wave holds
-        // the fourth k-step's fragments in registers, so after the barrier it first issues the LDS reads of the NEXT
-        // stage's first k-step and then runs the 16 MFMAs of the fourth k-step, which cover that LDS latency; global
-        // loads (unmasked, branch-free) and the LDS writes of the next stage are spread over the first three k-steps.
-        //
-        // Triangular operands.  In the congruence kernels the K block that lies on an operand's diagonal is half
-        // zeros: for stage s (16 k's) of such a block whole 16-row sub-tiles of the operand are structurally zero
-        //   step 2 (both products, last K block, B side lower triangular): column sub-tiles < s are dead,
-        //   step 1, first K block (A_L on the B side: k >= column): column sub-tiles > s are dead,
-        //   step 1, last K block (Linv on the A side: k <= row): row sub-tiles < s are dead.
-        // The stage body exists in variants that run only the live range [JLO..JHI] x [ILO..3] of a wave's 4 x 4
-        // sub-tiles; with the interleaved ownership the live sub-tiles are spread evenly over the four waves.
-        double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // staging registers, named so they are never an alloca
-        const int nst = (kt1 - kt0) * npass;
-        double fa0[4], fb0[4], fa1[4], fb1[4];   // two fragment sets, named (not indexed) so they stay in registers
-#define HDM_LDF(FA, FB, cA, cB, kk)                                                               \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) FB[i] = frag<AKM>(cA, (2 * i + wm) * 16 + l15, (kk) + lq); \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) FA[j] = frag<BKM>(cB, (2 * j + wn) * 16 + l15, (kk) + lq);
-#define HDM_MMA(FA, FB, JLO, JHI, ILO)                                                            \
-    _Pragma("unroll") for (int j = (JLO); j <= (JHI); ++j)                                        \
-        _Pragma("unroll") for (int i = (ILO); i < 4; ++i)                                         \
-            acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[i], acc[j][i], 0, 0, 0);
-        // LDS read instructions per fragment set: an M-major operand's four fragments pair up into two ds_read2_b64,
-        // a K-major operand's are too far apart and stay four ds_read_b64
-        constexpr int NR = (AKM ? 4 : 2) + (BKM ? 4 : 2);
-        // one stage that has a successor: 48 MFMAs, barrier, next stage's first fragments + look-ahead loads, 16 MFMAs
-#define HDM_STAGE(JLO, JHI, ILO)                                                                                     \
-    {                                                                                                                \
-        constexpr int NK = ((JHI) - (JLO) + 1) * (4 - (ILO));   /* live MFMAs per k-step */                          \
-        HDM_LDF(fa1, fb1, cA, cB, 4)                                                                                 \
-        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                                             \
-        HDM_LDF(fa0, fb0, cA, cB, 8)                                                                                 \
-        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                                             \
-        HDM_LDF(fa1, fb1, cA, cB, 12)                                                                                \
-        r2s4<AKM>(nA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(nB, tid, rb0, rb1, rb2, rb3);                              \
-        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                                             \
-        if constexpr (NK == 16) {                                                                                    \
-            /* 16 MFMAs with the second k-step's fragment reads, 16 with the third's, then the fourth's reads and */ \
-            /* the 8 LDS writes among the last 16 */                                                                 \
-            sgb_pairs<0x8, 2, 0x100, 1, NR>();                                                                       \
-            __builtin_amdgcn_sched_group_barrier(0x8, 16 - 2 * NR, 0);                                               \
-            sgb_pairs<0x8, 2, 0x100, 1, NR>();                                                                       \
-            __builtin_amdgcn_sched_group_barrier(0x8, 16 - 2 * NR, 0);                                               \
-            sgb_pairs<0x8, 1, 0x100, NR / 2, 2>();                                                                   \
-            sgb_pairs<0x8, 1, 0x200, 1, 8>();                                                                        \
-            __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                         \
-        } else {                                                                                                     \
-            sgb_spread<NK, 0x100, NR>();                                                                             \
-            sgb_spread<NK, 0x100, NR>();                                                                             \
-            sgb_spread<NK / 2, 0x100, NR>();                                                                         \
-            sgb_spread<NK - NK / 2, 0x200, 8>();                                                                     \
-        }                                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        __syncthreads();                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        HDM_LDF(fa0, fb0, nA, nB, 0)                                                                                 \
-        stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   /* stage t+2, or the last again */ \
-        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                                             \
-        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);                                                          \
-        if constexpr (NK == 16) {                                                                                    \
-            sgb_pairs<0x8, 1, 0x20, 1, 8>();                                                                         \
-            __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);                                                         \
-        } else {                                                                                                     \
-            sgb_spread<NK, 0x20, 8>();                                                                               \
-        }                                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-    }
-        // the last stage: nothing left to stage
-#define HDM_LAST(JLO, JHI, ILO)                                                                   \
-    {                                                                                             \
-        HDM_LDF(fa1, fb1, cA, cB, 4)                                                              \
-        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                          \
-        HDM_LDF(fa0, fb0, cA, cB, 8)                                                              \
-        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                          \
-        HDM_LDF(fa1, fb1, cA, cB, 12)                                                             \
-        HDM_MMA(fa0, fb0, JLO, JHI, ILO)                                                          \
-        HDM_MMA(fa1, fb1, JLO, JHI, ILO)                                                          \
-    }
-        stA.remain = nst; stB.remain = nst;
-        if (nst > 0) {
-            stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);
-            r2s4<AKM>(sA, tid, ra0, ra1, ra2, ra3); r2s4<BKM>(sB, tid, rb0, rb1, rb2, rb3);
-            stA.load_nomask(ra0, ra1, ra2, ra3); stB.load_nomask(rb0, rb1, rb2, rb3);   // stage 1, in flight
-        }
-        __syncthreads();
-        if ((VAR & 32) && p.dbg) t_pro = __builtin_amdgcn_s_memtime();
-        int cur = 0;
-        if (nst > 0) { HDM_LDF(fa0, fb0, sA, sB, 0) }
-        // one stage with a successor / the final stage, on the current LDS buffer
-#define HDM_RUN(JLO, JHI, ILO)                                                                    \
-    {                                                                                             \
-        const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;              \
-        double *nA = sA + (cur ^ 1) * STAGE_DOUBLES, *nB = sB + (cur ^ 1) * STAGE_DOUBLES;        \
-        HDM_STAGE(JLO, JHI, ILO)                                                                  \
-        cur ^= 1;                                                                                 \
-    }
-#define HDM_END(JLO, JHI, ILO)                                                                    \
-    {                                                                                             \
-        const double *cA = sA + cur * STAGE_DOUBLES, *cB = sB + cur * STAGE_DOUBLES;              \
-        HDM_LAST(JLO, JHI, ILO)                                                                   \
-    }
-        // The stage sequence of a tile is straight-line: plain loops over the full stages, and the eight stages of a
-        // diagonal K block unrolled with compile-time live ranges (stage s of such a block keeps sub-tiles s/2.. or
-        // ..s/2 of the wave's four: with the interleaved ownership that bound is the same for every wave).  A
-        // run-time switch between stage bodies INSIDE the loop is not an option: two copies of the body under a branch
-        // make the register allocator spill 350-480 VGPRs.
-        if constexpr (ROLE == HDM_ROLE_CONG2) {
-            // (tm > tn, full 128-row tile: diagonal and bottom-edge tiles left through the cell paths above)
-            const int nfull = tn * 8;                       // stages before the B operand's diagonal block, per product
-            for (int t = 0; t < nfull; ++t) HDM_RUN(0, 3, 0)
-            HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0) HDM_RUN(1, 3, 0) HDM_RUN(1, 3, 0)
-            HDM_RUN(2, 3, 0) HDM_RUN(2, 3, 0) HDM_RUN(3, 3, 0) HDM_RUN(3, 3, 0)
-            for (int t = 0; t < nfull; ++t) HDM_RUN(0, 3, 0)
-            HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0) HDM_RUN(1, 3, 0) HDM_RUN(1, 3, 0)
-            HDM_RUN(2, 3, 0) HDM_RUN(2, 3, 0) HDM_RUN(3, 3, 0) HDM_END(3, 3, 0)
-        } else if constexpr (ROLE == HDM_ROLE_CONG2D) {
-            // one product; in the last K block both operands are on their diagonal: stage s keeps row and column
-            // sub-tiles >= s, i.e. the wave's own [s/2..3] x [s/2..3]: 60 of the block's 128 sub-tile products
-            const int nfull = tn * 8;
-            for (int t = 0; t < nfull; ++t) HDM_RUN(0, 3, 0)
-            HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0) HDM_RUN(1, 3, 1) HDM_RUN(1, 3, 1)
-            HDM_RUN(2, 3, 2) HDM_RUN(2, 3, 2) HDM_RUN(3, 3, 3) HDM_END(3, 3, 3)
-        } else if constexpr (ROLE == HDM_ROLE_CONG1) {
-            // first K block: A_L on the B side, live column sub-tiles <= s; last K block: Linv on the A side, rows >= s
-            HDM_RUN(0, 0, 0) HDM_RUN(0, 0, 0) HDM_RUN(0, 1, 0) HDM_RUN(0, 1, 0)
-            HDM_RUN(0, 2, 0) HDM_RUN(0, 2, 0) HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0)
-            const int nmid = (tm - tn - 1) * 8;
-            for (int t = 0; t < nmid; ++t) HDM_RUN(0, 3, 0)
-            HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 0) HDM_RUN(0, 3, 1) HDM_RUN(0, 3, 1)
-            HDM_RUN(0, 3, 2) HDM_RUN(0, 3, 2) HDM_RUN(0, 3, 3) HDM_END(0, 3, 3)
-        } else {
-            for (int t = 0; t + 1 < nst; ++t) HDM_RUN(0, 3, 0)
-            if (nst > 0) HDM_END(0, 3, 0)
-        }
-#undef HDM_RUN
-#undef HDM_END
-#undef HDM_LAST
-#undef HDM_STAGE
-#undef HDM_LDF
-#undef HDM_MMA
-    } else {
+    {
         double2 ra[4], rb[4];
         const int kt1x = kt0 + (kt1 - kt0) * npass;
         if (kt0 < kt1) {
@@ -763,6 +870,7 @@ __device__ __forceinline__ void hdm_gemm_tile(const HdmGemmDev &p, const int z, 
             __syncthreads();
             cur ^= 1;
         }
+    }
     }
 
     if ((VAR & 32) && p.dbg) t_loop = __builtin_amdgcn_s_memtime();

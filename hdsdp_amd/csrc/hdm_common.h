@@ -3,7 +3,7 @@
 #pragma once
 #include <cstddef>
 // Slack (bytes) appended to every device buffer that the role 1-3 GEMM kernels read as an operand: their staging loads
-// carry no row mask (gemm_f64.hip, Stager::load_nomask), so the last tile of the last matrix in a buffer may read up
+// carry no row mask (gemm_tile.h, SStager::load_nomask), so the last tile of the last matrix in a buffer may read up
 // to 127 rows past its end.  `ld` = elements between consecutive rows (K-major) or 1 (M-major).
 static inline size_t hdm_operand_pad(long ld) { return (size_t) 128 * (size_t) (ld < 16 ? 16 : ld) * 8 + 4096; }
 #define HDM_OPERAND_PAD_DOUBLES 8192   /* the same slack for the [p-block][row][16] congruence output, in doubles */
