@@ -207,22 +207,62 @@ def cpu_baseline_blas3(n, m):
         return {"value": None, "unit": "it/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
 
 
-class PowerClockSampler:
-    """rocm-smi (power, shader clock) sampled in a background thread while the timed region runs: the fp64 matrix pipe at this
-    density is power-limited (profiles/r03_f_power_clock.txt), so the line carries what the board drew and clocked at.  Reading
-    needs no privileges; no rocm-smi, no samples."""
+def device_pci_bus(index):
+    """'dddd:bb:dd.f' of a visible device, or None"""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(index)
+        return "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        return None
 
-    def __init__(self):
+
+def under_profiler():
+    """rocprofv3 preloads its tool library into this process AND into every child: a child started from here would exec with
+    the GPU already initialised by that library, which this pool refuses.  Under a profiler bench.py starts no child processes."""
+    return "rocprof" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCPROFILER_LIBRARY_CTOR") or os.environ.get("ROCP_TOOL_LIBRARIES"))
+
+
+class PowerClockSampler:
+    """Board power and shader clock sampled in a background thread while the timed region runs: the fp64 matrix pipe at this
+    density is power-limited (profiles/r03_f_power_clock.txt), so the line carries what the board drew and clocked at.  Read
+    from the amdgpu hwmon files of the card this process computes on (no child process, nothing beside the timed region but two file reads
+    every 0.2 s); where those are not readable, rocm-smi in a child process -- never under a profiler.  No source, no samples."""
+
+    def __init__(self, pci_bus=None):
+        import glob
         import shutil
         import threading
-        self.exe = shutil.which("rocm-smi")
         self.samples = []
+        self.source = None
+        self._pw = self._fq = None
+        # the card THIS process computes on, by its PCI address (a box shows the hwmon files of every GPU of its host)
+        dev = os.path.join("/sys/bus/pci/devices", pci_bus) if pci_bus else None
+        if dev and os.path.isdir(dev):
+            pw = [f for pat in ("power1_average", "power1_input") for f in glob.glob(os.path.join(dev, "hwmon", "hwmon*", pat))]
+            fq = glob.glob(os.path.join(dev, "hwmon", "hwmon*", "freq1_input"))
+            if pw and os.access(pw[0], os.R_OK):
+                self._pw, self._fq = pw[0], (fq[0] if fq and os.access(fq[0], os.R_OK) else None)
+                self.source = "amdgpu hwmon of %s (%s%s)" % (pci_bus, os.path.basename(pw[0]), ", freq1_input" if self._fq else "")
+        self.exe = None if (self._pw or under_profiler()) else shutil.which("rocm-smi")
+        if self.exe:
+            self.source = "rocm-smi card0"
         self._stop = threading.Event()
-        self._th = threading.Thread(target=self._run, daemon=True) if self.exe else None
+        self._th = threading.Thread(target=self._run, daemon=True) if (self._pw or self.exe) else None
 
     def _run(self):
         import re
+        import time
         while not self._stop.is_set():
+            if self._pw:
+                try:
+                    w = float(open(self._pw).read()) * 1e-6
+                    f = float(open(self._fq).read()) * 1e-6 if self._fq else float("nan")
+                    self.samples.append((w, f))
+                except (OSError, ValueError):
+                    return
+                time.sleep(0.2)
+                continue
             try:
                 out = subprocess.run([self.exe, "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=10).stdout
             except Exception:
@@ -248,7 +288,8 @@ class PowerClockSampler:
             return None
         w, f = np.array([x[0] for x in self.samples]), np.array([x[1] for x in self.samples])
         return {"samples": len(self.samples), "board_power_w": [float(w.min()), float(w.mean()), float(w.max())],
-                "shader_clock_mhz": [float(np.nanmin(f)), float(np.nanmean(f)), float(np.nanmax(f))], "source": "rocm-smi card0, [min, mean, max] over the timed region"}
+                "shader_clock_mhz": [float(np.nanmin(f)), float(np.nanmean(f)), float(np.nanmax(f))],
+                "source": "%s, [min, mean, max] over the timed region" % self.source}
 
 
 def rccl_self_test_in_child(ids, timeout_s=240):
@@ -413,7 +454,7 @@ def main():
     for w in range(args.warmup):
         step(False, args.steps + args.warmup - 1 - w)
     lib.HMiSetKernelTiming(1)
-    sampler = PowerClockSampler() if (rank == 0 and world == 1 and shards == 1) else None
+    sampler = PowerClockSampler(device_pci_bus(local % ndev)) if (rank == 0 and world == 1 and shards == 1) else None
     barrier()
     if sampler:
         sampler.start()
@@ -516,7 +557,7 @@ def main():
                                                     "all_reduce": ex.bytes_ar // (args.steps + args.warmup)}
     if small is not None:
         out["small_configs"] = small
-    if not args.no_cpu and world == 1:
+    if not args.no_cpu and world == 1 and not under_profiler():
         out["cpu_baseline"] = cpu_baseline(n, m)
         out["cpu_baseline_blas3"] = cpu_baseline_blas3(n, m)
     else:
