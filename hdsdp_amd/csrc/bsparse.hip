@@ -401,3 +401,6 @@ int HdmBsp::solve_host(const double *rhs, double *sol, hipStream_t s) {
     for (int i = 0; i < m; ++i) sol[i] = hvec[perm[i]];
     return 0;
 }
+
+// one kernel of this translation unit (= one code object): what the preload thread asks the runtime about (engine.hip: preload_modules)
+const void *hdm_module_handle_bsparse() { return (const void *) bs_pad_diag_kernel; }

@@ -704,6 +704,94 @@ int HdmChol::factor(hipStream_t s, int *info_host) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The two products of a block column -- panel L_ik = A_ik inv(L_kk)^T and trailing update A_ij -= L_ik L_jk^T -- have K = 128:
+// eight stages of the general GEMM's 128 x 128 tile, 14 us of MFMAs for ONE workgroup per tile behind a prologue and an
+// epilogue, 22-24 us per launch with most of the chip idle (the first update of a 2000 x 2000 matrix has 120 tiles for 256
+// CUs), twice per block column beside the 56 us diagonal sweep.  hdm_k128_kernel cuts the same products into 64 x 64 tiles:
+// four waves of 32 x 32 (four accumulators, 128 MFMAs each = 3.4 us), fragments straight from global memory (both operands
+// are M-major: an MFMA operand is one 8-byte buffer load per lane, sixteen k-steps in flight per wave, addresses on the scalar
+// unit), no LDS, no barrier.  Same products in the same order of k as the general kernel: the factor is bit-identical
+// (tests/test_gpu_kernels.py::test_cholesky_small_tile_products_give_the_same_bits).  HDM_CHOL_K128=0: the general kernel.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned hdm_k2 __attribute__((ext_vector_type(2)));
+// UPDATE: C(lower 64 x 64 tiles) -= A B^T, a wave owns 32 x 32 (NJ = 2 column sub-tiles).  Panel (!UPDATE, NJ = 4): C = A B^T
+// with 64 x 128 tiles -- a workgroup owns ALL 128 columns of its 64 rows, so the product may overwrite its own A operand
+// (C == A): every load of the workgroup is complete before its first store (the barrier below).
+template <int NJ, bool UPDATE>
+__global__ __launch_bounds__(256) void hdm_k128_kernel(const double *__restrict__ A, long lda, const double *__restrict__ B, long ldb,
+                                                       double *C, long ldc) {
+    constexpr int KB = (NJ == 2) ? 8 : 4;     // k-steps per block; two blocks in flight
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (UPDATE && ti < tj) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int r0 = ti * 64 + (wave & 1) * 32, c0 = tj * (32 * NJ) + (wave >> 1) * (16 * NJ);
+    // operand element (row r0 + 16 i + l15, k + lq): base + lane offset + 128 i bytes, k advanced through the scalar offset
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A + r0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(B + c0), 0, 0x7fffffff, 0x00020000);
+    const unsigned va = (unsigned) ((l15 + lq * lda) * 8), vb = (unsigned) ((l15 + lq * ldb) * 8);
+    const unsigned sa = (unsigned) (4 * lda * 8), sb = (unsigned) (4 * ldb * 8);     // bytes per k-step
+    hdm_c4 acc[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = (hdm_c4){0.0, 0.0, 0.0, 0.0};
+    hdm_k2 fa[2][KB][NJ], fb[2][KB][2];   // [set][k-step of the block][sub-tile]
+#define K128_LOAD(SET, BLK)                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < KB; ++q) {                                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+            fb[SET][q][i] = __builtin_amdgcn_raw_buffer_load_b64(ra, va + 128 * i, ((BLK) * KB + q) * sa, 0);    \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                           \
+            fa[SET][q][j] = __builtin_amdgcn_raw_buffer_load_b64(rb, vb + 128 * j, ((BLK) * KB + q) * sb, 0);    \
+    }
+#define K128_MMA(SET)                                                                                            \
+    _Pragma("unroll") for (int q = 0; q < KB; ++q)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                           \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+                acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(__builtin_bit_cast(double, fa[SET][q][j]),      \
+                                                                 __builtin_bit_cast(double, fb[SET][q][i]), acc[j][i], 0, 0, 0);
+    constexpr int NBLK = 32 / KB;             // K = 128 = 32 k-steps
+    K128_LOAD(0, 0) K128_LOAD(1, 1)
+#pragma unroll
+    for (int b = 0; b < NBLK; b += 2) {
+        K128_MMA(0)
+        if (b + 2 < NBLK) { K128_LOAD(0, b + 2) }
+        K128_MMA(1)
+        if (b + 3 < NBLK) { K128_LOAD(1, b + 3) }
+    }
+#undef K128_LOAD
+#undef K128_MMA
+    if (!UPDATE) __syncthreads();             // in-place panel: nobody stores before everybody has loaded
+    // lane l, register r of acc[j][i]: C[r0 + 16 i + l15][c0 + 16 j + lq + 4 r]
+    double *cl = C + (r0 + l15) + (long) (c0 + lq) * ldc;
+    const bool diag = UPDATE && (ti == tj);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                double *q = cl + 16 * i + (long) (16 * j + 4 * r) * ldc;
+                if (UPDATE) {
+                    if (diag && (r0 + 16 * i + l15) < (c0 + 16 * j + lq + 4 * r)) continue;   // above the diagonal: not ours
+                    *q = -1.0 * acc[j][i][r] + 1.0 * (*q);
+                } else {
+                    *q = 1.0 * acc[j][i][r];
+                }
+            }
+}
+
+// the rows x 128 panel times a 128 x 128 block (in place allowed), or the lower tiles of the rows x rows update; rows a multiple of 64
+static int hdm_k128_launch(bool update, const double *A, long lda, const double *B, long ldb, double *C, long ldc, int rows,
+                           hipStream_t s) {
+    if (update) hipLaunchKernelGGL((hdm_k128_kernel<2, true>), dim3(rows / 64, rows / 64), dim3(256), 0, s, A, lda, B, ldb, C, ldc);
+    else hipLaunchKernelGGL((hdm_k128_kernel<4, false>), dim3(rows / 64, 1), dim3(256), 0, s, A, lda, B, ldb, C, ldc);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 __global__ void hdm_zero_word_kernel(int *p) { *p = 0; }
 
 int HdmChol::enqueue_factor(hipStream_t s) {
@@ -727,6 +815,12 @@ int HdmChol::enqueue_factor(hipStream_t s) {
         const int rows = env_colh.empty() ? npad - (k + 1) * NB : (env_colh[k] - k) * NB;
         if (rows <= 0) continue;
         double *P = Akk + NB;  // panel below the diagonal block
+        static const bool k128 = [] { const char *e = getenv("HDM_CHOL_K128"); return !(e && atoi(e) == 0); }();
+        if (k128 && rows % 64 == 0 && ld < (1L << 20)) {
+            if (hdm_k128_launch(false, P, ld, Dinv + (long) k * NB * NB, NB, P, ld, rows, s)) return 1;
+            if (hdm_k128_launch(true, P, ld, P, ld, Akk + (long) NB * (ld + 1), ld, rows, s)) return 1;
+            continue;
+        }
         HdmGemmArgs g = {};
         g.A = P; g.lda = ld; g.B = Dinv + (long) k * NB * NB; g.ldb = NB; g.C = P; g.ldc = ld;
         g.M = rows; g.N = NB; g.K = NB; g.batch = 1; g.alpha = 1.0; g.beta = 0.0;
@@ -944,3 +1038,6 @@ int HdmChol::inverse_full(double *out_dev, long ldo, hipStream_t s) {
     g.epilogue = HDM_EPI_STORE;
     return hdm_launch_gemm(g, s);
 }
+
+// one kernel of this translation unit (= one code object): what the preload thread asks the runtime about (engine.hip: preload_modules)
+const void *hdm_module_handle_chol() { return (const void *) hdm_potrf_diag_kernel; }

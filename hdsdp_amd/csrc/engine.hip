@@ -69,12 +69,33 @@ int g_main_device_request = -1;   // HMiSetDevices / HDSDP_MI355X_GPUS: device o
 
 void stats_print_at_exit();
 
+// Code objects come up beside the caller's own start-up work, not inside its first HKKTBuildUp (hdm_common.h:
+// hdm_module_handle_*).  One helper thread per process, started when the first context opens, joined at exit (the atexit
+// handler is registered after the HIP runtime's own, so it runs before the runtime is taken down).
+std::thread g_preload_thread;
+std::once_flag g_preload_once;
+void preload_join() { if (g_preload_thread.joinable()) g_preload_thread.join(); }
+void preload_modules(int dev) {
+    if (const char *e = getenv("HDSDP_MI355X_PRELOAD")) if (!atoi(e)) return;
+    std::call_once(g_preload_once, [dev] {
+        g_preload_thread = std::thread([dev] {
+            if (hipSetDevice(dev) != hipSuccess) return;
+            const void *handles[] = {hdm_module_handle_small(), hdm_module_handle_chol(), hdm_module_handle_schur(),
+                                     hdm_module_handle_lanczos(), hdm_module_handle_gemm_f64(), hdm_module_handle_lu(),
+                                     hdm_module_handle_bsparse(), hdm_module_handle_gemm_persist(), (const void *) mi_scale_kernel};
+            for (const void *h : handles) { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, h); }
+        });
+        atexit(preload_join);
+    });
+}
+
 int ctx_open(Ctx &c, int dev) {
     HDM_HIP_CHECK(hipSetDevice(dev));
     c.device = dev;
     HDM_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) HDM_HIP_CHECK(hipEventCreate(&c.ev[i]));
     c.init = true;
+    preload_modules(dev);
     return 0;
 }
 

@@ -335,3 +335,6 @@ int hdm_timing_collect(double *ms, double *flops, long *launches) {
 
 // diagnostic: per-workgroup timestamps of the next launches with the given role (HDM_VAR=32 builds the stamps in)
 void hdm_set_debug_buffer(unsigned long long *dev, int role) { g_dbg = dev; g_dbg_role = role; }
+
+// one kernel of this translation unit (= one code object): what the preload thread asks the runtime about (engine.hip: preload_modules)
+const void *hdm_module_handle_gemm_f64() { return (const void *) hdm_gemm_kernel<false, false, HDM_ROLE_GENERIC, 0>; }

@@ -57,3 +57,6 @@ int hdm_launch_persist(bool a_kmajor, bool b_kmajor, int role, int variant, dim3
     }
     return 1;
 }
+
+// one kernel of this translation unit (= one code object): what the preload thread asks the runtime about (engine.hip: preload_modules)
+const void *hdm_module_handle_gemm_persist() { return (const void *) hdm_gemm_persist_kernel<false, false, HDM_ROLE_CONG2, 64>; }

@@ -138,3 +138,16 @@ void hdm_gemm_reserve_cus(int cus);   // CUs the persistent GEMM launches leave 
 void hdm_timing_enable(int on);
 void hdm_set_debug_buffer(unsigned long long *dev, int role);
 int hdm_timing_collect(double *ms, double *flops, long *launches);  // arrays of HDM_NROLES; resets
+
+// One kernel handle per translation unit with device code.  The HIP runtime loads a translation unit's code object when its
+// first kernel is launched (10 ms for the first HKKTBuildUp of a process, which is a fifth of a whole solve of a 100 x 100
+// block); the engine asks for one function attribute per unit on a helper thread when its first context opens instead, beside
+// whatever the caller does next (presolve, the other cones' creation).  HDSDP_MI355X_PRELOAD=0: load on first use.
+const void *hdm_module_handle_gemm_f64();
+const void *hdm_module_handle_gemm_persist();
+const void *hdm_module_handle_chol();
+const void *hdm_module_handle_schur();
+const void *hdm_module_handle_lanczos();
+const void *hdm_module_handle_lu();
+const void *hdm_module_handle_small();
+const void *hdm_module_handle_bsparse();

@@ -1231,3 +1231,6 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
     if (steps) *steps = k;
     return 0;
 }
+
+// one kernel of this translation unit (= one code object): what the preload thread asks the runtime about (engine.hip: preload_modules)
+const void *hdm_module_handle_lanczos() { return (const void *) hdm_lanczos_step_kernel; }

@@ -367,3 +367,6 @@ int HdmLu::solve_host(const double *rhs, double *sol, int nrhs, hipStream_t s) {
     }
     return 0;
 }
+
+// one kernel of this translation unit (= one code object): what the preload thread asks the runtime about (engine.hip: preload_modules)
+const void *hdm_module_handle_lu() { return (const void *) hdm_lu_mirror_pad_kernel; }

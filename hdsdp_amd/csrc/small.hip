@@ -412,3 +412,6 @@ int hdm_small_phase_a(const HdmSmallArgs &args, hipStream_t s) {
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// one kernel of this translation unit (= one code object): what the preload thread asks the runtime about (engine.hip: preload_modules)
+const void *hdm_module_handle_small() { return (const void *) hdm_small_phase_a_kernel; }

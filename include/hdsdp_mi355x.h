@@ -448,6 +448,8 @@ void HMiSDPAFree(HMiSDPA **pp);
  *  HDM_PERSIST                    1         persistent GEMM workgroups; 0: one workgroup per tile         test_gpu_switches.py, test_gpu_kernels.py
  *  HDM_PERSIST_RESERVE_CUS        0 / 8     CUs a persistent launch leaves to the collectives             test_gpu_switches.py, test_gpu_kernels.py
  *  HDM_DIAG_SWEEP                 1         register-sweep diagonal block; 0: LDS-panel kernel            test_gpu_switches.py, test_gpu_kernels.py
+ *  HDM_CHOL_K128                  1         Cholesky panel / update as 64-row tiles straight from global  test_gpu_switches.py, test_gpu_kernels.py
+ *                                           memory; 0: the general GEMM kernel
  *  HDM_TRSV_FLOW                  1         single-launch substitution; 0: per-block launches             test_gpu_switches.py, test_gpu_kernels.py
  *  HDM_TRSV_FLOW_FAIL_ONCE        0         test hook: throw the first single-launch result away          test_gpu_kernels.py::test_fallback_chains_of_the_factor_and_solve_kernels
  *  HDM_GRAPHS                     0         0 / 1 / 2: hipGraph replay of factorisation / substitutions   test_gpu_switches.py, test_gpu_kernels.py
@@ -456,6 +458,8 @@ void HMiSDPAFree(HMiSDPA **pp);
  *  HDM_LANCZOS_FUSED              1         small blocks: three Lanczos steps per launch                  test_gpu_switches.py
  *  HDM_LANCZOS_GROUP              1         large blocks: steps between Ritz checks queued back to back   test_gpu_switches.py
  *  HDM_LANCZOS_BIG                1         large blocks: those steps in one launch of co-resident groups test_gpu_switches.py
+ *  HDSDP_MI355X_PRELOAD           1         code objects are loaded on a helper thread when the first    test_gpu_switches.py
+ *                                           context opens; 0: each on its first launch
  *  -- output only (no code path changes) --------------------------------------------------------------------------------
  *  HDSDP_MI355X_CALL_STATS        0         table of wall time below the C ABI at exit                    tools/small_driver_stats.sh
  *  HDSDP_MI355X_TRACE             0         synchronise and report after every entry                      (diagnostic)

@@ -316,9 +316,9 @@ print("FALLBACK_OK")
 
 
 @pytest.mark.parametrize("env", [{"HDM_TRSV_FLOW": "0"}, {"HDM_GRAPHS": "1"}, {"HDM_GRAPHS": "2", "HDM_TRSV_FLOW": "0"},
-                                 {"HDM_TRSV_FLOW_FAIL_ONCE": "1"}, {"HDM_DIAG_SWEEP": "0"}, {"HDM_PERSIST": "0"}],
+                                 {"HDM_TRSV_FLOW_FAIL_ONCE": "1"}, {"HDM_DIAG_SWEEP": "0"}, {"HDM_PERSIST": "0"}, {"HDM_CHOL_K128": "0"}],
                          ids=["per-block-substitution", "graph-replayed-factorisation", "graph-replayed-substitution", "flow-gives-up-once",
-                              "lds-panel-diagonal-block", "one-tile-per-workgroup"])
+                              "lds-panel-diagonal-block", "one-tile-per-workgroup", "general-gemm-panel-and-update"])
 def test_fallback_chains_of_the_factor_and_solve_kernels(env):
     """the paths behind the defaults stay covered: the per-block substitution launches (HDM_TRSV_FLOW=0, also what a
     timed-out single-launch substitution falls back to), the LDS-panel diagonal-block kernel (HDM_DIAG_SWEEP=0), the
@@ -363,6 +363,21 @@ def test_graph_replayed_factorisations_give_the_eager_bits():
                            env=dict(os.environ, **extra))
         assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
         h.append(re.search(r"DHASH (\w+)", r.stdout).group(1))
+    assert h[0] == h[1], h
+
+
+def test_cholesky_small_tile_products_give_the_same_bits():
+    """the panel and trailing-update products of the blocked Cholesky as 64-row tiles with fragments straight from global memory
+    (hdm_k128_kernel, the default) and through the general GEMM kernel (HDM_CHOL_K128=0) sum the same terms in the same order:
+    the factors' diagonals of the nine factorisations of the script above, and the Schur matrix, are the same bits"""
+    import os, subprocess, sys, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = []
+    for extra in ({}, {"HDM_CHOL_K128": "0"}):
+        r = subprocess.run([sys.executable, "-c", FALLBACK_SCRIPT % root], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **extra))
+        assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        h.append((re.search(r"DHASH (\w+)", r.stdout).group(1), re.search(r"MHASH (\w+)", r.stdout).group(1)))
     assert h[0] == h[1], h
 
 

@@ -24,8 +24,8 @@ SETTINGS = [
     {"HDM_LANCZOS_WHOLE": "0", "HDM_LANCZOS_FUSED": "0", "HDM_LANCZOS_GROUP": "0"}, {"HDM_LANCZOS_BIG": "0"},
     {"HDM_LANCZOS_BIG": "0", "HDM_LANCZOS_GROUP": "0"},
     {"HDM_SYM_COMBINE_SKY": "0"}, {"HDM_SHARE_T_SLABS": "0"}, {"HDM_NSPLIT": "24"}, {"HDM_BC": "8"}, {"HDM_TCAP_GIB": "1"},
-    {"HDM_PERSIST": "0"}, {"HDM_PERSIST_RESERVE_CUS": "200"},
-    {"HDM_DIAG_SWEEP": "0"}, {"HDM_TRSV_FLOW": "0"}, {"HDM_GRAPHS": "1"}, {"HDM_GRAPHS": "2"},
+    {"HDM_PERSIST": "0"}, {"HDM_PERSIST_RESERVE_CUS": "200"}, {"HDSDP_MI355X_PRELOAD": "0"},
+    {"HDM_DIAG_SWEEP": "0"}, {"HDM_CHOL_K128": "0"}, {"HDM_TRSV_FLOW": "0"}, {"HDM_GRAPHS": "1"}, {"HDM_GRAPHS": "2"},
     {"SWITCH_WORKER_SHARDS": "2"},                                       # in-process device group, defaults
     {"SWITCH_WORKER_SHARDS": "3", "HDSDP_MI355X_A2A_PIECES": "1"},       # one blocking exchange
     {"SWITCH_WORKER_SHARDS": "2", "HDSDP_MI355X_STAGED_A2A": "0"},       # congruence complete, then exchange
