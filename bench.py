@@ -217,6 +217,38 @@ def device_pci_bus(index):
         return None
 
 
+def mfma_busy_from_profiles(role):
+    """MFMA-busy share of one role's kernel from the newest kept PMC summary (profiles/*_summary_pmc_SQ_VALU_MFMA_BUSY*.txt)
+    whose traffic.json names the kernel sources of this build; None otherwise"""
+    import glob
+    import re
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from prof_summary import kernel_source_sha
+        sha = kernel_source_sha(ROOT)
+        best = None
+        for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+            try:
+                if json.load(open(tj)).get("kernel_source_sha") == sha:
+                    best = tj
+            except Exception:
+                pass
+        if not best:
+            return None
+        f = glob.glob(best.replace("_traffic.json", "_summary_pmc_SQ_VALU_MFMA_BUSY*.txt"))
+        if not f:
+            return None
+        pat = {1: "<false, true, 1", 2: "<false, false, 2", 3: "<true, true, 3"}[role]
+        for line in open(f[0]):
+            if "hdm_gemm_persist_kernel" + pat in line and "SQ_VALU_MFMA_BUSY_CYCLES" in line:
+                g = float(re.search(r"GRBM_GUI_ACTIVE=([0-9.e+]+)", line).group(1))
+                b = float(re.search(r"SQ_VALU_MFMA_BUSY_CYCLES=([0-9.e+]+)", line).group(1))
+                return round(b / (g / 8.0 * 1024.0), 4)
+    except Exception:
+        return None
+    return None
+
+
 def under_profiler():
     """rocprofv3 preloads its tool library into this process AND into every child: a child started from here would exec with
     the GPU already initialised by that library, which this pool refuses.  Under a profiler bench.py starts no child processes."""
@@ -522,6 +554,13 @@ def main():
         # dominant kernel against it; `frac` above stays against the vendor peak
         "box_mfma_loop_tflops": None if probe_tf is None else round(probe_tf, 2),
         "frac_of_box_mfma_loop": None if not probe_tf else round(achieved / probe_tf, 4),
+        # the board runs this load at its power limit: against what the matrix pipe can do at the shader clock sampled over the
+        # timed region (peak x clock / 2.4 GHz); `frac` above stays against the vendor peak at 2.4 GHz
+        "frac_at_sampled_clock": (None if not (power_clock and power_clock["shader_clock_mhz"][1] > 0) else
+                                  round(achieved / (FP64_MFMA_PEAK_TFLOPS * power_clock["shader_clock_mhz"][1] / 2400.0), 4)),
+        # busy share of the matrix pipe in the dominant kernel, from the PMC pass of the newest kept profile set of these kernel
+        # sources (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024)); None when that set was taken on other sources
+        "mfma_busy_profiled": mfma_busy_from_profiles(dom),
     }
     out = {
         "metric": "IPM iterations/sec (Schur build+factor+solve), n=%d m=%d dense SDP" % (n, m),
