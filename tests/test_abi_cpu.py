@@ -315,3 +315,58 @@ def test_every_environment_switch_is_listed_in_the_header_and_covered():
         m = re.match(r"^ \*  ([A-Z][A-Z_0-9]+)\s", line)
         if m and "test_gpu_switches.py" in line:
             assert m.group(1) in run, m.group(1) + " is said to be covered by test_gpu_switches.py but no setting names it"
+
+
+def test_full_stages_of_the_gemm_roles_carry_no_vector_alu_instruction(tmp_path):
+    """every vector ALU instruction between the MFMAs of the fp64 GEMM K loop costs the matrix pipe about 11 cycles
+    (profiles/r04_h_issue_mix.txt), so the stage body's addressing is arranged to need none.  That is a property of the machine
+    code, which a compiler update or an innocent edit of gemm_tile.h can take away without any test of results noticing: the
+    built library's gfx950 code object is disassembled and every full stage of the four persistent kernels -- a barrier-to-barrier
+    stretch with exactly 64 MFMAs and nothing else of a tile in it -- is held to zero vector ALU instructions."""
+    lib = os.path.join(ROOT, "hdsdp_amd", "libhdsdp_mi355x.so")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(lib) and shutil.which("objcopy") and os.path.exists(os.path.join(llvm, "clang-offload-bundler"))):
+        pytest.skip("library or binutils / ROCm LLVM tools not available")
+    fat = str(tmp_path / "fatbin.bin")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+    data = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), data)]
+    dis = None
+    for k, st in enumerate(starts):          # one bundle per translation unit: find the persistent kernels' code object
+        en = starts[k + 1] if k + 1 < len(starts) else len(data)
+        b, o = str(tmp_path / ("b%d.bin" % k)), str(tmp_path / ("co%d.o" % k))
+        open(b, "wb").write(data[st:en])
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + b, "--output=" + o], capture_output=True)
+        if not os.path.exists(o):
+            continue
+        syms = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-t", o], capture_output=True, text=True).stdout
+        if "hdm_gemm_persist_kernel" in syms:
+            dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", o], capture_output=True, text=True).stdout
+            break
+    assert dis, "no code object with the persistent GEMM kernels in the library"
+    funcs, cur = {}, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            funcs[cur] = []
+        elif cur and line.startswith("\t"):
+            funcs[cur].append(line.split()[0])
+    kernels = {k: v for k, v in funcs.items() if "hdm_gemm_persist_kernel" in k}
+    assert len(kernels) == 4, sorted(kernels)
+    for name, ins in kernels.items():
+        windows, w = [], []
+        for op in ins:
+            if op == "s_barrier":
+                windows.append(w)
+                w = []
+            else:
+                w.append(op)
+        full = [x for x in windows if sum(o.startswith("v_mfma") for o in x) == 64 and len(x) <= 160]
+        assert len(full) >= 1, (name, len(full))
+        for x in full:
+            valu = [o for o in x if o.startswith("v_") and not o.startswith("v_mfma")]
+            assert not valu, (name, valu)
+            assert sum(o.startswith("ds_read") for o in x) == 32 and sum(o.startswith("buffer_load_dwordx4") for o in x) == 8, name
