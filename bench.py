@@ -28,7 +28,9 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X vendor figure for dense fp64 matrix; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 
 
-# HBM bytes per launch of the hot kernels come from the newest profiles/*_traffic.json (tools/gpu_profile.sh: separate
+# `roofline.traffic`: L2-miss (fabric) bytes per launch of the hot kernels -- FETCH_SIZE / WRITE_SIZE count memory-side requests,
+# Infinity-Cache hits INCLUDED (/opt/skills/guides/MI355X_MICROARCH.md), so the figure is an upper bound on HBM bytes, not HBM
+# bytes.  It comes from the newest profiles/*_traffic.json taken at this (n, m) (tools/gpu_profile.sh <tag> [--m 8000]: separate
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, condensed by tools/prof_summary.py --traffic;
 # FETCH_SIZE x 2 for the gfx950 wide-read correction + WRITE_SIZE, KiB).  bench.py cannot run the profiler on itself, so
 # the file is matched on the kernel's NAME (role and variant are template arguments): a kernel that was renamed or
@@ -39,7 +41,12 @@ KERNEL_SYMBOL = {1: KERNEL_NAME + "<false, true, 1, 64>", 2: KERNEL_NAME + "<fal
                  3: KERNEL_NAME + "<true, true, 3, 64>"}
 
 
-def traffic_bytes_per_launch(role):
+def _profile_size(d):
+    """(n, m) a traffic file was taken at; files from before round 5 carry no size and were all taken at n = m = 2000"""
+    return (int(d.get("n", 2000)), int(d.get("m", 2000)))
+
+
+def traffic_bytes_per_launch(role, n=2000, m=2000):
     """(bytes per launch or None, description of the source).  The newest profiles/*_traffic.json BY ITS OWN TIMESTAMP
     (`taken_utc`, written by tools/prof_summary.py --traffic) is used, and only if it was measured on the kernel sources
     this build was made from (`kernel_source_sha`) with the same launch form (`persist`): anything else gives None and
@@ -56,10 +63,10 @@ def traffic_bytes_per_launch(role):
                 d = json.load(fh)
         except Exception:
             continue
-        if "taken_utc" in d and (best is None or d["taken_utc"] > best[1]["taken_utc"]):
+        if "taken_utc" in d and _profile_size(d) == (n, m) and (best is None or d["taken_utc"] > best[1]["taken_utc"]):
             best = (f, d)
     if best is None:
-        return None, "no profiles/*_traffic.json carries a timestamp and a kernel source hash"
+        return None, "no profiles/*_traffic.json taken at n=%d m=%d carries a timestamp and a kernel source hash" % (n, m)
     f, d = best
     tag = "%s (taken %s on kernel sources %s)" % (os.path.basename(f), d["taken_utc"], d.get("kernel_source_sha"))
     if d.get("kernel_source_sha") != kernel_source_sha(ROOT):
@@ -217,9 +224,9 @@ def device_pci_bus(index):
         return None
 
 
-def mfma_busy_from_profiles(role):
+def mfma_busy_from_profiles(role, n=2000, m=2000):
     """MFMA-busy share of one role's kernel from the newest kept PMC summary (profiles/*_summary_pmc_SQ_VALU_MFMA_BUSY*.txt)
-    whose traffic.json names the kernel sources of this build; None otherwise"""
+    whose traffic.json names the kernel sources of this build and this (n, m); None otherwise"""
     import glob
     import re
     try:
@@ -229,7 +236,8 @@ def mfma_busy_from_profiles(role):
         best = None
         for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
             try:
-                if json.load(open(tj)).get("kernel_source_sha") == sha:
+                dj = json.load(open(tj))
+                if dj.get("kernel_source_sha") == sha and _profile_size(dj) == (n, m):
                     best = tj
             except Exception:
                 pass
@@ -523,12 +531,13 @@ def main():
     dom = max((1, 2, 3), key=lambda r: kms[r])
     dom_ms = kms[dom] / max(1, kln[dom])
     achieved = (kfl[dom] / max(1, kln[dom])) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    traffic = traffic_bytes_per_launch(dom) if (n, m, world, shards) == (2000, 2000, 1, 1) else (None, "measured for n=m=2000 on one GPU only")
+    traffic = traffic_bytes_per_launch(dom, n, m) if (world, shards) == (1, 1) else (None, "measured on one GPU only")
     roofline = {
         "bound": "mfma", "kernel": names[dom],
         "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
         "traffic": traffic[0], "traffic_source": traffic[1],
+        "traffic_is": "L2-miss (fabric) bytes per launch, Infinity-Cache hits included: an upper bound on HBM bytes",
         # what one launch has to move at the least: step 1 reads A_L (skyline, 8.5 n^2/2... per constraint) and writes
         # U's lower tiles; step 2 reads U and writes the blocked lower triangle; the Gram product reads its operand once and writes its
         # slabs.  traffic / algorithmic is the re-read factor: operand panels are re-read per tile and only partly served by L2 --
@@ -560,7 +569,7 @@ def main():
                                   round(achieved / (FP64_MFMA_PEAK_TFLOPS * power_clock["shader_clock_mhz"][1] / 2400.0), 4)),
         # busy share of the matrix pipe in the dominant kernel, from the PMC pass of the newest kept profile set of these kernel
         # sources (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024)); None when that set was taken on other sources
-        "mfma_busy_profiled": mfma_busy_from_profiles(dom) if (n, m, world, shards) == (2000, 2000, 1, 1) else None,
+        "mfma_busy_profiled": mfma_busy_from_profiles(dom, n, m) if (world, shards) == (1, 1) else None,
     }
     out = {
         "metric": "IPM iterations/sec (Schur build+factor+solve), n=%d m=%d dense SDP" % (n, m),

@@ -58,8 +58,9 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, lo
     return 0;
 }
 
-// Gram partial sums of the K splits [z0, z0 + nz): slabs z0.. <- Ahat * Ahat^T over their share of this rank's p-range
-int gram_splits(MiCone *c, int z0, int nz) {
+// Gram partial sums of the K splits [z0, z0 + nz): slabs slab0.. <- (or +=, `accumulate`) Ahat * Ahat^T over their share of this
+// rank's p-range.  slab0 < 0: slab z0 (one slab per split, the sharded builds' form)
+int gram_splits(MiCone *c, int z0, int nz, int slab0 = -1, bool accumulate = false) {
     HdmGemmArgs gq = {};
     gq.A = c->AhatAll; gq.B = c->AhatAll; gq.a_kmajor = 1; gq.b_kmajor = 1;
     gq.lda = 16; gq.ldb = 16; gq.a_kblk = (long) c->Lr * 16; gq.b_kblk = (long) c->Lr * 16;
@@ -70,7 +71,9 @@ int gram_splits(MiCone *c, int z0, int nz) {
     gq.k_chunk = chunk * 16; gq.slab_stride = c->R * c->R; gq.alpha = 1.0; gq.role = HDM_ROLE_GRAM;
     gq.k_base = (long) z0 * gq.k_chunk;
     gq.spanA = gq.spanB = (long) c->world * c->npb_loc * c->Lr * 16 + HDM_OPERAND_PAD_DOUBLES;
-    gq.C = c->slabs + (long) z0 * gq.slab_stride;
+    gq.C = c->slabs + (long) (slab0 < 0 ? z0 : slab0) * gq.slab_stride;
+    gq.beta = accumulate ? 1.0 : 0.0;
+    gq.queue_global = c->gram_queue_global ? 1 : 0;
     {   // (m+3)(m+4)/2 inner products of length n(n+1)/2 (this rank's share), 2 flops each
         const double rows = (double) c->m + 3.0;
         gq.flops = rows * (rows + 1.0) * 0.5 * ((double) c->n * (c->n + 1) * 0.5) * 2.0 / c->world * ((double) nz / c->nsplit);
@@ -80,8 +83,11 @@ int gram_splits(MiCone *c, int z0, int nz) {
 
 int gram_all(MiCone *c) {
     // Gm(lower) = sum over this rank's p-range of Ahat * Ahat^T, rows in segment order
-    if (gram_splits(c, 0, c->nsplit)) return 1;
-    return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, c->R, g.stream);
+    // nslab < nsplit (one device, long packed index): the splits run in groups of nslab, launch after launch on the engine stream,
+    // group g accumulating into the slabs group g - 1 left (fixed order: bitwise reproducible) -- cone_alloc_gemm_work says why
+    for (int z0 = 0; z0 < c->nsplit; z0 += c->nslab)
+        if (gram_splits(c, z0, std::min(c->nslab, c->nsplit - z0), 0, z0 > 0)) return 1;
+    return hdm_slab_reduce(c->slabs, c->R * c->R, std::min(c->nslab, c->nsplit), c->Gm, c->R * c->R, c->R, g.stream);
 }
 
 // world > 1: the all-to-all that re-shards Ahat from "by constraint" to "by packed-index range", and the Gram product.

@@ -64,9 +64,11 @@ struct MiCone {
     double *AhatLoc = nullptr; // [world*npb_loc][Lr][16] congruence output of the owned rows
     double *AhatAll = nullptr; // [world][npb_loc][Lr][16] after the transpose (== AhatLoc when world == 1)
     bool ext_ahat = false;     // buffers supplied by the caller (torch-owned, for RCCL)
-    double *slabs = nullptr;   // nsplit x R x R
+    double *slabs = nullptr;   // nslab x R x R
     double *Gm = nullptr;      // R x R augmented Gram (lower valid)
-    int nsplit = 1;
+    int nsplit = 1;            // K splits of the Gram product
+    int nslab = 1;             // slabs they are summed into (== nsplit unless the splits run in groups: one device, gram_all)
+    bool gram_queue_global = false;   // the Gram launch's workgroups draw (split, tile) jobs from ONE queue in split order
     long R = 0;                // world * Lr
     // R1 work
     double *U = nullptr, *V = nullptr, *Gr1 = nullptr, *Ct = nullptr, *W = nullptr, *Xinv = nullptr, *Yinv = nullptr;
@@ -306,6 +308,16 @@ int cone_alloc_gemm_work(MiCone *c) {
         c->slabs = nullptr;
         if (ns <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the Gram slabs\n"); return 1; }
         ns = std::max(8L, (ns / 2) & ~7L);
+    }
+    c->nslab = c->nsplit;
+    if (c->world == 1) {
+        // EXPERIMENT knobs (round 5): HDM_GRAM_KSTAGES = stages (16 k each) per (split, tile) job -> more splits than slabs, run in
+        // groups of nslab; HDM_GRAM_QUEUE=1: one global job queue in split order
+        if (const char *e = getenv("HDM_GRAM_KSTAGES")) {
+            const long kst = std::max(16L, atol(e));
+            c->nsplit = (int) std::max<long>(c->nslab, (kblocks + kst - 1) / kst);
+        }
+        if (const char *e = getenv("HDM_GRAM_QUEUE")) c->gram_queue_global = atoi(e) != 0;
     }
     HDM_HIP_CHECK(hipMalloc((void **) &c->Gm, sizeof(double) * (size_t) c->R * c->R));
     // the "S row" (At = I) never changes

@@ -1049,14 +1049,18 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_persist_kernel(HdmGemmDev p, 
     __shared__ int s_idx;
     const int nb = p.a.batch, ntiles = p.ntiles;
     const int x = (int) __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;   // HW_REG_XCC_ID[3:0]
-    for (int dx = 0; dx < 8; ++dx) {
-        const int xq = (x + dx) & 7;
+    // queue_global: one queue (cnt[0]) for all XCDs, entry by entry in order -- every workgroup of the chip is then on the entry
+    // at the queue's front or the one after it, so the operand bytes in use at any time are those of ~one entry (a K split of the
+    // Gram product), which is what the memory-side cache can hold (engine_cone.h: cone_alloc_gemm_work)
+    const bool one_queue = p.a.queue_global != 0;
+    for (int dx = 0; dx < (one_queue ? 1 : 8); ++dx) {
+        const int xq = one_queue ? 0 : ((x + dx) & 7);
         while (true) {
             __syncthreads();                 // the previous tile's LDS images and s_idx are done with
             if (threadIdx.x == 0) s_idx = atomicAdd(&cnt[xq], 1);
             __syncthreads();
             const int idx = __builtin_amdgcn_readfirstlane(s_idx);
-            const int z = xq + 8 * (idx / ntiles);
+            const int z = one_queue ? idx / ntiles : xq + 8 * (idx / ntiles);
             if (z >= nb) break;
             hdm_gemm_tile<AKM, BKM, ROLE, VAR>(p, z, idx % ntiles, (long) z * ntiles + idx % ntiles);
         }

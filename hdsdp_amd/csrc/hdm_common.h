@@ -117,6 +117,8 @@ struct HdmGemmArgs {
                                        // builds run congruence step 2 by packed-index range, see engine.hip)
     int epilogue;     // HdmEpilogue
     int batch;        // number of batch entries (grid z for STORE/BLOCKED), or #K-splits for SLAB
+    int queue_global; // persistent launches: ONE job queue for the whole chip, batch entry (K split) by batch entry in order,
+                      // instead of one queue per XCD over the entries x, x + 8, ... (gemm_tile.h: hdm_gemm_persist_kernel)
     double alpha, beta;
     int role;         // HdmRole
     double flops;     // algorithmic flops of this launch (valid data only), for the live roofline

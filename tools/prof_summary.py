@@ -31,10 +31,13 @@ def kernel_source_sha(root=None):
 def traffic(dirs):
     """--traffic <FETCH_SIZE run dir> <WRITE_SIZE run dir>: HBM bytes per launch of every kernel as JSON, the way
     /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (separate --pmc passes; the counters are in KiB;
-    FETCH_SIZE x 2 for the wide-read correction): {kernel name: {fetch_kib, write_kib, launches, bytes_per_launch}}.
+    FETCH_SIZE x 2 for the wide-read correction; `--nm NxM` first names the bench size the passes ran at): {kernel name: {fetch_kib, write_kib, launches, bytes_per_launch}}.
     bench.py reads the newest profiles/*_traffic.json and matches on the kernel name, so a renamed or re-templated
     kernel shows up as `traffic: null` instead of a stale number."""
     import json
+    nm = "2000x2000"
+    if dirs and dirs[0] == "--nm":
+        nm, dirs = dirs[1], dirs[2:]
     agg = defaultdict(lambda: {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -52,7 +55,9 @@ def traffic(dirs):
         out[k.replace("void ", "")] = {"fetch_kib": fk, "write_kib": wk, "launches": nf,
                                        "bytes_per_launch": (2.0 * fk + wk) * 1024.0}
     import time
-    print(json.dumps({"unit": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024",
+    print(json.dumps({"unit": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024: L2-miss (fabric) bytes, "
+                              "Infinity-Cache hits included -- an upper bound on HBM bytes",
+                      "n": int(nm.split("x")[0]), "m": int(nm.split("x")[1]),
                       "kernel_source_sha": kernel_source_sha(), "persist": os.environ.get("HDM_PERSIST", "1") != "0",
                       "taken_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "kernels": out}, indent=1))
 
