@@ -214,6 +214,33 @@ def cpu_baseline_blas3(n, m):
         return {"value": None, "unit": "it/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
 
 
+def sharded_step_profile(profiles, stage_ms_ranks):
+    """Condense the per-shard profiles of the LAST timed step's build (api.SDPCone.build_profile, one per rank) into what a
+    multi-GPU line needs to diagnose itself: for every stage [min, max] over the ranks; per exchange piece the same for step 2
+    of its tile columns, the exchange WAIT (engine stream idle because the piece had not arrived), its Gram splits, the
+    bytes a rank sent and the achieved GB/s (bytes / time from hand-over to arrival, host clock: a lower bound).
+    `stage_ms_ranks`: per rank the host-timed stages of the step (assemble+factor S, build-up, factor M, three solves)."""
+    prof = [p for p in profiles if p]
+    if not prof:
+        return None
+    mm = lambda xs: [round(float(min(xs)), 3), round(float(max(xs)), 3)]
+    P = prof[0]["pieces"]
+    out = {"ranks": len(prof), "pieces": P, "staged": prof[0]["staged"], "min_max_over_ranks_ms": {}}
+    keys = [k for k in ("invert_ms", "congruence_step1_ms", "congruence_ms", "slab_reduce_ms", "allreduce_ms", "extract_ms") if k in prof[0]]
+    for k in keys:
+        out["min_max_over_ranks_ms"][k] = mm([p[k] for p in prof])
+    for k, name in (("step2_piece_ms", "congruence_step2_by_piece"), ("exchange_wait_ms", "exchange_wait_by_piece"),
+                    ("exchange_wait_host_ms", "exchange_wait_host_by_piece"), ("gram_piece_ms", "gram_by_piece")):
+        out["min_max_over_ranks_ms"][name] = [mm([p[k][j] for p in prof]) for j in range(P)]
+        out["min_max_over_ranks_ms"][name.replace("_by_piece", "_total")] = mm([sum(p[k]) for p in prof])
+    out["bytes_sent_per_rank"] = mm([sum(p["piece_bytes_sent"]) for p in prof])
+    out["piece_bytes_sent"] = [round(float(np.mean([p["piece_bytes_sent"][j] for p in prof]))) for j in range(P)]
+    out["piece_gb_per_s"] = [mm([p["piece_bytes_sent"][j] / max(p["piece_flight_ms"][j], 1e-6) * 1e-6 for p in prof]) for j in range(P)]
+    if stage_ms_ranks:
+        out["replicated_ms"] = {k: mm([s[k] for s in stage_ms_ranks]) for k in ("assemble_S+chol_S", "factor_M", "solve3")}
+    return out
+
+
 def device_pci_bus(index):
     """'dddd:bb:dd.f' of a visible device, or None"""
     try:
@@ -377,7 +404,11 @@ def plan_devices(gpus, ndev, world, loopback, self_test=rccl_self_test_in_child)
         plan.update(transport_request=api.TRANSPORT_COPY, transport="device copies", rccl_ranks=0,
                     transport_fallback_reason="shards share devices (--loopback): RCCL needs one device per rank")
         return plan
-    ok, why = self_test(ids)
+    if under_profiler():
+        # the profiler's preloaded library has the GPU initialised in any child before its exec: no self-test child
+        ok, why = False, "under a profiler: RCCL self-test child not started"
+    else:
+        ok, why = self_test(ids)
     if ok:
         plan.update(transport_request=api.TRANSPORT_RCCL, transport="rccl", rccl_ranks=gpus, transport_fallback_reason=None)
     else:
@@ -506,15 +537,30 @@ def main():
     power_clock = sampler.stop() if sampler else None
     lib.HMiSetKernelTiming(0)
     import ctypes as C
-    kms, kfl = np.zeros(5), np.zeros(5)      # roles 0-3 + [4] = the full diagonal tiles of congruence step 2 (their own kernel)
+    kms, kfl, kis = np.zeros(5), np.zeros(5), np.zeros(5)   # roles 0-3 + [4] = the full diagonal tiles of congruence step 2 (their own kernel)
     kln = np.zeros(5, dtype=np.int64)
-    lib.HMiGetKernelTiming(kms.ctypes.data_as(C.POINTER(C.c_double)), kfl.ctypes.data_as(C.POINTER(C.c_double)),
-                           kln.ctypes.data_as(C.POINTER(C.c_int64)))
+    lib.HMiGetKernelTimingEx(kms.ctypes.data_as(C.POINTER(C.c_double)), kfl.ctypes.data_as(C.POINTER(C.c_double)),
+                             kis.ctypes.data_as(C.POINTER(C.c_double)), kln.ctypes.data_as(C.POINTER(C.c_int64)))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64,
                           device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # where the last step's sharded build went, per rank: in-process device group -> one profile per shard; torchrun -> gathered
+    stage_now = {k: v / args.steps * 1e3 for k, v in stage.items()}
+    shard_prof = None
+    if world == 1 and shards > 1:
+        shard_prof = sharded_step_profile([cone.build_profile(r) for r in range(shards)], [stage_now])
+    elif world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, (cone.build_profile(0), stage_now))
+        shard_prof = sharded_step_profile([g_[0] for g_ in gathered], [g_[1] for g_ in gathered])
+    streamed_ranks = None
+    if world > 1:   # how many ranks stream their constraint rows (engine_create.h decides from the device's capacity: all or none)
+        ts = torch.tensor([1.0 if cone.streaming()[0] else 0.0], dtype=torch.float64,
+                          device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(ts)
+        streamed_ranks = int(ts.item())
     if rank != 0:
         if world > 1:
             torch.distributed.barrier()
@@ -547,6 +593,14 @@ def main():
         "power_clock": power_clock,
         "avg_launch_ms": round(float(dom_ms), 4), "launches": int(kln[dom]),
         "flops_per_launch": float(kfl[dom] / max(1, kln[dom])),
+        # flops the dominant kernel's MFMA instructions EXECUTED over its algorithmic flops (host count from the tile lists and
+        # the kernel's stage sequences, csrc/gemm_f64.hip: issued_mfma_flops; held to SQ_VALU_MFMA_BUSY_CYCLES / 64 of the kept
+        # profile to 2e-5): the granularity loss -- 16 x 16 sub-blocks straddling a diagonal, live ranges of triangular K
+        # blocks, padding rows.  `achieved_issued` prices the launches with the executed count (what the matrix pipe really did)
+        "issued_over_valid": round(float(kis[dom] / max(kfl[dom], 1.0)), 4),
+        "achieved_issued": round(float(kis[dom] / max(kms[dom], 1e-9) / 1e9), 3),
+        "issued_over_valid_by_role": {short[r]: round(float(kis[r] / max(kfl[r], 1.0)), 4) for r in (1, 2, 3)},
+        "issued_over_valid_congruence_step2_whole": round(float((kis[2] + kis[4]) / max(kfl[2] + kfl[4], 1.0)), 4),
         # the same launch priced with SURVEY 8(d)'s per-unit figure (the reference's M3 count: 3 n^3 per constraint
         # for S^-1 A S^-1, n(n+1) per row pair for the trace part): congruence = steps 1+2 together
         "survey_count": survey_equiv(n, m, world, kms, kln, args.steps),
@@ -586,6 +640,7 @@ def main():
                    "rccl_ranks": ((world if torch.distributed.get_backend() == "nccl" else 0) if world > 1 else plan["rccl_ranks"]),
                    "stage_ms": {k: round(v / args.steps * 1e3, 3) for k, v in stage.items()},
                    "constraint_data": ("streamed: regenerated %d rows at a time" % cone.streaming()[1]) if cone.streaming()[0] else "resident",
+                   "streamed_ranks": streamed_ranks,
                    "setup_s": round(setup_s, 1),
                    "whole_step_tflops_survey_count": round(survey_flops(n, m) / (ms_per_step * 1e-3) / 1e12, 2),
                    "whole_step_tflops_executed": round(executed_flops(n, m) / (ms_per_step * 1e-3) / 1e12, 2)},
@@ -603,6 +658,8 @@ def main():
     if ex is not None:
         out["config"]["exchange_bytes_per_step"] = {"all_to_all": ex.bytes_a2a // (args.steps + args.warmup),
                                                     "all_reduce": ex.bytes_ar // (args.steps + args.warmup)}
+    if shard_prof is not None:
+        out["sharded_step"] = shard_prof
     if small is not None:
         out["small_configs"] = small
     if not args.no_cpu and world == 1 and not under_profiler():

@@ -34,11 +34,11 @@ EXPORTS = [
     "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeCheckIsInteriorExpert",
     "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetCoeffNorm", "HMiConeGetObjNorm",
     "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
-    "HMiConeGetTraces", "HMiConeGetPath", "HMiConeSweepInfo", "HMiConeGetStreaming", "HMiConeUseSweepCopy", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeBuildPrimalXSXDirection",
+    "HMiConeGetTraces", "HMiConeGetPath", "HMiConeSweepInfo", "HMiConeGetStreaming", "HMiConeUseSweepCopy", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeGetBuildProfile", "HMiConeBuildPrimalXSXDirection",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiKKTGetRows", "HMiDeviceInit",
     "HMiSetDevices", "HMiSetDevicesEx", "HMiRcclGroupSelfTest", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
     "HMiDeviceSynchronize", "HMiStream", "HMiVersion", "HMiGetStageTimes", "HMiGemmNT", "HMiPotrf",
-    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiKKTTileInfo", "HMiKKTNegativePivots", "HMiBspSolve", "HMiRcmOrder", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
+    "HMiMfmaPeakProbe", "HMiDiagBlockProbe", "HMiCholEnvelopeSolve", "HMiCholEnvelopeProbe", "HMiKKTEnvelopeInfo", "HMiKKTTileInfo", "HMiKKTNegativePivots", "HMiBspSolve", "HMiRcmOrder", "HMiSetKernelTiming", "HMiGetKernelTiming", "HMiGetKernelTimingEx", "HMiPresolveCSC", "HMiMfmaIssueProbe", "HMiSetDebugBuffer",
     "HMiReadSDPA", "HMiSDPAGetDims", "HMiSDPAGetBlock", "HMiSDPAGetBlock64", "HMiSDPAGetRHS", "HMiSDPAFree",
 ]
 
@@ -152,6 +152,7 @@ def load_library():
         "HMiConeSetExchange": (None, [vp, vp, vp, vp]),
         "HMiConeSetExchangePieces": (None, [vp, vp, vp, C.c_int]),
         "HMiConeGetExchangeStats": (None, [vp, ip, ip]),
+        "HMiConeGetBuildProfile": (C.c_int, [vp, C.c_int, dp, C.c_int]),
         "HMiConeBuildPrimalXSXDirection": (None, [vp, dp, dp, C.c_int]),
         "HMiConeGetExchangeBuffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]),
         "HMiConeSetExchangeBuffers": (C.c_int, [vp, vp, vp]),
@@ -204,6 +205,7 @@ def load_library():
         "HMiSetDebugBuffer": (None, [vp, C.c_int]),
         "HMiSetKernelTiming": (None, [C.c_int]),
         "HMiGetKernelTiming": (C.c_int, [dp, dp, C.POINTER(C.c_int64)]),
+        "HMiGetKernelTimingEx": (C.c_int, [dp, dp, dp, C.POINTER(C.c_int64)]),
     }
     for name in EXPORTS:
         fn = getattr(lib, name)  # AttributeError == missing export
@@ -468,6 +470,22 @@ class SDPCone:
         p, s = C.c_int(0), C.c_int(0)
         load_library().HMiConeGetExchangeStats(self._h, C.byref(p), C.byref(s))
         return p.value, s.value
+
+    def build_profile(self, shard=0):
+        """where the last SHARDED Schur build of one shard spent its time (HMiConeGetBuildProfile; ms, bytes): None when no
+        sharded build has run on it"""
+        buf = np.zeros(8 + 6 * 64)
+        k = int(load_library().HMiConeGetBuildProfile(self._h, int(shard), _dptr(buf), int(buf.size)))
+        if k <= 0:
+            return None
+        P = int(buf[0])
+        per = buf[8:8 + 6 * P].reshape(P, 6)
+        return {"pieces": P, "staged": bool(buf[1]), "invert_ms": float(buf[2]),
+                ("congruence_step1_ms" if buf[1] else "congruence_ms"): float(buf[3]), "slab_reduce_ms": float(buf[4]),
+                "allreduce_ms": float(buf[5]), "extract_ms": float(buf[6]), "world": int(buf[7]),
+                "step2_piece_ms": per[:, 0].tolist(), "exchange_wait_ms": per[:, 1].tolist(),
+                "exchange_wait_host_ms": per[:, 2].tolist(), "gram_piece_ms": per[:, 3].tolist(),
+                "piece_bytes_sent": per[:, 4].tolist(), "piece_flight_ms": per[:, 5].tolist()}
 
     def presolve(self):
         m = self.m

@@ -798,6 +798,7 @@ int HdmChol::enqueue_factor(hipStream_t s) {
     // (a kernel, not hipMemsetAsync: this chain is captured into a hipGraph, and under HDM_POISON a replay of the captured
     // MEMSET node was seen to leave 0xFFFFFFFF in the word -- profiles/r04_c_poison.txt; a kernel node behaves like its neighbours)
     hipLaunchKernelGGL(hdm_zero_word_kernel, dim3(1), dim3(1), 0, s, info_dev);
+    HDM_HIP_CHECK(hipGetLastError());   // a launch that did not happen would leave the previous chain's info word in place
     const long ld = npad;
     const size_t shm = (NB * NB + LDW * PB) * sizeof(double);
     static const bool diag_sweep = [] { const char *e = getenv("HDM_DIAG_SWEEP"); return !(e && atoi(e) == 0); }();

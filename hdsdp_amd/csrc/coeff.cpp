@@ -4,9 +4,31 @@
 // corner is stated where it is implemented.
 #include "coeff.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <utility>
+
+// host threads for the passes over a block's entries (presolve here, staging of the upload in engine_create.h):
+// HDSDP_MI355X_HOST_THREADS, default min(16, hardware threads)
+int mi_host_threads() {
+    static const int n = [] {
+        if (const char *e = getenv("HDSDP_MI355X_HOST_THREADS")) return std::max(1, atoi(e));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int) std::max(1u, std::min(16u, hw ? hw : 1u));
+    }();
+    return n;
+}
+void mi_parallel(int nthreads, const std::function<void(int)> &fn) {
+    if (nthreads <= 0) nthreads = mi_host_threads();
+    if (nthreads == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(fn, t);
+    fn(0);
+    for (auto &t : th) t.join();
+}
 
 namespace {
 
@@ -86,6 +108,37 @@ bool probe_rank_one_dense(int n, const std::vector<double> &A, double &sign, std
     return true;
 }
 
+// The first column of probe_rank_one_dense on the sorted entry list (same positions, same arithmetic, same order of the sum):
+// false iff the probe would give up after column 0 -- or finds no non-zero diagonal entry at all.
+bool dense_probe_may_pass(int n, const std::vector<int> &idx, const std::vector<double> &val) {
+    const PackedIndex px{n};
+    auto at = [&](long pos) {   // value at a packed position (0 where nothing is stored)
+        auto it = std::lower_bound(idx.begin(), idx.end(), (int) pos);
+        return (it != idx.end() && *it == (int) pos) ? val[(size_t) (it - idx.begin())] : 0.0;
+    };
+    int pc = 0;
+    while (pc < n && at(px.columns_before(pc)) == 0) ++pc;
+    if (pc == n) return false;
+    const double d = at(px.columns_before(pc));
+    const double s = (d > 0) ? 1.0 : -1.0, scale = std::sqrt(std::fabs(d));
+    const long origin = px.columns_before(pc) - pc;
+    // a[0 .. n-1] = A[origin + r] / scale: one contiguous range of packed positions
+    std::vector<double> a((size_t) n, 0.0);
+    {
+        size_t k = (size_t) (std::lower_bound(idx.begin(), idx.end(), (int) origin) - idx.begin());   // (origin >= 0)
+        for (; k < idx.size() && idx[k] < origin + n; ++k) a[(size_t) (idx[k] - origin)] = val[k];
+        for (int r = 0; r < n; ++r) a[r] /= scale;
+    }
+    double resid = 0.0;
+    size_t k = 0;
+    for (long r = 0; r < n; ++r) {          // column 0 occupies packed positions 0 .. n-1
+        double v = 0.0;
+        if (k < idx.size() && idx[k] == r) v = val[k++];
+        resid += std::fabs(v - s * a[0] * a[r]);
+    }
+    return !(resid > kRankOneTol);
+}
+
 // Descending order by key with the reference's tie behaviour: its quicksort takes the first element of a range as the pivot,
 // closes in from both ends (from the right past keys <= pivot, from the left past keys >= pivot), exchanges, and finally
 // puts the pivot where the ends met; keys and indices move together.  Ties therefore end up in an order of their own, which
@@ -123,7 +176,8 @@ int mi_coeff_build(MiCoeff &c, int n, long nnz, const int *idx, const double *va
     const long P = px.size();
     c = MiCoeff();
     c.stored = nnz;
-    if (nnz <= 0) return 0;                                  // ZERO
+    if (nnz < 0) return 1;                                   // column pointers that run backwards
+    if (nnz == 0) return 0;                                  // ZERO
     if (nnz > P) return 1;
     c.idx.assign(idx, idx + nnz);
     c.val.assign(val, val + nnz);
@@ -134,6 +188,8 @@ int mi_coeff_build(MiCoeff &c, int n, long nnz, const int *idx, const double *va
         for (long k = 0; k < nnz; ++k) { c.idx[k] = idx[o[k]]; c.val[k] = val[o[k]]; }
     }
     if (c.idx.front() < 0 || c.idx.back() >= P) return 1;
+    for (long k = 1; k < nnz; ++k)
+        if (c.idx[k] == c.idx[k - 1]) return 1;              // the same packed position twice: not a matrix (the classes would disagree on its value)
     {   // trace: the diagonal positions are the column starts
         long j = 0, first = 0;
         for (long k = 0; k < nnz; ++k) {
@@ -147,9 +203,15 @@ int mi_coeff_build(MiCoeff &c, int n, long nnz, const int *idx, const double *va
     if ((double) nnz > kDenseShare * (double) P) {
         c.type = MI_COEFF_DENSE;
         c.nnz = (int) P;
-        std::vector<double> full((size_t) P, 0.0);
-        for (long k = 0; k < nnz; ++k) full[c.idx[k]] = c.val[k];
-        one = probe_rank_one_dense(n, full, sgn, a);
+        // The probe reads the whole packed matrix only if it IS rank one; for anything else its residual passes the tolerance in
+        // the first column.  That first column is decided on the sorted entries (n positions of the candidate factor + the
+        // entries of column 0: two short walks), and the 8 P-byte dense image -- 16 MB at n = 2000, per constraint -- is made
+        // only for a matrix that survives it.
+        if (dense_probe_may_pass(n, c.idx, c.val)) {
+            std::vector<double> full((size_t) P, 0.0);
+            for (long k = 0; k < nnz; ++k) full[c.idx[k]] = c.val[k];
+            one = probe_rank_one_dense(n, full, sgn, a);
+        }
     } else {
         c.type = MI_COEFF_SPARSE;
         c.nnz = (int) nnz;
@@ -221,8 +283,14 @@ template <class Off> static int block_from_csc(MiBlockData &blk, int m, int n, c
     blk.m = m;
     blk.rows.assign((size_t) m, MiCoeff());
     if (mi_coeff_build(blk.obj, n, (long) (beg[1] - beg[0]), idx + beg[0], val + beg[0])) return 1;
-    for (int i = 0; i < m; ++i)
-        if (mi_coeff_build(blk.rows[i], n, (long) (beg[i + 2] - beg[i + 1]), idx + beg[i + 1], val + beg[i + 1])) return 1;
+    // the columns are independent: host threads take them one by one (19 GB of entries at n = m = 2000: copy, order check,
+    // trace, class and rank-one probe are all passes over memory)
+    std::atomic<int> next{0}, bad{0};
+    mi_parallel((long) (beg[m + 1] - beg[1]) >= (1L << 22) ? 0 : 1, [&](int) {
+        for (int i = next.fetch_add(1); i < m; i = next.fetch_add(1))
+            if (mi_coeff_build(blk.rows[i], n, (long) (beg[i + 2] - beg[i + 1]), idx + beg[i + 1], val + beg[i + 1])) bad.store(1);
+    });
+    if (bad.load()) return 1;
     mi_block_plan(blk);
     return 0;
 }

@@ -23,7 +23,12 @@
 // (interface/def_hdsdp_user_data.h:22-32).  One column holds at most P < 2^31 entries (n <= 65535).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
+
+// fn(t) on `nthreads` host threads (0: HDSDP_MI355X_HOST_THREADS, default min(16, hardware threads)); returns when all are done
+int mi_host_threads();
+void mi_parallel(int nthreads, const std::function<void(int)> &fn);
 
 enum MiCoeffType { MI_COEFF_ZERO = 0, MI_COEFF_SPARSE = 1, MI_COEFF_DENSE = 2, MI_COEFF_SPR1 = 3, MI_COEFF_DSR1 = 4 };
 

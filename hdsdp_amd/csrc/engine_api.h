@@ -191,6 +191,30 @@ void HMiSetShardMinDim(int nMin) { if (g_group) g_group->min_n = nMin; }
 int HMiConeGetShardCount(hdsdp_cone *cone) {
     return (cone && cone->coneBuildSchur == gc_build_schur) ? ((MiConeGroup *) cone->coneData)->G->W : 1;
 }
+// the last sharded build's profile of shard `shard` (a plain cone is its own shard 0): see include/hdsdp_mi355x.h for the layout
+int HMiConeGetBuildProfile(hdsdp_cone *cone, int shard, double *out, int cap) {
+    MiCone *c = nullptr;
+    if (cone->coneBuildSchur == gc_build_schur) {
+        MiConeGroup *cg = (MiConeGroup *) cone->coneData;
+        if (shard < 0 || shard >= (int) cg->shard.size()) return -1;
+        c = cg->shard[shard];
+    } else {
+        if (shard != 0) return -1;
+        c = (MiCone *) cone->coneData;
+    }
+    const MiCone::BuildProfile &pf = c->prof;
+    if (!pf.valid) return 0;
+    const int need = 8 + 6 * pf.pieces;
+    if (!out || cap < need) return -need;
+    out[0] = pf.pieces; out[1] = pf.staged; out[2] = pf.invert; out[3] = pf.staged ? pf.step1 : pf.cong;
+    out[4] = pf.reduce; out[5] = pf.allreduce_host; out[6] = pf.extract; out[7] = c->world;
+    for (int k = 0; k < pf.pieces; ++k) {
+        double *o = out + 8 + 6 * k;
+        o[0] = pf.step2[k]; o[1] = pf.wait_gpu[k]; o[2] = pf.wait_host[k]; o[3] = pf.gram[k]; o[4] = pf.bytes[k]; o[5] = pf.flight[k];
+    }
+    return need;
+}
+
 void HMiConeGetGroupTraffic(hdsdp_cone *cone, int64_t *bytesAllToAll, int64_t *bytesAllReduce) {
     int64_t a = 0, b = 0;
     if (cone && cone->coneBuildSchur == gc_build_schur) { MiConeGroup *cg = (MiConeGroup *) cone->coneData; a = cg->bytes_a2a; b = cg->bytes_ar; }

@@ -128,6 +128,14 @@ unsigned long long piece_tile_cols(const MiCone *c, int k, int P) {
     return mask;
 }
 
+static inline double host_now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static inline int prof_record(hipEvent_t &ev, hipStream_t s) {
+    if (!ev && hipEventCreate(&ev) != hipSuccess) return 1;
+    return hipEventRecord(ev, s) != hipSuccess;
+}
+
 // `staged`: congruence step 2 was launched piece by piece and c->piece_ev[k] marks the point where piece k's p-blocks
 // are final, so piece k can leave while the later tile columns are still being computed; otherwise the whole stream
 // is drained first.
@@ -138,13 +146,19 @@ hdsdp_retcode exchange_and_gram(MiCone *c, bool staged = false) {
     }
     if (!staged) HIP_RC(hipStreamSynchronize(g.stream));
     const int P = exchange_pieces(c);
+    const double sent_share = (double) (c->world - 1) * 8.0;   // bytes this shard sends per double of a piece
     if (P <= 1) {
         if (staged) HIP_RC(hipStreamSynchronize(g.stream));
+        const double t0 = host_now();
         if (c->alltoall) { if (c->alltoall(c->xctx)) return HDSDP_RETCODE_FAILED; }
         else {
             if (c->a2a_start(c->xctx, 0, (int64_t) c->npb_loc * c->Lr * 16, 0) || c->a2a_wait(c->xctx, 0)) return HDSDP_RETCODE_FAILED;
         }
-        return gram_all(c) ? HDSDP_RETCODE_FAILED : HDSDP_RETCODE_OK;
+        c->prof.wait_host[0] = c->prof.flight[0] = (host_now() - t0) * 1e3;
+        c->prof.bytes[0] = sent_share * (double) c->npb_loc * c->Lr * 16;
+        if (prof_record(c->pe_ga[0], g.stream) || gram_splits(c, 0, c->nsplit) || prof_record(c->pe_gb[0], g.stream)) return HDSDP_RETCODE_FAILED;
+        return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, c->R, g.stream) ? HDSDP_RETCODE_FAILED
+                                                                                                     : HDSDP_RETCODE_OK;
     }
     const int zper = c->nsplit / P;
     for (int k = 0; k < P; ++k) {
@@ -152,6 +166,8 @@ hdsdp_retcode exchange_and_gram(MiCone *c, bool staged = false) {
         piece_range(c, k, P, &lo, &hi);
         const int64_t off = (int64_t) lo * c->Lr * 16, end = (int64_t) hi * c->Lr * 16;   // doubles inside a chunk
         if (staged) HIP_RC(hipEventSynchronize(c->piece_ev[k]));
+        c->pt_start[k] = host_now();
+        c->prof.bytes[k] = sent_share * (double) (end - off);
         if (c->a2a_start(c->xctx, off, end - off, k)) {
             if (k == 0 && c->alltoall) {
                 // the piecewise flavour is not available in this process group: one blocking exchange from now on
@@ -165,8 +181,13 @@ hdsdp_retcode exchange_and_gram(MiCone *c, bool staged = false) {
         }
     }
     for (int k = 0; k < P; ++k) {
+        const double t0 = host_now();
         if (c->a2a_wait(c->xctx, k)) return HDSDP_RETCODE_FAILED;
-        if (gram_splits(c, k * zper, zper)) return HDSDP_RETCODE_FAILED;
+        const double t1 = host_now();
+        c->prof.wait_host[k] = (t1 - t0) * 1e3;
+        c->prof.flight[k] = (t1 - c->pt_start[k]) * 1e3;
+        if (prof_record(c->pe_ga[k], g.stream) || gram_splits(c, k * zper, zper) || prof_record(c->pe_gb[k], g.stream))
+            return HDSDP_RETCODE_FAILED;
     }
     return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, c->R, g.stream) ? HDSDP_RETCODE_FAILED
                                                                                                  : HDSDP_RETCODE_OK;
@@ -384,6 +405,7 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     }
     if (staged) {
         RC(congruence_rows(c, ch, c->Afull, c->astride, afull_span, c->mloc, 0, 1));
+        if (prof_record(c->pe_s1, g.stream)) return HDSDP_RETCODE_FAILED;
         const unsigned long long all = (NT >= 64) ? ~0ULL : ((1ULL << NT) - 1);
         unsigned long long done = 0;
         for (int k = 0; k < P; ++k) {
@@ -392,15 +414,19 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
             done |= mk;
             if (!c->piece_ev[k]) HIP_RC(hipEventCreateWithFlags(&c->piece_ev[k], hipEventDisableTiming));
             HIP_RC(hipEventRecord(c->piece_ev[k], g.stream));
+            if (prof_record(c->pe_s2[k], g.stream)) return HDSDP_RETCODE_FAILED;
         }
     }
     HIP_RC(hipEventRecord(g.ev[2], g.stream));
+    c->prof.valid = false;
     if (c->world > 1) { RC(exchange_and_gram(c, staged)); }
     else { RC(gram_all(c)); }
     HIP_RC(hipEventRecord(g.ev[3], g.stream));
     if (c->world > 1) {
         HIP_RC(hipStreamSynchronize(g.stream));
+        const double t0 = host_now();
         if (!c->allreduce || c->allreduce(c->xctx, c->Gm, (int64_t) c->R * c->R)) return HDSDP_RETCODE_FAILED;
+        c->prof.allreduce_host = (host_now() - t0) * 1e3;
     }
     const int hsd = (typeKKT == KKT_TYPE_HOMOGENEOUS);
     const long pI = (c->world == 1) ? c->mloc : (c->m + c->world - 1) / c->world;  // rows owned by rank 0 = position of the "I row"
@@ -413,6 +439,22 @@ hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int type
     for (int i = 0; i < 4; ++i) {
         (void) hipEventElapsedTime(&ms, g.ev[i], g.ev[i + 1]);
         g.stage_ms[i] = ms;
+    }
+    if (c->world > 1) {
+        // the sharded build's profile: every event above has completed (ev[4] is the last on the stream)
+        auto el = [](hipEvent_t a, hipEvent_t b) { float t = 0.f; return (a && b && hipEventElapsedTime(&t, a, b) == hipSuccess) ? (double) t : 0.0; };
+        MiCone::BuildProfile &pf = c->prof;
+        const int Pp = std::max(1, std::min(c->last_pieces, MiCone::BuildProfile::MAXP));
+        pf.pieces = Pp; pf.staged = staged ? 1 : 0;
+        pf.invert = g.stage_ms[0]; pf.cong = g.stage_ms[1]; pf.extract = g.stage_ms[3];
+        pf.step1 = staged ? el(g.ev[1], c->pe_s1) : 0.0;
+        for (int k = 0; k < Pp; ++k) {
+            pf.step2[k] = staged ? el(k == 0 ? c->pe_s1 : c->pe_s2[k - 1], c->pe_s2[k]) : 0.0;
+            pf.wait_gpu[k] = el(k == 0 ? g.ev[2] : c->pe_gb[k - 1], c->pe_ga[k]);
+            pf.gram[k] = el(c->pe_ga[k], c->pe_gb[k]);
+        }
+        pf.reduce = el(c->pe_gb[Pp - 1], g.ev[3]);
+        pf.valid = true;
     }
     return HDSDP_RETCODE_OK;
 }

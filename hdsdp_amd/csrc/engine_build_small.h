@@ -170,6 +170,10 @@ void cone_destroy_data(void **pcd) {
     if (c->chk_host) (void) hipHostFree(c->chk_host);
     if (c->checker) { c->checker->destroy(); delete c->checker; }
     for (hipEvent_t e : c->piece_ev) if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t e : c->pe_s2) if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t e : c->pe_ga) if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t e : c->pe_gb) if (e) (void) hipEventDestroy(e);
+    if (c->pe_s1) (void) hipEventDestroy(c->pe_s1);
     if (c->dS) (void) hipFree(c->dS);
     if (c->Xup) (void) hipFree(c->Xup);
     if (c->Pr1) (void) hipFree(c->Pr1);

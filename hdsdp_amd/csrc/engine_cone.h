@@ -79,6 +79,22 @@ struct MiCone {
     int a2a_pieces = 1;
     hipEvent_t piece_ev[64] = {};                // staged exchange: congruence step 2 finished the p-blocks of piece k
     int last_pieces = 1, last_staged = 0;        // HMiConeGetExchangeStats
+    // Where the last sharded Schur build of this shard spent its time (HMiConeGetBuildProfile; bench.py prints min / max over
+    // the ranks): device times between HIP events on the engine stream, host times around the two blocking hooks.
+    struct BuildProfile {
+        static constexpr int MAXP = 64;
+        bool valid = false;
+        int pieces = 1, staged = 0;
+        double invert = 0, step1 = 0, cong = 0, reduce = 0, allreduce_host = 0, extract = 0;
+        double step2[MAXP] = {};       // step 2 of the tile columns piece k needs (staged builds)
+        double wait_gpu[MAXP] = {};    // engine stream idle before piece k's Gram splits: the piece had not arrived
+        double wait_host[MAXP] = {};   // host time inside the wait hook for piece k
+        double gram[MAXP] = {};        // Gram splits of piece k
+        double bytes[MAXP] = {};       // bytes this shard sent for piece k
+        double flight[MAXP] = {};      // host time from handing piece k to the transport until its wait returned
+    } prof;
+    hipEvent_t pe_s1 = nullptr, pe_s2[BuildProfile::MAXP] = {}, pe_ga[BuildProfile::MAXP] = {}, pe_gb[BuildProfile::MAXP] = {};
+    double pt_start[BuildProfile::MAXP] = {};    // host clock (s) at a2a_start of piece k
     hmi_allreduce_fn allreduce = nullptr;
     void *xctx = nullptr;
     bool work_ready = false;
@@ -242,16 +258,24 @@ int cone_alloc_gemm_work(MiCone *c) {
             HDM_HIP_CHECK(hdm_memset_sync(c->AhatAll, 0, ahat));
         }
     }
-    // Gram split-K: the grid is tiles x nsplit workgroups on 512 resident slots (256 CUs x 2).  The split index
-    // is the fast workgroup index, and workgroups are dealt round-robin over the 8 XCDs: with nsplit a multiple
-    // of 8 every XCD keeps to its own K ranges, so the ~64 tiles it runs concurrently share their row/column
-    // panels in that XCD's L2 (profiles/r01_a: with nsplit = 15 the Gram kernel fetched 513 GB per launch,
-    // i.e. every tile load went to the fabric).  Short K ranges (small problems): among the multiples of 8 pick the
-    // one whose last scheduling round is fullest; long K ranges are handled below.
+    // Gram split-K.  The product over the packed index (K = 8 n(n+1) p-blocks of 16) is cut into K splits; a job is (split, tile),
+    // a persistent workgroup draws jobs from ONE queue in split order (HdmGemmArgs.queue_global), partial sums go to slabs that
+    // are reduced in fixed order.  What sets the split length (round 5, profiles/r05_a_8000_*, r05_b_*, r05_c_*): the Gram
+    // kernel is matrix-pipe bound at whatever clock the board's power limit leaves, and what costs power beside the MFMAs is
+    // HBM traffic.  A tile re-reads its two operand panels from the fabric for every job (L2 holds a few stages of them), so the
+    // fabric sees 13-60 x the algorithmic bytes -- which is harmless as long as they are served by the 256 MiB memory-side cache,
+    // i.e. as long as the operand bytes all workgroups of the chip are working on fit there.  With one queue in split order that
+    // is the panel of ONE split (+ the next one's beginning): R rows x k_chunk x 8 B.  At n = 2000, m = 8000 the former form (80
+    // splits of 25 000 k, one per XCD in flight) had 8 x 1.6 GB in use: 7.6 TB of HBM reads per Gram product, 99.7 % MFMA busy at
+    // 2.11 GHz, 68 TFLOP/s; with 256 stages (4096 k, 262 MB) per job 2.37 GHz and 75.5 TFLOP/s (1698 vs 1877 ms, same box;
+    // 192 / 384 / 512 stages: +0.7 / +2.4 / +5.7 %).  More splits than slabs: the splits run in groups of nslab, launch after
+    // launch, group g accumulating into the slabs of group g - 1 (gram_all); 16 slabs cost 0.4 % against 80.
+    // Short K ranges (small problems): among the multiples of 8 pick the split count whose last scheduling round is fullest.
     const long RT = (c->R + HDM_TILE - 1) / HDM_TILE;
     const long tiles = RT * (RT + 1) / 2;
     const long kblocks = c->npb_loc;
-    const long slab_cap = std::max(1L, (long) ((4LL << 30) / (sizeof(double) * (double) c->R * c->R)));  // <= 4 GiB of slabs
+    const double slab_bytes = sizeof(double) * (double) c->R * c->R;
+    const long slab_cap = std::max(1L, (long) ((4LL << 30) / slab_bytes));  // <= 4 GiB of slabs
     const long kcap = std::max(1L, kblocks / 64);
     long ns = 1;
     double best = -1.0;
@@ -260,22 +284,31 @@ int cone_alloc_gemm_work(MiCone *c) {
         const double rounds = (double) (tiles * cand) / 512.0;
         double eff = rounds / std::ceil(rounds);
         if (rounds < 2.0) eff *= 0.5 + 0.25 * rounds;  // too few workgroups to hide the tail
-        if (cand < 8 && kcap >= 8 && slab_cap >= 8) eff *= 0.5;  // prefer XCD-aligned splits when possible
+        if (cand < 8 && kcap >= 8 && slab_cap >= 8) eff *= 0.5;
         if (eff > best + 1e-9) { best = eff; ns = cand; }
     }
-    // Long K ranges: many SHORT splits.  Co-resident workgroups progress at slightly different rates (about 2 %), so
-    // over a long tile they drift out of the few-stage window in which the XCD's L2 still holds a neighbour's operand
-    // panel; with short tiles every round restarts aligned.  Measured Gram kernel at n = m = 2000: 129.9 / 124.6 /
-    // 121.1 / 116.6 ms at 64 / 256 / 512 / 1024 splits.  The price is nsplit x R^2 doubles of slabs (<= 40 GiB).
+    long total_splits = 0;   // > 0: one device, long K range: splits in all (ns = slabs)
     {
-        const long big_cap = (long) ((40LL << 30) / (sizeof(double) * (double) c->R * c->R));
-        const long byk = kblocks / 96;   // >= 96 k blocks (of 16) per workgroup keeps prologue + epilogue under 4 %
-        if (byk >= 128) {
+        const long byk = kblocks / 96;   // >= 96 k blocks (of 16) per job keeps prologue + epilogue under 4 %
+        const char *ek = getenv("HDM_GRAM_KSTAGES");   // A/B and test knob: stages per job, at any size
+        if ((byk >= 128 || ek) && c->world == 1) {
+            // stages per job: the split's operand panel (R rows) fills the memory-side cache; at least 96, at most 2048
+            long kst = (long) ((double) (1L << 28) / (128.0 * (double) c->R));
+            kst = std::max(96L, std::min(kst, 2048L));
+            if (ek) kst = std::max(1L, atol(ek));
+            total_splits = std::max(8L, (kblocks + kst - 1) / kst);
+            while (!ek && total_splits * tiles < 4096 && total_splits * 2 <= std::min(byk, 1024L)) total_splits *= 2;   // eight rounds of jobs, if K allows
+            const long cap8 = std::max(8L, (long) ((8LL << 30) / slab_bytes));             // <= 8 GiB of slabs, at least 8
+            ns = std::max(ns, std::min(total_splits, cap8));
+        } else if (byk >= 128) {
+            // sharded block: one slab per split (the exchange pieces are whole groups of splits whose launches overlap the
+            // transfers, engine_build.h); as many splits as 40 GiB of slabs and 96 stages per job allow, at most 1024
+            const long big_cap = (long) ((40LL << 30) / slab_bytes);
             const long big = std::min(std::min(1024L, byk), big_cap) & ~7L;
             if (big > ns) ns = big;
         }
     }
-    if (const char *e = getenv("HDM_NSPLIT")) ns = std::max(1L, std::min(atol(e), kblocks / 16));   // A/B knob
+    if (const char *e = getenv("HDM_NSPLIT")) ns = std::max(1L, std::min(atol(e), kblocks / 16));   // A/B knob: the slab count
     // One GPU: the congruence intermediates T are dead by the time the Gram product writes its split-K slabs, so the two
     // share ONE buffer (the larger of the two sizes: 33 GB instead of 32 + 33 GB at n = m = 2000).  The only thing step 2
     // reads of T that step 1 does not write is the strict upper triangle of T's diagonal tiles: with the buffer shared
@@ -309,16 +342,10 @@ int cone_alloc_gemm_work(MiCone *c) {
         if (ns <= 8) { fprintf(stderr, "[hdsdp_mi355x] out of device memory for the Gram slabs\n"); return 1; }
         ns = std::max(8L, (ns / 2) & ~7L);
     }
-    c->nslab = c->nsplit;
-    if (c->world == 1) {
-        // EXPERIMENT knobs (round 5): HDM_GRAM_KSTAGES = stages (16 k each) per (split, tile) job -> more splits than slabs, run in
-        // groups of nslab; HDM_GRAM_QUEUE=1: one global job queue in split order
-        if (const char *e = getenv("HDM_GRAM_KSTAGES")) {
-            const long kst = std::max(16L, atol(e));
-            c->nsplit = (int) std::max<long>(c->nslab, (kblocks + kst - 1) / kst);
-        }
-        if (const char *e = getenv("HDM_GRAM_QUEUE")) c->gram_queue_global = atoi(e) != 0;
-    }
+    c->nslab = c->nsplit;                                   // (the allocation loops above may have halved it)
+    if (total_splits > c->nslab) c->nsplit = (int) total_splits;
+    c->gram_queue_global = true;
+    if (const char *e = getenv("HDM_GRAM_QUEUE")) c->gram_queue_global = atoi(e) != 0;   // 0: one queue per XCD over the splits x, x + 8, ...
     HDM_HIP_CHECK(hipMalloc((void **) &c->Gm, sizeof(double) * (size_t) c->R * c->R));
     // the "S row" (At = I) never changes
     if (c->rank == 0) {

@@ -9,35 +9,86 @@ int grp_sum_launch(const double *const *ptrs, int W, long lo, long cnt, double *
 }
 // ---------------------------------------------------------------- cone construction
 static int upload_dense_rows(MiCone *c) {
-    // densify every owned constraint into a full symmetric n16 x n16 matrix (via packed staging)
+    // Every owned constraint becomes an A_L form in skyline storage.  The entries travel as they are -- (packed index, value),
+    // 12 bytes each -- and are scattered on the device into the zeroed target (hdm_scatter_low): host threads copy a group of
+    // rows into one of two pinned staging buffers while the other one crosses PCIe.  (Up to round 4 the host densified every
+    // row into a packed image first -- a 16 MB memset and an 800 K-entry scatter per row on one core, one synchronisation per
+    // 16 rows: most of the 14 s the reference's driver spent in its pre-solver at n = m = 2000.)
     const long P = (long) c->n * (c->n + 1) / 2;
     const long nn = (long) c->n16 * c->n16;
     HDM_HIP_CHECK(hipMalloc((void **) &c->Afull, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc) + hdm_operand_pad(c->n16)));
     HDM_HIP_CHECK(hdm_memset_sync(c->Afull, 0, sizeof(double) * (size_t) c->astride * std::max(1, c->mloc)));
-    const int chunk = (int) std::max(1L, std::min<long>(64, (256L << 20) / (P * 8)));
-    double *stage_dev = nullptr, *stage_host = nullptr;
-    HDM_HIP_CHECK(hipMalloc((void **) &stage_dev, sizeof(double) * (size_t) P * chunk));
-    HDM_HIP_CHECK(hipHostMalloc((void **) &stage_host, sizeof(double) * (size_t) P * chunk, hipHostMallocDefault));
-    for (int r0 = 0; r0 < c->mloc; r0 += chunk) {
-        int nc = std::min(chunk, c->mloc - r0);
-        memset(stage_host, 0, sizeof(double) * (size_t) P * nc);
-        for (int q = 0; q < nc; ++q) {
-            const MiCoeff &co = c->blk.rows[c->own[r0 + q]];
-            for (size_t e = 0; e < co.idx.size(); ++e) stage_host[(size_t) q * P + co.idx[e]] = co.val[e];
-        }
-        HDM_HIP_CHECK(hipMemcpyAsync(stage_dev, stage_host, sizeof(double) * (size_t) P * nc, hipMemcpyHostToDevice, g.stream));
-        if (hdm_unpack_low(stage_dev, P, c->Afull + (long) r0 * c->astride, c->astride, c->n, c->n16, nc, g.stream)) return 1;
-        HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
+    long maxrow = 1;
+    for (int q = 0; q < c->mloc; ++q) maxrow = std::max<long>(maxrow, (long) c->blk.rows[c->own[q]].idx.size());
+    const long cap = std::max(maxrow, (long) ((192L << 20) / 12));      // entries per staging buffer (192 MiB, or one row)
+    const int rowcap = 1024;
+    struct Stage { int *hi = nullptr, *di = nullptr; double *hv = nullptr, *dv = nullptr; long *hb = nullptr, *db = nullptr; hipEvent_t ev = nullptr; bool used = false; } st[2];
+    int rc = 0;
+    for (auto &b : st) {
+        if (hipHostMalloc((void **) &b.hi, sizeof(int) * (size_t) cap, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **) &b.hv, sizeof(double) * (size_t) cap, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **) &b.hb, sizeof(long) * (rowcap + 1), hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **) &b.di, sizeof(int) * (size_t) cap) != hipSuccess || hipMalloc((void **) &b.dv, sizeof(double) * (size_t) cap) != hipSuccess ||
+            hipMalloc((void **) &b.db, sizeof(long) * (rowcap + 1)) != hipSuccess || hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess)
+            rc = 1;
     }
-    {   // objective
+    int which = 0;
+    for (int r0 = 0; r0 < c->mloc && !rc;) {
+        Stage &b = st[which];
+        which ^= 1;
+        if (b.used && hipEventSynchronize(b.ev) != hipSuccess) { rc = 1; break; }   // its previous group has left the buffer
+        int nc = 0;
+        long tot = 0, mx = 0;
+        b.hb[0] = 0;
+        while (r0 + nc < c->mloc && nc < rowcap) {
+            const long k = (long) c->blk.rows[c->own[r0 + nc]].idx.size();
+            if (nc > 0 && tot + k > cap) break;
+            tot += k; mx = std::max(mx, k); nc += 1;
+            b.hb[nc] = tot;
+        }
+        std::atomic<int> next{0};
+        mi_parallel(tot >= (1L << 20) ? 0 : 1, [&](int) {
+            for (int q = next.fetch_add(1); q < nc; q = next.fetch_add(1)) {
+                const MiCoeff &co = c->blk.rows[c->own[r0 + q]];
+                if (co.idx.empty()) continue;
+                memcpy(b.hi + b.hb[q], co.idx.data(), sizeof(int) * co.idx.size());
+                memcpy(b.hv + b.hb[q], co.val.data(), sizeof(double) * co.val.size());
+            }
+        });
+        if (tot > 0) {
+            if (hipMemcpyAsync(b.di, b.hi, sizeof(int) * (size_t) tot, hipMemcpyHostToDevice, g.stream) != hipSuccess ||
+                hipMemcpyAsync(b.dv, b.hv, sizeof(double) * (size_t) tot, hipMemcpyHostToDevice, g.stream) != hipSuccess ||
+                hipMemcpyAsync(b.db, b.hb, sizeof(long) * (size_t) (nc + 1), hipMemcpyHostToDevice, g.stream) != hipSuccess ||
+                hdm_scatter_low(b.di, b.dv, b.db, mx, c->Afull + (long) r0 * c->astride, c->astride, c->n, c->n16, nc, g.stream))
+                rc = 1;
+        }
+        if (hipEventRecord(b.ev, g.stream) != hipSuccess) rc = 1;
+        b.used = true;
+        r0 += nc;
+    }
+    if (hipStreamSynchronize(g.stream) != hipSuccess) rc = 1;
+    for (auto &b : st) {
+        if (b.hi) (void) hipHostFree(b.hi);
+        if (b.hv) (void) hipHostFree(b.hv);
+        if (b.hb) (void) hipHostFree(b.hb);
+        if (b.di) (void) hipFree(b.di);
+        if (b.dv) (void) hipFree(b.dv);
+        if (b.db) (void) hipFree(b.db);
+        if (b.ev) (void) hipEventDestroy(b.ev);
+    }
+    if (rc) return 1;
+    {   // objective: full symmetric (it feeds the S assembly), through a packed image
+        double *stage_dev = nullptr, *stage_host = nullptr;
+        HDM_HIP_CHECK(hipMalloc((void **) &stage_dev, sizeof(double) * (size_t) P));
+        HDM_HIP_CHECK(hipHostMalloc((void **) &stage_host, sizeof(double) * (size_t) P, hipHostMallocDefault));
         memset(stage_host, 0, sizeof(double) * (size_t) P);
         for (size_t e = 0; e < c->blk.obj.idx.size(); ++e) stage_host[c->blk.obj.idx[e]] = c->blk.obj.val[e];
         HDM_HIP_CHECK(hipMemcpyAsync(stage_dev, stage_host, sizeof(double) * (size_t) P, hipMemcpyHostToDevice, g.stream));
         if (hdm_unpack_sym(stage_dev, P, c->Cfull, nn, c->n, c->n16, 1, g.stream)) return 1;
         HDM_HIP_CHECK(hipStreamSynchronize(g.stream));
+        (void) hipFree(stage_dev);
+        (void) hipHostFree(stage_host);
     }
-    (void) hipFree(stage_dev);
-    (void) hipHostFree(stage_host);
     return 0;
 }
 
@@ -179,7 +230,12 @@ static hdsdp_retcode make_synth_cone(MiCone **out, int nCol, int nRow, int rank,
         const double schur = 3.0 * 8.0 * (double) c->m * c->m + (16.0 * (1L << 30));
         size_t fr = 0, tot = 0;
         bool stream = false;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) stream = (afull + ahat + work + schur > (double) fr);
+        // one device: against what is FREE now (whatever else lives on the device counts).  A shard of a sharded block
+        // (process per GPU or device group): against the device's CAPACITY, so that every rank of a job on identical devices
+        // takes the same decision -- streaming changes the launch staging, and ranks that disagreed would run differently
+        // labelled, differently timed steps (equal results); a resident allocation that then fails is an error with a message.
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess)
+            stream = (afull + ahat + work + schur > (c->world > 1 ? 0.97 * (double) tot : (double) fr));
         (void) hipGetLastError();
         if (const char *e = getenv("HDSDP_MI355X_STREAM_A")) stream = (atoi(e) != 0);
         c->streamed = stream && c->mloc > 0;

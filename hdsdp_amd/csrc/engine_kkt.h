@@ -26,6 +26,12 @@ int HMiGetKernelTiming(double *ms, double *flops, int64_t *launches) {
     for (int r = 0; r < HDM_NROLES; ++r) launches[r] = l[r];
     return 0;
 }
+int HMiGetKernelTimingEx(double *ms, double *flops, double *issued, int64_t *launches) {
+    long l[HDM_NROLES];
+    if (hdm_timing_collect(ms, flops, l, issued)) return 1;
+    for (int r = 0; r < HDM_NROLES; ++r) launches[r] = l[r];
+    return 0;
+}
 void HMiGetStageTimes(double *ms, int n) {
     for (int i = 0; i < n && i < 8; ++i) ms[i] = g.stage_ms[i];
 }

@@ -25,7 +25,7 @@
 // host side: tile lists (heaviest first) cached in device memory
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct TimedLaunch { hipEvent_t e0, e1; int role; double flops; };
+struct TimedLaunch { hipEvent_t e0, e1; int role; double flops, issued; };
 bool g_timing = false;
 thread_local bool g_capturing = false;   // per host thread: each shard of a device group captures its own chains
 std::vector<TimedLaunch> g_timed;
@@ -111,6 +111,58 @@ int get_tiles(int MT, int NT, int klimit, int lower_only, unsigned long long col
 }  // namespace
 
 static int launch_tiles(const HdmGemmArgs &args, int subset, hipStream_t stream);
+
+// Flops the MFMA instructions of one launch EXECUTE (2048 per v_mfma_f64_16x16x4_f64), counted on the host from the tile
+// list and the kernel's own stage sequences (gemm_tile.h: hdm_gemm_tile) -- next to HdmGemmArgs.flops, the algorithmic count
+// on valid data.  The difference is granularity: 16 x 16 sub-blocks that straddle a diagonal, the live ranges of the
+// triangular K blocks (stage-level skipping keeps 1280 of a diagonal block's 2048 MFMAs per tile where 1152 would do), the
+// cell-dealt tiles' diagonal blocks run in full, rows past the matrix edge, the zero stage that closes an odd stage count.
+// Held to the counters: SQ_VALU_MFMA_BUSY_CYCLES / 64 of profiles/r05_a_8000_* is this count to 2e-5 for the four kernels.
+static double issued_mfma_flops(const HdmGemmArgs &a, int subset) {
+    const int MT = (a.M + HDM_TILE - 1) / HDM_TILE, NT = (a.N + HDM_TILE - 1) / HDM_TILE;
+    const unsigned long long colmask = (NT > 64) ? 0ULL : a.tile_col_mask;
+    const int npass = (a.role == HDM_ROLE_CONG2 && a.A2) ? 2 : ((a.role == HDM_ROLE_GENERIC && a.A2) ? 2 : 1);
+    auto pairs = [](long nst) { return nst <= 0 ? 0L : ((nst + 1) / 2) * 2; };
+    double mf = 0.0;   // MFMA instructions of ONE batch entry (SLAB: summed over the splits below)
+    const int nz = (a.epilogue == HDM_EPI_SLAB) ? a.batch : 1;
+    for (int z = 0; z < nz; ++z)
+        for (int tm = 0; tm < MT; ++tm)
+            for (int tn = 0; tn < NT; ++tn) {
+                if (a.lower_only && tm < tn) continue;
+                if (colmask && !((colmask >> tn) & 1ULL)) continue;
+                if (a.klimit == HDM_KLIM_BAND && tm < tn) continue;
+                const int m0 = tm * HDM_TILE, n0 = tn * HDM_TILE;
+                const int rvd = std::min(8, (a.M - m0 + 15) >> 4);
+                if (subset) {
+                    const bool full_diag = (tm == tn) && rvd >= 8;
+                    if ((subset == 1) != full_diag) continue;
+                }
+                long kbeg = 0, kend = a.K;
+                if (a.klimit == HDM_KLIM_BY_M) kend = std::min<long>(a.K, (long) (tm + 1) * HDM_TILE);
+                if (a.klimit == HDM_KLIM_BY_N) kend = std::min<long>(a.K, (long) (tn + 1) * HDM_TILE);
+                if (a.klimit == HDM_KLIM_BAND) { kbeg = (long) tn * HDM_TILE; kend = std::min<long>(a.K, (long) (tm + 1) * HDM_TILE); }
+                if (a.epilogue == HDM_EPI_SLAB) { kbeg = a.k_base + (long) z * a.k_chunk; kend = std::min(kend, kbeg + a.k_chunk); }
+                const long nst = std::max(0L, kend / HDM_BK - kbeg / HDM_BK) * npass;
+                if (a.role == HDM_ROLE_GENERIC) { mf += 256.0 * nst; continue; }
+                const int rvc = std::max(4, rvd);   // the cell lists exist for 4..7 valid sub-tile rows
+                const bool symdiag = (a.role == HDM_ROLE_CONG2D);
+                if (!symdiag && a.lower_only && tm == tn) {                              // diagonal tile, cell-dealt
+                    const int cells = (rvd < 8) ? rvc * (rvc + 1) / 2 : 36;
+                    mf += 4.0 * cells * pairs(nst);
+                } else if (!symdiag && tm != tn && m0 + HDM_TILE > a.M && n0 + HDM_TILE <= a.N) {   // bottom-edge tile
+                    mf += 4.0 * (8 * rvc) * pairs(nst);
+                } else if (a.role == HDM_ROLE_CONG2) {      // both products: full stages, then the diagonal block's live ranges 16+12+8+4
+                    mf += 2.0 * ((double) tn * 8 * 256 + 1280);
+                } else if (a.role == HDM_ROLE_CONG2D) {     // one product, both operands triangular in the last block: 16+9+4+1
+                    mf += (double) tn * 8 * 256 + 960;
+                } else if (a.role == HDM_ROLE_CONG1) {      // first and last K block triangular on one side each
+                    mf += 2.0 * 1280 + (double) (tm - tn - 1) * 2048;
+                } else {
+                    mf += 256.0 * pairs(nst);
+                }
+            }
+    return mf * 2048.0 * ((a.epilogue == HDM_EPI_SLAB) ? 1.0 : (double) a.batch);
+}
 
 int hdm_launch_gemm(const HdmGemmArgs &args, hipStream_t stream) {
     if (args.M <= 0 || args.N <= 0 || args.batch <= 0) return 0;
@@ -307,7 +359,7 @@ static int launch_tiles(const HdmGemmArgs &args, int subset, hipStream_t stream)
     if (timed) {
         HDM_HIP_CHECK(hipEventRecord(e1, stream));
         std::lock_guard<std::mutex> lk(g_tl_mutex);
-        g_timed.push_back({e0, e1, args.role, args.flops});
+        g_timed.push_back({e0, e1, args.role, args.flops, issued_mfma_flops(args, subset)});
     }
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
@@ -317,8 +369,8 @@ void hdm_timing_enable(int on) { g_timing = (on != 0); }
 void hdm_gemm_capture_mode(int on) { g_capturing = (on != 0); }
 void hdm_gemm_reserve_cus(int cus) { g_reserved_cus = std::max(0, cus); }
 
-int hdm_timing_collect(double *ms, double *flops, long *launches) {
-    for (int r = 0; r < HDM_NROLES; ++r) { ms[r] = 0.0; flops[r] = 0.0; launches[r] = 0; }
+int hdm_timing_collect(double *ms, double *flops, long *launches, double *issued) {
+    for (int r = 0; r < HDM_NROLES; ++r) { ms[r] = 0.0; flops[r] = 0.0; launches[r] = 0; if (issued) issued[r] = 0.0; }
     std::lock_guard<std::mutex> lk(g_tl_mutex);
     for (auto &t : g_timed) {
         float e = 0.f;
@@ -326,6 +378,7 @@ int hdm_timing_collect(double *ms, double *flops, long *launches) {
         HDM_HIP_CHECK(hipEventElapsedTime(&e, t.e0, t.e1));
         const int r = (t.role >= 0 && t.role < HDM_NROLES) ? t.role : 0;
         ms[r] += e; flops[r] += t.flops; launches[r] += 1;
+        if (issued) issued[r] += t.issued;
         (void) hipEventDestroy(t.e0);
         (void) hipEventDestroy(t.e1);
     }

@@ -1052,7 +1052,9 @@ __global__ __launch_bounds__(256, 2) void hdm_gemm_persist_kernel(HdmGemmDev p, 
     // queue_global: one queue (cnt[0]) for all XCDs, entry by entry in order -- every workgroup of the chip is then on the entry
     // at the queue's front or the one after it, so the operand bytes in use at any time are those of ~one entry (a K split of the
     // Gram product), which is what the memory-side cache can hold (engine_cone.h: cone_alloc_gemm_work)
-    const bool one_queue = p.a.queue_global != 0;
+    // (compile-time off for the congruence roles: only the Gram product asks for it -- measured without gain there, profiles/
+    // r05_d_* -- and a run-time flag kept live across the tile loop cost the step-1 kernel two SGPR spills inside its stages)
+    const bool one_queue = (ROLE == HDM_ROLE_GRAM) && p.a.queue_global != 0;
     for (int dx = 0; dx < (one_queue ? 1 : 8); ++dx) {
         const int xq = one_queue ? 0 : ((x + dx) & 7);
         while (true) {

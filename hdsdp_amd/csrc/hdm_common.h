@@ -139,7 +139,7 @@ void hdm_gemm_reserve_cus(int cus);   // CUs the persistent GEMM launches leave 
 // per-role live timing with HIP events on the launch stream (off by default)
 void hdm_timing_enable(int on);
 void hdm_set_debug_buffer(unsigned long long *dev, int role);
-int hdm_timing_collect(double *ms, double *flops, long *launches);  // arrays of HDM_NROLES; resets
+int hdm_timing_collect(double *ms, double *flops, long *launches, double *issued = nullptr);  // arrays of HDM_NROLES; resets.  issued: flops the launches' MFMA instructions executed (gemm_f64.hip: issued_mfma_flops)
 
 // One kernel handle per translation unit with device code.  The HIP runtime loads a translation unit's code object when its
 // first kernel is launched (10 ms for the first HKKTBuildUp of a process, which is a fifth of a whole solve of a 100 x 100

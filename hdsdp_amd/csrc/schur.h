@@ -23,6 +23,9 @@ int hdm_sparse_pairs(const int *rp, const int *ti, const int *tj, const double *
                      const int *rows_global, const HdmMatView &Mv, hipStream_t s);
 int hdm_sparse_dot(const int *rp, const int *ti, const int *tj, const double *tv, const double *Y, long ldy, int mloc,
                    const int *rows_global, double scale, double *out, hipStream_t s);
+// entries (packed lower index, value) of `batch` matrices, row q's at [beg[q], beg[q + 1]), scattered into zeroed A_L-form skyline storage
+int hdm_scatter_low(const int *idx, const double *val, const long *beg, long max_per_row, double *full, long fstride, int n, int ld,
+                    int batch, hipStream_t s);
 int hdm_unpack_low(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s);
 int hdm_synth_fill_low(double *full, long fstride, int n, int ld, int c0, int batch, hipStream_t s);
 int hdm_lower_half(const double *full, double *low, int n, long ld, hipStream_t s);

@@ -103,6 +103,29 @@ __global__ __launch_bounds__(256) void hdm_synth_low_kernel(double *__restrict__
     write_low_tile(s, full + (long) blockIdx.y * fstride, (long) ld, n, tj + t, tj);
 }
 
+// Entries (packed lower index, value) of a batch of matrices -> A_L form in skyline storage, scattered on the device: row q's
+// entries are ent[beg[q] .. beg[q + 1]).  The target was zeroed by the caller; the diagonal takes half its value (A_L form).
+// Column of a packed position p: the largest j with j (2n - j + 1) / 2 <= p, from the quadratic's root in fp64 and corrected.
+__global__ __launch_bounds__(256) void hdm_scatter_low_kernel(const int *__restrict__ idx, const double *__restrict__ val,
+                                                               const long *__restrict__ beg, double *__restrict__ full,
+                                                               long fstride, int n, int ld) {
+    const int q = blockIdx.y;
+    const long e0 = beg[q], e1 = beg[q + 1];
+    double *dst = full + (long) q * fstride;
+    const double tn1 = 2.0 * n + 1.0;
+    for (long e = e0 + (long) blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += (long) gridDim.x * blockDim.x) {
+        const long p = idx[e];
+        long j = (long) ((tn1 - sqrt(tn1 * tn1 - 8.0 * (double) p)) * 0.5);
+        if (j < 0) j = 0;
+        if (j > n - 1) j = n - 1;
+        while (j + 1 < n && (j + 1) * (2L * n - (j + 1) + 1) / 2 <= p) ++j;
+        while (j > 0 && j * (2L * n - j + 1) / 2 > p) --j;
+        const long i = j + (p - j * (2L * n - j + 1) / 2);
+        const double v = val[e];
+        dst[hdm_sky_off((int) i, (int) j, ld)] = (i == j) ? 0.5 * v : v;
+    }
+}
+
 // full symmetric -> A_L form in skyline storage (objective matrix)
 __global__ void hdm_lower_half_kernel(const double *__restrict__ full, double *__restrict__ low, int n, long ld) {
     long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -744,6 +767,15 @@ int hdm_unpack_low(const double *packed, long pstride, double *full, long fstrid
     int nt = (ld + 31) / 32;
     dim3 grid(nt * (nt + 1) / 2, batch), block(32, 8);
     hipLaunchKernelGGL(hdm_unpack_low_kernel, grid, block, 0, s, packed, pstride, full, fstride, n, ld, nt);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int hdm_scatter_low(const int *idx, const double *val, const long *beg, long max_per_row, double *full, long fstride, int n, int ld,
+                    int batch, hipStream_t s) {
+    if (batch <= 0) return 0;
+    const unsigned gx = (unsigned) std::max(1L, std::min(256L, (max_per_row + 1023) / 1024));
+    hipLaunchKernelGGL(hdm_scatter_low_kernel, dim3(gx, batch), dim3(256), 0, s, idx, val, beg, full, fstride, n, ld);
     HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

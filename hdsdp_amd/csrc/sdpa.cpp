@@ -120,7 +120,11 @@ hdsdp_retcode HMiReadSDPA(const char *fname, HMiSDPA **out) {
     }
     fclose(f);
     p->beg.resize(p->nblk); p->beg32.resize(p->nblk); p->idx.resize(p->nblk); p->val.resize(p->nblk);
-    for (int b = 0; b < p->nblk; ++b) bucket(p->m + 1, trips[b], p->beg[b], p->idx[b], p->val[b]);
+    for (int b = 0; b < p->nblk; ++b) {
+        bucket(p->m + 1, trips[b], p->beg[b], p->idx[b], p->val[b]);
+        // the reference-style int column pointers of a block that fits them, made here so that the accessors only read
+        if (p->beg[b].back() <= 2147483647LL) p->beg32[b].assign(p->beg[b].begin(), p->beg[b].end());
+    }
     if (p->nlp > 0) bucket(p->m + 1, lpt, p->lpBeg, p->lpIdx, p->lpVal);
     *out = p;
     return HDSDP_RETCODE_OK;
@@ -139,15 +143,13 @@ hdsdp_retcode HMiSDPAGetBlock64(const HMiSDPA *p, int iBlk, int *dim, const int6
     if (val) *val = p->val[iBlk].data();
     return HDSDP_RETCODE_OK;
 }
-hdsdp_retcode HMiSDPAGetBlock(const HMiSDPA *cp, int iBlk, int *dim, const int **beg, const int **idx, const double **val) {
-    HMiSDPA *p = const_cast<HMiSDPA *>(cp);          // (the 32-bit pointers are a cache filled on first use)
+hdsdp_retcode HMiSDPAGetBlock(const HMiSDPA *p, int iBlk, int *dim, const int **beg, const int **idx, const double **val) {
     if (iBlk < 0 || iBlk >= p->nblk) return HDSDP_RETCODE_FAILED;
     if (p->beg[iBlk].back() > 2147483647LL) {
         fprintf(stderr, "[hdsdp_mi355x] block %d holds %lld entries: beyond the reference's int column pointers, use HMiSDPAGetBlock64\n",
                 iBlk, (long long) p->beg[iBlk].back());
         return HDSDP_RETCODE_FAILED;
     }
-    if (p->beg32[iBlk].empty()) p->beg32[iBlk].assign(p->beg[iBlk].begin(), p->beg[iBlk].end());
     if (dim) *dim = p->dims[iBlk];
     if (beg) *beg = p->beg32[iBlk].data();
     if (idx) *idx = p->idx[iBlk].data();

@@ -220,7 +220,9 @@ hdsdp_retcode HMiConeCreateSynthetic(hdsdp_cone **pCone, int iCone, int nCol, in
  *                        column at a time and never holds a 2^31-entry array; the library's own host copy goes back as soon as
  *                        the block's device layout is written (blocks on the congruence + Gram path).
  * Both give the device data HMiConeCreateSDP gives on the same entries (tests/test_gpu_ingest.py: bit-identical dual matrix and
- * Schur matrix on every CSC golden). */
+ * Schur matrix on every CSC golden).  All three ways in refuse (RETCODE_FAILED) a column whose pointers run backwards, a packed
+ * index outside [0, n(n+1)/2) and a packed index named twice in one column (tests/test_abi_cpu.py::
+ * test_presolve_refuses_malformed_columns). */
 hdsdp_retcode HMiConeCreateSDP64(hdsdp_cone **pCone, int iCone, int nRow, int nCol, const int64_t *coneMatBeg,
                                  const int *coneMatIdx, const double *coneMatElem, int rank, int world);
 typedef struct HMiConeBuilder_s HMiConeBuilder;
@@ -331,6 +333,18 @@ void HMiConeBuildPrimalXSXDirection(hdsdp_cone *cone, double *dPrimalScalMatrix,
 /* what the last HKKTBuildUp did: pieces of the exchange (1 = one blocking all-to-all) and, when the congruence's second
  * step was staged by packed-index range, the number of launches it was cut into (0 = not staged) */
 void HMiConeGetExchangeStats(hdsdp_cone *cone, int *pieces, int *stagedLaunches);
+/* Where the last SHARDED Schur build (world > 1) of one shard spent its time, so that a multi-GPU bench line says where a step went
+ * and not only how long it took (the cone loop being sharded: interface/hdsdp_schur.c:256-268).  `shard`: index inside an in-process
+ * device group (0 for a process-per-GPU cone).  Milliseconds; device times are differences of HIP events on the shard's engine stream,
+ * host times wall clock around the two blocking hooks.  Layout of `out` (8 + 6 * pieces doubles):
+ *   [0] pieces of the exchange   [1] 1 = congruence step 2 ran by packed-index range (staged)   [2] triangular inverse of the factor
+ *   [3] congruence step 1 (staged) or both congruence steps (not staged)   [4] slab reduction   [5] all-reduce of the Gram matrix (host)
+ *   [6] extraction into M and the vectors   [7] world
+ *   then per piece k:  [8+6k] step 2 of the tile columns piece k needs   [+1] engine stream idle before piece k's Gram splits (the
+ *   piece had not arrived: the exchange WAIT)   [+2] host time inside the wait hook   [+3] Gram splits of piece k   [+4] bytes this shard
+ *   sent for piece k   [+5] host time from handing piece k to the transport until its wait returned
+ * Returns the doubles written, 0 when no sharded build has run, -(doubles needed) when `cap` is too small, -1 for a bad shard. */
+int HMiConeGetBuildProfile(hdsdp_cone *cone, int shard, double *out, int cap);
 /* exchange buffers (device pointers, `world` chunks of *chunkCount doubles each); the caller may instead
  * supply its own (e.g. torch-allocated) buffers before the first HKKTBuildUp: world * chunkCount doubles of payload
  * plus 8192 doubles of slack behind it (the Gram kernel stages whole 128-row tiles without a row mask) */
@@ -442,7 +456,12 @@ void HMiSDPAFree(HMiSDPA **pp);
  *                                           batch (MiCone::streamed)
  *  HDM_TCAP_GIB                   32        GiB of congruence intermediates per launch group              test_gpu_switches.py, test_gpu_group.py
  *  HDM_BC                         1024      constraints per congruence launch (upper bound)               test_gpu_switches.py
- *  HDM_NSPLIT                     by size   K splits of the Gram product                                  test_gpu_switches.py
+ *  HDM_NSPLIT                     by size   slabs of the Gram product's K splits                          test_gpu_switches.py
+ *  HDM_GRAM_KSTAGES               by size   stages (16 k) per (split, tile) job of the Gram product on one    test_gpu_switches.py (with HDM_NSPLIT=8: more
+ *                                           device; more splits than slabs run in groups (gram_all)           splits than slabs)
+ *  HDM_GRAM_QUEUE                 1         Gram jobs from ONE queue in split order; 0: one queue per XCD      test_gpu_switches.py
+ *  HDSDP_MI355X_HOST_THREADS      min(16,   host threads of the ingest (presolve per column, staging of the    test_gpu_switches.py; the threaded form: test_gpu_ingest.py (syn2000x32)
+ *                                 cores)    upload)
  *  HDM_SHARE_T_SLABS              1         intermediates and Gram slabs share one buffer (one GPU)       test_gpu_switches.py
  *  -- fallbacks kept reachable (the default is the fast form) ----------------------------------------------------------
  *  HDM_PERSIST                    1         persistent GEMM workgroups; 0: one workgroup per tile         test_gpu_switches.py, test_gpu_kernels.py
@@ -484,6 +503,10 @@ void HMiGetStageTimes(double *ms, int n);
  * Each array has 5 entries: total ms, algorithmic flops and launch count since the last call. */
 void HMiSetKernelTiming(int on);
 int HMiGetKernelTiming(double *ms, double *flops, int64_t *launches);
+/* the same with a fourth array: the flops the launches' MFMA instructions EXECUTED (2048 per v_mfma_f64_16x16x4_f64), counted on the
+ * host from the tile lists and the kernels' stage sequences -- issued / algorithmic is the granularity loss of a role (sub-blocks that
+ * straddle a diagonal, live ranges of triangular K blocks, padding rows); bench.py: roofline.issued_over_valid */
+int HMiGetKernelTimingEx(double *ms, double *flops, double *issued, int64_t *launches);
 /* diagnostic builds (HDM_VAR=32): per-workgroup s_memtime stamps of launches with the given role, 8 words each */
 void HMiSetDebugBuffer(void *dev, int role);
 

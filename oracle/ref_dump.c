@@ -533,6 +533,51 @@ int main(int argc, char **argv) {
         dump_s("TraceSinv_pri", kkt->dTraceSinv);
         free(X);
     }
+    /* state "C": the two cone slots a solve moves between builds -- a dual perturbation (HConeSetPerturb,
+       hdsdp_conic_sdp.c:2237-2241: added to the diagonal of S and of the checker, never of the step, :383, :441) and a
+       reduced residual (HConeReduceResi, :2225-2229; Phase A shrinks it every iteration, hdsdp_algo.c:244; Phase B starts
+       with residual 0 and perturbation -10 x residual, hdsdp_algo.c:1698-1704).  c1: perturbation on top of the state
+       above; c2: the residual reduced as well; c3: Phase B's form, residual 0 and the whole shift carried by the
+       perturbation (the dual matrix is then the one of the main dump). */
+    {
+        const double perts[3] = { 0.02 * fabs(Rd), 0.02 * fabs(Rd), fabs(Rd) };
+        const double resis[3] = { Rd, 0.6 * Rd, 0.0 };
+        double par[6];
+        for (int k = 0; k < 3; ++k) { par[2 * k] = perts[k]; par[2 * k + 1] = resis[k]; }
+        dump_d("c_par", par, 6);
+        for (int k = 0; k < 3; ++k) {
+            HConeSetPerturb(cone, perts[k]);
+            HConeReduceResi(cone, resis[k]);
+            int ok = 0; double ld = 0.0;
+            HDSDP_CALL(HConeCheckIsInterior(cone, tau, y, &ok));
+            snprintf(nm, 64, "c%d_interior", k + 1); dump_i(nm, &ok, 1);
+            if (!ok) continue;
+            HDSDP_CALL(HConeGetLogBarrier(cone, tau, y, BUFFER_DUALVAR, &ld));
+            snprintf(nm, 64, "c%d_logdet", k + 1); dump_s(nm, ld);
+            HDSDP_CALL(HKKTBuildUp(kkt, KKT_TYPE_HOMOGENEOUS));
+            snprintf(nm, 64, "c%d_ASinvCSinv_hsd", k + 1); dump_d(nm, kkt->dASinvCSinvVec, m);
+            { double sc[4] = { kkt->dCSinv, kkt->dCSinvCSinv, kkt->dCSinvRdSinv, kkt->dTraceSinv };
+              snprintf(nm, 64, "c%d_hsd_scalars", k + 1); dump_d(nm, sc, 4); }
+            HDSDP_CALL(HKKTBuildUp(kkt, KKT_TYPE_INFEASIBLE));
+            snprintf(nm, 64, "c%d_M_inf", k + 1); dump_d2(nm, kkt->kktMatElem, m, m);
+            snprintf(nm, 64, "c%d_ASinv_inf", k + 1); dump_d(nm, kkt->dASinvVec, m);
+            snprintf(nm, 64, "c%d_ASinvRdSinv_inf", k + 1); dump_d(nm, kkt->dASinvRdSinvVec, m);
+            snprintf(nm, 64, "c%d_TraceSinv_inf", k + 1); dump_s(nm, kkt->dTraceSinv);
+            for (int i = 0; i < m; ++i) *kkt->kktDiag[i] += diag_add;
+            HKKTExport(kkt, d2, NULL, NULL, NULL, NULL, NULL, NULL);
+            HDSDP_CALL(HKKTFactorize(kkt));
+            HDSDP_CALL(HKKTSolve(kkt, d2, NULL));
+            snprintf(nm, 64, "c%d_sol_ASinv", k + 1); dump_d(nm, d2, m);
+            HDSDP_CALL(HKKTBuildUp(kkt, KKT_TYPE_CORRECTOR));
+            snprintf(nm, 64, "c%d_ASinv_cor", k + 1); dump_d(nm, kkt->dASinvVec, m);
+            snprintf(nm, 64, "c%d_ASinvRdSinv_cor", k + 1); dump_d(nm, kkt->dASinvRdSinvVec, m);
+            /* the checker takes the perturbation too (:441), the step buffer does not (:383-385): trial point through the
+               expert check with the caller's own diagonal term */
+            HDSDP_CALL(HConeCheckIsInteriorExpert(cone, tau, -1.0, y, -0.5 * resis[k], BUFFER_DUALCHECK, &ok));
+            HDSDP_CALL(HConeGetLogBarrier(cone, 0.0, NULL, BUFFER_DUALCHECK, &ld));
+            { double r3[2] = { (double) ok, ld }; snprintf(nm, 64, "c%d_ck_expert", k + 1); dump_d(nm, r3, 2); }
+        }
+    }
     printf("ref_dump ok: n=%d m=%d nnz=%ld logdet=%.12e\n", n, m, nnz, logdet);
 exit_cleanup:
     if (retcode != HDSDP_RETCODE_OK) fprintf(stderr, "ref_dump: reference returned %d\n", (int) retcode);

@@ -95,6 +95,31 @@ def test_host_presolve_matches_reference(name):
     assert p["obj_type"] == int(g["obj_type"][0])
 
 
+def test_presolve_refuses_malformed_columns():
+    """the ingest's presolve (csrc/coeff.cpp: mi_coeff_build) takes the caller's columns as they come: column pointers that
+    run backwards and a packed position given twice are refused (RETCODE_FAILED), not read as a zero matrix or as a matrix
+    whose value depends on the coefficient class"""
+    from hdsdp_amd import api
+    n, m = 6, 2
+    P = n * (n + 1) // 2
+    diag = np.array([0, 6, 11, 15, 18, 20], dtype=np.int32)          # packed positions of the diagonal
+    good_beg = np.array([0, 6, 8, 10], dtype=np.int32)
+    idx = np.concatenate([diag, [0, 7], [3, 9]]).astype(np.int32)
+    val = np.ones(idx.size)
+    p = api.presolve_csc(n, m, good_beg, idx, val)                      # the well-formed block passes
+    assert p["coef_nnz"].tolist() == [2, 2]
+    with pytest.raises(RuntimeError):                                   # column 2 ends before it begins
+        api.presolve_csc(n, m, np.array([0, 6, 10, 8], dtype=np.int32), idx, val)
+    dup = idx.copy()
+    dup[7] = 0                                                          # A_1 names packed position 0 twice
+    with pytest.raises(RuntimeError):
+        api.presolve_csc(n, m, good_beg, dup, val)
+    far = idx.copy()
+    far[9] = P                                                          # one past the last packed position
+    with pytest.raises(RuntimeError):
+        api.presolve_csc(n, m, good_beg, far, val)
+
+
 def test_product_never_touches_the_oracle():
     """the oracle is test infrastructure: nothing under hdsdp_amd/ may import, link or exec it"""
     pkg = os.path.join(ROOT, "hdsdp_amd")
@@ -275,6 +300,39 @@ def test_device_plan_labels_and_the_gpu_tests_expectations_agree():
     assert 'parametrize("transport", ["rccl", "copy"])' in src and "transport=want" in body and "got == want" in body
     table = open(HEADER).read().split("environment switches")[1]
     assert "test_config5_at_size_on_eight_devices[rccl|copy]" in table
+
+
+def test_a_multi_gpu_bench_line_says_where_its_step_went():
+    """bench.sharded_step_profile (pure) condenses the per-rank profiles of the last sharded build (HMiConeGetBuildProfile) into
+    the `sharded_step` object of the bench line: every stage and every exchange piece as [min, max] over the ranks, the exchange
+    WAIT per piece, bytes sent and achieved GB/s -- so that the first 8-GPU line diagnoses itself.  Here: two fake ranks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def rank(scale):
+        return {"pieces": 2, "staged": True, "invert_ms": 0.6 * scale, "congruence_step1_ms": 40.0 * scale, "slab_reduce_ms": 1.0,
+                "allreduce_ms": 0.8 * scale, "extract_ms": 0.1, "world": 2, "step2_piece_ms": [30.0, 50.0 * scale],
+                "exchange_wait_ms": [0.0, 12.0 * scale], "exchange_wait_host_ms": [1.0, 20.0], "gram_piece_ms": [25.0, 26.0],
+                "piece_bytes_sent": [4.0e9, 4.0e9], "piece_flight_ms": [80.0, 100.0 * scale]}
+
+    stages = [{"assemble_S+chol_S": 2.0, "buildup": 200.0, "factor_M": 1.4, "solve3": 1.2},
+              {"assemble_S+chol_S": 2.1, "buildup": 201.0, "factor_M": 1.5, "solve3": 1.2}]
+    d = bench.sharded_step_profile([rank(1.0), rank(1.5)], stages)
+    mmx = d["min_max_over_ranks_ms"]
+    assert d["ranks"] == 2 and d["pieces"] == 2 and d["staged"] is True
+    assert mmx["congruence_step1_ms"] == [40.0, 60.0] and mmx["allreduce_ms"] == [0.8, 1.2]
+    assert mmx["exchange_wait_by_piece"] == [[0.0, 0.0], [12.0, 18.0]] and mmx["exchange_wait_total"] == [12.0, 18.0]
+    assert mmx["congruence_step2_by_piece"][1] == [50.0, 75.0] and mmx["gram_total"] == [51.0, 51.0]
+    assert d["bytes_sent_per_rank"] == [8.0e9, 8.0e9] and d["piece_bytes_sent"] == [4000000000, 4000000000]
+    assert d["piece_gb_per_s"][0] == [50.0, 50.0] and d["piece_gb_per_s"][1][0] == pytest.approx(26.667, abs=1e-3)
+    assert d["replicated_ms"]["factor_M"] == [1.4, 1.5]
+    assert bench.sharded_step_profile([None, None], stages) is None          # one GPU: no sharded build, no object
+    # the line carries it in both multi-GPU modes, and the fields come from the C ABI's profile
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'out["sharded_step"] = shard_prof' in src and "all_gather_object" in src and "cone.build_profile(r) for r in range(shards)" in src
+    assert "HMiConeGetBuildProfile" in open(HEADER).read()
 
 
 def test_library_exports_nothing_but_the_declared_surface():

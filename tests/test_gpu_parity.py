@@ -140,9 +140,57 @@ def test_schur_against_reference(name):
             check_close(ex["ASinv"], g["ASinv_pri"], name + " primal")
             check_close(ex["ASinvRdSinv"], g["ASinvRdSinv_pri"], name + " primal")
             check_close([ex["TraceSinv"]], g["TraceSinv_pri"], name + " primal")
+        # --- state "C": the two cone slots a solve moves between builds (oracle/ref_dump.c) -- a dual perturbation on the
+        # diagonal of S and of the checker (hdsdp_conic_sdp.c:383, :441, :2237-2241), a reduced residual (:2225-2229;
+        # hdsdp_algo.c:244), and Phase B's form: residual 0, the shift carried by the perturbation (hdsdp_algo.c:1698-1704)
+        if "c_par" in g:
+            _state_c(name, g, cone, kkt, tau, y, m)
         kkt.destroy()
     finally:
         cone.destroy()
+
+
+def _state_c(name, g, cone, kkt, tau, y, m):
+    from hdsdp_amd import api
+    msk = lower_mask(m)
+    for kc in (1, 2, 3):
+        pert, Rdc = float(g["c_par"][2 * kc - 2]), float(g["c_par"][2 * kc - 1])
+        tag = "%s state c%d" % (name, kc)
+        cone.set_perturb(pert)
+        cone.reduce_resi(Rdc)
+        assert cone.check_is_interior(tau, y) == bool(g["c%d_interior" % kc][0]), tag
+        if not g["c%d_interior" % kc][0]:
+            continue
+        ld = float(g["c%d_logdet" % kc][0])
+        assert abs(cone.log_barrier(tau) - ld) <= 1e-12 * abs(ld), tag
+        kkt.build_up(api.KKT_TYPE_HOMOGENEOUS)
+        ex = kkt.export()
+        check_close(ex["ASinvCSinv"], g["c%d_ASinvCSinv_hsd" % kc], tag)
+        for got, ref in zip((ex["CSinv"], ex["CSinvCSinv"], ex["CSinvRdSinv"], ex["TraceSinv"]), g["c%d_hsd_scalars" % kc]):
+            check_close([got], [ref], tag)
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        ex = kkt.export()
+        check_close(kkt.M[msk], g["c%d_M_inf" % kc][msk], tag)
+        check_close(ex["ASinv"], g["c%d_ASinv_inf" % kc], tag)
+        check_close(ex["ASinvRdSinv"], g["c%d_ASinvRdSinv_inf" % kc], tag)
+        check_close([ex["TraceSinv"]], g["c%d_TraceSinv_inf" % kc], tag)
+        kkt.add_to_diag(float(g["diag_add"][0]))
+        kkt.factorize()
+        x = kkt.solve(np.array(g["c%d_ASinv_inf" % kc], dtype=np.float64))
+        ref = g["c%d_sol_ASinv" % kc]
+        assert np.linalg.norm(x - ref) <= 1e-8 * np.linalg.norm(ref), tag
+        Mbefore = kkt.M.copy()
+        kkt.build_up(api.KKT_TYPE_CORRECTOR)
+        ex = kkt.export()
+        check_close(ex["ASinv"], g["c%d_ASinv_cor" % kc], tag)
+        check_close(ex["ASinvRdSinv"], g["c%d_ASinvRdSinv_cor" % kc], tag)
+        assert np.array_equal(Mbefore, kkt.M)
+        # the checker takes the perturbation too, on top of the caller's own diagonal term
+        ok_e, ld_e = g["c%d_ck_expert" % kc]
+        assert cone.check_is_interior_expert(tau, -1.0, y, -0.5 * Rdc, api.BUFFER_DUALCHECK) == bool(ok_e), tag
+        if ok_e:
+            assert abs(cone.log_barrier_of(api.BUFFER_DUALCHECK) - ld_e) <= 1e-11 * abs(ld_e), tag
+    cone.set_perturb(0.0)
 
 
 @pytest.mark.parametrize("name", ["mcp100_A", "gpp100_B", "theta1_A"])

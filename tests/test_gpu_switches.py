@@ -24,6 +24,9 @@ SETTINGS = [
     {"HDM_LANCZOS_WHOLE": "0", "HDM_LANCZOS_FUSED": "0", "HDM_LANCZOS_GROUP": "0"}, {"HDM_LANCZOS_BIG": "0"},
     {"HDM_LANCZOS_BIG": "0", "HDM_LANCZOS_GROUP": "0"},
     {"HDM_SYM_COMBINE_SKY": "0"}, {"HDM_SHARE_T_SLABS": "0"}, {"HDM_NSPLIT": "24"}, {"HDM_BC": "8"}, {"HDM_TCAP_GIB": "1"},
+    {"HDM_GRAM_QUEUE": "0"},                                             # Gram jobs from one queue per XCD (the form up to round 4)
+    {"HDM_GRAM_KSTAGES": "16", "HDM_NSPLIT": "8"},                       # more K splits than slabs: groups of 8 accumulate into the slabs
+    {"HDSDP_MI355X_HOST_THREADS": "1"},                                  # ingest on one host thread
     {"HDM_PERSIST": "0"}, {"HDM_PERSIST_RESERVE_CUS": "200"}, {"HDSDP_MI355X_PRELOAD": "0"},
     {"HDM_DIAG_SWEEP": "0"}, {"HDM_CHOL_K128": "0"}, {"HDM_TRSV_FLOW": "0"}, {"HDM_GRAPHS": "1"}, {"HDM_GRAPHS": "2"},
     {"SWITCH_WORKER_SHARDS": "2"},                                       # in-process device group, defaults

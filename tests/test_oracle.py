@@ -78,6 +78,34 @@ def test_oracle_matches_reference(name):
     check_close(pk["ASinv"], g["ASinv_pri"], "ASinv_pri")
     check_close(pk["ASinvRdSinv"], g["ASinvRdSinv_pri"], "ASinvRdSinv_pri")
     check_close([pk["TraceSinv"]], g["TraceSinv_pri"], "TraceSinv_pri")
+    # state "C" (ref_dump.c): a dual perturbation on the diagonal of S (hdsdp_conic_sdp.c:383, :2237-2241), then a reduced
+    # residual (:2225-2229), then Phase B's form -- residual 0, the shift carried by the perturbation (hdsdp_algo.c:1698-1704)
+    for kc in (1, 2, 3):
+        pert, Rdc = float(g["c_par"][2 * kc - 2]), float(g["c_par"][2 * kc - 1])
+        Sc = blk.assemble_S(tau, y, Rdc - pert)
+        Lc, infoc = blk.factor(Sc)
+        assert (infoc == 0) == bool(g["c%d_interior" % kc][0]), kc
+        if infoc != 0:
+            continue
+        ldc = float(g["c%d_logdet" % kc][0])
+        assert abs(blk.logdet(Lc) - ldc) <= 1e-12 * abs(ldc)
+        Sic = blk.inverse(Lc)
+        kk = blk.kkt_build(Sic, Rdc, 0)
+        check_close(kk["M"][mm], g["c%d_M_inf" % kc][mm], "state C M")
+        check_close(kk["ASinv"], g["c%d_ASinv_inf" % kc], "state C ASinv")
+        check_close(kk["ASinvRdSinv"], g["c%d_ASinvRdSinv_inf" % kc], "state C ASinvRdSinv")
+        check_close([kk["TraceSinv"]], g["c%d_TraceSinv_inf" % kc], "state C TraceSinv")
+        hh = blk.kkt_build(Sic, Rdc, 2)
+        check_close(hh["ASinvCSinv"], g["c%d_ASinvCSinv_hsd" % kc], "state C ASinvCSinv")
+        for got, ref in zip((hh["CSinv"], hh["CSinvCSinv"], hh["CSinvRdSinv"], hh["TraceSinv"]), g["c%d_hsd_scalars" % kc]):
+            check_close([got], [ref], "state C hsd scalar")
+        cc = blk.kkt_build(Sic, Rdc, 1)
+        check_close(cc["ASinv"], g["c%d_ASinv_cor" % kc], "state C cor ASinv")
+        check_close(cc["ASinvRdSinv"], g["c%d_ASinvRdSinv_cor" % kc], "state C cor ASinvRdSinv")
+        Mc = kk["M"].copy()
+        Mc[np.arange(m), np.arange(m)] += float(g["diag_add"][0])
+        xc = oracle_py.pcg_solve(Mc, g["c%d_ASinv_inf" % kc])
+        assert np.linalg.norm(xc - g["c%d_sol_ASinv" % kc]) <= 1e-8 * np.linalg.norm(g["c%d_sol_ASinv" % kc])
     # the Schur solves (Jacobi PCG to the reference's tolerances)
     Ms = k["M"].copy()
     Ms[np.arange(m), np.arange(m)] += float(g["diag_add"][0])
