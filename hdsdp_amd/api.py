@@ -33,7 +33,7 @@ EXPORTS = [
     "HMiConeCreateSDP", "HMiConeCreateSDP64", "HMiConeBuilderBegin", "HMiConeBuilderAddColumn", "HMiConeBuilderStored", "HMiConeBuilderFinish", "HMiConeBuilderAbort", "HMiConeCreateSynthetic", "HMiConeDestroy", "HMiConeSetStart", "HMiConeUpdate",
     "HMiConeCheckIsInterior", "HMiConeGetLogBarrier", "HMiConeRatioTest", "HMiLanczosStartVector", "HMiConeGetPrimal", "HMiConeCheckIsInteriorExpert",
     "HMiConeAddStepToBufferAndCheck", "HMiConeReduceResi", "HMiConeSetPerturb", "HMiConeGetCoeffNorm", "HMiConeGetObjNorm",
-    "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeGetDualMatrix",
+    "HMiConeScalByConstant", "HMiConeComputeATimesXpy", "HMiConeComputeXDotS", "HMiConeComputeTraceCX", "HMiConeGetDual", "HMiConeGetPresolve", "HMiConeDetectFeature", "HMiConeGetDualMatrix",
     "HMiConeGetTraces", "HMiConeGetPath", "HMiConeSweepInfo", "HMiConeGetStreaming", "HMiConeUseSweepCopy", "HMiKKTSetHostMirror", "HMiConeSetExchange", "HMiConeSetExchangePieces", "HMiConeGetExchangeStats", "HMiConeGetBuildProfile", "HMiConeBuildPrimalXSXDirection",
     "HMiConeGetExchangeBuffers", "HMiConeSetExchangeBuffers", "HMiKKTDeviceMatrix", "HMiKKTGetRows", "HMiDeviceInit",
     "HMiSetDevices", "HMiSetDevicesEx", "HMiRcclGroupSelfTest", "HMiGetDeviceGroup", "HMiSetShardMinDim", "HMiConeGetShardCount", "HMiConeGetGroupTraffic", "HMiRcclSelfTest", "HMiGetCallStats", "HMiCallStatName", "HMiResetCallStats", "HMiKKTPhaseAEligible", "HMiKKTPhaseA",
@@ -142,6 +142,7 @@ def load_library():
         "HMiConeGetDual": (None, [vp, dp, dp]),
         "HMiConeGetLogBarrier": (C.c_int, [vp, C.c_double, dp, C.c_int, dp]),
         "HMiConeGetPresolve": (None, [vp, ip, ip, ip, ip, ip, ip]),
+        "HMiConeDetectFeature": (None, [vp, dp, ip, dp]),
         "HMiConeGetDualMatrix": (C.c_int, [vp, dp]),
         "HMiConeGetTraces": (C.c_int, [vp, dp]),
         "HMiConeGetPath": (C.c_int, [vp]),
@@ -486,6 +487,13 @@ class SDPCone:
                 "step2_piece_ms": per[:, 0].tolist(), "exchange_wait_ms": per[:, 1].tolist(),
                 "exchange_wait_host_ms": per[:, 2].tolist(), "gram_piece_ms": per[:, 3].tolist(),
                 "piece_bytes_sent": per[:, 4].tolist(), "piece_flight_ms": per[:, 5].tolist()}
+
+    def detect_feature(self, b):
+        """the cone's getstat slot (HConeDetectFeature): (int features[20], double features[20]), zero where the cone decides nothing"""
+        fi, fd = np.zeros(20, dtype=np.int32), np.zeros(20)
+        bb = np.ascontiguousarray(b, dtype=np.float64)
+        load_library().HMiConeDetectFeature(self._h, _dptr(bb), _iptr(fi), _dptr(fd))
+        return fi, fd
 
     def presolve(self):
         m = self.m

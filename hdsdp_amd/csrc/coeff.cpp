@@ -218,6 +218,12 @@ int mi_coeff_build(MiCoeff &c, int n, long nnz, const int *idx, const double *va
         std::vector<int> row, col;
         rows_and_cols(n, c.idx, row, col);
         one = probe_rank_one_sparse(n, row, col, c.val, sgn, a);
+        if (!one && nnz == n) {
+            bool eye = true;
+            for (long k = 0; k < nnz && eye; ++k) eye = (row[k] == col[k]) && (c.val[k] == c.val[0]);
+            c.is_eye = eye;
+            c.eye_val = c.val[0];
+        }
     }
     c.rank = n;
     if (!one) return 0;
@@ -243,6 +249,9 @@ int mi_coeff_build(MiCoeff &c, int n, long nnz, const int *idx, const double *va
     c.factor.swap(a);
     c.factor_nnz = kept;
     c.rank = 1;
+    if (c.type == MI_COEFF_SPR1 && kept == 1 && c.sign == 1.0)
+        for (int r = 0; r < n; ++r)
+            if (c.factor[r] != 0.0) { if (c.factor[r] == 1.0) c.unit_col = r; break; }
     return 0;
 }
 

@@ -45,6 +45,11 @@ struct MiCoeff {
     double sign = 0.0;
     std::vector<double> factor;  // dense length-n factor
     int factor_nnz = 0;
+    // a multiple of the identity as the reference's feature detection sees it (SPARSE class, exactly n stored entries, all on
+    // the diagonal, all equal: linalg/hdsdp_sdpdata.c:906-931); decided while the entries are at hand
+    bool is_eye = false;
+    double eye_val = 0.0;
+    int unit_col = -1;  // i if the matrix is e_i e_i' exactly (SPR1, one factor entry 1.0, sign 1.0: hdsdp_sdpdata.c:963-975), else -1
     // the entries are on the device (or not needed there): give the host copy back; class, counts, trace and factor stay
     void release() { std::vector<int>().swap(idx); std::vector<double>().swap(val); }
 };

@@ -102,6 +102,9 @@ double HMiConeComputeTraceCX(hdsdp_cone *cone, double *dConePrimal) { return con
 void HMiConeGetDual(hdsdp_cone *cone, double *dConeDual, double *dConeDual2) {
     cone->coneDRecover(cone->coneData, dConeDual, dConeDual2);
 }
+void HMiConeDetectFeature(hdsdp_cone *cone, double *rowRHS, int coneIntFeatures[20], double coneDblFeatures[20]) {   // hdsdp_conic.c:423-428
+    cone->getstat(cone->coneData, rowRHS, coneIntFeatures, coneDblFeatures);
+}
 void HMiConeReduceResi(hdsdp_cone *cone, double dResiReduction) { cone->coneReduceResi(cone->coneData, dResiReduction); }
 void HMiConeSetPerturb(hdsdp_cone *cone, double dDualPerturb) { cone->coneSetPerturb(cone->coneData, dDualPerturb); }
 void HMiConeGetPrimal(hdsdp_cone *cone, double dBarrierMu, double *dRowDual, double *dRowDualStep, double *dConePrimal,

@@ -204,6 +204,8 @@ hdsdp_cone *new_cone_shell(MiCone *c, int iCone) {
     h->coneAxpyBufferAndCheck = cone_axpy_check;
     h->coneReduceResi = cone_reduce_resi;
     h->coneSetPerturb = cone_set_perturb;
+    h->getstat = cone_getstat;
+    h->coneView = cone_view;
     h->coneGetCoeffNorm = cone_coeff_norm;
     h->coneGetObjNorm = cone_obj_norm;
     h->coneScal = cone_scal;

@@ -734,6 +734,63 @@ hdsdp_retcode cone_ratio_test(void *cd, double dTauStep, double *dy, double dAda
     return HDSDP_RETCODE_OK;
 }
 
+// The cone's `getstat` slot: the reference's feature detection (sdpDenseConeFeatureDetectImpl / sdpSparseConeFeatureDetectImpl,
+// interface/hdsdp_conic_sdp.c:2651-2758; read once by the driver, interface/hdsdp.c:163-168) answered from the engine's own
+// presolve, so that a driver whose SDP blocks live here needs no CPU cone beside them (second variant).
+// Same decisions: class counts with the objective's class included (:1368-1381); "no primal interior" for a rank-one row whose
+// right-hand side is below 1e-3 of its Frobenius norm (|sign| for a normalised factor); an implied trace bound from a row that
+// is a multiple of the identity with b / multiple > 0 -- whose VALUE the reference then resets to 0 (:2714), kept as a
+// behaviour -- or from unit-column rows e_i e_i' covering every column (their b summed); "very dense" from 0.7 m DENSE rows.
+// A block most constraints are zero on (the reference's sparse SDP cone) reports the counts only (:2747-2758).
+void cone_getstat(void *cd, double *rowRHS, int intF[20], double dblF[20]) {
+    MiCone *c = (MiCone *) cd;
+    enum { F_NOPINT = 2, F_VERYDENSE = 4, F_IMPTRACE = 5, F_NZERO = 15, F_NSP = 16, F_NDS = 17, F_NSPR1 = 18, F_NDSR1 = 19, D_IMPTRACEX = 11 };
+    int stats[5] = {0, 0, 0, 0, 0};
+    if (c->synthetic) stats[MI_COEFF_DENSE] = c->m + 1;
+    else {
+        for (int t = 0; t < 5; ++t) stats[t] = c->blk.counts[t];
+        // the objective is counted with the class it had BEFORE the rank-one detection (:1373 counts it when the data is
+        // processed, the presolve re-counts rows only, :1502-1504): theta1's all-ones objective stays "dense" in the features
+        const double P = 0.5 * (double) c->n * (c->n + 1);
+        stats[c->blk.obj.stored == 0 ? MI_COEFF_ZERO : ((double) c->blk.obj.stored > 0.3 * P ? MI_COEFF_DENSE : MI_COEFF_SPARSE)] += 1;
+    }
+    intF[F_NZERO] = stats[MI_COEFF_ZERO]; intF[F_NDS] = stats[MI_COEFF_DENSE]; intF[F_NSP] = stats[MI_COEFF_SPARSE];
+    intF[F_NSPR1] = stats[MI_COEFF_SPR1]; intF[F_NDSR1] = stats[MI_COEFF_DSR1];
+    const bool compact = (c->world == 1 && !c->synthetic && (int) c->blk.rows.size() == c->m);
+    if (compact && (double) c->mloc <= 0.3 * (double) c->m) return;          // the reference's sparse SDP cone: counts only
+    if (!c->synthetic && rowRHS) {
+        bool nopint = false, imptrace = false;
+        for (int i = 0; i < c->m; ++i) {
+            const MiCoeff &a = c->blk.rows[i];
+            if (a.rank == 1 && (a.type == MI_COEFF_SPR1 || a.type == MI_COEFF_DSR1) && fabs(rowRHS[i]) < 1e-3 * fabs(a.sign)) nopint = true;
+        }
+        if (nopint) intF[F_NOPINT] = 1;
+        for (int i = 0; i < c->m && !imptrace; ++i) {
+            const MiCoeff &a = c->blk.rows[i];
+            if (a.is_eye && rowRHS[i] / a.eye_val > 0.0) imptrace = true;
+        }
+        double implied = 0.0;                                                // (reset whether or not an identity row was found)
+        std::vector<int> seen((size_t) std::max(c->m, c->n), 0);
+        if (!imptrace)
+            for (int i = 0; i < c->m; ++i) {
+                const MiCoeff &a = c->blk.rows[i];
+                const int at = a.unit_col;
+                if (at < 0 || seen[at]) continue;
+                seen[at] = 1;
+                implied += rowRHS[i];
+            }
+        int covered = 0;
+        for (int i = 0; i < c->m; ++i) covered += seen[i];
+        if (covered == c->n) imptrace = true;
+        if (imptrace) { intF[F_IMPTRACE] = 1; dblF[D_IMPTRACEX] = implied; }
+    }
+    if ((double) stats[MI_COEFF_DENSE] >= 0.7 * (double) c->m) intF[F_VERYDENSE] = 1;
+}
+void cone_view(void *cd) {
+    const MiCone *c = (const MiCone *) cd;
+    printf("- MI355X engine cone of %d x %d and %d rows (device path %d).\n", c->n, c->n, c->m, c->path);
+}
+
 // ---- the remaining cone utilities of the reference's vtable (hdsdp_conic.c:137-153) ------------------------------------
 // norms of the data: |A|_abs = sum |a_ij|, |A|_F over the full symmetric matrices (hdsdp_sdpdata.c:208-309 computes the same
 // numbers per storage class); the synthetic family has no host copy, its norms come from one pass over the device data

@@ -138,6 +138,7 @@ static hdsdp_retcode make_sdp_cone_from_block(MiCone **out, MiBlockData &src, bo
             MiCoeff &d = c->blk.rows[i];
             const MiCoeff &o = src.rows[i];
             d.type = o.type; d.nnz = o.nnz; d.rank = o.rank; d.stored = o.stored; d.trace = o.trace; d.sign = o.sign; d.factor_nnz = o.factor_nnz;
+            d.is_eye = o.is_eye; d.eye_val = o.eye_val; d.unit_col = o.unit_col;
         }
     }
     if (cone_alloc_common(c)) return HDSDP_RETCODE_MEMORY;
@@ -149,7 +150,10 @@ static hdsdp_retcode make_sdp_cone_from_block(MiCone **out, MiBlockData &src, bo
     const char *forcesp = getenv("HDSDP_MI355X_FORCE_PATH");
     if (forcesp && world == 1) c->path = atoi(forcesp);
     if (c->mloc == 0) c->path = PATH_GEMM;   // no constraint touches this block: only the objective's scalars remain
-    if (upload_dense_rows(c)) return HDSDP_RETCODE_MEMORY;   // dense copies also feed the S assembly
+    {
+        CreateTimer t_(1);
+        if (upload_dense_rows(c)) return HDSDP_RETCODE_MEMORY;   // dense copies also feed the S assembly
+    }
     if (c->path == PATH_R1) {
         c->mloc16 = (int) hdm_roundup(std::max(1, c->mloc), 16);
         const size_t av = sizeof(double) * (size_t) c->n16 * c->mloc16;
@@ -204,7 +208,10 @@ static hdsdp_retcode make_sdp_cone_from_block(MiCone **out, MiBlockData &src, bo
     // the entries -- 19 GB at n = m = 2000, 40 %-filled -- goes back now.  The rank-one and gather paths keep theirs (small,
     // and their host-side norms and plans read them).
     if (c->path == PATH_GEMM) { for (MiCoeff &co : c->blk.rows) co.release(); c->blk.obj.release(); }
-    if (cone_build_zs(c)) return HDSDP_RETCODE_FAILED;
+    {
+        CreateTimer t_(2);
+        if (cone_build_zs(c)) return HDSDP_RETCODE_FAILED;
+    }
     *out = c;
     return HDSDP_RETCODE_OK;
 }

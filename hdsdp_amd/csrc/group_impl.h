@@ -391,6 +391,10 @@ template <class F> hdsdp_retcode grun(MiConeGroup *cg, F f) {
 void gc_setstart(void *cd, double v) { for (MiCone *c : ((MiConeGroup *) cd)->shard) cone_setstart(c, v); }
 void gc_reduce_resi(void *cd, double v) { for (MiCone *c : ((MiConeGroup *) cd)->shard) cone_reduce_resi(c, v); }
 void gc_set_perturb(void *cd, double v) { for (MiCone *c : ((MiConeGroup *) cd)->shard) cone_set_perturb(c, v); }
+// feature detection and view: shard 0 holds class, rank, sign and factor of EVERY row (make_sdp_cone_from_block keeps those for
+// the rows a shard does not own), which is all cone_getstat reads
+void gc_getstat(void *cd, double *rowRHS, int intF[20], double dblF[20]) { cone_getstat(((MiConeGroup *) cd)->shard[0], rowRHS, intF, dblF); }
+void gc_view(void *cd) { cone_view(((MiConeGroup *) cd)->shard[0]); }
 int gc_getdim(void *cd) { return ((MiConeGroup *) cd)->n; }
 int64_t gc_getsymnnz(void *cd) { MiConeGroup *cg = (MiConeGroup *) cd; return (int64_t) cg->m * cg->m; }
 
@@ -573,6 +577,8 @@ hdsdp_retcode group_create_cone(hdsdp_cone **pCone, int iCone, int nRow, int nCo
     h->coneAxpyBufferAndCheck = gc_axpy_check;
     h->coneReduceResi = gc_reduce_resi;
     h->coneSetPerturb = gc_set_perturb;
+    h->getstat = gc_getstat;
+    h->coneView = gc_view;
     h->coneGetCoeffNorm = gc_coeff_norm;
     h->coneGetObjNorm = gc_obj_norm;
     h->coneScal = gc_scal;
@@ -600,10 +606,14 @@ template <class Off> static hdsdp_retcode cone_create_csc(hdsdp_cone **pCone, in
                                                           const int *idx, const double *val, int rank, int world) {
     if (!pCone || nRow < 1 || nCol < 1 || nCol > 65535 || world < 1 || rank < 0 || rank >= world || !beg) return HDSDP_RETCODE_FAILED;
     MiBlockData blk;
-    if (mi_block_from_csc(blk, nRow, nCol, beg, idx, val)) {
-        fprintf(stderr, "[hdsdp_mi355x] cone data: a packed index lies outside [0, n(n+1)/2)\n");
-        return HDSDP_RETCODE_FAILED;
+    {
+        CreateTimer t_(0);
+        if (mi_block_from_csc(blk, nRow, nCol, beg, idx, val)) {
+            fprintf(stderr, "[hdsdp_mi355x] cone data: a column's pointers run backwards, or a packed index lies outside [0, n(n+1)/2) or is given twice\n");
+            return HDSDP_RETCODE_FAILED;
+        }
     }
+    g_create_bytes += 12.0 * (double) blk.stored;
     return cone_from_block(pCone, iCone, blk, rank, world);
 }
 // column-by-column ingest (engine_api.h: HMiConeBuilder*): the block's presolved columns as they arrive

@@ -78,14 +78,25 @@ class ShardPlan:
                 best, ns = eff, cand
         big_cap = int((slab_cap_gib << 30) / (8.0 * self.R * self.R))
         byk = kblocks // 96
-        if byk >= 128:
+        splits = ns
+        if byk >= 128 and self.world == 1:
+            # one device, long packed index (round 5): K splits sized so that one split's operand panel fills the 256 MiB
+            # memory-side cache, run in groups over at most 8 GiB of slabs (engine_cone.h: cone_alloc_gemm_work)
+            kst = max(96, min(int((1 << 28) / (128.0 * self.R)), 2048))
+            splits = max(8, -(-kblocks // kst))
+            while splits * tiles < 4096 and splits * 2 <= min(byk, 1024):
+                splits *= 2
+            ns = max(ns, min(splits, max(8, int((8 << 30) / (8.0 * self.R * self.R)))))
+            splits = max(splits, ns)
+        elif byk >= 128:
             big = min(1024, byk, big_cap) & ~7
             ns = max(ns, big)
+            splits = ns
         slab = ns * self.R * self.R * 8
         if self.world == 1:
             # one GPU: T is dead when the Gram product starts, the two share one buffer of the larger size
             tb = parts.pop("congruence intermediates T")
-            parts["congruence intermediates T / Gram slabs (%d splits), one shared buffer" % ns] = max(tb, slab)
+            parts["congruence intermediates T / Gram slabs (%d slabs for %d splits), one shared buffer" % (ns, splits)] = max(tb, slab)
         else:
             parts["Gram slabs (%d splits)" % ns] = slab
         parts["Gram matrix"] = self.R * self.R * 8

@@ -251,6 +251,11 @@ hdsdp_retcode HMiConeRatioTest(hdsdp_cone *cone, double barHsdTauStep, double *r
 hdsdp_retcode HMiConeCheckIsInteriorExpert(hdsdp_cone *cone, double dCCoef, double dACoefScal, double *dACoef, double dEyeCoef,
                                            int whichBuffer, int *isInterior);
 hdsdp_retcode HMiConeAddStepToBufferAndCheck(hdsdp_cone *cone, double dStep, int whichBuffer, int *isInterior);
+/* HConeDetectFeature (interface/hdsdp_conic.c:423-428): the cone's `getstat` slot -- class counts, "no primal interior", implied
+ * trace bound, "very dense" as the reference's feature detection decides them (interface/hdsdp_conic_sdp.c:2651-2758), answered
+ * from the engine's own presolve: a driver whose SDP blocks live here needs no CPU cone beside them.
+ * Entries the cone does not decide are left as the caller set them. */
+void HMiConeDetectFeature(hdsdp_cone *cone, double *rowRHS, int coneIntFeatures[20], double coneDblFeatures[20]);
 void HMiConeReduceResi(hdsdp_cone *cone, double dResiReduction);
 void HMiConeSetPerturb(hdsdp_cone *cone, double dDualPerturb);
 /* the remaining HCone* utilities of a dense SDP block (hdsdp_conic.h:44-61; hdsdp_conic_sdp.c:1558-1614, :2470-2560):
@@ -471,7 +476,14 @@ void HMiSDPAFree(HMiSDPA **pp);
  *                                           memory; 0: the general GEMM kernel
  *  HDM_TRSV_FLOW                  1         single-launch substitution; 0: per-block launches             test_gpu_switches.py, test_gpu_kernels.py
  *  HDM_TRSV_FLOW_FAIL_ONCE        0         test hook: throw the first single-launch result away          test_gpu_kernels.py::test_fallback_chains_of_the_factor_and_solve_kernels
- *  HDM_GRAPHS                     0         0 / 1 / 2: hipGraph replay of factorisation / substitutions   test_gpu_switches.py, test_gpu_kernels.py
+ *  HDM_GRAPHS                     0         DIAGNOSTIC ONLY, not a supported position: 1 / 2 replay the    (diagnostic; still run by test_gpu_switches.py and
+ *                                           factorisation / substitution chains from a hipGraph.  No gain     test_gpu_kernels.py so that it keeps working)
+ *                                            and two runtime hazards on record: a replayed
+ *                                           MEMSET node once wrote bytes that were not its captured value
+ *                                           (profiles/r04_c_poison.txt; not reproducible stand-alone:
+ *                                           tools/probes/memset_node_probe.hip, profiles/r05_e_memset_node_
+ *                                           probe.txt -- the captured chains hold kernel nodes only since),
+ *                                           and rocprofv3 dies beneath hipGraphLaunch (profiles/r04_a_*)
  *  HDM_SYM_COMBINE_SKY            1         S assembly in storage order; 0: element-indexed kernel        test_gpu_switches.py
  *  HDM_LANCZOS_WHOLE              1         small blocks: whole ratio test in one launch                  test_gpu_switches.py
  *  HDM_LANCZOS_FUSED              1         small blocks: three Lanczos steps per launch                  test_gpu_switches.py

@@ -16,6 +16,7 @@
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -55,13 +56,40 @@ static void getstat_trampoline(void *coneData, double *rowRHS, int intFeatures[2
 }
 static void view_nothing(void *coneData) { (void) coneData; }
 
+/* timing only: the reference's HConeProcData (its CPU cone copies and classifies the user data, interface/hdsdp_conic_sdp.c:
+   1356-1409) runs before HConePresolveData and is part of what its driver prints as "Pre-solver" time */
+hdsdp_retcode HConeProcData(hdsdp_cone *HCone) {
+    static hdsdp_retcode (*real)(hdsdp_cone *) = NULL;
+    if (!real) real = (hdsdp_retcode (*)(hdsdp_cone *)) dlsym(RTLD_NEXT, "HConeProcData");
+    if (!real) { fprintf(stderr, "drop_attach: the reference's HConeProcData was not found\n"); return HDSDP_RETCODE_FAILED; }
+    const char *sw = getenv("HDSDP_DROP_ATTACH");
+    if (sw && atoi(sw) == 2 && (HCone->cone == HDSDP_CONETYPE_DENSE_SDP || HCone->cone == HDSDP_CONETYPE_SPARSE_SDP)) {
+        /* second variant of the glue: the block will live on the engine alone -- its getstat and view slots
+           included -- so the reference's CPU cone is never built: no copy of the user data into sdp_coeff objects, no second
+           rank-one detection, no dense buffers */
+        fprintf(stderr, "drop_attach: cone %d: the reference's HConeProcData is skipped (HDSDP_DROP_ATTACH=2)\n", HCone->iCone);
+        return HDSDP_RETCODE_OK;
+    }
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    hdsdp_retcode rc = real(HCone);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    fprintf(stderr, "drop_attach: cone %d: the reference's own HConeProcData on its CPU cone took %.3f s\n", HCone->iCone,
+            (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec));
+    return rc;
+}
+
 hdsdp_retcode HConePresolveData(hdsdp_cone *HCone) {
     static hdsdp_retcode (*real)(hdsdp_cone *) = NULL;
     if (!real) real = (hdsdp_retcode (*)(hdsdp_cone *)) dlsym(RTLD_NEXT, "HConePresolveData");
     if (!real) { fprintf(stderr, "drop_attach: the reference's HConePresolveData was not found\n"); return HDSDP_RETCODE_FAILED; }
-    hdsdp_retcode rc = real(HCone);
-    if (rc != HDSDP_RETCODE_OK) return rc;
+    struct timespec ts0, ts1, ts2;
     const char *sw = getenv("HDSDP_DROP_ATTACH");
+    const int engine_only = sw && atoi(sw) == 2 && (HCone->cone == HDSDP_CONETYPE_DENSE_SDP || HCone->cone == HDSDP_CONETYPE_SPARSE_SDP);
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    hdsdp_retcode rc = engine_only ? HDSDP_RETCODE_OK : real(HCone);
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    if (rc != HDSDP_RETCODE_OK) return rc;
     /* dense SDP cones, and the reference's sparse SDP cones (blocks on which most constraints are zero,
        hdsdp_conic_sdp.c:1814-1886): the engine keeps only the constraints that have data on a block */
     if ((sw && atoi(sw) == 0) || (HCone->cone != HDSDP_CONETYPE_DENSE_SDP && HCone->cone != HDSDP_CONETYPE_SPARSE_SDP) ||
@@ -89,9 +117,12 @@ hdsdp_retcode HConePresolveData(hdsdp_cone *HCone) {
     HCone->coneATimesXpy = g->coneATimesXpy;                   HCone->coneTraceCX = g->coneTraceCX;
     HCone->coneXDotS = g->coneXDotS;                           HCone->coneGetCoeffNorm = g->coneGetCoeffNorm;
     HCone->coneGetObjNorm = g->coneGetObjNorm;                 HCone->coneScal = g->coneScal;
-    HCone->getstat = getstat_trampoline;
-    HCone->coneView = view_nothing;
-    fprintf(stderr, "drop_attach: cone %d (n = %d, m = %d) attached to the MI355X engine\n", HCone->iCone, u->nConicCol, u->nConicRow);
+    if (engine_only) { HCone->getstat = g->getstat; HCone->coneView = g->coneView; }   /* the engine answers from its own presolve */
+    else { HCone->getstat = getstat_trampoline; HCone->coneView = view_nothing; }
+    clock_gettime(CLOCK_MONOTONIC, &ts2);
+    fprintf(stderr, "drop_attach: cone %d (n = %d, m = %d) attached to the MI355X engine (the reference's own HConePresolveData on its CPU cone "
+                    "%.3f s, HMiConeCreateSDP %.3f s)\n", HCone->iCone, u->nConicCol, u->nConicRow,
+            (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec), (ts2.tv_sec - ts1.tv_sec) + 1e-9 * (ts2.tv_nsec - ts1.tv_nsec));
     free(g);                                       /* the shell only carried the slots */
     return HDSDP_RETCODE_OK;
 }

@@ -415,6 +415,14 @@ int main(int argc, char **argv) {
         int ot = (int) sdpDataMatGetType(dc->sdpObj); dump_i("obj_type", &ot, 1);
         int ds = dc->isDualSparse; dump_i("dual_sparse", &ds, 1);
     }
+    /* feature detection (HConeDetectFeature -> the cone's getstat slot, hdsdp_conic_sdp.c:2651-2745; read once by the driver,
+       hdsdp.c:163): class counts, "no primal interior", implied trace bound, "very dense" */
+    {
+        int fi[20]; double fd[20];
+        memset(fi, 0, sizeof(fi)); memset(fd, 0, sizeof(fd));
+        HConeDetectFeature(cone, pb.b, fi, fd);
+        dump_i("feat_int", fi, 20); dump_d("feat_dbl", fd, 20);
+    }
     /* S as a dense lower-valid n x n column-major array */
     {
         double *S = calloc((size_t) n * n, sizeof(double));

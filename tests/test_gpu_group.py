@@ -414,3 +414,42 @@ def test_unchanged_driver_shards_by_environment(tmp_path):
     import re
     dobj = float(re.search(r"dObj\s+([-+0-9.eE]+)", out).group(1))
     assert abs(dobj - (-36.746433644)) <= 1e-6 * 36.746433644, dobj
+
+
+def test_a_sharded_build_says_where_its_time_went(group):
+    """HMiConeGetBuildProfile: after a sharded Schur build every shard reports its stages -- triangular inverse, congruence step
+    1, step 2 per exchange piece, the exchange WAIT per piece (engine stream idle because the piece had not arrived), the Gram
+    splits per piece, slab reduction, all-reduce -- and the bytes it sent per piece; bench.py puts min / max over the ranks on a
+    multi-GPU line (`sharded_step`).  On one device (loopback) the transfers are device copies: the waits of the shard that
+    queued first are next to nothing, and the bytes add up to what the exchange moves."""
+    from hdsdp_amd import api
+    n, m, world = 384, 96, 2
+    y = 0.02 * np.cos(0.3 * np.arange(m))
+    group(world)
+    cone = api.SDPCone.synthetic(n, m)
+    try:
+        assert cone.shard_count() == world
+        cone.set_start(-500.0)
+        assert cone.check_is_interior(1.0, y)
+        assert cone.build_profile(0) is None                      # no sharded build yet
+        kkt = api.KKT(m, [cone])
+        kkt.build_up(api.KKT_TYPE_INFEASIBLE)
+        profs = [cone.build_profile(r) for r in range(world)]
+        pieces, launches = cone.exchange_stats()
+        for p in profs:
+            assert p is not None and p["world"] == world and p["pieces"] == pieces and p["staged"] == (launches > 0)
+            for k in ("step2_piece_ms", "exchange_wait_ms", "exchange_wait_host_ms", "gram_piece_ms", "piece_bytes_sent", "piece_flight_ms"):
+                assert len(p[k]) == pieces and all(np.isfinite(v) and v >= 0.0 for v in p[k]), k
+            assert p["invert_ms"] > 0 and p["allreduce_ms"] > 0 and sum(p["gram_piece_ms"]) > 0
+            assert (p["congruence_step1_ms"] if p["staged"] else p["congruence_ms"]) > 0
+            if p["staged"]:
+                assert sum(p["step2_piece_ms"]) > 0
+        # every shard sends (world - 1) / world of its transformed rows: the group's own byte count agrees
+        a2a_bytes, _ = cone.group_traffic()
+        assert abs(sum(profs[0]["piece_bytes_sent"]) - a2a_bytes) <= 1e-9 * a2a_bytes
+        # the engine stream never sat idle for long before a piece's Gram splits on the shard that was served first
+        assert min(sum(p["exchange_wait_ms"]) for p in profs) < 5.0
+        assert cone.build_profile(world) is None                  # no such shard
+        kkt.destroy()
+    finally:
+        cone.destroy()

@@ -65,6 +65,11 @@ def test_schur_against_reference(name):
                 # none of this may have touched the factor of S itself
                 assert abs(cone.log_barrier_of(api.BUFFER_DUALVAR) - float(g["logdet"][0])) <= 1e-12 * abs(float(g["logdet"][0]))
 
+        # --- the getstat slot: the reference's feature detection from the engine's own presolve (hdsdp_conic_sdp.c:2651-2745)
+        if "feat_int" in g:
+            fi, fd = cone.detect_feature(g["b"] if "b" in g else cone.traces())
+            assert np.array_equal(fi, g["feat_int"]), (name, fi.tolist(), g["feat_int"].tolist())
+            assert np.allclose(fd, g["feat_dbl"], rtol=1e-12, atol=0.0), (name, fd.tolist(), g["feat_dbl"].tolist())
         kkt = api.KKT(m, [cone])
         msk = lower_mask(m)
         # --- KKT_TYPE_INFEASIBLE

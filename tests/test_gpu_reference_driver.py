@@ -58,7 +58,9 @@ CASES = {"theta1": (-23.0, 28), "gpp100": (44.9435, None), "mcp100": (-226.15735
          "arrow128": (3564.58337, 38)}
 
 
-@pytest.mark.parametrize("attach", ["0", "1"], ids=["cpu-cones+engine-operator", "engine-cones"])
+# attach 2 (second variant): as 1, but the reference's CPU cone is never built -- its HConeProcData is skipped
+# and the engine's cone answers the driver's one-time feature detection (getstat) and view from its own presolve
+@pytest.mark.parametrize("attach", ["0", "1", "2"], ids=["cpu-cones+engine-operator", "engine-cones", "engine-cones-no-cpu-cone"])
 @pytest.mark.parametrize("inst", sorted(CASES))
 def test_reference_driver_runs_on_the_engine(inst, attach, tmp_path):
     if not os.path.exists(EXE):
@@ -72,7 +74,7 @@ def test_reference_driver_runs_on_the_engine(inst, attach, tmp_path):
         fname = str(tmp_path / (inst + ".dat-s"))
         write_blocks_sdpa(fname, with_lp=inst.endswith("lp"))
     elif inst.startswith("syn"):
-        if inst == "syn200" and attach == "0":
+        if inst == "syn200" and attach != "1":
             pytest.skip("the CPU-cone mode at n = m = 200 is half a minute of reference CPU time for no extra coverage")
         import sys
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -102,7 +104,8 @@ def test_reference_driver_runs_on_the_engine(inst, attach, tmp_path):
     except OSError:
         pass
     assert r.returncode == 0, out[-3000:]
-    assert ("attached to the MI355X engine" in out) == (attach == "1")
+    assert ("attached to the MI355X engine" in out) == (attach in ("1", "2"))
+    assert ("HConeProcData is skipped" in out) == (attach == "2")
     assert "SDP Status: Primal dual optimal" in out, out[-3000:]
     pobj = float(re.search(r"pObj\s+([-+0-9.eE]+)", out).group(1))
     dobj = float(re.search(r"dObj\s+([-+0-9.eE]+)", out).group(1))
