@@ -29,6 +29,8 @@ struct MiCone {
     // cone_rows(), which regenerates a batch into Abatch (counter-based generator: any range of matrices, any number of times,
     // bit-identical).  The sweeps read the zero-suppressed copy when it fits (built the same way, in two passes).
     bool streamed = false;
+    bool rows_from_zs = false; // streamed INGESTED rows (round 5): the zero-suppressed copy is the only image of the constraint data, a
+                               // batch of A_L forms is expanded from it (hdm_zs_expand) where the synthetic family runs its generator
     double *Abatch = nullptr;  // regeneration buffer, Bs matrices
     int Bs = 0;
     double *Cfull = nullptr;   // n16 x n16 objective, full symmetric
@@ -216,7 +218,7 @@ int cone_alloc_gemm_work(MiCone *c) {
         // short.  If what is free does not cover a generous bound of what the builders take, the copy goes (the sweeps then read
         // the dense storage).
         size_t fr = 0, tot = 0;
-        if (c->zs_state == 1 && hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        if (c->zs_state == 1 && !c->rows_from_zs && hipMemGetInfo(&fr, &tot) == hipSuccess) {
             const double rows = (double) std::max(1, c->mloc);
             const double want = std::min(32.0 * (1L << 30), (double) nn * rows) +
                                 sizeof(double) * (double) c->world * c->npb_loc * c->Lr * 16 * (c->world == 1 ? 1.0 : 2.0) +
@@ -389,6 +391,7 @@ void cone_get_kkt_map(void *cd, int iCol, int *schurMatCol) {
 const double *cone_rows(MiCone *c, int q0, int count) {
     if (!c->streamed) return c->Afull ? c->Afull + (long) q0 * c->astride : nullptr;
     if (!c->Abatch || count > c->Bs || q0 < 0 || q0 + count > c->mloc) return nullptr;
+    if (c->rows_from_zs) return hdm_zs_expand(c->zs, q0, count, c->Abatch, c->astride, g.stream) ? nullptr : c->Abatch;
     if (c->world == 1) {                       // owned rows are consecutive in the global numbering
         if (hdm_synth_fill_low(c->Abatch, c->astride, c->n, c->n16, c->own[q0], count, g.stream)) return nullptr;
     } else {

@@ -57,6 +57,8 @@ int hdm_zs_build(const double *A, long astride, int m, long sky, double max_fill
 int hdm_zs_build_from(const std::function<const double *(int, int)> &source, int batch, long astride, int m, long sky,
                       double max_fill, HdmZs *out, hipStream_t s);
 void hdm_zs_free(HdmZs *z);
+// matrices c0 .. c0 + count - 1 of the copy back into A_L-form skyline storage at A (stride astride): values, zeros elsewhere
+int hdm_zs_expand(const HdmZs &z, int c0, int count, double *A, long astride, hipStream_t s);
 // <A_c, X>, <A_c, Y> of all matrices from the copy (what hdm_sym_dot2 computes from the dense storage; other summation order)
 int hdm_sym_dot2_zs(const HdmZs &z, int n, long lda, const double *X, const double *Y, long ldx, double *outx, double *outy,
                     const int *rows_global, double sx, double sy, hipStream_t s);

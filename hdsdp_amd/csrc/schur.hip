@@ -390,6 +390,30 @@ __global__ __launch_bounds__(256) void hdm_zs_fill_kernel(const double *__restri
     if (threadIdx.x == 0) run[blockIdx.x] = running;
 }
 
+// The copy back into A_L-form skyline storage: matrices c0 .. c0 + count - 1 of the copy, chunk by chunk (zeros where the mask has
+// none).  A cone whose ingested rows are too many to stay resident keeps ONLY the copy and expands a batch of rows whenever the
+// congruence (or any other reader of the dense form) asks for one -- what the counter-based generator does for the synthetic
+// family (engine_cone.h: cone_rows).  blockIdx.y splits the matrices of a chunk over several workgroups.
+__global__ __launch_bounds__(256) void hdm_zs_expand_kernel(const unsigned long long *__restrict__ meta, const double *__restrict__ val,
+                                                             const unsigned long long *__restrict__ base, int mtot, int c0, int count,
+                                                             double *__restrict__ A, long astride, long sky) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long p0 = (long) blockIdx.x * 1024 + 256 * wave + lane;
+    const double *src = val + base[blockIdx.x];
+    for (int c = blockIdx.y; c < count; c += gridDim.y) {
+        const unsigned long long *rec = meta + ((long) blockIdx.x * mtot + c0 + c) * 24;
+        double *a = A + (long) c * astride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long mk = rec[4 * wave + q];
+            const unsigned off = reinterpret_cast<const unsigned *>(rec + 16)[4 * wave + q];
+            const long p = p0 + 64 * q;
+            const double v = ((mk >> lane) & 1ULL) ? src[off + hdm_lanes_below(mk)] : 0.0;
+            if (p < sky) a[p] = v;
+        }
+    }
+}
+
 // S(lower incl. diag) = tau*C - sum_i y_i A_i + eye*I from the zero-suppressed copy: the sums of hdm_sym_combine_sky_kernel
 // term by term in the same order, without the terms whose a is an exact zero.
 // Workgroup = one chunk, two waves: wave w owns mask words 8 w .. 8 w + 7 (lane l of word q = position 1024 b + 512 w + 64 q + l),
@@ -902,6 +926,15 @@ int hdm_zs_build_from(const std::function<const double *(int, int)> &source, int
     if (hipStreamSynchronize(s) != hipSuccess) return fail(1);
     (void) hipFree(run_dev);
     out->nchunk = nchunk; out->sky = sky; out->nnz = (long) run; out->m = m;
+    return 0;
+}
+
+int hdm_zs_expand(const HdmZs &z, int c0, int count, double *A, long astride, hipStream_t s) {
+    if (!z.val || c0 < 0 || count < 0 || c0 + count > z.m) return 1;
+    if (count == 0) return 0;
+    const unsigned gy = (unsigned) std::max(1, std::min(count, 16));
+    hipLaunchKernelGGL(hdm_zs_expand_kernel, dim3((unsigned) z.nchunk, gy), dim3(256), 0, s, z.meta, z.val, z.base, z.m, c0, count, A, astride, z.sky);
+    HDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
 

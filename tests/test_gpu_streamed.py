@@ -104,3 +104,104 @@ def test_config5_at_size_on_one_device(mode, monkeypatch):
         kkt.destroy()
     finally:
         cone.destroy()
+
+
+@pytest.mark.parametrize("name,bc", [("syn96x40_B", 16), ("syn200", 64), ("mix40_B", 8)])
+def test_ingested_rows_kept_only_as_the_compressed_copy(name, bc, monkeypatch):
+    """round 5: INGESTED rows that do not stay resident live in the zero-suppressed copy alone (csrc/engine_create.h:
+    upload_streamed_rows) and a batch of A_L forms is expanded from it wherever the dense form is read (congruence, data norms,
+    A X, indefinite-X builds) -- what the counter-based generator does for the synthetic family.  A CSC block taken in both ways
+    (HDSDP_MI355X_STREAM_A = 0 / 1, several batches with a ragged last one) gives the same operator in every quantity, with the
+    sweeps reading the copy and with the sweeps expanding batches; and the reference's numbers (the golden's M)."""
+    import os
+    import sys
+    from hdsdp_amd import api
+    from test_gpu_group import _phase_a, _compare
+    from util import check_close, lower_mask, y_of
+    g = load_golden(name)
+    n, m = int(g["dims"][0]), int(g["dims"][1])
+    if "csc_beg" in g:
+        beg, idx, val = g["csc_beg"], g["csc_idx"], g["csc_val"]
+    else:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        import oracle_py
+        beg, idx, val, _ = oracle_py.synth_csc(n, m)
+    monkeypatch.setenv("HDM_BC", str(bc))
+    monkeypatch.setenv("HDSDP_MI355X_FORCE_GEMM", "1")      # (mix40: its five classes through the congruence + Gram path)
+    Rd, y = float(g["Rd"][0]), y_of(g)
+    out = []
+    for stream, sweep_copy in (("0", True), ("1", True), ("1", False)):
+        monkeypatch.setenv("HDSDP_MI355X_STREAM_A", stream)
+        cone = api.SDPCone.from_csc(n, m, beg, idx, val)
+        try:
+            on, rows = cone.streaming()
+            assert on == (stream == "1") and (rows > 0) == on, (on, rows)
+            cone.use_sweep_copy(sweep_copy)
+            kkt = api.KKT(m, [cone])
+            if name != "mix40_B":
+                out.append(_phase_a(api, cone, kkt, Rd, y))
+            else:                      # (a constraint that is zero: singular M, and S = C - sum y A is not definite without the residual)
+                cone.set_start(Rd)
+                assert cone.check_is_interior(float(g["tau"][0]), y)
+                kkt.build_up(api.KKT_TYPE_HOMOGENEOUS)
+                ex = kkt.export()
+                out.append({"M_hsd": kkt.M.copy(), "ASinv": ex["ASinv"].copy(), "ASinvCSinv": ex["ASinvCSinv"].copy(),
+                            "norms": np.array([cone.coeff_norm(1), cone.coeff_norm(2)])})
+                check_close(kkt.M[lower_mask(m)], g["M_hsd"][lower_mask(m)], name + " streamed ingest")
+            kkt.destroy()
+        finally:
+            cone.destroy()
+    _compare(out[0], out[1], m, tol=1e-12)
+    _compare(out[0], out[2], m, tol=1e-12)
+
+
+def test_an_ingested_config5_block_fits_one_device():
+    """BASELINE configs[4]'s shape as INGESTED data -- n = 2000, m = 8000, 6.7e9 entries (81 GB of CSC) pushed through the
+    column-by-column builder from the SURVEY 8(d) stream -- on ONE device: its 136 GB of A_L forms never exist, the rows live in
+    the 57 GB compressed copy and are expanded 1000 at a time.  Held to tests/golden/full8000_rows.npz like the synthetic cone
+    (rows of M, both vectors, log det S, residual rows of the solves, at the bench state and at the cond(S) = 1e3 state)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from hdsdp_amd import api
+    from test_gpu_parity import _splitmix_u, check_row_subset_state
+    from test_gpu_ingest import _packed_positions
+    free, total = torch.cuda.mem_get_info()
+    if free < 250 * (1 << 30):
+        pytest.skip(f"needs about 250 GiB of free HBM, {free >> 30} GiB free")
+    g = load_golden("full8000_rows")
+    n, m = int(g["n"]), int(g["m"])
+    P = n * (n + 1) // 2
+    ii, jj = _packed_positions(n)
+    diag = ii == jj
+    k = np.arange(P, dtype=np.uint64)
+    y0 = _splitmix_u(np.uint64(2 * m * P) + np.arange(m, dtype=np.uint64))
+
+    def column(c):
+        base = np.uint64(2 * c * P)
+        v = _splitmix_u(base + np.uint64(2) * k)
+        w = _splitmix_u(base + np.uint64(2) * k + np.uint64(1))
+        keep = diag | (w >= 0.2)
+        return np.flatnonzero(keep).astype(np.int32), v[keep]
+
+    Cp = diag.astype(np.float64)
+
+    def columns():
+        with ThreadPoolExecutor(12) as pool:
+            for c, (pi, pv) in enumerate(pool.map(column, range(m))):
+                Cp[pi] += y0[c] * pv
+                if c % 1000 == 999:
+                    print("ingest: column", c + 1, flush=True)     # (a long quiet stretch looks like a hang to the box)
+                yield c + 1, pi, pv
+        yield 0, np.arange(P, dtype=np.int32), Cp
+
+    cone = api.SDPCone.from_columns(n, m, columns())
+    try:
+        on, rows = cone.streaming()
+        assert (on, rows) == (True, 1000) and cone.path == 0 and cone.stored_entries > 6_500_000_000
+        assert cone.sweep_info()[0]
+        kkt = api.KKT(m, [cone], host_mirror=False)
+        check_row_subset_state(cone, kkt, g, "bench")
+        check_row_subset_state(cone, kkt, g, "hard")
+        kkt.destroy()
+    finally:
+        cone.destroy()
