@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/headline_stats_$1
 mkdir -p $O
-export HDSDP_DROP_ATTACH=1 HDSDP_MI355X_CALL_STATS=1
+export HDSDP_DROP_ATTACH=${HDSDP_DROP_ATTACH:-1} HDSDP_MI355X_CALL_STATS=1
 # (graph replay off UNDER THE PROFILER: rocprofiler-sdk 7.2's HSA queue write interceptor dereferences a packet pointer outside
 # mapped memory beneath a hipGraphLaunch -- a replay of the dual factor's long-lived exec, several hundred replays into the
 # solve; frames, disassembly of the faulting instruction and what was ruled out on our side: profiles/r04_a_headline_segv.txt.
