@@ -26,7 +26,6 @@ int hdm_sparse_dot(const int *rp, const int *ti, const int *tj, const double *tv
 // entries (packed lower index, value) of `batch` matrices, row q's at [beg[q], beg[q + 1]), scattered into zeroed A_L-form skyline storage
 int hdm_scatter_low(const int *idx, const double *val, const long *beg, long max_per_row, double *full, long fstride, int n, int ld,
                     int batch, hipStream_t s);
-int hdm_unpack_low(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s);
 int hdm_synth_fill_low(double *full, long fstride, int n, int ld, int c0, int batch, hipStream_t s);
 int hdm_lower_half(const double *full, double *low, int n, long ld, hipStream_t s);
 // strict upper triangle of the 128 x 128 diagonal tiles of `batch` column-major n x n matrices (ld = n) <- 0

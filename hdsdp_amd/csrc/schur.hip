@@ -85,15 +85,6 @@ __device__ __forceinline__ void write_low_tile(const Src &src, double *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void hdm_unpack_low_kernel(const double *__restrict__ packed, long pstride,
-                                                              double *__restrict__ full, long fstride, int n, int ld,
-                                                              int nt) {
-    int t = blockIdx.x, tj = 0;
-    while (t >= nt - tj) { t -= nt - tj; ++tj; }
-    PackedSrc s{packed + (long) blockIdx.y * pstride, n};
-    write_low_tile(s, full + (long) blockIdx.y * fstride, (long) ld, n, tj + t, tj);
-}
-
 __global__ __launch_bounds__(256) void hdm_synth_low_kernel(double *__restrict__ full, long fstride, int n, int ld, int nt,
                                                              int c0) {
     int t = blockIdx.x, tj = 0;
@@ -787,14 +778,6 @@ __global__ __launch_bounds__(256) void hdm_sparse_dot_kernel(const int *__restri
 // ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
-int hdm_unpack_low(const double *packed, long pstride, double *full, long fstride, int n, int ld, int batch, hipStream_t s) {
-    int nt = (ld + 31) / 32;
-    dim3 grid(nt * (nt + 1) / 2, batch), block(32, 8);
-    hipLaunchKernelGGL(hdm_unpack_low_kernel, grid, block, 0, s, packed, pstride, full, fstride, n, ld, nt);
-    HDM_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
 int hdm_scatter_low(const int *idx, const double *val, const long *beg, long max_per_row, double *full, long fstride, int n, int ld,
                     int batch, hipStream_t s) {
     if (batch <= 0) return 0;
@@ -1080,4 +1063,4 @@ int hdm_sky_to_square(const double *sky, double *sq, int n, hipStream_t s) {
 }
 
 // one kernel of this translation unit (= one code object): what the preload thread asks the runtime about (engine.hip: preload_modules)
-const void *hdm_module_handle_schur() { return (const void *) hdm_unpack_low_kernel; }
+const void *hdm_module_handle_schur() { return (const void *) hdm_scatter_low_kernel; }
