@@ -193,6 +193,28 @@ def test_reference_goldens_through_sharded_blocks(name, world, group, monkeypatc
     assert seen == [world], seen
 
 
+@pytest.mark.parametrize("name,world", [("theta1_B", 2), ("mix40_A", 3)])
+def test_sharded_ingested_blocks_with_rows_in_the_compressed_copy(name, world, group, monkeypatch):
+    """the same complete golden check with the shards' INGESTED rows streamed (HDSDP_MI355X_STREAM_A=1, round 5): every shard keeps
+    its own rows only as the zero-suppressed copy and expands them a few at a time for the congruence -- sharded builds, staged
+    exchange, sweeps summed over the shards, all on expanded batches"""
+    import test_gpu_parity
+    monkeypatch.setenv("HDSDP_MI355X_FORCE_GEMM", "1")
+    monkeypatch.setenv("HDSDP_MI355X_STREAM_A", "1")
+    monkeypatch.setenv("HDM_BC", "8")
+    group(world)
+    seen = []
+    real = test_gpu_parity._make_cone
+
+    def spy(nm, g):
+        cone, n, m = real(nm, g)
+        seen.append((cone.shard_count(), cone.streaming()[0]))
+        return cone, n, m
+    monkeypatch.setattr(test_gpu_parity, "_make_cone", spy)
+    test_gpu_parity.test_schur_against_reference(name)
+    assert seen == [(world, True)], seen
+
+
 def test_two_sharded_blocks_in_one_operator(group):
     """two group cones (and a plain one) accumulate into ONE Schur operator, every build type: the sum over the shards
     must touch each block's own contribution only (a corrector build that reduced the operator-wide accumulator would
