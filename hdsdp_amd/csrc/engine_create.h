@@ -19,9 +19,15 @@ struct RowUploader {
     static constexpr int rowcap = 1024;
     int which = 0;
     int init(const MiCone *c) {
-        long maxrow = 1;
-        for (int q = 0; q < c->mloc; ++q) maxrow = std::max<long>(maxrow, (long) c->blk.rows[c->own[q]].idx.size());
-        cap = std::max(maxrow, (long) ((192L << 20) / 12));      // entries per staging buffer (192 MiB, or one row)
+        long maxrow = 1, total = 0;
+        for (int q = 0; q < c->mloc; ++q) {
+            const long k = (long) c->blk.rows[c->own[q]].idx.size();
+            maxrow = std::max(maxrow, k);
+            total += k;
+        }
+        // entries per staging buffer: 192 MiB worth, or one row if that is more -- and never more than the block holds (a problem
+        // of many small blocks creates many cones: each would otherwise pin 384 MiB of host memory for a few KB of entries)
+        cap = std::max(maxrow, std::min((long) ((192L << 20) / 12), std::max(1L, total)));
         for (auto &b : st) {
             if (hipHostMalloc((void **) &b.hi, sizeof(int) * (size_t) cap, hipHostMallocDefault) != hipSuccess ||
                 hipHostMalloc((void **) &b.hv, sizeof(double) * (size_t) cap, hipHostMallocDefault) != hipSuccess ||
