@@ -295,13 +295,20 @@ int cone_alloc_gemm_work(MiCone *c) {
         const long byk = kblocks / 96;   // >= 96 k blocks (of 16) per job keeps prologue + epilogue under 4 %
         const char *ek = getenv("HDM_GRAM_KSTAGES");   // A/B and test knob: stages per job, at any size
         if ((byk >= 128 || ek) && c->world == 1) {
-            // stages per job: the split's operand panel (R rows) fills the memory-side cache; at least 96, at most 2048
+            // stages per job, the smaller of two bounds (at least 96, at most 2048):
+            //  * the split's operand panel (R rows) fills the memory-side cache: 2^28 B / (128 B x R);
+            //  * what a job costs beside its K loop.  Per job about two stage times of prologue + epilogue (a share 2 / kst of
+            //    its time), and at the end of the launch the 512 workgroups run dry over about half a job (a share
+            //    256 kst / (tiles x kblocks) of the launch): least at kst = sqrt(tiles x kblocks / 128) -- 364 stages at
+            //    n = m = 2000 (343 splits), the floor of 96 at n = m = 1000 (336 splits, the count of rounds 2-4), beyond the
+            //    cache bound at m = 8000.
             long kst = (long) ((double) (1L << 28) / (128.0 * (double) c->R));
+            kst = std::min(kst, (long) std::sqrt((double) tiles * (double) kblocks / 128.0));
             kst = std::max(96L, std::min(kst, 2048L));
             if (ek) kst = std::max(1L, atol(ek));
             total_splits = std::max(8L, (kblocks + kst - 1) / kst);
-            while (!ek && total_splits * tiles < 4096 && total_splits * 2 <= std::min(byk, 1024L)) total_splits *= 2;   // eight rounds of jobs, if K allows
-            const long cap8 = std::max(8L, (long) ((8LL << 30) / slab_bytes));             // <= 8 GiB of slabs, at least 8
+            // slabs: what fits the buffer the intermediates have anyway (one device: the two share it), at least 8 GiB worth, at least 8
+            const long cap8 = std::max(8L, (long) (std::max((double) (8LL << 30), (double) nn * (double) c->Bc) / slab_bytes));
             ns = std::max(ns, std::min(total_splits, cap8));
         } else if (byk >= 128) {
             // sharded block: the exchange pieces are whole groups of splits whose launches overlap the transfers

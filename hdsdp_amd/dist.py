@@ -82,11 +82,10 @@ class ShardPlan:
         if byk >= 128 and self.world == 1:
             # one device, long packed index (round 5): K splits sized so that one split's operand panel fills the 256 MiB
             # memory-side cache, run in groups over at most 8 GiB of slabs (engine_cone.h: cone_alloc_gemm_work)
-            kst = max(96, min(int((1 << 28) / (128.0 * self.R)), 2048))
+            kst = min(int((1 << 28) / (128.0 * self.R)), int(np.sqrt(tiles * kblocks / 128.0)))
+            kst = max(96, min(kst, 2048))
             splits = max(8, -(-kblocks // kst))
-            while splits * tiles < 4096 and splits * 2 <= min(byk, 1024):
-                splits *= 2
-            ns = max(ns, min(splits, max(8, int((8 << 30) / (8.0 * self.R * self.R)))))
+            ns = max(ns, min(splits, max(8, int(max(8 << 30, parts["congruence intermediates T"]) / (8.0 * self.R * self.R)))))
             splits = max(splits, ns)
         elif byk >= 128:
             # sharded: as many splits as before (a multiple of 8: the exchange pieces are groups of them), at most 8 GiB of slabs
