@@ -312,11 +312,13 @@ int cone_alloc_gemm_work(MiCone *c) {
             ns = std::max(ns, std::min(total_splits, cap8));
         } else if (byk >= 128) {
             // sharded block: the exchange pieces are whole groups of splits whose launches overlap the transfers
-            // (engine_build.h), so the split count is a multiple of 8: as many as 96 stages per job allow, at most 1024 (and
-            // what 40 GiB of slabs would have held, the rule up to round 4: the same jobs).  The slabs themselves are
-            // at most 8 GiB: a piece's splits run in groups of them, piece after piece accumulating (gram_range)
-            const long big_cap = (long) ((40LL << 30) / slab_bytes);
-            const long big = std::min(std::min(1024L, byk), big_cap) & ~7L;
+            // (engine_build.h), so the split count is a multiple of 8 (at most 1024), of the length the one-device rule gives.
+            // The slabs themselves are at most 8 GiB: a piece's splits run in groups of them, piece after piece
+            // accumulating (gram_range)
+            long kst = (long) ((double) (1L << 28) / (128.0 * (double) c->R));
+            kst = std::min(kst, (long) std::sqrt((double) tiles * (double) kblocks / 128.0));   // (the one-device rule above)
+            kst = std::max(96L, std::min(kst, 2048L));
+            const long big = std::min(1024L, ((kblocks + kst - 1) / kst + 7) & ~7L);
             if (big > ns) {
                 total_splits = big;
                 ns = std::max(ns, std::min(big, std::max(8L, (long) ((8LL << 30) / slab_bytes))));

@@ -89,7 +89,9 @@ class ShardPlan:
             splits = max(splits, ns)
         elif byk >= 128:
             # sharded: as many splits as before (a multiple of 8: the exchange pieces are groups of them), at most 8 GiB of slabs
-            big = min(1024, byk, big_cap) & ~7
+            kst = min(int((1 << 28) / (128.0 * self.R)), int(np.sqrt(tiles * kblocks / 128.0)))
+            kst = max(96, min(kst, 2048))
+            big = min(1024, (-(-kblocks // kst) + 7) & ~7)
             if big > ns:
                 splits = big
                 ns = max(ns, min(big, max(8, int((8 << 30) / (8.0 * self.R * self.R)))))
