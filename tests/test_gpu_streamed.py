@@ -188,12 +188,15 @@ def test_an_ingested_config5_block_fits_one_device():
     import time
     # (several minutes without a dot from pytest: progress goes to a file under gpurun_out/, which the GPU box watches)
     pdir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out")
-    os.makedirs(pdir, exist_ok=True)
     t0 = time.time()
 
     def note(msg):
-        with open(os.path.join(pdir, "ingest8000_progress.txt"), "a") as f:
-            f.write("%7.1f s  %s\n" % (time.time() - t0, msg))
+        try:                                   # (a progress note must never be the reason the test fails)
+            os.makedirs(pdir, exist_ok=True)
+            with open(os.path.join(pdir, "ingest8000_progress.txt"), "a") as f:
+                f.write("%7.1f s  %s\n" % (time.time() - t0, msg))
+        except OSError:
+            pass
 
     def columns():
         with ThreadPoolExecutor(12) as pool:
