@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void hdm_lanczos_fused_kernel(const double *_
 //
 // At n = 2000 a step was four dependent launches (three matrix-vector products, the recurrence) of 5-10 us of work each behind
 // 10 us of launch gap each: 0.11 ms per step, and 186 of the 243 ratio tests of a headline solve run all 30 steps.  Here a
-// step is five grid-wide barriers apart instead: workgroup b owns the columns b, b + G, ... of each product -- all three are
+// step is three grid-wide barriers apart instead (five up to round 4): workgroup b owns the columns b, b + G, ... of each product -- all three are
 // column dots (t1 = Linv^T v down the columns of Linv, t2 = -dS t1 down the columns of the symmetric dS, w = Linv t2 down the
 // columns of a transposed copy of Linv made once per test) with the operand vector in LDS and 32-64 loads in flight per
 // thread -- and of the recurrence; the two inner products of the recurrence are per-workgroup partial sums that every
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(1024) void hdm_lanczos_fused_kernel(const double *_
 struct LzgArgs {
     const double *Linv; long ldl; const double *LinvT; long ldt; const double *dS; long ldd;
     int n; double *V; long ldv; int k0, nsteps; double hprev;
-    double *blk, *t1, *t2, *pa, *pb, *out; unsigned *sync;   // sync: 64 + LZG_WG words, see lzg_barrier
+    double *blk, *t1, *t2, *xw, *out; unsigned *sync;        // xw: x = w - beta v_{k-1}, whole (n); sync: 64 + LZG_WG words, see lzg_barrier
     unsigned epoch0;           // barrier epochs of this launch: epoch0 + 1, + 2, ... (the words are never reset)
     double *dbg;               // diagnostic (HDSDP_MI355X_RATIO_DEBUG=2): workgroup 0 adds up the 100 MHz ticks of its 9 phases here
 };
@@ -295,7 +295,7 @@ __device__ __forceinline__ void lzg_col_dots(const double *__restrict__ A, long 
 template <int TRIPS>
 __global__ __launch_bounds__(256) void hdm_lanczos_group_kernel(LzgArgs a) {
     __shared__ double xs[TRIPS * 256];
-    __shared__ double res[16], red[4][4], vown[16], pown[16];
+    __shared__ double res[16], red[4][4], pown[16];
     __shared__ double bc;
     __shared__ int s_ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -307,10 +307,10 @@ __global__ __launch_bounds__(256) void hdm_lanczos_group_kernel(LzgArgs a) {
         __syncthreads();
     };
     // sum of the G per-workgroup partial sums, the same order in every workgroup
-    auto total = [&](const double *p) {
+    auto total = [&](const double *p) {       // p: the G partial sums in LDS
         double t = 0.0;
         if (wave == 0) {
-            for (int q = lane; q < G; q += 64) t += lzg_ld(p + q);
+            for (int q = lane; q < G; q += 64) t += p[q];
             for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
             if (lane == 0) bc = t;
         }
@@ -329,15 +329,21 @@ __global__ __launch_bounds__(256) void hdm_lanczos_group_kernel(LzgArgs a) {
             tk = now;
         }
     };
+    // THREE grid-wide barriers per step (five up to round 4).  After the third product every workgroup publishes its owned
+    // elements of x = w - beta_{k-1} v_{k-1}; behind ONE barrier everybody then has the whole x and the whole v_k within reach
+    // (a few KB, L2-resident) and finishes the step by itself: the per-workgroup partial sums of alpha = <x, v_k> and of
+    // |x - alpha v_k|^2 -- the very sums the owners used to publish, each over its elements in the same order, added up in the
+    // same fixed order, so the numbers are the five-barrier form's, bit for bit -- and the new basis vector, which stays in LDS
+    // as the next step's operand.  The owners still store their elements of v_{k+1} for the Ritz steps and the next launch.
+    __shared__ double psum[LZG_WG];
     for (int s = 0; s < a.nsteps; ++s) {
         const int k = a.k0 + s;
         const double *vk = a.V + (long) k * a.ldv;
-        if (tid < 16) {                          // the owned elements of v_k and v_{k-1}, for the recurrence
+        if (tid < 16) {                          // the owned elements of v_{k-1}, for the recurrence (stored three barriers ago or more)
             const int j = b + tid * G;
-            vown[tid] = (j < n) ? lzg_ld(vk + j) : 0.0;
             pown[tid] = (j < n && k > 0) ? lzg_ld(a.V + j + (long) (k - 1) * a.ldv) : 0.0;
         }
-        load_vec(vk);
+        if (s == 0) load_vec(vk);                // (later steps: xs holds v_k, made below)
         lzg_col_dots<TRIPS, 1>(a.Linv, a.ldl, n, xs, b, G, res, red);                 // t1 = Linv^T v
         if (tid < 16 && b + tid * G < n) lzg_st(a.t1 + b + tid * G, res[tid]);
         stamp(0);
@@ -351,47 +357,74 @@ __global__ __launch_bounds__(256) void hdm_lanczos_group_kernel(LzgArgs a) {
         stamp(3);
         load_vec(a.t2);
         lzg_col_dots<TRIPS, 2>(a.LinvT, a.ldt, n, xs, b, G, res, red);                // w = Linv t2
-        // the three-term recurrence on the owned elements (hdsdp_lanczos.c:199-218); thread 0 keeps the partial sums
-        if (tid == 0) {
-            double p = 0.0;
-            for (int c = 0; b + c * G < n; ++c) {
-                double x = res[c];
-                if (k > 0) x -= hprev * pown[c];
-                res[c] = x;
-                p += x * vown[c];
-            }
-            lzg_st(a.pa + b, p);
+        // the three-term recurrence on the owned elements (hdsdp_lanczos.c:199-218): x = w - beta_{k-1} v_{k-1}, for everybody
+        if (tid < 16 && b + tid * G < n) {
+            double x = res[tid];
+            if (k > 0) x -= hprev * pown[tid];
+            lzg_st(a.xw + b + tid * G, x);
         }
         stamp(4);
         if (!lzg_barrier(a.sync, a.epoch0 + (++nbar), b, G, &s_ok)) { if (b == 0 && tid == 0) a.out[2 * a.nsteps + 1] = 1.0; return; }
         stamp(5);
-        const double alp = -total(a.pa);
-        if (tid == 0) {
+        // thread q < G redoes workgroup q's partial sum of alpha over that workgroup's elements q, q + G, ... in order.  With a
+        // full grid (G = 256 = the threads of a workgroup) those are the thread's own elements of the LDS vector too: one pass of
+        // loads serves both sums and the new vector.
+        double xr[TRIPS], vr[TRIPS];
+        const bool own_deal = (G == 256);
+        if (own_deal) {
+#pragma unroll
+            for (int it = 0; it < TRIPS; ++it) {
+                const int i = tid + 256 * it;
+                xr[it] = (i < n) ? lzg_ld(a.xw + i) : 0.0;
+                vr[it] = (i < n) ? lzg_ld(vk + i) : 0.0;
+            }
             double p = 0.0;
-            for (int c = 0; b + c * G < n; ++c) {
-                const double x = res[c] + alp * vown[c];
-                res[c] = x;
+#pragma unroll
+            for (int it = 0; it < TRIPS; ++it) if (tid + 256 * it < n) p += xr[it] * vr[it];
+            psum[tid] = p;
+        } else if (tid < G) {
+            double p = 0.0;
+            for (int j = tid; j < n; j += G) p += lzg_ld(a.xw + j) * lzg_ld(vk + j);
+            psum[tid] = p;
+        }
+        __syncthreads();
+        const double alp = -total(psum);
+        if (own_deal) {
+            double p = 0.0;
+#pragma unroll
+            for (int it = 0; it < TRIPS; ++it) {
+                xr[it] = xr[it] + alp * vr[it];
+                if (tid + 256 * it < n) p += xr[it] * xr[it];
+            }
+            psum[tid] = p;
+        } else if (tid < G) {
+            double p = 0.0;
+            for (int j = tid; j < n; j += G) {
+                const double x = lzg_ld(a.xw + j) + alp * lzg_ld(vk + j);
                 p += x * x;
             }
-            lzg_st(a.pb + b, p);
+            psum[tid] = p;
         }
-        stamp(6);
-        if (!lzg_barrier(a.sync, a.epoch0 + (++nbar), b, G, &s_ok)) { if (b == 0 && tid == 0) a.out[2 * a.nsteps + 1] = 1.0; return; }
-        stamp(7);
-        const double nrm = sqrt(total(a.pb));
+        __syncthreads();
+        const double nrm = sqrt(total(psum));
         if (b == 0 && tid == 0) { a.out[2 * s] = alp; a.out[2 * s + 1] = nrm; }
         done = s + 1;
         if (!(nrm > 0.0)) break;                 // (the same number in every workgroup)
-        if (tid < 16 && b + tid * G < n) {
+        const double rn = 1.0 / nrm;
+#pragma unroll
+        for (int it = 0; it < TRIPS; ++it) {     // v_{k+1}, whole, into LDS: the next step's operand
+            const int i = tid + 256 * it;
+            if (own_deal) xs[i] = (i < n) ? xr[it] * rn : 0.0;
+            else xs[i] = (i < n) ? (lzg_ld(a.xw + i) + alp * lzg_ld(vk + i)) * rn : 0.0;
+        }
+        __syncthreads();
+        if (tid < 16 && b + tid * G < n) {       // the owners' elements of it, for the Ritz steps and the next launch
             const int j = b + tid * G;
-            const double xn = res[tid] * (1.0 / nrm);
-            lzg_st(a.V + j + (long) (k + 1) * a.ldv, xn);
-            a.blk[j] = xn;
+            lzg_st(a.V + j + (long) (k + 1) * a.ldv, xs[j]);
+            a.blk[j] = xs[j];
         }
         hprev = nrm;
-        stamp(8);
-        if (!lzg_barrier(a.sync, a.epoch0 + (++nbar), b, G, &s_ok)) { if (b == 0 && tid == 0) a.out[2 * a.nsteps + 1] = 1.0; return; }
-        stamp(9);
+        stamp(6);
     }
     if (b == 0 && tid == 0) a.out[2 * a.nsteps] = (double) done;
 }
@@ -1125,10 +1158,10 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
                 grp_k0 = k;
                 grp_n = std::min(std::min(checkFreq - (k % checkFreq), md - k), 8);
                 LzgArgs a = {};
-                a.epoch0 = sync_epoch; sync_epoch += 5u * (unsigned) grp_n;     // (the barrier words are never reset: epochs only grow)
+                a.epoch0 = sync_epoch; sync_epoch += 3u * (unsigned) grp_n;     // (the barrier words are never reset: epochs only grow)
                 scal_h[44 + 2 * grp_n + 1] = 0.0;                               // give-up word of this launch
                 a.Linv = Linv; a.ldl = ldl; a.LinvT = LT; a.ldt = n16; a.dS = dS; a.ldd = ldd; a.n = n16; a.V = V; a.ldv = n16;
-                a.k0 = k; a.nsteps = grp_n; a.hprev = hprev; a.blk = bv; a.t1 = b1; a.t2 = b2; a.pa = part; a.pb = part + 1024;
+                a.k0 = k; a.nsteps = grp_n; a.hprev = hprev; a.blk = bv; a.t1 = b1; a.t2 = b2; a.xw = b1 + n16;     // (the vector blocks are n16 x 8: column 1 of b1 is free)
                 a.out = scal + 44; a.sync = gsync; a.dbg = dbg2 ? bz + 4 * (size_t) n16 : nullptr;
                 if (n16 <= 2048) hipLaunchKernelGGL(hdm_lanczos_group_kernel<8>, dim3(big_wg), dim3(256), 0, s, a);
                 else hipLaunchKernelGGL(hdm_lanczos_group_kernel<16>, dim3(big_wg), dim3(256), 0, s, a);
@@ -1222,9 +1255,8 @@ int HdmLanczos::solve(const double *Linv, long ldl, const double *dS, long ldd, 
     if (big && dbg2) {
         double t[10];
         HDM_HIP_CHECK(hipMemcpy(t, bz + 4 * (size_t) n16, sizeof(t), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[hdsdp_mi355x ratio] group kernel, workgroup 0, us: Linv^T v %.0f | wait %.0f | dS t1 %.0f | wait %.0f | Linv t2 + recurrence %.0f | wait %.0f | "
-                        "alpha %.0f | wait %.0f | norm %.0f | wait %.0f\n", t[0] / 100, t[1] / 100, t[2] / 100, t[3] / 100, t[4] / 100, t[5] / 100, t[6] / 100,
-                t[7] / 100, t[8] / 100, t[9] / 100);
+        fprintf(stderr, "[hdsdp_mi355x ratio] group kernel, workgroup 0, us: Linv^T v %.0f | wait %.0f | dS t1 %.0f | wait %.0f | Linv t2 + x %.0f | wait %.0f | "
+                        "alpha, norm, v_{k+1} %.0f\n", t[0] / 100, t[1] / 100, t[2] / 100, t[3] / 100, t[4] / 100, t[5] / 100, t[6] / 100);
     }
     nComputed += 1;
     if (maxStep) *maxStep = step;
