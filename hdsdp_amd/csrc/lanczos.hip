@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) void hdm_lanczos_group_kernel(LzgArgs a) {
     // elements of x = w - beta_{k-1} v_{k-1}; behind ONE barrier everybody then has the whole x and the whole v_k within reach
     // (a few KB, L2-resident) and finishes the step by itself: the per-workgroup partial sums of alpha = <x, v_k> and of
     // |x - alpha v_k|^2 -- the very sums the owners used to publish, each over its elements in the same order, added up in the
-    // same fixed order, so the numbers are the five-barrier form's, bit for bit -- and the new basis vector, which stays in LDS
-    // as the next step's operand.  The owners still store their elements of v_{k+1} for the Ritz steps and the next launch.
+    // same fixed order (the five-barrier form's numbers up to how the compiler contracts the multiply-adds; every workgroup
+    // gets the same ones) -- and the new basis vector, which stays in LDS as the next step's operand.  The owners still store their elements of v_{k+1} for the Ritz steps and the next launch.
     __shared__ double psum[LZG_WG];
     for (int s = 0; s < a.nsteps; ++s) {
         const int k = a.k0 + s;
