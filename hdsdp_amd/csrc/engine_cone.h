@@ -467,27 +467,47 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
         auto comp = [&](int i) { return i == 0 ? tau : i == 1 ? eye_now : yo[i - 2]; };
         bool same = true;
         for (int i = 0; i < np && same; ++i) same = (comp(i) == c->pS[i]);
-        if (same && target == c->S) return 0;                                  // S already is T(p)
-        double alpha = 0.0;
+        if (same && target == c->S) { g_asm_counts[0] += 1; return 0; }        // S already is T(p)
+        double alpha = 0.0, eye_delta = 0.0;
         bool hit = same;
         if (!same && c->pD_ok && aff_mode >= 2) {
-            int kmax = 0;
-            for (int i = 1; i < np; ++i) if (fabs(c->pD[i]) > fabs(c->pD[kmax])) kmax = i;
-            if (c->pD[kmax] != 0.0) {
-                alpha = (comp(kmax) - c->pS[kmax]) / c->pD[kmax];
-                hit = std::isfinite(alpha);
-                for (int i = 0; i < np && hit; ++i) {
-                    const double d = comp(i) - c->pS[i], e = alpha * c->pD[i];
-                    hit = fabs(d - e) <= 1.8e-15 * (fabs(comp(i)) + fabs(c->pS[i]) + fabs(e));
-                }
+            // Is p = pS + alpha pD + delta e_eye for some alpha, delta?  alpha from the largest multiplier component of pD (tau
+            // if it has none), checked on tau and every multiplier; the identity coefficient is free: the driver's trial points
+            // move y along the tested direction with the residual held, and its corrector ends at y + a (b d2 - d1) with the
+            // residual reduced (interface/hdsdp_algo.c:911-921) -- the tested direction plus a multiple of the identity, which
+            // costs n additions on top of S + alpha dS.  Tolerance 8e-15 relative per component: the driver forms those points
+            // in another association than pS + alpha pD, and the differences measured on a whole solve reach 4e-15 (a 1.8e-15
+            // bound, rounds 3-4, turned 157 of 345 such requests of the headline solve into 15.6 GB sweeps for one or two
+            // components at 2e-15: HDSDP_MI355X_AFFINE_DEBUG=1 prints every miss).
+            int kmax = -1;
+            for (int i = 2; i < np; ++i) if (c->pD[i] != 0.0 && (kmax < 0 || fabs(c->pD[i]) > fabs(c->pD[kmax]))) kmax = i;
+            if (kmax < 0 && c->pD[0] != 0.0) kmax = 0;
+            if (kmax >= 0) alpha = (comp(kmax) - c->pS[kmax]) / c->pD[kmax];
+            hit = std::isfinite(alpha);
+            double worst = 0.0; int bad = 0, wi = -1;
+            for (int i = 0; i < np; ++i) {
+                if (i == 1) continue;
+                const double d = comp(i) - c->pS[i], e = alpha * c->pD[i];
+                const double sc = fabs(comp(i)) + fabs(c->pS[i]) + fabs(e);
+                if (fabs(d - e) > 8e-15 * sc) { hit = false; bad += 1; }
+                if (sc > 0.0 && fabs(d - e) / sc > worst) { worst = fabs(d - e) / sc; wi = i; }
             }
+            eye_delta = (comp(1) - c->pS[1]) - alpha * c->pD[1];
+            static const bool affdbg = [] { const char *e = getenv("HDSDP_MI355X_AFFINE_DEBUG"); return e && atoi(e); }();
+            if (affdbg && !hit)
+                fprintf(stderr, "[hdsdp_mi355x affine] miss: alpha %.6e, %d of %d components off the tested line, worst relative %.3e at %d\n", alpha, bad, np, worst, wi);
         }
         if (hit && same) {                                                     // the same point into the other buffer: a copy
             HDM_HIP_CHECK(hipMemcpyAsync(target, c->S, sizeof(double) * (size_t) c->n16 * c->n16, hipMemcpyDeviceToDevice, g.stream));
+            g_asm_counts[1] += 1;
             return 0;
         }
+        if (hit && c->dS && !(target != c->S || c->aff_chain < 16)) g_asm_counts[4] += 1;
+        else if (!hit) g_asm_counts[3] += 1;
         if (hit && c->dS && (target != c->S || c->aff_chain < 16)) {
-            if (hdm_axpy_mat(target, c->S, c->dS, alpha, (long) c->n16 * c->n16, g.stream)) return 1;
+            g_asm_counts[2] += 1;
+            if (eye_delta == 0.0 ? hdm_axpy_mat(target, c->S, c->dS, alpha, (long) c->n16 * c->n16, g.stream)
+                                 : hdm_axpy_mat_eye(target, c->S, c->dS, alpha, eye_delta, c->n16, c->n, g.stream)) return 1;
             if (target == c->S) {
                 for (int i = 0; i < np; ++i) c->pS[i] = comp(i);
                 c->aff_chain += 1;
@@ -495,6 +515,8 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
             return 0;
         }
     }
+    if (target == c->dS) g_asm_counts[5] += 1;
+    else if (!(track && c->pS_ok)) g_asm_counts[track ? 3 : 6] += 1;          // (no point known yet: a first assembly)
     HDM_HIP_CHECK(hipMemcpyAsync(c->ydev, yo, sizeof(double) * c->mloc, hipMemcpyHostToDevice, g.stream));
     if (track && (target == c->S || target == c->dS)) {
         std::vector<double> &pp = (target == c->S) ? c->pS : c->pD;

@@ -53,7 +53,16 @@ struct CreateTimer {
     explicit CreateTimer(int k_) : k(k_) {}
     ~CreateTimer() { if (!t_ctx) g_create_sec[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
+// how the requests for a dual / step matrix of single-device blocks were answered (engine_cone.h: cone_assemble): [0] the buffer
+// already held the point, [1] a copy of S, [2] S + alpha dS on the last ratio test's line, [3] a sweep for a dual matrix because
+// the point was not on that line (or no line was known), [4] a sweep because 16 affine updates in a row are refreshed, [5] a
+// sweep for a step matrix (every ratio test), [6] sweeps of blocks that do not track points (small, sharded)
+long g_asm_counts[7] = {0, 0, 0, 0, 0, 0, 0};
 void stats_print_at_exit() {
+    if (g_asm_counts[0] + g_asm_counts[1] + g_asm_counts[2] + g_asm_counts[3] + g_asm_counts[4] + g_asm_counts[5] + g_asm_counts[6] > 0)
+        fprintf(stderr, "[hdsdp_mi355x] dual / step matrices asked for: %ld already in the buffer, %ld copies, %ld on the last ratio test's line (S + alpha dS), "
+                        "%ld dual-matrix sweeps off that line, %ld refresh sweeps, %ld step-matrix sweeps, %ld sweeps of untracked blocks\n",
+                g_asm_counts[0], g_asm_counts[1], g_asm_counts[2], g_asm_counts[3], g_asm_counts[4], g_asm_counts[5], g_asm_counts[6]);
     if (g_create_bytes > 0.0) {
         const double tc = g_create_sec[0] + g_create_sec[1] + g_create_sec[2];
         fprintf(stderr, "[hdsdp_mi355x] cone creation from caller data: %.3f s for %.2f GB of entries (%.2f GB/s): presolve of the columns %.3f s, "

@@ -30,3 +30,4 @@ void hdm_lanczos_start_vector(int n, double *p);
 int hdm_mirror_lower(double *A, long ld, int n, hipStream_t s);
 int hdm_sym_scale(double *A, long ld, int n, double diag_add, double scale, hipStream_t s);   // A <- scale*(sym(A) + diag_add*I)
 int hdm_axpy_mat(double *out, const double *S, const double *dS, double step, long count, hipStream_t s);   // out = S + step*dS
+int hdm_axpy_mat_eye(double *out, const double *S, const double *dS, double step, double eye, long ld, int n, hipStream_t s);   // out = S + step*dS + eye*I

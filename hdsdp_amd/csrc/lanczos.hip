@@ -995,6 +995,22 @@ __global__ void hdm_axpy_mat_kernel(double *out, const double *S, const double *
     if (e < count) out[e] = S[e] + step * dS[e];
 }
 
+// out = S + step * dS + eye * I for an n x n matrix of leading dimension ld (out may alias S)
+__global__ void hdm_axpy_mat_eye_kernel(double *out, const double *S, const double *dS, double step, double eye, long ld, int n) {
+    long e = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ld * ld) return;
+    const long i = e % ld, j = e / ld;
+    double v = S[e] + step * dS[e];
+    if (i == j && i < n) v += eye;
+    out[e] = v;
+}
+int hdm_axpy_mat_eye(double *out, const double *S, const double *dS, double step, double eye, long ld, int n, hipStream_t s) {
+    const long count = ld * ld;
+    hipLaunchKernelGGL(hdm_axpy_mat_eye_kernel, dim3((unsigned) ((count + 255) / 256)), dim3(256), 0, s, out, S, dS, step, eye, ld, n);
+    HDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int hdm_axpy_mat(double *out, const double *S, const double *dS, double step, long count, hipStream_t s) {
     hipLaunchKernelGGL(hdm_axpy_mat_kernel, dim3((unsigned) ((count + 255) / 256)), dim3(256), 0, s, out, S, dS, step, count);
     HDM_HIP_CHECK(hipGetLastError());

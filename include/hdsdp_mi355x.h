@@ -495,6 +495,8 @@ void HMiSDPAFree(HMiSDPA **pp);
  *  HDSDP_MI355X_CALL_STATS        0         table of wall time below the C ABI at exit                    tools/small_driver_stats.sh
  *  HDSDP_MI355X_TRACE             0         synchronise and report after every entry                      (diagnostic)
  *  HDSDP_MI355X_RATIO_DEBUG       0         one line per ratio test: Lanczos steps, time                  (diagnostic)
+ *  HDSDP_MI355X_AFFINE_DEBUG      0         one line per dual-matrix request that missed the last ratio    (diagnostic)
+ *                                           test's line (engine_cone.h: cone_assemble)
  *  HDM_POISON                     0         new device memory is filled with 0xFF (NaN): a read of         (diagnostic; tools/poison_run.sh)
  *                                           never-written memory turns the results into NaNs
  */
