@@ -494,8 +494,13 @@ int cone_assemble(MiCone *c, double tau, const double *y_host, double *target, c
             }
             eye_delta = (comp(1) - c->pS[1]) - alpha * c->pD[1];
             static const bool affdbg = [] { const char *e = getenv("HDSDP_MI355X_AFFINE_DEBUG"); return e && atoi(e); }();
-            if (affdbg && !hit)
-                fprintf(stderr, "[hdsdp_mi355x affine] miss: alpha %.6e, %d of %d components off the tested line, worst relative %.3e at %d\n", alpha, bad, np, worst, wi);
+            if (affdbg && !hit) {
+                double dd = 0.0, pp = 0.0, dp = 0.0;
+                for (int i = 2; i < np; ++i) { const double d = comp(i) - c->pS[i]; dd += d * d; pp += c->pD[i] * c->pD[i]; dp += d * c->pD[i]; }
+                fprintf(stderr, "[hdsdp_mi355x affine] miss (%s): alpha %.6e, %d of %d components off the tested line, worst relative %.3e at %d; "
+                                "d tau %.3e, d eye %.3e, |d y| %.3e, |pD y| %.3e, cos %.9f\n", target == c->S ? "S" : "checker", alpha, bad, np, worst, wi,
+                        comp(0) - c->pS[0], comp(1) - c->pS[1], sqrt(dd), sqrt(pp), (dd > 0 && pp > 0) ? dp / sqrt(dd * pp) : 0.0);
+            }
         }
         if (hit && same) {                                                     // the same point into the other buffer: a copy
             HDM_HIP_CHECK(hipMemcpyAsync(target, c->S, sizeof(double) * (size_t) c->n16 * c->n16, hipMemcpyDeviceToDevice, g.stream));
